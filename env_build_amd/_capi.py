@@ -1,0 +1,118 @@
+"""ctypes binding of include/envbuild.h.
+
+`CApi(path)` binds one shared library exporting the C-ABI.  The product only ever binds
+env_build_amd/lib/libenvbuild_hip.so through `hip_api()`, which raises if the library is missing
+or fails to load — there is no CPU fallback anywhere in the package.  (tests/ bind the CPU oracle
+with the same class to compare the two libraries call-for-call.)
+"""
+import ctypes as C
+import os
+
+EB_ABI_VERSION = 1
+TASK_ID = {'left': 0, 'straight': 1, 'right': 2}
+MODE_TRAINING, MODE_SELECTING = 0, 1
+# vehicle mode ids (EB_VMODE_*), in the order of the twelve lists of E2E:354
+VMODES = ('dl', 'du', 'dr', 'rd', 'rl', 'ru', 'ur', 'ud', 'ul', 'lu', 'lr', 'ld')
+VMODE_ID = {m: i for i, m in enumerate(VMODES)}
+VMODE_EMPTY = 255
+
+DONE_NAMES = ('not_done_yet', 'collision', 'break_road_constrain', 'deviate_too_much',
+              'break_stability', 'break_red_light', 'good_done')  # E2E:208-221
+
+
+class EbConfig(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('task', C.c_int32), ('n_veh', C.c_int32),
+                ('n_future', C.c_int32), ('mode', C.c_int32), ('device', C.c_int32)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+
+# name -> (restype, argtypes); must list every symbol include/envbuild.h declares
+PROTOTYPES = {
+    'eb_last_error': (C.c_char_p, []),
+    'eb_abi_version': (C.c_int, []),
+    'eb_backend': (C.c_char_p, []),
+    'eb_create': (C.c_int, [C.POINTER(EbConfig), C.POINTER(_P)]),
+    'eb_destroy': (C.c_int, [_P]),
+    'eb_sync': (C.c_int, [_P]),
+    'eb_set_paths': (C.c_int, [_P, _P, _P, _P, _P, _I]),
+    'eb_set_veh_modes': (C.c_int, [_P, _P, _I]),
+    'eb_f_xu': (C.c_int, [_P, _I, _P, _P, C.c_float, _P, _P, _P]),
+    'eb_action_transform': (C.c_int, [_P, _I, _P, _P, _P]),
+    'eb_compute_rewards': (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
+    'eb_compute_next_obses': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P]),
+    'eb_rollout_step': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'eb_rollout_tape': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'eb_find_closest_point': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
+    'eb_tracking_error': (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    'eb_veh_predict': (C.c_int, [_P, _I, _P, _P, _P]),
+    'eb_ss': (C.c_int, [_P, _I, _P, _P, _P, _I, C.c_double, _P, _P]),
+    'eb_env_ego_step': (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
+    'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+}
+
+
+class EbError(RuntimeError):
+    pass
+
+
+class CApi(object):
+    def __init__(self, path):
+        if not os.path.isfile(path):
+            raise EbError('shared library not found: %s' % path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(self.lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if self.lib.eb_abi_version() != EB_ABI_VERSION:
+            raise EbError('%s: ABI version %d, expected %d'
+                          % (path, self.lib.eb_abi_version(), EB_ABI_VERSION))
+        self.backend = self.lib.eb_backend().decode()
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.eb_last_error()
+            msg = msg.decode() if msg else ''
+            if rc == -1:
+                raise ValueError('envbuild(%s): %s' % (self.backend, msg))
+            raise EbError('envbuild(%s) error %d: %s' % (self.backend, rc, msg))
+
+    def create(self, task, n_veh, n_future, mode, device=0):
+        cfg = EbConfig(EB_ABI_VERSION, TASK_ID[task] if isinstance(task, str) else int(task),
+                       int(n_veh), int(n_future), int(mode), int(device))
+        h = _P()
+        self.check(self.lib.eb_create(C.byref(cfg), C.byref(h)))
+        return h
+
+    def __getattr__(self, name):
+        # eb_xxx(...) with return-code checking: api.rollout_step(h, ...)
+        fn = getattr(self.lib, 'eb_' + name)
+
+        def call(*args):
+            self.check(fn(*args))
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+
+HIP_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib',
+                            'libenvbuild_hip.so')
+_hip_api = None
+
+
+def hip_api():
+    """The product's only backend.  Raises (never falls back) when the HIP library is absent."""
+    global _hip_api
+    if _hip_api is None:
+        if not os.path.isfile(HIP_LIB_PATH):
+            raise EbError('HIP extension missing: %s — run `python -c "import __graft_entry__ as g; '
+                          'g.build()"` (hipcc --offload-arch=gfx950).  env_build_amd has no CPU '
+                          'fallback.' % HIP_LIB_PATH)
+        _hip_api = CApi(HIP_LIB_PATH)
+        if _hip_api.backend != 'hip':
+            raise EbError('%s is not the HIP backend' % HIP_LIB_PATH)
+    return _hip_api

@@ -1,0 +1,201 @@
+/*
+ * envbuild.h — C-ABI of the MI355X-native hot path of idthanm/env_build.
+ *
+ * The reference has no FFI layer: its boundary is the Python class surface of
+ * dynamics_and_models.py / endtoend.py.  Each entry point below replaces
+ * the arithmetic of one reference method; the Python façade in env_build_amd/ keeps the
+ * reference's class/method names and calls these through ctypes (INTEGRATION.md shows the
+ * binding a maintainer would add to the reference itself).
+ *
+ * Two shared libraries export this identical symbol set:
+ *   - env_build_amd/lib/libenvbuild_hip.so   (product; HIP kernels for gfx950; all data
+ *     pointers are DEVICE pointers unless marked HOST)
+ *   - oracle/_build/libenvbuild_oracle.so    (test infrastructure only; plain C; all data
+ *     pointers are host pointers; `stream` ignored)
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (EB_E*); eb_last_error() returns a
+ *     thread-local message.  No exceptions / aborts cross the ABI.
+ *   - the caller owns every data buffer; a handle owns only its path tables / mode table.
+ *   - a handle is bound to one device and is not thread-safe; distinct handles are independent.
+ *   - launches are asynchronous on `stream` (a hipStream_t; NULL = the handle's own stream);
+ *     eb_sync() blocks until the handle's work is done.
+ *   - all floating point is IEEE fp32, evaluated op-for-op in the reference's order with no FMA
+ *     contraction; sin/cos/atan use the deterministic kernels documented in DESIGN.md so that
+ *     the HIP path and the oracle agree bit-for-bit.
+ *   - row layouts are the reference's: obs row = [ego 6 | tracking 3*(n_future+1) | veh 4*n_veh]
+ *     (DAM:104-106, 189-194, 356), fp32, row-major [n_env, obs_dim].
+ */
+#ifndef ENVBUILD_H
+#define ENVBUILD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EB_ABI_VERSION 1
+
+/* error codes */
+#define EB_OK 0
+#define EB_EINVAL (-1)   /* bad argument (task, sizes, null pointer) */
+#define EB_ESTATE (-2)   /* handle not fully configured (paths / modes missing) */
+#define EB_EDEVICE (-3)  /* HIP runtime error, no device, launch failure */
+#define EB_ENOMEM (-4)
+
+/* task ids: training_task strings of the reference (DAM:91, E2E:46) */
+#define EB_TASK_LEFT 0
+#define EB_TASK_STRAIGHT 1
+#define EB_TASK_RIGHT 2
+
+/* mode: DAM:93 / DAM:334 — 'training' selects the path per env by ref_indexes (DAM:342-353);
+ * anything else tracks the single current path of ref_path (DAM:334-339). */
+#define EB_MODE_TRAINING 0
+#define EB_MODE_SELECTING 1
+
+/* vehicle mode ids, in the order of the twelve lists of E2E:354 */
+#define EB_VMODE_DL 0
+#define EB_VMODE_DU 1
+#define EB_VMODE_DR 2
+#define EB_VMODE_RD 3
+#define EB_VMODE_RL 4
+#define EB_VMODE_RU 5
+#define EB_VMODE_UR 6
+#define EB_VMODE_UD 7
+#define EB_VMODE_UL 8
+#define EB_VMODE_LU 9
+#define EB_VMODE_LR 10
+#define EB_VMODE_LD 11
+#define EB_VMODE_COUNT 12
+#define EB_VMODE_EMPTY 255 /* unused candidate slot */
+
+/* done codes of eb_judge_done, in the priority order of E2E:200-221 */
+#define EB_DONE_NOT_YET 0
+#define EB_DONE_COLLISION 1
+#define EB_DONE_BREAK_ROAD 2
+#define EB_DONE_DEVIATE 3
+#define EB_DONE_STABILITY 4
+#define EB_DONE_RED_LIGHT 5
+#define EB_DONE_GOOD 6
+
+#define EB_MAX_PATHS 3
+#define EB_MAX_VEH 64
+
+typedef struct eb_handle_s* eb_handle;
+
+typedef struct eb_config {
+    int32_t abi_version; /* EB_ABI_VERSION */
+    int32_t task;        /* EB_TASK_* */
+    int32_t n_veh;       /* vehicle slots per env, 1..EB_MAX_VEH (native: 8 / 9 / 5, UTL:40-42) */
+    int32_t n_future;    /* num_future_data (DAM:91), >= 0 */
+    int32_t mode;        /* EB_MODE_* */
+    int32_t device;      /* HIP device ordinal; ignored by the oracle */
+} eb_config;
+
+const char* eb_last_error(void);
+int eb_abi_version(void);
+/* "hip" or "oracle" */
+const char* eb_backend(void);
+
+int eb_create(const eb_config* cfg, eb_handle* out);
+int eb_destroy(eb_handle h);
+int eb_sync(eb_handle h);
+
+/* ReferencePath tables (DAM:598-700 builds them; host side stays Python).  HOST pointers.
+ * xs/ys/phis: n_paths concatenated arrays, path k occupying lens[k] floats each. */
+int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phis,
+                 const int32_t* lens, int32_t n_paths);
+/* VEHICLE_MODE_LIST[task] (UTL:44-46): the mode of every vehicle slot as EB_VMODE_* ids.
+ * HOST pointer, n == n_veh.  The turn class of predict_for_a_mode (DAM:416-421) and the
+ * per-mode slot counts of _construct_veh_vector_short (E2E:449-451) derive from it. */
+int eb_set_veh_modes(eb_handle h, const uint8_t* mode_id, int32_t n);
+
+/* VehicleDynamics.f_xu (DAM:52-83).  states [n,6], actions [n,2] -> next [n,6], params [n,4]. */
+int eb_f_xu(eb_handle h, int32_t n, const float* states, const float* actions, float tau,
+            float* next_states, float* params, void* stream);
+
+/* EnvironmentModel._action_transformation_for_end2end (DAM:128-132). [n,2] -> [n,2]. */
+int eb_action_transform(eb_handle h, int32_t n, const float* actions, float* scaled,
+                        void* stream);
+
+/* EnvironmentModel.compute_rewards (DAM:186-320).  obs [n_env,D], actions [n_env,2] ALREADY
+ * scaled.  out5 = 5 contiguous arrays of n_env floats: rewards, punish_term_for_training,
+ * real_punish_term, veh2veh4real, veh2road4real.  out_dict16 (nullable) = 16 arrays of n_env in
+ * the key order of DAM:302-318. */
+int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float* actions,
+                       float* out5, float* out_dict16, void* stream);
+
+/* EnvironmentModel.compute_next_obses (DAM:322-358): ego_predict + tracking + veh_predict.
+ * ref_idx: [n_env] int32, used in training mode (may be NULL otherwise); path_id: the current
+ * path of ref_path in the other modes. */
+int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
+                          const int32_t* ref_idx, int32_t path_id, float* obs_out, void* stream);
+
+/* EnvironmentModel.rollout_out (DAM:118-126): action transform -> rewards on the current obs ->
+ * next obs, fused in one launch.  actions are the raw [-1,1] policy outputs.
+ * scaled_actions (nullable) receives self.actions (DAM:120). */
+int eb_rollout_step(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
+                    const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
+                    float* scaled_actions, void* stream);
+
+/* Open-loop rollout of `horizon` steps over an action tape [horizon, n_env, 2] (the MPC callers'
+ * cost_function, mpc/main.py:470-479).  out5_steps: [horizon, 5, n_env]; obs_work is a scratch
+ * obs buffer [n_env, D]; obs_out receives the final obs.  Equivalent to `horizon` calls of
+ * eb_rollout_step. */
+int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in,
+                    const float* action_tape, const int32_t* ref_idx, int32_t path_id,
+                    float* obs_work, float* obs_out, float* out5_steps, void* stream);
+
+/* ReferencePath.find_closest_point (DAM:702-715), ratio = 10.  out_index: [n] int32 (already
+ * multiplied by ratio); out_points: 3 arrays of n floats (x, y, phi).  ref_idx nullable ->
+ * path_id for every row. */
+int eb_find_closest_point(eb_handle h, int32_t n, const float* xs, const float* ys,
+                          const int32_t* ref_idx, int32_t path_id, int32_t* out_index,
+                          float* out_points, void* stream);
+
+/* ReferencePath.tracking_error_vector (DAM:735-770). out [n, 3*(n_future+1)]. */
+int eb_tracking_error(eb_handle h, int32_t n, const float* xs, const float* ys,
+                      const float* phis, const float* vs, const int32_t* ref_idx,
+                      int32_t path_id, int32_t n_future, float* out, void* stream);
+
+/* EnvironmentModel.veh_predict (DAM:394-427). veh [n_env, 4*n_veh] -> same shape. */
+int eb_veh_predict(eb_handle h, int32_t n_env, const float* veh, float* veh_out, void* stream);
+
+/* EnvironmentModel.ss (DAM:134-184). actions raw [-1,1]; lam is the python float (double). out [n_env]. */
+int eb_ss(eb_handle h, int32_t n_env, const float* obs, const float* actions,
+          const int32_t* ref_idx, int32_t path_id, double lam, float* out, void* stream);
+
+/* ---- real-env step pieces (endtoend.py), batched over n_env independent single-ego envs ---- */
+
+/* CrossroadEnd2end._get_next_ego_state (E2E:269-283): f_xu at 10 Hz, v_x floored at 0 (NOT
+ * clipped at 35), phi wrapped by deal_with_phi (UTL:232-237).  actions are SCALED (E2E:133).
+ * ego [n,6] -> next_ego [n,6], params [n,4] (alpha_f, alpha_r, miu_f, miu_r). */
+int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actions,
+                    float* next_ego, float* params, void* stream);
+
+/* CrossroadEnd2end._get_obs (E2E:285-303) = ego vector (E2E:329-338) | tracking_error_vector on
+ * the env's path | _construct_veh_vector_short (E2E:340-464).
+ *   ego [n_env,6]; ref_idx nullable [n_env] (else path_id);
+ *   cand [n_env, m_cand, 4] = (x, y, v, phi) of every vehicle in all_vehicles;
+ *   cand_mode [n_env, m_cand] = EB_VMODE_* of each (route classified by the caller, E2E:355-385)
+ *   or EB_VMODE_EMPTY;  light_flag [n_env] = (v_light != 0) | virtual_red_light_vehicle
+ *   (E2E:387-388).  obs_out [n_env, D]. */
+int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx,
+               int32_t path_id, int32_t m_cand, const float* cand, const uint8_t* cand_mode,
+               const uint8_t* light_flag, float* obs_out, void* stream);
+
+/* CrossroadEnd2end._judge_done (E2E:200-256) with Traffic.collision_check (TRF:263-295),
+ * _get_ego_dynamics' r_bound and corner points (E2E:163-177) and judge_feasible (UTL:73-104).
+ *   ego [n_env,6]; params [n_env,4]; obs [n_env,D] (delta_y = obs[:,6], E2E:224);
+ *   cand / cand_mode as in eb_get_obs (every non-empty candidate takes part in the collision
+ *   test); cand_lw [n_env, m_cand, 2] = (l, w) per candidate, NULL -> (4.8, 2.0);
+ *   v_light [n_env] uint8.  done_code [n_env] uint8 = EB_DONE_*. */
+int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* params,
+                  const float* obs, int32_t m_cand, const float* cand, const uint8_t* cand_mode,
+                  const float* cand_lw, const uint8_t* v_light, uint8_t* done_code, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVBUILD_H */

@@ -1,0 +1,920 @@
+/*
+ * envbuild_oracle.c — TEST INFRASTRUCTURE.  CPU restatement (plain C, fp32, no FMA contraction)
+ * of the reference's hot path, exporting the C-ABI of include/envbuild.h with HOST pointers.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (env_build_amd/) never does and fails loudly when its HIP library is missing.
+ *
+ * Every function cites the reference lines it follows (DAM = dynamics_and_models.py,
+ * E2E = endtoend.py, UTL = endtoend_env_utils.py, TRF = traffic.py under /root/reference).
+ *
+ * Pinning status: the reference ships no golden vectors or asserting tests, and its
+ * arithmetic executor (TensorFlow) plus `bezier` are absent from this image.  The oracle is pinned
+ * against fixtures under tests/golden/ produced by running the reference's OWN Python files,
+ * unmodified, over NumPy-fp32 stand-ins for the tf.* symbols (oracle/gen_golden.py).  At the
+ * TF-kernel boundary itself (Eigen's sin/cos/atan) parity is UNPINNED: TF's, NumPy's and this
+ * file's transcendental kernels each carry <= 2 ulp error, which is why the fixture comparison
+ * uses rtol 1e-5 (+ a stated atol) rather than bit equality.
+ *
+ * Deliberate choices (all documented in DESIGN.md):
+ *  - sin/cos/atan are the deterministic Cephes-style fp32 kernels below (only IEEE + - * / and
+ *    rint), NOT libm, so the HIP kernels can reproduce them bit-for-bit.
+ *  - python-float constants are rounded to fp32 at the op where they meet a tensor, in the
+ *    reference's evaluation order.
+ */
+#include "../include/envbuild.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#if defined(__FP_FAST_FMAF) && !defined(EB_ALLOW_FMA)
+/* compiled with -ffp-contract=off in oracle/Makefile; this is only a reminder */
+#endif
+
+static __thread char g_err[256];
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+const char* eb_last_error(void) { return g_err; }
+int eb_abi_version(void) { return EB_ABI_VERSION; }
+const char* eb_backend(void) { return "oracle"; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* constants: python doubles rounded to fp32 where they meet a tensor                          */
+/* ------------------------------------------------------------------------------------------ */
+#define PI_D 3.141592653589793
+static const float PI_F = (float)PI_D;              /* np.pi -> fp32 */
+static const float TWO_PI_F = (float)(2 * PI_D);    /* 2 * np.pi (python double) -> fp32, DAM:424 */
+static const float LWS = (float)((4.8 - 2.0) / 2.); /* (L - W) / 2., DAM:210, UTL:14 */
+static const float HALF_CROSS = 25.0f;              /* CROSSROAD_SIZE/2, UTL:17 */
+static const float LANE_W = 3.75f;                  /* UTL:15 */
+static const float EXP_V = 8.0f;                    /* EXPECTED_V, UTL:18 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* deterministic fp32 transcendental kernels (Cephes single-precision scheme)                  */
+/* ------------------------------------------------------------------------------------------ */
+static void eb_sincosf(float x, float* s_out, float* c_out) {
+    /* k = nearest integer to x / (pi/2); r = x - k*pi/2 by 3-term Cody-Waite (exact products
+     * for |k| < 2^12); minimax polynomials on |r| <= pi/4. */
+    float kf = nearbyintf(x * 0.636619747f);
+    int k = (int)kf;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.83751296997070312e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    float s = r + r * z * ps;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    float c = 1.0f - 0.5f * z + z * z * pc;
+    switch (k & 3) {
+        case 0: *s_out = s; *c_out = c; break;
+        case 1: *s_out = c; *c_out = -s; break;
+        case 2: *s_out = -s; *c_out = -c; break;
+        default: *s_out = -c; *c_out = s; break;
+    }
+}
+
+static float eb_atanf(float x) {
+    float ax = fabsf(x);
+    float y, t;
+    if (ax > 2.414213562373095f) {
+        y = 1.5707963267948966f;
+        t = -1.0f / ax;
+    } else if (ax > 0.4142135623730950f) {
+        y = 0.7853981633974483f;
+        t = (ax - 1.0f) / (ax + 1.0f);
+    } else {
+        y = 0.0f;
+        t = ax;
+    }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    y = y + (p * z * t + t);
+    return x < 0.0f ? -y : y;
+}
+
+static inline float sq(float x) { return x * x; }
+static inline float deg2rad(float d) { return d * PI_F / 180.0f; } /* x * np.pi / 180., DAM:54 */
+static inline float rad2deg(float r) { return r * 180.0f / PI_F; } /* x * 180 / np.pi, DAM:81 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* handle                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+struct eb_handle_s {
+    eb_config cfg;
+    int n_paths;
+    int lens[EB_MAX_PATHS];
+    float* px[EB_MAX_PATHS];
+    float* py[EB_MAX_PATHS];
+    float* pphi[EB_MAX_PATHS];
+    uint8_t vmode[EB_MAX_VEH]; /* EB_VMODE_* per slot */
+    uint8_t turn[EB_MAX_VEH];  /* 0 none, 1 left-turn, 2 right-turn: DAM:416-421 */
+    int modes_set;
+};
+
+enum { TURN_NONE = 0, TURN_LEFT = 1, TURN_RIGHT = 2 };
+static int turn_of_mode(int m) {
+    switch (m) {
+        case EB_VMODE_DL: case EB_VMODE_RD: case EB_VMODE_UR: case EB_VMODE_LU: return TURN_LEFT;  /* DAM:416 */
+        case EB_VMODE_DR: case EB_VMODE_RU: case EB_VMODE_UL: case EB_VMODE_LD: return TURN_RIGHT; /* DAM:418 */
+        default: return TURN_NONE;
+    }
+}
+
+static int obs_dim(const eb_config* c) { return 6 + 3 * (c->n_future + 1) + 4 * c->n_veh; }
+
+int eb_create(const eb_config* cfg, eb_handle* out) {
+    if (!cfg || !out) return fail(EB_EINVAL, "eb_create: null argument");
+    if (cfg->abi_version != EB_ABI_VERSION) return fail(EB_EINVAL, "eb_create: ABI version mismatch");
+    if (cfg->task < 0 || cfg->task > 2) return fail(EB_EINVAL, "eb_create: task must be left/straight/right");
+    if (cfg->n_veh < 1 || cfg->n_veh > EB_MAX_VEH) return fail(EB_EINVAL, "eb_create: n_veh out of range");
+    if (cfg->n_future < 0 || cfg->n_future > 64) return fail(EB_EINVAL, "eb_create: n_future out of range");
+    if (cfg->mode != EB_MODE_TRAINING && cfg->mode != EB_MODE_SELECTING)
+        return fail(EB_EINVAL, "eb_create: bad mode");
+    eb_handle h = (eb_handle)calloc(1, sizeof *h);
+    if (!h) return fail(EB_ENOMEM, "eb_create: out of memory");
+    h->cfg = *cfg;
+    *out = h;
+    return EB_OK;
+}
+
+int eb_destroy(eb_handle h) {
+    if (!h) return EB_OK;
+    for (int k = 0; k < EB_MAX_PATHS; ++k) { free(h->px[k]); free(h->py[k]); free(h->pphi[k]); }
+    free(h);
+    return EB_OK;
+}
+
+int eb_sync(eb_handle h) { (void)h; return EB_OK; }
+
+int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phis,
+                 const int32_t* lens, int32_t n_paths) {
+    if (!h || !xs || !ys || !phis || !lens) return fail(EB_EINVAL, "eb_set_paths: null argument");
+    if (n_paths < 1 || n_paths > EB_MAX_PATHS) return fail(EB_EINVAL, "eb_set_paths: n_paths out of range");
+    size_t off = 0;
+    for (int k = 0; k < n_paths; ++k) {
+        if (lens[k] < 3) return fail(EB_EINVAL, "eb_set_paths: path too short");
+        size_t nb = (size_t)lens[k] * sizeof(float);
+        free(h->px[k]); free(h->py[k]); free(h->pphi[k]);
+        h->px[k] = (float*)malloc(nb); h->py[k] = (float*)malloc(nb); h->pphi[k] = (float*)malloc(nb);
+        if (!h->px[k] || !h->py[k] || !h->pphi[k]) return fail(EB_ENOMEM, "eb_set_paths: out of memory");
+        memcpy(h->px[k], xs + off, nb); memcpy(h->py[k], ys + off, nb); memcpy(h->pphi[k], phis + off, nb);
+        h->lens[k] = lens[k];
+        off += (size_t)lens[k];
+    }
+    h->n_paths = n_paths;
+    return EB_OK;
+}
+
+int eb_set_veh_modes(eb_handle h, const uint8_t* mode_id, int32_t n) {
+    if (!h || !mode_id) return fail(EB_EINVAL, "eb_set_veh_modes: null argument");
+    if (n != h->cfg.n_veh) return fail(EB_EINVAL, "eb_set_veh_modes: n != n_veh");
+    for (int j = 0; j < n; ++j)
+        if (mode_id[j] >= EB_VMODE_COUNT) return fail(EB_EINVAL, "eb_set_veh_modes: bad mode id");
+    for (int j = 0; j < n; ++j) {
+        h->vmode[j] = mode_id[j];
+        h->turn[j] = (uint8_t)turn_of_mode(mode_id[j]);
+    }
+    h->modes_set = 1;
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a2: VehicleDynamics.f_xu, DAM:52-83                                                         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float C_f, C_r, a, b, mass, I_z, miu, g;
+} veh_params_t;
+static const veh_params_t VP = {-155495.0f, -155495.0f, 1.19f, 1.46f, 1520.0f, 2642.0f, 0.8f, 9.81f}; /* DAM:37-45 */
+
+static void f_xu_row(const float* st, const float* ac, float tau, float* nx, float* pr) {
+    float v_x = st[0], v_y = st[1], r = st[2], x = st[3], y = st[4], phi = st[5]; /* DAM:53 */
+    phi = deg2rad(phi);                                                          /* DAM:54 */
+    float steer = ac[0], a_x = ac[1];                                            /* DAM:55 */
+    const float C_f = VP.C_f, C_r = VP.C_r, a = VP.a, b = VP.b, mass = VP.mass, I_z = VP.I_z,
+                miu = VP.miu, g = VP.g;                                          /* DAM:56-63 */
+    if (pr) {
+        float F_zf = b * mass * g / (a + b), F_zr = a * mass * g / (a + b);      /* DAM:65 */
+        float F_xf = a_x < 0 ? mass * a_x / 2 : 0.0f;                            /* DAM:66 */
+        float F_xr = a_x < 0 ? mass * a_x / 2 : mass * a_x;                      /* DAM:67 */
+        float miu_f = sqrtf(sq(miu * F_zf) - sq(F_xf)) / F_zf;                   /* DAM:68 */
+        float miu_r = sqrtf(sq(miu * F_zr) - sq(F_xr)) / F_zr;                   /* DAM:69 */
+        float alpha_f = eb_atanf((v_y + a * r) / (v_x + 1e-8f)) - steer;         /* DAM:70 */
+        float alpha_r = eb_atanf((v_y - b * r) / (v_x + 1e-8f));                 /* DAM:71 */
+        pr[0] = alpha_f; pr[1] = alpha_r; pr[2] = miu_f; pr[3] = miu_r;          /* DAM:83 */
+    }
+    float sn, cs;
+    eb_sincosf(phi, &sn, &cs);
+    float k1 = a * C_f - b * C_r;
+    nx[0] = v_x + tau * (a_x + v_y * r);                                          /* DAM:73 */
+    nx[1] = (mass * v_y * v_x + tau * k1 * r - tau * C_f * steer * v_x - tau * mass * sq(v_x) * r) /
+            (mass * v_x - tau * (C_f + C_r));                                     /* DAM:74-76 */
+    nx[2] = (-I_z * r * v_x - tau * k1 * v_y + tau * a * C_f * steer * v_x) /
+            (tau * (sq(a) * C_f + sq(b) * C_r) - I_z * v_x);                      /* DAM:77-78 */
+    nx[3] = x + tau * (v_x * cs - v_y * sn);                                      /* DAM:79 */
+    nx[4] = y + tau * (v_x * sn + v_y * cs);                                      /* DAM:80 */
+    nx[5] = rad2deg(phi + tau * r);                                               /* DAM:81 */
+}
+
+int eb_f_xu(eb_handle h, int32_t n, const float* states, const float* actions, float tau,
+            float* next_states, float* params, void* stream) {
+    (void)stream;
+    if (!h || n < 0 || !states || !actions || !next_states) return fail(EB_EINVAL, "eb_f_xu: bad argument");
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+        f_xu_row(states + 6 * (size_t)i, actions + 2 * (size_t)i, tau, next_states + 6 * (size_t)i,
+                 params ? params + 4 * (size_t)i : NULL);
+    return EB_OK;
+}
+
+/* a4: _action_transformation_for_end2end, DAM:128-132 */
+static void action_transform_row(const float* in, float* out) {
+    float a0 = fminf(fmaxf(in[0], -1.05f), 1.05f), a1 = fminf(fmaxf(in[1], -1.05f), 1.05f);
+    out[0] = 0.4f * a0;
+    out[1] = 2.25f * a1 - 0.75f;
+}
+
+int eb_action_transform(eb_handle h, int32_t n, const float* actions, float* scaled, void* stream) {
+    (void)stream;
+    if (!h || n < 0 || !actions || !scaled) return fail(EB_EINVAL, "eb_action_transform: bad argument");
+    for (int i = 0; i < n; ++i) action_transform_row(actions + 2 * (size_t)i, scaled + 2 * (size_t)i);
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a5: EnvironmentModel.compute_rewards, DAM:186-320                                           */
+/* ------------------------------------------------------------------------------------------ */
+static void road_terms(int task, float px, float py, float* train, float* real) {
+    const float LWN = LANE_W * 3.0f; /* LANE_WIDTH*LANE_NUMBER = 11.25 */
+    float t = *train, q = *real;
+    if (task == EB_TASK_LEFT) { /* DAM:233-251 */
+        if (py < -HALF_CROSS && px < 1.0f) t += sq(px - 1.0f);
+        if (py < -HALF_CROSS && LANE_W - px < 1.0f) t += sq(LANE_W - px - 1.0f);
+        if (px < 0.0f && LWN - py < 1.0f) t += sq(LWN - py - 1.0f);
+        if (px < -HALF_CROSS && py - 0.0f < 1.0f) t += sq(py - 0.0f - 1.0f);
+        if (py < -HALF_CROSS && px < 1.0f) q += sq(px - 1.0f);
+        if (py < -HALF_CROSS && LANE_W - px < 1.0f) q += sq(LANE_W - px - 1.0f);
+        if (px < -HALF_CROSS && LWN - py < 1.0f) q += sq(LWN - py - 1.0f);
+        if (px < -HALF_CROSS && py - 0.0f < 1.0f) q += sq(py - 0.0f - 1.0f);
+    } else if (task == EB_TASK_STRAIGHT) { /* DAM:252-272 */
+        const float LW2 = 2.0f * LANE_W;
+        for (int pass = 0; pass < 2; ++pass) {
+            float* acc = pass == 0 ? &t : &q;
+            if (py < -HALF_CROSS && px - LANE_W < 1.0f) *acc += sq(px - LANE_W - 1.0f);
+            if (py < -HALF_CROSS && LW2 - px < 1.0f) *acc += sq(LW2 - px - 1.0f);
+            if (py > HALF_CROSS && LWN - px < 1.0f) *acc += sq(LWN - px - 1.0f);
+            if (py > HALF_CROSS && px - 0.0f < 1.0f) *acc += sq(px - 0.0f - 1.0f);
+        }
+    } else { /* right, DAM:273-295 */
+        const float LW2 = 2.0f * LANE_W;
+        for (int pass = 0; pass < 2; ++pass) {
+            float* acc = pass == 0 ? &t : &q;
+            if (py < -HALF_CROSS && px - LW2 < 1.0f) *acc += sq(px - LW2 - 1.0f);
+            if (py < -HALF_CROSS && LWN - px < 1.0f) *acc += sq(LWN - px - 1.0f);
+            if (px > HALF_CROSS && 0.0f - py < 1.0f) *acc += sq(0.0f - py - 1.0f);
+            if (px > HALF_CROSS && py - (-LWN) < 1.0f) *acc += sq(py - (-LWN) - 1.0f);
+        }
+    }
+    *train = t; *real = q;
+}
+
+/* out5: rewards, punish_train, punish_real, veh2veh4real, veh2road4real; d16 nullable. */
+static void rewards_row(const eb_config* c, const float* obs, const float* act, float* o5, float* d16) {
+    const float* ego = obs;
+    const float* trk = obs + 6;
+    const float* veh = obs + 6 + 3 * (c->n_future + 1);
+    float steers = act[0], a_xs = act[1];              /* DAM:196 */
+    float punish_steer = -sq(steers);                  /* DAM:198 */
+    float punish_a_x = -sq(a_xs);                      /* DAM:199 */
+    float punish_yaw_rate = -sq(ego[2]);               /* DAM:202 */
+    float devi_y = -sq(trk[0]);                        /* DAM:205 */
+    float devi_phi = -sq(deg2rad(trk[1]));             /* DAM:206 */
+    float devi_v = -sq(trk[2]);                        /* DAM:207 */
+    float es, ec;
+    eb_sincosf(deg2rad(ego[5]), &es, &ec);
+    float efx = ego[3] + LWS * ec, efy = ego[4] + LWS * es; /* DAM:211-212 */
+    float erx = ego[3] - LWS * ec, ery = ego[4] - LWS * es; /* DAM:213-214 */
+    float v2v_real = 0.0f, v2v_train = 0.0f;                /* DAM:215-216 */
+    for (int j = 0; j < c->n_veh; ++j) {                    /* DAM:218-229 */
+        const float* v = veh + 4 * j;
+        float vs, vc;
+        eb_sincosf(deg2rad(v[3]), &vs, &vc);
+        float vfx = v[0] + LWS * vc, vfy = v[1] + LWS * vs;
+        float vrx = v[0] - LWS * vc, vry = v[1] - LWS * vs;
+        const float ex[2] = {efx, erx}, ey[2] = {efy, ery}, wx[2] = {vfx, vrx}, wy[2] = {vfy, vry};
+        for (int p = 0; p < 2; ++p)
+            for (int q = 0; q < 2; ++q) {
+                float d = sqrtf(sq(ex[p] - wx[q]) + sq(ey[p] - wy[q]));
+                float t35 = d - 3.5f, t25 = d - 2.5f;
+                v2v_train += t35 < 0.0f ? sq(t35) : 0.0f;
+                v2v_real += t25 < 0.0f ? sq(t25) : 0.0f;
+            }
+    }
+    float road_train = 0.0f, road_real = 0.0f;              /* DAM:231-232 */
+    /* the reference interleaves, per ego point, 4 training terms then 4 real terms; each
+     * accumulator only ever sees its own terms, in front-then-rear order */
+    road_terms(c->task, efx, efy, &road_train, &road_real);
+    road_terms(c->task, erx, ery, &road_train, &road_real);
+    float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                    5.0f * punish_steer + 0.05f * punish_a_x; /* DAM:297-298 */
+    o5[0] = rewards;
+    o5[1] = v2v_train + road_train; /* DAM:299 */
+    o5[2] = v2v_real + road_real;   /* DAM:300 */
+    o5[3] = v2v_real;
+    o5[4] = road_real;
+    if (d16) { /* DAM:302-318 */
+        d16[0] = punish_steer; d16[1] = punish_a_x; d16[2] = punish_yaw_rate;
+        d16[3] = devi_v; d16[4] = devi_y; d16[5] = devi_phi;
+        d16[6] = 5.0f * punish_steer; d16[7] = 0.05f * punish_a_x; d16[8] = 0.02f * punish_yaw_rate;
+        d16[9] = 0.05f * devi_v; d16[10] = 0.8f * devi_y; d16[11] = 30.0f * devi_phi;
+        d16[12] = v2v_train; d16[13] = road_train; d16[14] = v2v_real; d16[15] = road_real;
+    }
+}
+
+int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float* actions,
+                       float* out5, float* out_dict16, void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || !obs || !actions || !out5) return fail(EB_EINVAL, "eb_compute_rewards: bad argument");
+    const int D = obs_dim(&h->cfg);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_env; ++i) {
+        float o5[5], d16[16];
+        rewards_row(&h->cfg, obs + (size_t)D * i, actions + 2 * (size_t)i, o5, out_dict16 ? d16 : NULL);
+        for (int k = 0; k < 5; ++k) out5[(size_t)k * n_env + i] = o5[k];
+        if (out_dict16)
+            for (int k = 0; k < 16; ++k) out_dict16[(size_t)k * n_env + i] = d16[k];
+    }
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a8: ReferencePath closest point + tracking error, DAM:577-580, 702-770                      */
+/* ------------------------------------------------------------------------------------------ */
+static int closest_index(const eb_handle h, int p, float x, float y) { /* DAM:702-715 */
+    const int len = h->lens[p];
+    const float* px = h->px[p];
+    const float* py = h->py[p];
+    float best = INFINITY;
+    int best_i = 0;
+    for (int i = 0; i < len; i += 10) { /* np.arange(0, path_len, ratio), DAM:704 */
+        float d = sq(x - px[i]) + sq(y - py[i]); /* DAM:712 */
+        if (d < best) { best = d; best_i = i; }  /* tf.argmin: first minimum, DAM:714 */
+    }
+    /* NaN inputs: np/tf argmin returns the first NaN position; with every d NaN that is 0 */
+    return best_i;
+}
+
+static inline int clamp_index(int i, int len) { /* indexs2points, DAM:727-728 */
+    if (i < 0) i = 0;
+    if (i >= len) i = len - 1;
+    return i;
+}
+
+static inline float deal_with_phi_diff(float d) { /* DAM:577-580 */
+    if (d > 180.0f) d = d - 360.0f;
+    if (d < -180.0f) d = d + 360.0f;
+    return d;
+}
+
+static float two2one(int task, float ex, float ey, float rx, float ry) { /* DAM:736-752 */
+    float delta;
+    if (task == EB_TASK_LEFT) {
+        delta = sqrtf(sq(ex - (-HALF_CROSS)) + sq(ey - (-HALF_CROSS))) -
+                sqrtf(sq(rx - (-HALF_CROSS)) + sq(ry - (-HALF_CROSS)));
+        if (ey < -HALF_CROSS) delta = ex - rx;
+        if (ex < -HALF_CROSS) delta = ey - ry;
+        return -delta;
+    } else if (task == EB_TASK_STRAIGHT) {
+        delta = ex - rx;
+        return -delta;
+    } else {
+        delta = -(sqrtf(sq(ex - HALF_CROSS) + sq(ey - (-HALF_CROSS))) -
+                  sqrtf(sq(rx - HALF_CROSS) + sq(ry - (-HALF_CROSS))));
+        if (ey < -HALF_CROSS) delta = ex - rx;
+        if (ex > HALF_CROSS) delta = -(ey - ry);
+        return -delta;
+    }
+}
+
+/* out: 3*(n+1) floats */
+static void tracking_row(const eb_handle h, int p, float ex, float ey, float ephi, float ev, int n,
+                         float* out) {
+    const int len = h->lens[p];
+    int idx = closest_index(h, p, ex, ey);              /* DAM:754 */
+    int ci = clamp_index(idx, len);
+    float rx = h->px[p][ci], ry = h->py[p][ci], rphi = h->pphi[p][ci];
+    out[0] = two2one(h->cfg.task, ex, ey, rx, ry);      /* DAM:758 */
+    out[1] = deal_with_phi_diff(ephi - rphi);           /* DAM:759 */
+    out[2] = ev - EXP_V;                                /* DAM:760 */
+    int cur = idx;
+    for (int k = 0; k < n; ++k) {                       /* future_n_data, DAM:717-724 */
+        cur += 80;
+        if (cur >= len - 2) cur = len - 2;
+        int fi = clamp_index(cur, len);
+        out[3 + 3 * k + 0] = h->px[p][fi] - ex;         /* DAM:764 */
+        out[3 + 3 * k + 1] = h->py[p][fi] - ey;         /* DAM:765 */
+        out[3 + 3 * k + 2] = deal_with_phi_diff(ephi - h->pphi[p][fi]); /* DAM:766 */
+    }
+}
+
+static int check_paths(eb_handle h, const char* who) {
+    if (!h) return fail(EB_EINVAL, who);
+    if (h->n_paths < 1) return fail(EB_ESTATE, "paths not set (eb_set_paths)");
+    return EB_OK;
+}
+
+/* path used by row i: ref_idx[i] when given, else path_id; <0 / >= n_paths -> -1 (zeros) */
+static inline int row_path(const eb_handle h, const int32_t* ref_idx, int path_id, int i) {
+    int p = ref_idx ? ref_idx[i] : path_id;
+    return (p >= 0 && p < h->n_paths) ? p : -1;
+}
+
+int eb_find_closest_point(eb_handle h, int32_t n, const float* xs, const float* ys,
+                          const int32_t* ref_idx, int32_t path_id, int32_t* out_index,
+                          float* out_points, void* stream) {
+    (void)stream;
+    int rc = check_paths(h, "eb_find_closest_point: null handle");
+    if (rc) return rc;
+    if (n < 0 || !xs || !ys || !out_index) return fail(EB_EINVAL, "eb_find_closest_point: bad argument");
+    if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_find_closest_point: bad path_id");
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        int p = row_path(h, ref_idx, path_id, i);
+        if (p < 0) {
+            out_index[i] = 0;
+            if (out_points) { out_points[i] = 0; out_points[(size_t)n + i] = 0; out_points[2 * (size_t)n + i] = 0; }
+            continue;
+        }
+        int idx = closest_index(h, p, xs[i], ys[i]);
+        out_index[i] = idx;
+        if (out_points) {
+            int ci = clamp_index(idx, h->lens[p]);
+            out_points[i] = h->px[p][ci];
+            out_points[(size_t)n + i] = h->py[p][ci];
+            out_points[2 * (size_t)n + i] = h->pphi[p][ci];
+        }
+    }
+    return EB_OK;
+}
+
+int eb_tracking_error(eb_handle h, int32_t n, const float* xs, const float* ys, const float* phis,
+                      const float* vs, const int32_t* ref_idx, int32_t path_id, int32_t n_future,
+                      float* out, void* stream) {
+    (void)stream;
+    int rc = check_paths(h, "eb_tracking_error: null handle");
+    if (rc) return rc;
+    if (n < 0 || !xs || !ys || !phis || !vs || !out || n_future < 0) return fail(EB_EINVAL, "eb_tracking_error: bad argument");
+    if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_tracking_error: bad path_id");
+    const int T = 3 * (n_future + 1);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        int p = row_path(h, ref_idx, path_id, i);
+        float* o = out + (size_t)T * i;
+        if (p < 0) { for (int k = 0; k < T; ++k) o[k] = 0.0f; continue; } /* DAM:342, 352 */
+        tracking_row(h, p, xs[i], ys[i], phis[i], vs[i], n_future, o);
+    }
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a10: veh_predict / predict_for_a_mode, DAM:394-427                                          */
+/* ------------------------------------------------------------------------------------------ */
+static void veh_predict_one(const float* v, int turn, float* o) {
+    float x = v[0], y = v[1], vv = v[2], phi = v[3];   /* DAM:406 */
+    float phi_rad = deg2rad(phi);                       /* DAM:407 */
+    int middle = (x > -HALF_CROSS && x < HALF_CROSS) && (y > -HALF_CROSS && y < HALF_CROSS); /* DAM:409-410 */
+    float sn, cs;
+    eb_sincosf(phi_rad, &sn, &cs);
+    float dx = vv / 10.0f * cs;                         /* DAM:413 */
+    float dy = vv / 10.0f * sn;                         /* DAM:414 */
+    float dphi = 0.0f;
+    if (turn == TURN_LEFT) dphi = middle ? (vv / 26.875f) / 10.0f : 0.0f;          /* DAM:417 */
+    else if (turn == TURN_RIGHT) dphi = middle ? -(vv / 15.625f) / 10.0f : 0.0f;   /* DAM:419 */
+    float nphi = phi_rad + dphi;                        /* DAM:423 */
+    if (nphi > PI_F) nphi = nphi - TWO_PI_F;            /* DAM:424 */
+    if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;          /* DAM:425 */
+    o[0] = x + dx; o[1] = y + dy; o[2] = vv;            /* DAM:422-423 */
+    o[3] = rad2deg(nphi);                               /* DAM:426 */
+}
+
+static int check_modes(eb_handle h) {
+    if (!h->modes_set) return fail(EB_ESTATE, "vehicle modes not set (eb_set_veh_modes)");
+    return EB_OK;
+}
+
+int eb_veh_predict(eb_handle h, int32_t n_env, const float* veh, float* veh_out, void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || !veh || !veh_out) return fail(EB_EINVAL, "eb_veh_predict: bad argument");
+    int rc = check_modes(h);
+    if (rc) return rc;
+    const int N = h->cfg.n_veh;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_env; ++i)
+        for (int j = 0; j < N; ++j)
+            veh_predict_one(veh + ((size_t)i * N + j) * 4, h->turn[j], veh_out + ((size_t)i * N + j) * 4);
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a6/a7: compute_next_obses + ego_predict, DAM:322-358, 386-392                               */
+/* ------------------------------------------------------------------------------------------ */
+static void next_obs_row(const eb_handle h, const float* obs, const float* act, int p, float* out) {
+    const eb_config* c = &h->cfg;
+    const int T = 3 * (c->n_future + 1);
+    float nx[6];
+    f_xu_row(obs, act, (float)(1 / 10.), nx, NULL);      /* prediction at base_frequency 10, DAM:85-87, 387 */
+    nx[0] = fminf(fmaxf(nx[0], 0.0f), 35.0f);            /* clip_by_value(v_xs, 0., 35.), DAM:390 */
+    for (int k = 0; k < 6; ++k) out[k] = nx[k];
+    if (p < 0) for (int k = 0; k < T; ++k) out[6 + k] = 0.0f;   /* DAM:342, 352 */
+    else tracking_row(h, p, nx[3], nx[4], nx[5], nx[0], c->n_future, out + 6); /* DAM:335-339 / 347-351 */
+    const float* veh = obs + 6 + T;
+    for (int j = 0; j < c->n_veh; ++j) veh_predict_one(veh + 4 * j, h->turn[j], out + 6 + T + 4 * j); /* DAM:355 */
+}
+
+static int check_rollout(eb_handle h, const int32_t* ref_idx, int path_id, const char* who) {
+    int rc = check_paths(h, who);
+    if (rc) return rc;
+    rc = check_modes(h);
+    if (rc) return rc;
+    if (h->cfg.mode == EB_MODE_TRAINING) {
+        if (!ref_idx) return fail(EB_EINVAL, "training mode needs ref_idx (EnvironmentModel.reset(obses, ref_indexes))");
+    } else if (path_id < 0 || path_id >= h->n_paths) return fail(EB_EINVAL, "bad path_id");
+    return EB_OK;
+}
+
+int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
+                          const int32_t* ref_idx, int32_t path_id, float* obs_out, void* stream) {
+    (void)stream;
+    int rc = check_rollout(h, ref_idx, path_id, "eb_compute_next_obses: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs || !actions || !obs_out) return fail(EB_EINVAL, "eb_compute_next_obses: bad argument");
+    const int D = obs_dim(&h->cfg);
+    const int training = h->cfg.mode == EB_MODE_TRAINING;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_env; ++i) {
+        int p = training ? row_path(h, ref_idx, 0, i) : path_id;
+        next_obs_row(h, obs + (size_t)D * i, actions + 2 * (size_t)i, p, obs_out + (size_t)D * i);
+    }
+    return EB_OK;
+}
+
+/* a11: rollout_out, DAM:118-126 */
+int eb_rollout_step(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
+                    const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
+                    float* scaled_actions, void* stream) {
+    (void)stream;
+    int rc = check_rollout(h, ref_idx, path_id, "eb_rollout_step: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs_in || !actions || !obs_out || !out5) return fail(EB_EINVAL, "eb_rollout_step: bad argument");
+    const int D = obs_dim(&h->cfg);
+    const int training = h->cfg.mode == EB_MODE_TRAINING;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_env; ++i) {
+        float act[2], o5[5];
+        action_transform_row(actions + 2 * (size_t)i, act);        /* DAM:120 */
+        rewards_row(&h->cfg, obs_in + (size_t)D * i, act, o5, NULL); /* DAM:121-122 */
+        int p = training ? row_path(h, ref_idx, 0, i) : path_id;
+        float tmp[6 + 3 * 65 + 4 * EB_MAX_VEH];
+        next_obs_row(h, obs_in + (size_t)D * i, act, p, tmp);       /* DAM:123 */
+        memcpy(obs_out + (size_t)D * i, tmp, sizeof(float) * D);
+        for (int k = 0; k < 5; ++k) out5[(size_t)k * n_env + i] = o5[k];
+        if (scaled_actions) { scaled_actions[2 * (size_t)i] = act[0]; scaled_actions[2 * (size_t)i + 1] = act[1]; }
+    }
+    return EB_OK;
+}
+
+int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in,
+                    const float* action_tape, const int32_t* ref_idx, int32_t path_id,
+                    float* obs_work, float* obs_out, float* out5_steps, void* stream) {
+    if (horizon < 1 || !obs_work || !obs_out || !action_tape || !out5_steps)
+        return fail(EB_EINVAL, "eb_rollout_tape: bad argument");
+    const float* cur = obs_in;
+    /* ping-pong so that the last step lands in obs_out */
+    for (int t = 0; t < horizon; ++t) {
+        float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
+        int rc = eb_rollout_step(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
+                                 out5_steps + (size_t)t * 5 * n_env, NULL, stream);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a12: EnvironmentModel.ss, DAM:134-184                                                       */
+/* ------------------------------------------------------------------------------------------ */
+int eb_ss(eb_handle h, int32_t n_env, const float* obs, const float* actions, const int32_t* ref_idx,
+          int32_t path_id, double lam, float* out, void* stream) {
+    (void)stream;
+    int rc = check_rollout(h, ref_idx, path_id, "eb_ss: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs || !actions || !out) return fail(EB_EINVAL, "eb_ss: bad argument");
+    const eb_config* c = &h->cfg;
+    const int D = obs_dim(c), T = 3 * (c->n_future + 1);
+    const int training = c->mode == EB_MODE_TRAINING;
+    /* (1-lam): python float minus python float in double, then cast where it meets the tensor */
+    const float one_m_lam = (float)(1.0 - lam);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_env; ++i) {
+        const float* o = obs + (size_t)D * i;
+        float act[2];
+        action_transform_row(actions + 2 * (size_t)i, act);          /* DAM:135 */
+        float nobs[6 + 3 * 65 + 4 * EB_MAX_VEH];
+        int p = training ? row_path(h, ref_idx, 0, i) : path_id;
+        next_obs_row(h, o, act, p, nobs);                             /* DAM:136 */
+        float s0, c0, s1, c1;
+        eb_sincosf(deg2rad(o[5]), &s0, &c0);
+        eb_sincosf(deg2rad(nobs[5]), &s1, &c1);
+        float ex[2] = {o[3] + LWS * c0, o[3] - LWS * c0}, ey[2] = {o[4] + LWS * s0, o[4] - LWS * s0};            /* DAM:144-148 */
+        float nex[2] = {nobs[3] + LWS * c1, nobs[3] - LWS * c1}, ney[2] = {nobs[4] + LWS * s1, nobs[4] - LWS * s1}; /* DAM:150-154 */
+        float acc = 0.0f;                                             /* DAM:156 */
+        for (int j = 0; j < c->n_veh; ++j) {                          /* DAM:157-183 */
+            const float* v = o + 6 + T + 4 * j;
+            const float* nv = nobs + 6 + T + 4 * j;
+            float e2v = sqrtf(sq(o[3] - v[0]) + sq(o[4] - v[1]));     /* DAM:159 */
+            float vs_, vc_, ns_, nc_;
+            eb_sincosf(deg2rad(v[3]), &vs_, &vc_);
+            eb_sincosf(deg2rad(nv[3]), &ns_, &nc_);
+            float wx[2] = {v[0] + LWS * vc_, v[0] - LWS * vc_}, wy[2] = {v[1] + LWS * vs_, v[1] - LWS * vs_};
+            float nwx[2] = {nv[0] + LWS * nc_, nv[0] - LWS * nc_}, nwy[2] = {nv[1] + LWS * ns_, nv[1] - LWS * ns_};
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    float d = sqrtf(sq(ex[a] - wx[b]) + sq(ey[a] - wy[b]));       /* DAM:176-177 */
+                    float nd = sqrtf(sq(nex[a] - nwx[b]) + sq(ney[a] - nwy[b]));  /* DAM:178-179 */
+                    float next_g = nd - 2.5f, g = d - 2.5f;                       /* DAM:180-181 */
+                    float t = next_g - one_m_lam * g;                             /* DAM:182 */
+                    if (t < 0.0f && e2v < 10.0f) acc += sq(t);
+                }
+        }
+        out[i] = acc;
+    }
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* real-env step pieces (endtoend.py), batched.  The reference evaluates these with a mix of    */
+/* np.float32 scalars and python doubles whose promotion depends on the NumPy version           */
+/* (SURVEY.md Appendix A); the restatement is fp32 throughout (NumPy >= 2 semantics), with the   */
+/* deterministic sin/cos above.  Masks agree with the reference off-threshold (tests record     */
+/* margins).                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+static inline float deal_with_phi(float phi) { /* UTL:232-237 */
+    while (phi > 180.0f) phi -= 360.0f;
+    while (phi <= -180.0f) phi += 360.0f;
+    return phi;
+}
+
+/* a14: _get_next_ego_state, E2E:269-283 */
+int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actions, float* next_ego,
+                    float* params, void* stream) {
+    (void)stream;
+    if (!h || n < 0 || !ego || !actions || !next_ego || !params) return fail(EB_EINVAL, "eb_env_ego_step: bad argument");
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        float nx[6], pr[4];
+        f_xu_row(ego + 6 * (size_t)i, actions + 2 * (size_t)i, (float)(1 / 10.), nx, pr); /* E2E:279 */
+        nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;   /* E2E:281 */
+        nx[5] = deal_with_phi(nx[5]);           /* E2E:282 */
+        memcpy(next_ego + 6 * (size_t)i, nx, sizeof nx);
+        memcpy(params + 4 * (size_t)i, pr, sizeof pr);
+    }
+    return EB_OK;
+}
+
+/* a16: _construct_veh_vector_short, E2E:340-464 */
+typedef struct { float x, y, v, phi; } veh4;
+
+static int veh_in_range(int task, int m, const veh4* v, float ego_x, float ego_y) { /* E2E:393-411 */
+    const float C2 = HALF_CROSS;
+    switch (m) {
+        case EB_VMODE_DL: return v->x > -C2 - 10.0f && v->y > ego_y - 2.0f;
+        case EB_VMODE_DU: return ego_y - 2.0f < v->y && v->y < C2 + 10.0f && v->x < ego_x + 5.0f;
+        case EB_VMODE_DR: return v->x < C2 + 10.0f && v->y > ego_y;
+        case EB_VMODE_RU: return v->x < C2 + 10.0f && v->y < C2 + 10.0f;
+        case EB_VMODE_UR:
+            if (task == EB_TASK_STRAIGHT) return v->x < ego_x + 7.0f && ego_y < v->y && v->y < C2 + 10.0f;
+            if (task == EB_TASK_RIGHT) return v->x < C2 + 10.0f && v->y < C2;
+            return 1;
+        case EB_VMODE_UD: return fmaxf(ego_y - 2.0f, -C2) < v->y && v->y < C2 && ego_x > v->x;
+        case EB_VMODE_UL: return -C2 - 10.0f < v->x && v->x < ego_x && v->y < C2;
+        case EB_VMODE_LR: return -C2 - 10.0f < v->x && v->x < C2 + 10.0f;
+        default: return 1; /* rd rl lu ld: "not interest in case of traffic light", E2E:398-411 */
+    }
+}
+
+/* <0 when a sorts before b under the mode's key (E2E:414-428); 0 = equal keys (stable order) */
+static int veh_cmp(int task, int m, const veh4* a, const veh4* b) {
+#define ASC(f) do { if (a->f < b->f) return -1; if (a->f > b->f) return 1; } while (0)
+#define DESC(f) do { if (a->f > b->f) return -1; if (a->f < b->f) return 1; } while (0)
+    switch (m) {
+        case EB_VMODE_DL: ASC(y); DESC(x); return 0;           /* key (y, -x) */
+        case EB_VMODE_DU: ASC(y); return 0;
+        case EB_VMODE_DR: ASC(y); ASC(x); return 0;
+        case EB_VMODE_RU: ASC(x); DESC(y); return 0;           /* key (-x, y), reverse=True */
+        case EB_VMODE_UR:
+            if (task == EB_TASK_STRAIGHT) { ASC(y); return 0; }
+            if (task == EB_TASK_RIGHT) { ASC(y); DESC(x); return 0; } /* key (-y, x), reverse=True */
+            return 0;
+        case EB_VMODE_UD: ASC(y); return 0;
+        case EB_VMODE_UL: ASC(y); ASC(x); return 0;            /* key (-y, -x), reverse=True */
+        case EB_VMODE_LR: DESC(x); return 0;                   /* key -x */
+        default: return 0;
+    }
+#undef ASC
+#undef DESC
+}
+
+static veh4 veh_fill_value(int m) { /* mode2fillvalue, E2E:439-447 */
+    const float C2 = HALF_CROSS, LW = LANE_W;
+    veh4 f = {0, 0, 0, 0};
+    switch (m) {
+        case EB_VMODE_DL: f.x = LW / 2; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_DU: f.x = LW * 1.5f; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_DR: f.x = LW * 2.5f; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_RU: f.x = C2 + 15; f.y = LW * 2.5f; f.phi = 180; break;
+        case EB_VMODE_UR: f.x = -LW / 2; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_UD: f.x = -LW * 1.5f; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_UL: f.x = -LW * 2.5f; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_LR: f.x = -(C2 + 20); f.y = -LW * 1.5f; f.phi = 0; break;
+        default: break; /* the reference defines no fill value for rd rl lu ld (never requested) */
+    }
+    return f;
+}
+
+static void build_veh_row(const eb_handle h, int m_cand, const float* cand, const uint8_t* cmode,
+                          float ego_x, float ego_y, int light, float* out) {
+    const int task = h->cfg.task, N = h->cfg.n_veh;
+    int taken_rank[EB_MAX_VEH]; /* per slot: how many earlier slots share its mode */
+    for (int s = 0; s < N; ++s) {
+        int k = 0;
+        for (int t = 0; t < s; ++t) k += h->vmode[t] == h->vmode[s];
+        taken_rank[s] = k;
+    }
+    /* virtual red-light cars appended after the real ones, E2E:386-390 */
+    const int virt = task != EB_TASK_RIGHT && light && ego_y < -HALF_CROSS;
+    for (int s = 0; s < N; ++s) {
+        const int m = h->vmode[s];
+        /* gather this mode's candidates in insertion order */
+        veh4 lst[256 + 1];
+        int cnt = 0;
+        for (int i = 0; i < m_cand && cnt < 256; ++i)
+            if (cmode[i] == m) {
+                veh4 v = {cand[4 * i], cand[4 * i + 1], cand[4 * i + 2], cand[4 * i + 3]};
+                if (veh_in_range(task, m, &v, ego_x, ego_y)) lst[cnt++] = v;
+            }
+        if (virt && (m == EB_VMODE_DL || m == EB_VMODE_DU)) {
+            veh4 v = {m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f};
+            if (veh_in_range(task, m, &v, ego_x, ego_y)) lst[cnt++] = v;
+        }
+        /* stable insertion sort under the mode's key */
+        for (int i = 1; i < cnt; ++i) {
+            veh4 key = lst[i];
+            int j = i - 1;
+            while (j >= 0 && veh_cmp(task, m, &key, &lst[j]) < 0) { lst[j + 1] = lst[j]; --j; }
+            lst[j + 1] = key;
+        }
+        veh4 r = taken_rank[s] < cnt ? lst[taken_rank[s]] : veh_fill_value(m); /* slice_or_fill, E2E:431-437 */
+        out[4 * s] = r.x; out[4 * s + 1] = r.y; out[4 * s + 2] = r.v; out[4 * s + 3] = r.phi; /* E2E:460-462 */
+    }
+}
+
+/* a16: _get_obs, E2E:285-303 */
+int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx, int32_t path_id,
+               int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag,
+               float* obs_out, void* stream) {
+    (void)stream;
+    int rc = check_paths(h, "eb_get_obs: null handle");
+    if (rc) return rc;
+    rc = check_modes(h);
+    if (rc) return rc;
+    if (n_env < 0 || !ego || m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)) || !obs_out)
+        return fail(EB_EINVAL, "eb_get_obs: bad argument (m_cand <= 256)");
+    if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_get_obs: bad path_id");
+    const eb_config* c = &h->cfg;
+    const int D = obs_dim(c), T = 3 * (c->n_future + 1);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_env; ++i) {
+        const float* e = ego + 6 * (size_t)i;
+        float* o = obs_out + (size_t)D * i;
+        for (int k = 0; k < 6; ++k) o[k] = e[k];                       /* E2E:329-338 */
+        int p = row_path(h, ref_idx, path_id, i);
+        if (p < 0) for (int k = 0; k < T; ++k) o[6 + k] = 0.0f;
+        else tracking_row(h, p, e[3], e[4], e[5], e[0], c->n_future, o + 6); /* E2E:293-297 */
+        build_veh_row(h, m_cand, cand + (size_t)i * m_cand * 4, cand_mode + (size_t)i * m_cand, e[3], e[4],
+                      light_flag ? light_flag[i] : 0, o + 6 + T);
+    }
+    return EB_OK;
+}
+
+/* judge_feasible, UTL:73-104 */
+static int judge_feasible(float x, float y, int task) {
+    const float C2 = HALF_CROSS, LW = LANE_W;
+    int middle = (-C2 < y && y < C2) && (-C2 < x && x < C2);
+    if (task == EB_TASK_LEFT)
+        return (0.0f < x && x < LW && y <= -C2) || (0.0f < y && y < LW * 3.0f && x < -C2) || middle;
+    if (task == EB_TASK_STRAIGHT)
+        return (LW < x && x < LW * 2.0f && y <= -C2) || (0.0f < x && x < LW * 3.0f && y >= C2) || middle;
+    return (LW * 2.0f < x && x < LW * 3.0f && y <= -C2) || (-LW * 3.0f < y && y < 0.0f && x > C2) || middle;
+}
+
+/* a17: _judge_done, E2E:200-256 */
+int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* params, const float* obs,
+                  int32_t m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
+                  const uint8_t* v_light, uint8_t* done_code, void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || !ego || !params || !obs || m_cand < 0 || (m_cand > 0 && (!cand || !cand_mode)) || !done_code)
+        return fail(EB_EINVAL, "eb_judge_done: bad argument");
+    const int task = h->cfg.task, D = obs_dim(&h->cfg);
+    const float EGO_L = 4.8f, EGO_W = 2.0f;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_env; ++i) {
+        const float* e = ego + 6 * (size_t)i;
+        const float v_x = e[0], r = e[2], x = e[3], y = e[4], phi = e[5];
+        /* Traffic.collision_check, TRF:263-295 */
+        float es, ec;
+        eb_sincosf(phi / 180.0f * PI_F, &es, &ec);
+        const float ego_lw = (EGO_L - EGO_W) / 2;
+        float ex0 = x + ec * ego_lw, ey0 = y + es * ego_lw, ex1 = x - ec * ego_lw, ey1 = y - es * ego_lw;
+        int collision = 0;
+        for (int k = 0; k < m_cand; ++k) {
+            if (cand_mode[(size_t)i * m_cand + k] == EB_VMODE_EMPTY) continue;
+            const float* v = cand + ((size_t)i * m_cand + k) * 4;
+            float vl = cand_lw ? cand_lw[((size_t)i * m_cand + k) * 2] : EGO_L;
+            float vw = cand_lw ? cand_lw[((size_t)i * m_cand + k) * 2 + 1] : EGO_W;
+            if (fabsf(v[0] - x) < 10.0f && fabsf(v[1] - y) < 10.0f) {
+                float s_lw = (vl - vw) / 2;
+                float ss_, sc_;
+                eb_sincosf(v[3] / 180.0f * PI_F, &ss_, &sc_);
+                float sx0 = v[0] + sc_ * s_lw, sy0 = v[1] + ss_ * s_lw, sx1 = v[0] - sc_ * s_lw, sy1 = v[1] - ss_ * s_lw;
+                float thr = sq((vw + EGO_W) / 2 + 0.5f);
+                if (sq(ex0 - sx0) + sq(ey0 - sy0) < thr) collision = 1;
+                else if (sq(ex0 - sx1) + sq(ey0 - sy1) < thr) collision = 1;
+                else if (sq(ex1 - sx1) + sq(ey1 - sy1) < thr) collision = 1;
+                else if (sq(ex1 - sx0) + sq(ey1 - sy0) < thr) collision = 1;
+            }
+        }
+        /* corner points: rotate_and_shift_coordination(+-l/2, +-w/2, 0, -x, -y, -phi), E2E:171-176, UTL:120-157 */
+        float rs, rc_;
+        eb_sincosf(-phi * PI_F / 180.0f, &rs, &rc_);
+        int feasible = 1;
+        for (int q = 0; q < 4; ++q) {
+            float cx = (q < 2 ? EGO_L : -EGO_L) / 2, cy = ((q & 1) ? -EGO_W : EGO_W) / 2;
+            float tx = cx * rc_ + cy * rs;
+            float ty = -cx * rs + cy * rc_;
+            float X = tx - (-x), Y = ty - (-y);
+            feasible &= judge_feasible(X, Y, task);
+        }
+        float miu_r = params[4 * (size_t)i + 3];
+        float r_bound = miu_r * 9.81f / (fabsf(v_x) + 1e-8f);          /* E2E:167 */
+        float delta_y = obs[(size_t)D * i + 6];                         /* E2E:224 */
+        int goal;
+        if (task == EB_TASK_LEFT) goal = x < -HALF_CROSS - 10.0f && 0.0f < y && y < 3.0f * LANE_W;        /* E2E:251 */
+        else if (task == EB_TASK_RIGHT) goal = x > HALF_CROSS + 10.0f && -3.0f * LANE_W < y && y < 0.0f;  /* E2E:253 */
+        else goal = y > HALF_CROSS + 10.0f && 0.0f < x && x < 3.0f * LANE_W;                              /* E2E:256 */
+        uint8_t code;
+        if (collision) code = EB_DONE_COLLISION;                                     /* E2E:208 */
+        else if (!feasible) code = EB_DONE_BREAK_ROAD;                               /* E2E:210, 227-229 */
+        else if (fabsf(delta_y) > 15.0f) code = EB_DONE_DEVIATE;                     /* E2E:212, 223-225 */
+        else if (!(-r_bound < r && r < r_bound)) code = EB_DONE_STABILITY;           /* E2E:214, 239 */
+        else if (v_light && v_light[i] != 0 && y > -HALF_CROSS && task != EB_TASK_RIGHT) code = EB_DONE_RED_LIGHT; /* E2E:245 */
+        else if (goal) code = EB_DONE_GOOD;
+        else code = EB_DONE_NOT_YET;
+        done_code[i] = code;
+    }
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers for the CPU-baseline leg of bench.py                                                */
+/* ------------------------------------------------------------------------------------------ */
+int eb_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
+/* exposes the deterministic kernels so tests can bound their error against libm */
+void eb_oracle_sincosf(const float* x, float* s, float* c, int n) {
+    for (int i = 0; i < n; ++i) eb_sincosf(x[i], s + i, c + i);
+}
+void eb_oracle_atanf(const float* x, float* y, int n) {
+    for (int i = 0; i < n; ++i) y[i] = eb_atanf(x[i]);
+}
