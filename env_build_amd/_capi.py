@@ -108,6 +108,10 @@ def hip_api():
     """The product's only backend.  Raises (never falls back) when the HIP library is absent."""
     global _hip_api
     if _hip_api is None:
+        # PyTorch-ROCm bundles its own libamdhip64; import it FIRST so that this library binds to the
+        # same HIP runtime (one runtime per process: shared device pointers and streams).  Loading
+        # ours first makes torch see no GPU.
+        import torch  # noqa: F401
         if not os.path.isfile(HIP_LIB_PATH):
             raise EbError('HIP extension missing: %s — run `python -c "import __graft_entry__ as g; '
                           'g.build()"` (hipcc --offload-arch=gfx950).  env_build_amd has no CPU '

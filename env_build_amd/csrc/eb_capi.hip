@@ -1,0 +1,419 @@
+// eb_capi.hip — the C-ABI of include/envbuild.h on top of the HIP kernels (libenvbuild_hip.so).
+//
+// A handle owns: its device ordinal, a stream, the device copies of the reference-path tables
+// (full resolution + the stride-10 (x,y) table the closest-point search scans) and the per-slot
+// vehicle-mode table.  Every data pointer passed to the compute entry points is a DEVICE pointer
+// owned by the caller; nothing here allocates per call, synchronises, or falls back to the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/envbuild.h"
+#include "eb_kernels.h"
+
+namespace {
+
+thread_local char g_err[512];
+
+int fail(int code, const char* msg) {
+    std::snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+int fail_hip(const char* what, hipError_t e) {
+    std::snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return EB_EDEVICE;
+}
+#define EB_HIP(call)                                      \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) return fail_hip(#call, e_); \
+    } while (0)
+
+}  // namespace
+
+struct eb_handle_s {
+    eb_config cfg;
+    eb::PathTables pt;        // device pointers
+    float* d_tables;          // one allocation: x|y|phi per path, then the stride-10 (x,y) tables
+    float2* d_red_all;
+    float* d_rad_all;         // 3 x 32 block radii for the pruned closest-point search
+    int n_cu;                 // compute units of the device (persistent grid size)
+    int red_off[3];
+    int red_total;
+    eb::VehModes modes;
+    int modes_set;
+};
+
+static int obs_dim(const eb_config& c) { return 6 + 3 * (c.n_future + 1) + 4 * c.n_veh; }
+static hipStream_t pick(eb_handle, void* stream) { return (hipStream_t)stream; }   // NULL = the HIP null stream
+
+extern "C" {
+
+const char* eb_last_error(void) { return g_err; }
+int eb_abi_version(void) { return EB_ABI_VERSION; }
+const char* eb_backend(void) { return "hip"; }
+
+int eb_create(const eb_config* cfg, eb_handle* out) {
+    if (!cfg || !out) return fail(EB_EINVAL, "eb_create: null argument");
+    if (cfg->abi_version != EB_ABI_VERSION) return fail(EB_EINVAL, "eb_create: ABI version mismatch");
+    if (cfg->task < 0 || cfg->task > 2) return fail(EB_EINVAL, "eb_create: task must be left/straight/right");
+    if (cfg->n_veh < 1 || cfg->n_veh > EB_MAX_VEH) return fail(EB_EINVAL, "eb_create: n_veh out of range");
+    if (cfg->n_future < 0 || cfg->n_future > 64) return fail(EB_EINVAL, "eb_create: n_future out of range");
+    if (cfg->mode != EB_MODE_TRAINING && cfg->mode != EB_MODE_SELECTING) return fail(EB_EINVAL, "eb_create: bad mode");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev < 1)
+        return fail(EB_EDEVICE, "eb_create: no HIP device visible (libenvbuild_hip has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= n_dev) return fail(EB_EINVAL, "eb_create: device ordinal out of range");
+    EB_HIP(hipSetDevice(cfg->device));
+    eb_handle h = new (std::nothrow) eb_handle_s();
+    if (!h) return fail(EB_ENOMEM, "eb_create: out of memory");
+    std::memset(h, 0, sizeof *h);
+    h->cfg = *cfg;
+    {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, cfg->device);
+        if (e != hipSuccess) { delete h; return fail_hip("hipGetDeviceProperties", e); }
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    *out = h;
+    return EB_OK;
+}
+
+int eb_destroy(eb_handle h) {
+    if (!h) return EB_OK;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    if (h->d_tables) hipFree(h->d_tables);
+    delete h;
+    return EB_OK;
+}
+
+int eb_sync(eb_handle h) {
+    if (!h) return fail(EB_EINVAL, "eb_sync: null handle");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(hipDeviceSynchronize());
+    return EB_OK;
+}
+
+int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phis, const int32_t* lens,
+                 int32_t n_paths) {
+    if (!h || !xs || !ys || !phis || !lens) return fail(EB_EINVAL, "eb_set_paths: null argument");
+    if (n_paths < 1 || n_paths > EB_MAX_PATHS) return fail(EB_EINVAL, "eb_set_paths: n_paths out of range");
+    size_t total = 0, red_total = 0;
+    for (int k = 0; k < n_paths; ++k) {
+        if (lens[k] < 3) return fail(EB_EINVAL, "eb_set_paths: path too short");
+        total += (size_t)lens[k];
+        red_total += (size_t)(lens[k] + 9) / 10;   // len(np.arange(0, path_len, 10)), DAM:704
+    }
+    for (int k = 0; k < n_paths; ++k)
+        if ((lens[k] + 9) / 10 > 512) return fail(EB_EINVAL, "eb_set_paths: path longer than 5120 points (32 search blocks)");
+    // host staging: [x | y | phi] full resolution, then float2 stride-10 tables
+    std::vector<float> host(3 * total + 2 * red_total + 4 + 96 + 8);
+    float* hx = host.data();
+    float* hy = hx + total;
+    float* hp = hy + total;
+    size_t red_byte_off = (3 * total * sizeof(float) + 15) / 16 * 16;   // 16-byte aligned float2 table
+    float* hred = reinterpret_cast<float*>(reinterpret_cast<char*>(host.data()) + red_byte_off);
+    std::memcpy(hx, xs, total * sizeof(float));
+    std::memcpy(hy, ys, total * sizeof(float));
+    std::memcpy(hp, phis, total * sizeof(float));
+    size_t off = 0, roff = 0;
+    for (int k = 0; k < n_paths; ++k) {
+        h->red_off[k] = (int)roff;
+        for (int i = 0; i < lens[k]; i += 10) {
+            hred[2 * roff] = xs[off + i];
+            hred[2 * roff + 1] = ys[off + i];
+            ++roff;
+        }
+        off += (size_t)lens[k];
+    }
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(hipDeviceSynchronize());
+    if (h->d_tables) { hipFree(h->d_tables); h->d_tables = nullptr; }
+    // block radii of the pruned search: R_b >= max_r |P_r - c_b| over block b = [16b, 16b+16), with
+    // c_b = P_min(16b+8, n-1); evaluated in double on the fp32 table values and inflated by 1e-4 m
+    const size_t rad_byte_off = (red_byte_off + 2 * red_total * sizeof(float) + 15) / 16 * 16;
+    float* hrad = reinterpret_cast<float*>(reinterpret_cast<char*>(host.data()) + rad_byte_off);
+    for (int i = 0; i < 96; ++i) hrad[i] = 0.0f;
+    for (int k = 0; k < n_paths; ++k) {
+        const float* rx = hred + 2 * (size_t)h->red_off[k];
+        const int n = (lens[k] + 9) / 10;
+        for (int b = 0; 16 * b < n; ++b) {
+            const int c = std::min(16 * b + 8, n - 1);
+            double r2 = 0.0;
+            for (int r = 16 * b; r < std::min(16 * b + 16, n); ++r) {
+                const double dx = (double)rx[2 * r] - (double)rx[2 * c], dy = (double)rx[2 * r + 1] - (double)rx[2 * c + 1];
+                r2 = std::max(r2, dx * dx + dy * dy);
+            }
+            hrad[32 * k + b] = (float)(std::sqrt(r2) * (1.0 + 1e-6) + 1e-4);
+        }
+    }
+    const size_t bytes = rad_byte_off + 96 * sizeof(float);
+    EB_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tables), bytes));
+    EB_HIP(hipMemcpy(h->d_tables, host.data(), bytes, hipMemcpyHostToDevice));
+    h->d_red_all = reinterpret_cast<float2*>(reinterpret_cast<char*>(h->d_tables) + red_byte_off);
+    h->d_rad_all = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_tables) + rad_byte_off);
+    std::memset(&h->pt, 0, sizeof h->pt);
+    off = 0;
+    for (int k = 0; k < n_paths; ++k) {
+        h->pt.x[k] = h->d_tables + off;
+        h->pt.y[k] = h->d_tables + total + off;
+        h->pt.phi[k] = h->d_tables + 2 * total + off;
+        h->pt.red[k] = h->d_red_all + h->red_off[k];
+        h->pt.len[k] = lens[k];
+        h->pt.red_len[k] = (lens[k] + 9) / 10;
+        off += (size_t)lens[k];
+    }
+    h->pt.n_paths = n_paths;
+    h->red_total = (int)red_total;
+    return EB_OK;
+}
+
+int eb_set_veh_modes(eb_handle h, const uint8_t* mode_id, int32_t n) {
+    if (!h || !mode_id) return fail(EB_EINVAL, "eb_set_veh_modes: null argument");
+    if (n != h->cfg.n_veh) return fail(EB_EINVAL, "eb_set_veh_modes: n != n_veh");
+    for (int j = 0; j < n; ++j)
+        if (mode_id[j] >= EB_VMODE_COUNT) return fail(EB_EINVAL, "eb_set_veh_modes: bad mode id");
+    for (int j = 0; j < n; ++j) {
+        h->modes.mode[j] = mode_id[j];
+        switch (mode_id[j]) {   // predict_for_a_mode, DAM:416-421
+            case EB_VMODE_DL: case EB_VMODE_RD: case EB_VMODE_UR: case EB_VMODE_LU: h->modes.turn[j] = eb::TURN_LEFT; break;
+            case EB_VMODE_DR: case EB_VMODE_RU: case EB_VMODE_UL: case EB_VMODE_LD: h->modes.turn[j] = eb::TURN_RIGHT; break;
+            default: h->modes.turn[j] = eb::TURN_NONE; break;
+        }
+    }
+    h->modes_set = 1;
+    return EB_OK;
+}
+
+static int check_paths(eb_handle h, const char* who) {
+    if (!h) return fail(EB_EINVAL, who);
+    if (h->pt.n_paths < 1) return fail(EB_ESTATE, "paths not set (eb_set_paths)");
+    return EB_OK;
+}
+static int check_modes(eb_handle h) {
+    if (!h->modes_set) return fail(EB_ESTATE, "vehicle modes not set (eb_set_veh_modes)");
+    return EB_OK;
+}
+static int check_rollout(eb_handle h, int n_env, const int32_t* ref_idx, int path_id, const char* who) {
+    int rc = check_paths(h, who);
+    if (rc) return rc;
+    rc = check_modes(h);
+    if (rc) return rc;
+    if (h->cfg.mode == EB_MODE_TRAINING) {
+        if (!ref_idx) return fail(EB_EINVAL, "training mode needs ref_idx (EnvironmentModel.reset(obses, ref_indexes))");
+    } else if (path_id < 0 || path_id >= h->pt.n_paths) return fail(EB_EINVAL, "bad path_id");
+    return EB_OK;
+}
+
+int eb_f_xu(eb_handle h, int32_t n, const float* states, const float* actions, float tau, float* next_states,
+            float* params, void* stream) {
+    if (!h || n < 0 || !states || !actions || !next_states) return fail(EB_EINVAL, "eb_f_xu: bad argument");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_f_xu(n, states, actions, tau, next_states, params, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_action_transform(eb_handle h, int32_t n, const float* actions, float* scaled, void* stream) {
+    if (!h || n < 0 || !actions || !scaled) return fail(EB_EINVAL, "eb_action_transform: bad argument");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_action_transform(n, actions, scaled, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float* actions, float* out5,
+                       float* out_dict16, void* stream) {
+    if (!h || n_env < 0 || !obs || !actions || !out5) return fail(EB_EINVAL, "eb_compute_rewards: bad argument");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_rewards(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, obs, actions, out5,
+                              out_dict16, pick(h, stream)));
+    return EB_OK;
+}
+
+static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
+                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
+                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s) {
+    const int NV = h->cfg.n_veh;
+    eb::RolloutArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.obs_in = obs_in; A.actions = actions; A.ref_idx = ref_idx; A.obs_out = obs_out; A.out5 = out5;
+    A.scaled_actions = scaled_actions;
+    A.red_all = h->d_red_all;
+    A.pt = h->pt;
+    A.training = h->cfg.mode == EB_MODE_TRAINING;
+    if (A.training) {
+        for (int k = 0; k < 3; ++k) A.red_off[k] = h->red_off[k];
+        A.red_base = 0;
+        A.red_total = h->red_total;
+    } else {
+        A.red_base = h->red_off[path_id];
+        A.red_total = h->pt.red_len[path_id];
+    }
+    A.red_total_pad = (A.red_total + 1) & ~1;
+    A.n_env = n_env; A.obs_dim = obs_dim(h->cfg); A.n_veh = NV; A.n_future = h->cfg.n_future;
+    A.nv_magic = (unsigned)((0x100000000ull + (unsigned)NV - 1) / (unsigned)NV);
+    A.rad_all = h->d_rad_all;
+    A.n_env_blocks = (n_env + eb::ROLLOUT_THREADS - 1) / eb::ROLLOUT_THREADS;
+    A.envs_per_vblock = std::min(64, std::max(1, eb::ROLLOUT_THREADS / NV));   // s_ego / s_mask hold 64 envs
+    A.path_id = path_id;
+    A.actions_raw = actions_raw;
+    A.do_rewards = do_rewards;
+    {
+        static const int ablate = std::getenv("EB_ABLATE") ? std::atoi(std::getenv("EB_ABLATE")) : 0;   // profiling aid
+        A.ablate = ablate;
+    }
+    std::memcpy(A.turn, h->modes.turn, sizeof A.turn);
+    const size_t lds = eb::rollout_lds_bytes(A.red_total_pad);
+    const int grid = A.n_env_blocks + (n_env + A.envs_per_vblock - 1) / A.envs_per_vblock;
+    EB_HIP(eb::launch_rollout(h->cfg.task, A, grid, lds, s));
+    return EB_OK;
+}
+
+int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
+                          const int32_t* ref_idx, int32_t path_id, float* obs_out, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_compute_next_obses: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs || !actions || !obs_out) return fail(EB_EINVAL, "eb_compute_next_obses: bad argument");
+    if (obs == obs_out) return fail(EB_EINVAL, "eb_compute_next_obses: in-place update is not supported");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    return rollout_common(h, n_env, obs, actions, ref_idx, path_id, obs_out, nullptr, nullptr, 0, 0, pick(h, stream));
+}
+
+int eb_rollout_step(eb_handle h, int32_t n_env, const float* obs_in, const float* actions, const int32_t* ref_idx,
+                    int32_t path_id, float* obs_out, float* out5, float* scaled_actions, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_step: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs_in || !actions || !obs_out || !out5) return fail(EB_EINVAL, "eb_rollout_step: bad argument");
+    if (obs_in == obs_out) return fail(EB_EINVAL, "eb_rollout_step: in-place update is not supported");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    return rollout_common(h, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions, 1, 1,
+                          pick(h, stream));
+}
+
+int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
+                    const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
+                    void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_tape: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps)
+        return fail(EB_EINVAL, "eb_rollout_tape: bad argument");
+    if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
+        return fail(EB_EINVAL, "eb_rollout_tape: obs_in, obs_work and obs_out must be distinct buffers");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t s = pick(h, stream);
+    const float* cur = obs_in;
+    for (int t = 0; t < horizon; ++t) {   // ping-pong so that the last step lands in obs_out
+        float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
+        rc = rollout_common(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
+                            out5_steps + (size_t)t * 5 * n_env, nullptr, 1, 1, s);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return EB_OK;
+}
+
+int eb_find_closest_point(eb_handle h, int32_t n, const float* xs, const float* ys, const int32_t* ref_idx,
+                          int32_t path_id, int32_t* out_index, float* out_points, void* stream) {
+    int rc = check_paths(h, "eb_find_closest_point: null handle");
+    if (rc) return rc;
+    if (n < 0 || !xs || !ys || !out_index) return fail(EB_EINVAL, "eb_find_closest_point: bad argument");
+    if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_find_closest_point: bad path_id");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_tracking(h->cfg.task, n, h->pt, xs, ys, nullptr, nullptr, ref_idx, path_id, 0, nullptr,
+                               out_index, out_points, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_tracking_error(eb_handle h, int32_t n, const float* xs, const float* ys, const float* phis, const float* vs,
+                      const int32_t* ref_idx, int32_t path_id, int32_t n_future, float* out, void* stream) {
+    int rc = check_paths(h, "eb_tracking_error: null handle");
+    if (rc) return rc;
+    if (n < 0 || !xs || !ys || !phis || !vs || !out || n_future < 0) return fail(EB_EINVAL, "eb_tracking_error: bad argument");
+    if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_tracking_error: bad path_id");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_tracking(h->cfg.task, n, h->pt, xs, ys, phis, vs, ref_idx, path_id, n_future, out, nullptr,
+                               nullptr, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_veh_predict(eb_handle h, int32_t n_env, const float* veh, float* veh_out, void* stream) {
+    if (!h || n_env < 0 || !veh || !veh_out) return fail(EB_EINVAL, "eb_veh_predict: bad argument");
+    int rc = check_modes(h);
+    if (rc) return rc;
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_veh_predict(n_env, h->cfg.n_veh, h->modes, veh, veh_out, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_ss(eb_handle h, int32_t n_env, const float* obs, const float* actions, const int32_t* ref_idx,
+          int32_t path_id, double lam, float* out, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_ss: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs || !actions || !out) return fail(EB_EINVAL, "eb_ss: bad argument");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_ss(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, obs,
+                         actions, ref_idx, path_id, h->cfg.mode == EB_MODE_TRAINING, (float)(1.0 - lam), out,
+                         pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actions, float* next_ego, float* params,
+                    void* stream) {
+    if (!h || n < 0 || !ego || !actions || !next_ego || !params) return fail(EB_EINVAL, "eb_env_ego_step: bad argument");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_env_ego_step(n, ego, actions, next_ego, params, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx, int32_t path_id,
+               int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag,
+               float* obs_out, void* stream) {
+    int rc = check_paths(h, "eb_get_obs: null handle");
+    if (rc) return rc;
+    rc = check_modes(h);
+    if (rc) return rc;
+    if (n_env < 0 || !ego || m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)) || !obs_out)
+        return fail(EB_EINVAL, "eb_get_obs: bad argument (m_cand <= 256)");
+    if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_get_obs: bad path_id");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
+                              ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* params, const float* obs,
+                  int32_t m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
+                  const uint8_t* v_light, uint8_t* done_code, void* stream) {
+    if (!h || n_env < 0 || !ego || !params || !obs || m_cand < 0 || (m_cand > 0 && (!cand || !cand_mode)) || !done_code)
+        return fail(EB_EINVAL, "eb_judge_done: bad argument");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_judge_done(h->cfg.task, n_env, obs_dim(h->cfg), ego, params, obs, m_cand, cand, cand_mode,
+                                 cand_lw, v_light, done_code, pick(h, stream)));
+    return EB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// eb_device.h — device-side arithmetic of the hot path, gfx950 only.
+//
+// Every function evaluates the reference's expression in the reference's op order, one IEEE fp32
+// rounding per op (the translation unit is compiled with -ffp-contract=off, and the pragma below
+// repeats that for the optimiser).  Citations: DAM = dynamics_and_models.py, E2E = endtoend.py,
+// UTL = endtoend_env_utils.py, TRF = traffic.py of the reference.
+//
+// sin/cos/atan are branch-light Cephes-scheme fp32 kernels (3-term Cody-Waite + minimax
+// polynomials, <= 2 ulp): cheaper than ocml's large-argument paths, and — because they use only
+// IEEE add/mul/div/rint — reproducible bit-for-bit by the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+#define EB_DEV __device__ __forceinline__
+
+namespace eb {
+
+constexpr float PI_F = 3.14159265358979323846f;       // np.pi -> fp32
+constexpr float TWO_PI_F = 6.28318530717958647692f;   // 2*np.pi -> fp32 (DAM:424)
+constexpr float LWS = (float)((4.8 - 2.0) / 2.);      // (L-W)/2. (DAM:210)
+constexpr float HALF_CROSS = 25.0f;                   // CROSSROAD_SIZE/2
+constexpr float LANE_W = 3.75f;
+constexpr float EXP_V = 8.0f;
+constexpr float TAU10 = (float)(1 / 10.);             // 1/base_frequency (DAM:85-87, 387)
+
+enum { TASK_LEFT = 0, TASK_STRAIGHT = 1, TASK_RIGHT = 2 };
+enum { TURN_NONE = 0, TURN_LEFT = 1, TURN_RIGHT = 2 };
+
+EB_DEV float sq(float x) { return x * x; }
+
+// IEEE-exact x / C for a compile-time constant C in 3 VALU ops (Markstein: q = x*rc, one exact
+// residual, one correction) instead of the ~11-op v_div_scale/v_rcp/v_div_fmas/v_div_fixup sequence.
+// Verified EXHAUSTIVELY against x / C over all 2^32 bit patterns for the five divisors used here
+// (tests/test_exact_math.py on CPU, eb_selftest on the GPU): bit-identical for every
+// |x| >= 3.1e-32 up to FLT_MAX; smaller non-zero magnitudes take the true division.
+// the unguarded core, also used with per-lane (c, 1/c) pairs (predict_record)
+EB_DEV float div_fast(float x, float c, float rc) {
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-q, c, x);
+    return __builtin_fmaf(r, rc, q);
+}
+
+template <typename C>
+EB_DEV float div_const(float x) {
+    constexpr float c = C::value;
+    constexpr float rc = 1.0f / C::value;
+    const unsigned mag2 = __builtin_bit_cast(unsigned, x) << 1;   // |x| bits * 2
+    if (__builtin_expect(mag2 - 1u < 2u * 0x0D000000u - 1u, 0))  // 0 < |x| < 2^-101 (~3.9e-31)
+        return x / c;
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-q, c, x);
+    return __builtin_fmaf(r, rc, q);
+}
+struct C180 { static constexpr float value = 180.0f; };
+struct CPi { static constexpr float value = 3.14159265358979323846f; };
+struct C10 { static constexpr float value = 10.0f; };
+struct C26875 { static constexpr float value = 26.875f; };
+struct C15625 { static constexpr float value = 15.625f; };
+
+EB_DEV float deg2rad(float d) { return div_const<C180>(d * PI_F); }  // x * np.pi / 180.  (DAM:54)
+EB_DEV float rad2deg(float r) { return div_const<CPi>(r * 180.0f); } // x * 180 / np.pi   (DAM:81)
+
+EB_DEV void sincos_det(float x, float& s_out, float& c_out) {
+    float kf = __builtin_rintf(x * 0.636619747f);
+    int k = (int)kf;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.83751296997070312e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    float s = r + r * z * ps;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    float c = 1.0f - 0.5f * z + z * z * pc;
+    float a = (k & 1) ? c : s;
+    float b = (k & 1) ? -s : c;
+    s_out = (k & 2) ? -a : a;
+    c_out = (k & 2) ? -b : b;
+}
+
+EB_DEV float atan_det(float x) {
+    float ax = __builtin_fabsf(x);
+    float y, t;
+    if (ax > 2.414213562373095f) {
+        y = 1.5707963267948966f;
+        t = -1.0f / ax;
+    } else if (ax > 0.4142135623730950f) {
+        y = 0.7853981633974483f;
+        t = (ax - 1.0f) / (ax + 1.0f);
+    } else {
+        y = 0.0f;
+        t = ax;
+    }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    y = y + (p * z * t + t);
+    return x < 0.0f ? -y : y;
+}
+
+// ---- a4: _action_transformation_for_end2end, DAM:128-132 -------------------------------------
+EB_DEV void action_transform(float a0, float a1, float& steer, float& a_x) {
+    a0 = __builtin_fminf(__builtin_fmaxf(a0, -1.05f), 1.05f);
+    a1 = __builtin_fminf(__builtin_fmaxf(a1, -1.05f), 1.05f);
+    steer = 0.4f * a0;
+    a_x = 2.25f * a1 - 0.75f;
+}
+
+// ---- a2: VehicleDynamics.f_xu, DAM:52-83 -------------------------------------------------------
+struct VehParams {  // DAM:37-45
+    static constexpr float C_f = -155495.0f, C_r = -155495.0f, a = 1.19f, b = 1.46f, mass = 1520.0f,
+                           I_z = 2642.0f, miu = 0.8f, g = 9.81f;
+};
+
+// sn/cs = sin/cos of deg2rad(st[5]) (shared with the reward's ego circle centres, DAM:211)
+EB_DEV void f_xu_core(const float (&st)[6], float steer, float a_x, float tau, float phi_rad, float sn,
+                      float cs, float (&nx)[6]) {
+    using P = VehParams;
+    const float v_x = st[0], v_y = st[1], r = st[2], x = st[3], y = st[4];
+    const float k1 = P::a * P::C_f - P::b * P::C_r;
+    nx[0] = v_x + tau * (a_x + v_y * r);                                                       // DAM:73
+    nx[1] = (P::mass * v_y * v_x + tau * k1 * r - tau * P::C_f * steer * v_x - tau * P::mass * sq(v_x) * r) /
+            (P::mass * v_x - tau * (P::C_f + P::C_r));                                          // DAM:74-76
+    nx[2] = (-P::I_z * r * v_x - tau * k1 * v_y + tau * P::a * P::C_f * steer * v_x) /
+            (tau * (sq(P::a) * P::C_f + sq(P::b) * P::C_r) - P::I_z * v_x);                     // DAM:77-78
+    nx[3] = x + tau * (v_x * cs - v_y * sn);                                                    // DAM:79
+    nx[4] = y + tau * (v_x * sn + v_y * cs);                                                    // DAM:80
+    nx[5] = rad2deg(phi_rad + tau * r);                                                         // DAM:81
+}
+
+EB_DEV void f_xu_params(const float (&st)[6], float steer, float a_x, float (&pr)[4]) {
+    using P = VehParams;
+    const float v_x = st[0], v_y = st[1], r = st[2];
+    const float F_zf = P::b * P::mass * P::g / (P::a + P::b), F_zr = P::a * P::mass * P::g / (P::a + P::b); // DAM:65
+    const float F_xf = a_x < 0 ? P::mass * a_x / 2 : 0.0f;                                      // DAM:66
+    const float F_xr = a_x < 0 ? P::mass * a_x / 2 : P::mass * a_x;                             // DAM:67
+    pr[2] = __builtin_sqrtf(sq(P::miu * F_zf) - sq(F_xf)) / F_zf;                               // DAM:68
+    pr[3] = __builtin_sqrtf(sq(P::miu * F_zr) - sq(F_xr)) / F_zr;                               // DAM:69
+    pr[0] = atan_det((v_y + P::a * r) / (v_x + 1e-8f)) - steer;                                 // DAM:70
+    pr[1] = atan_det((v_y - P::b * r) / (v_x + 1e-8f));                                         // DAM:71
+}
+
+// ---- a5 road-wall terms, DAM:231-295: adds one ego point's 4 training + 4 real terms ------------
+template <int TASK>
+EB_DEV void road_terms(float px, float py, float& t, float& q) {
+    constexpr float LWN = 11.25f;  // LANE_WIDTH*LANE_NUMBER
+    constexpr float LW2 = 7.5f;    // 2*LANE_WIDTH
+    if (TASK == TASK_LEFT) {       // DAM:233-251
+        float c1 = (py < -HALF_CROSS && px < 1.0f) ? sq(px - 1.0f) : 0.0f;
+        float c2 = (py < -HALF_CROSS && LANE_W - px < 1.0f) ? sq(LANE_W - px - 1.0f) : 0.0f;
+        float c3t = (px < 0.0f && LWN - py < 1.0f) ? sq(LWN - py - 1.0f) : 0.0f;
+        float c3r = (px < -HALF_CROSS && LWN - py < 1.0f) ? sq(LWN - py - 1.0f) : 0.0f;
+        float c4 = (px < -HALF_CROSS && py - 0.0f < 1.0f) ? sq(py - 0.0f - 1.0f) : 0.0f;
+        t += c1; t += c2; t += c3t; t += c4;
+        q += c1; q += c2; q += c3r; q += c4;
+    } else if (TASK == TASK_STRAIGHT) {  // DAM:252-272
+        float c1 = (py < -HALF_CROSS && px - LANE_W < 1.0f) ? sq(px - LANE_W - 1.0f) : 0.0f;
+        float c2 = (py < -HALF_CROSS && LW2 - px < 1.0f) ? sq(LW2 - px - 1.0f) : 0.0f;
+        float c3 = (py > HALF_CROSS && LWN - px < 1.0f) ? sq(LWN - px - 1.0f) : 0.0f;
+        float c4 = (py > HALF_CROSS && px - 0.0f < 1.0f) ? sq(px - 0.0f - 1.0f) : 0.0f;
+        t += c1; t += c2; t += c3; t += c4;
+        q += c1; q += c2; q += c3; q += c4;
+    } else {                             // DAM:273-295
+        float c1 = (py < -HALF_CROSS && px - LW2 < 1.0f) ? sq(px - LW2 - 1.0f) : 0.0f;
+        float c2 = (py < -HALF_CROSS && LWN - px < 1.0f) ? sq(LWN - px - 1.0f) : 0.0f;
+        float c3 = (px > HALF_CROSS && 0.0f - py < 1.0f) ? sq(0.0f - py - 1.0f) : 0.0f;
+        float c4 = (px > HALF_CROSS && py - (-LWN) < 1.0f) ? sq(py - (-LWN) - 1.0f) : 0.0f;
+        t += c1; t += c2; t += c3; t += c4;
+        q += c1; q += c2; q += c3; q += c4;
+    }
+}
+
+// ---- a5 per-vehicle collision terms, DAM:218-229 -------------------------------------------------
+// e = (front x, front y, rear x, rear y) of the ego; v = vehicle (x, y, v, phi); vs/vc = sin/cos of
+// deg2rad(v.phi).  t35/t25 get the four terms in the reference's order ff, fr, rf, rr.
+EB_DEV void veh2veh_terms(const float4 e, float vx, float vy, float vs, float vc, float (&t35)[4],
+                          float (&t25)[4]) {
+    const float vfx = vx + LWS * vc, vfy = vy + LWS * vs;  // DAM:221-222
+    const float vrx = vx - LWS * vc, vry = vy - LWS * vs;  // DAM:223-224
+    const float ex[2] = {e.x, e.z}, ey[2] = {e.y, e.w}, wx[2] = {vfx, vrx}, wy[2] = {vfy, vry};
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float d = __builtin_sqrtf(sq(ex[p] - wx[q]) + sq(ey[p] - wy[q]));  // DAM:227
+            const float a = d - 3.5f, b = d - 2.5f;
+            t35[2 * p + q] = a < 0.0f ? sq(a) : 0.0f;                                // DAM:228
+            t25[2 * p + q] = b < 0.0f ? sq(b) : 0.0f;                                // DAM:229
+        }
+}
+
+// ---- a10: predict_for_a_mode, DAM:405-427 ---------------------------------------------------------
+EB_DEV float4 veh_predict_one(float x, float y, float v, float phi_rad, float sn, float cs, int turn) {
+    const bool middle = (x > -HALF_CROSS && x < HALF_CROSS) && (y > -HALF_CROSS && y < HALF_CROSS);  // DAM:409-410
+    const float v10 = div_const<C10>(v);
+    const float dx = v10 * cs;   // DAM:413
+    const float dy = v10 * sn;   // DAM:414
+    float dphi = 0.0f;
+    if (turn == TURN_LEFT) dphi = middle ? div_const<C10>(div_const<C26875>(v)) : 0.0f;        // DAM:417
+    else if (turn == TURN_RIGHT) dphi = middle ? div_const<C10>(-div_const<C15625>(v)) : 0.0f; // DAM:419
+    float nphi = phi_rad + dphi;                                                 // DAM:423
+    if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                     // DAM:424
+    if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                                   // DAM:425
+    return make_float4(x + dx, y + dy, v, rad2deg(nphi));                        // DAM:422-427
+}
+
+// ---- a8: tracking error pieces, DAM:577-580, 736-760 ----------------------------------------------
+EB_DEV float deal_with_phi_diff(float d) {
+    if (d > 180.0f) d = d - 360.0f;
+    if (d < -180.0f) d = d + 360.0f;
+    return d;
+}
+
+template <int TASK>
+EB_DEV float two2one(float ex, float ey, float rx, float ry) {
+    if (TASK == TASK_LEFT) {
+        float delta = __builtin_sqrtf(sq(ex - (-HALF_CROSS)) + sq(ey - (-HALF_CROSS))) -
+                      __builtin_sqrtf(sq(rx - (-HALF_CROSS)) + sq(ry - (-HALF_CROSS)));
+        if (ey < -HALF_CROSS) delta = ex - rx;
+        if (ex < -HALF_CROSS) delta = ey - ry;
+        return -delta;
+    } else if (TASK == TASK_STRAIGHT) {
+        return -(ex - rx);
+    } else {
+        float delta = -(__builtin_sqrtf(sq(ex - HALF_CROSS) + sq(ey - (-HALF_CROSS))) -
+                        __builtin_sqrtf(sq(rx - HALF_CROSS) + sq(ry - (-HALF_CROSS))));
+        if (ey < -HALF_CROSS) delta = ex - rx;
+        if (ex > HALF_CROSS) delta = -(ey - ry);
+        return -delta;
+    }
+}
+
+EB_DEV int clamp_index(int i, int len) {  // indexs2points, DAM:727-728
+    i = i < 0 ? 0 : i;
+    return i >= len ? len - 1 : i;
+}
+
+// device view of the path tables owned by a handle
+struct PathTables {
+    const float* x[3];      // full resolution, lens[k] floats
+    const float* y[3];
+    const float* phi[3];
+    const float2* red[3];   // stride-10 (x, y) pairs, red_len[k] entries (DAM:704-706)
+    int len[3];
+    int red_len[3];
+    int n_paths;
+};
+
+// path used by row i: ref_idx[i] when given, else path_id; out of range -> -1 (zeros, DAM:342, 352)
+EB_DEV int row_path(const PathTables& pt, const int* ref_idx, int path_id, int i) {
+    const int p = ref_idx ? ref_idx[i] : path_id;
+    return (p >= 0 && p < pt.n_paths) ? p : -1;
+}
+
+EB_DEV float wrap_deal_with_phi(float phi) {  // UTL:232-237
+    while (phi > 180.0f) phi -= 360.0f;
+    while (phi <= -180.0f) phi += 360.0f;
+    return phi;
+}
+
+}  // namespace eb

@@ -1,0 +1,287 @@
+// eb_env_kernels.hip — batched real-env step pieces of CrossroadEnd2end (endtoend.py), gfx950.
+//
+// One thread per env: these are control-flow-heavy, tiny-data kernels (filter / select / pad of at
+// most a few dozen candidate vehicles, a priority chain of predicates); they run once per env step
+// next to the rollout kernel and are nowhere near a roofline, so they are written for clarity and
+// bit-for-bit agreement with the oracle.  fp32 throughout (see the oracle's note on the reference's
+// NumPy-version-dependent scalar promotion).
+#include "eb_device.h"
+#include "eb_kernels.h"
+#include "../../include/envbuild.h"
+
+#pragma clang fp contract(off)
+
+namespace eb {
+
+struct V4 { float x, y, v, phi; };
+
+// a14: _get_next_ego_state, E2E:269-283
+__global__ void env_ego_step_kernel(int n, const float* __restrict__ ego, const float* __restrict__ actions,
+                                    float* __restrict__ next_ego, float* __restrict__ params) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float st[6], nx[6], pr[4];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st[c] = ego[6 * (size_t)i + c];
+    const float steer = actions[2 * (size_t)i], a_x = actions[2 * (size_t)i + 1];
+    const float phi_rad = deg2rad(st[5]);
+    float sn, cs;
+    sincos_det(phi_rad, sn, cs);
+    f_xu_core(st, steer, a_x, TAU10, phi_rad, sn, cs, nx);   // E2E:279
+    f_xu_params(st, steer, a_x, pr);
+    nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;                     // E2E:281
+    nx[5] = wrap_deal_with_phi(nx[5]);                        // E2E:282
+#pragma unroll
+    for (int c = 0; c < 6; ++c) next_ego[6 * (size_t)i + c] = nx[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) params[4 * (size_t)i + c] = pr[c];
+}
+
+hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, float* next_ego, float* params,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(env_ego_step_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n, ego, actions, next_ego, params);
+    return hipGetLastError();
+}
+
+// ---- a16: _construct_veh_vector_short, E2E:340-464 ------------------------------------------------
+EB_DEV bool veh_in_range(int task, int m, const V4& v, float ego_x, float ego_y) {   // E2E:393-411
+    const float C2 = HALF_CROSS;
+    switch (m) {
+        case EB_VMODE_DL: return v.x > -C2 - 10.0f && v.y > ego_y - 2.0f;
+        case EB_VMODE_DU: return ego_y - 2.0f < v.y && v.y < C2 + 10.0f && v.x < ego_x + 5.0f;
+        case EB_VMODE_DR: return v.x < C2 + 10.0f && v.y > ego_y;
+        case EB_VMODE_RU: return v.x < C2 + 10.0f && v.y < C2 + 10.0f;
+        case EB_VMODE_UR:
+            if (task == TASK_STRAIGHT) return v.x < ego_x + 7.0f && ego_y < v.y && v.y < C2 + 10.0f;
+            if (task == TASK_RIGHT) return v.x < C2 + 10.0f && v.y < C2;
+            return true;
+        case EB_VMODE_UD: return __builtin_fmaxf(ego_y - 2.0f, -C2) < v.y && v.y < C2 && ego_x > v.x;
+        case EB_VMODE_UL: return -C2 - 10.0f < v.x && v.x < ego_x && v.y < C2;
+        case EB_VMODE_LR: return -C2 - 10.0f < v.x && v.x < C2 + 10.0f;
+        default: return true;
+    }
+}
+
+// sort key of each mode (E2E:414-428): <0 when a sorts before b, 0 when the keys tie
+EB_DEV int veh_cmp(int task, int m, const V4& a, const V4& b) {
+#define EB_ASC(f) do { if (a.f < b.f) return -1; if (a.f > b.f) return 1; } while (0)
+#define EB_DESC(f) do { if (a.f > b.f) return -1; if (a.f < b.f) return 1; } while (0)
+    switch (m) {
+        case EB_VMODE_DL: EB_ASC(y); EB_DESC(x); return 0;
+        case EB_VMODE_DU: EB_ASC(y); return 0;
+        case EB_VMODE_DR: EB_ASC(y); EB_ASC(x); return 0;
+        case EB_VMODE_RU: EB_ASC(x); EB_DESC(y); return 0;
+        case EB_VMODE_UR:
+            if (task == TASK_STRAIGHT) { EB_ASC(y); return 0; }
+            if (task == TASK_RIGHT) { EB_ASC(y); EB_DESC(x); return 0; }
+            return 0;
+        case EB_VMODE_UD: EB_ASC(y); return 0;
+        case EB_VMODE_UL: EB_ASC(y); EB_ASC(x); return 0;
+        case EB_VMODE_LR: EB_DESC(x); return 0;
+        default: return 0;
+    }
+#undef EB_ASC
+#undef EB_DESC
+}
+
+EB_DEV V4 veh_fill_value(int m) {   // mode2fillvalue, E2E:439-447
+    const float C2 = HALF_CROSS, LW = LANE_W;
+    V4 f = {0.0f, 0.0f, 0.0f, 0.0f};
+    switch (m) {
+        case EB_VMODE_DL: f.x = LW / 2; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_DU: f.x = LW * 1.5f; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_DR: f.x = LW * 2.5f; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_RU: f.x = C2 + 15; f.y = LW * 2.5f; f.phi = 180; break;
+        case EB_VMODE_UR: f.x = -LW / 2; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_UD: f.x = -LW * 1.5f; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_UL: f.x = -LW * 2.5f; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_LR: f.x = -(C2 + 20); f.y = -LW * 1.5f; f.phi = 0; break;
+        default: break;
+    }
+    return f;
+}
+
+// candidate i of mode m for this env; i == m_cand addresses the virtual red-light car (E2E:386-390)
+EB_DEV bool fetch_candidate(int m, int i, int m_cand, const float* cand, const uint8_t* cmode, bool virt, V4& v) {
+    if (i < m_cand) {
+        if (cmode[i] != m) return false;
+        v.x = cand[4 * i]; v.y = cand[4 * i + 1]; v.v = cand[4 * i + 2]; v.phi = cand[4 * i + 3];
+        return true;
+    }
+    if (!virt || (m != EB_VMODE_DL && m != EB_VMODE_DU)) return false;
+    v.x = m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f;
+    v.y = -HALF_CROSS + 2.5f; v.v = 0.0f; v.phi = 90.0f;
+    return true;
+}
+
+template <int TASK>
+__global__ void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTables pt, VehModes modes,
+                               const float* __restrict__ ego, const int* __restrict__ ref_idx, int path_id,
+                               int m_cand, const float* __restrict__ cand_all, const uint8_t* __restrict__ cmode_all,
+                               const uint8_t* __restrict__ light_flag, float* __restrict__ obs_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_env) return;
+    const float* e = ego + 6 * (size_t)i;
+    float* o = obs_out + (size_t)D * i;
+    const int T = 3 * (n_future + 1);
+    const float ev = e[0], ex = e[3], ey = e[4], ephi = e[5];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o[c] = e[c];                               // E2E:329-338
+    const int p = row_path(pt, ref_idx, path_id, i);
+    if (p < 0) { for (int c = 0; c < T; ++c) o[6 + c] = 0.0f; }
+    else {
+        // tracking_error_vector on the env's path, E2E:293-297
+        const float2* red = pt.red[p];
+        const int n = pt.red_len[p];
+        float best = __builtin_inff();
+        int bi = 0;
+        for (int r = 0; r < n; ++r) {
+            const float2 q = red[r];
+            const float d = sq(ex - q.x) + sq(ey - q.y);
+            if (d < best) { best = d; bi = r; }
+        }
+        const int idx = bi * 10, len = pt.len[p];
+        const int ci = clamp_index(idx, len);
+        o[6] = two2one<TASK>(ex, ey, pt.x[p][ci], pt.y[p][ci]);
+        o[7] = deal_with_phi_diff(ephi - pt.phi[p][ci]);
+        o[8] = ev - EXP_V;
+        int cur = idx;
+        for (int k = 0; k < n_future; ++k) {
+            cur += 80;
+            if (cur >= len - 2) cur = len - 2;
+            const int fi = clamp_index(cur, len);
+            o[9 + 3 * k] = pt.x[p][fi] - ex;
+            o[10 + 3 * k] = pt.y[p][fi] - ey;
+            o[11 + 3 * k] = deal_with_phi_diff(ephi - pt.phi[p][fi]);
+        }
+    }
+    const float* cand = cand_all + (size_t)i * m_cand * 4;
+    const uint8_t* cmode = cmode_all + (size_t)i * m_cand;
+    const bool virt = TASK != TASK_RIGHT && light_flag && light_flag[i] != 0 && ey < -HALF_CROSS;   // E2E:386-388
+    float* ov = o + 6 + T;
+    for (int s = 0; s < NV; ++s) {
+        const int m = modes.mode[s];
+        int rank = 0;
+        for (int t = 0; t < s; ++t) rank += modes.mode[t] == m;
+        // select the rank-th candidate of mode m under (sort key, insertion order): E2E:414-437
+        V4 prev = {0, 0, 0, 0};
+        int prev_i = -1;
+        bool found = true;
+        for (int it = 0; it <= rank && found; ++it) {
+            V4 best = {0, 0, 0, 0};
+            int best_i = -1;
+            for (int c = 0; c <= m_cand; ++c) {
+                V4 v;
+                if (!fetch_candidate(m, c, m_cand, cand, cmode, virt, v)) continue;
+                if (!veh_in_range(TASK, m, v, ex, ey)) continue;
+                if (prev_i >= 0) {
+                    const int cp = veh_cmp(TASK, m, prev, v);
+                    if (!(cp < 0 || (cp == 0 && prev_i < c))) continue;   // not after the previous pick
+                }
+                if (best_i < 0 || veh_cmp(TASK, m, v, best) < 0) { best = v; best_i = c; }
+            }
+            if (best_i < 0) found = false;
+            else { prev = best; prev_i = best_i; }
+        }
+        const V4 r = found ? prev : veh_fill_value(m);                     // slice_or_fill, E2E:431-437
+        ov[4 * s] = r.x; ov[4 * s + 1] = r.y; ov[4 * s + 2] = r.v; ov[4 * s + 3] = r.phi;
+    }
+}
+
+hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
+                          const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
+                          const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag, float* obs_out,
+                          hipStream_t s) {
+    const dim3 g((n_env + 63) / 64), b(64);
+    switch (task) {
+        case TASK_LEFT: hipLaunchKernelGGL(get_obs_kernel<TASK_LEFT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out); break;
+        case TASK_STRAIGHT: hipLaunchKernelGGL(get_obs_kernel<TASK_STRAIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out); break;
+        default: hipLaunchKernelGGL(get_obs_kernel<TASK_RIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out); break;
+    }
+    return hipGetLastError();
+}
+
+// ---- a17: _judge_done, E2E:200-256 ---------------------------------------------------------------
+EB_DEV bool judge_feasible(float x, float y, int task) {   // UTL:73-104
+    const float C2 = HALF_CROSS, LW = LANE_W;
+    const bool middle = (-C2 < y && y < C2) && (-C2 < x && x < C2);
+    if (task == TASK_LEFT)
+        return (0.0f < x && x < LW && y <= -C2) || (0.0f < y && y < LW * 3.0f && x < -C2) || middle;
+    if (task == TASK_STRAIGHT)
+        return (LW < x && x < LW * 2.0f && y <= -C2) || (0.0f < x && x < LW * 3.0f && y >= C2) || middle;
+    return (LW * 2.0f < x && x < LW * 3.0f && y <= -C2) || (-LW * 3.0f < y && y < 0.0f && x > C2) || middle;
+}
+
+__global__ void judge_done_kernel(int task, int n_env, int D, const float* __restrict__ ego,
+                                  const float* __restrict__ params, const float* __restrict__ obs, int m_cand,
+                                  const float* __restrict__ cand, const uint8_t* __restrict__ cand_mode,
+                                  const float* __restrict__ cand_lw, const uint8_t* __restrict__ v_light,
+                                  uint8_t* __restrict__ done_code) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_env) return;
+    const float EGO_L = 4.8f, EGO_W = 2.0f;
+    const float* e = ego + 6 * (size_t)i;
+    const float v_x = e[0], r = e[2], x = e[3], y = e[4], phi = e[5];
+    // Traffic.collision_check, TRF:263-295
+    float es, ec;
+    sincos_det(phi / 180.0f * PI_F, es, ec);
+    const float ego_lw = (EGO_L - EGO_W) / 2;
+    const float ex0 = x + ec * ego_lw, ey0 = y + es * ego_lw, ex1 = x - ec * ego_lw, ey1 = y - es * ego_lw;
+    bool collision = false;
+    for (int k = 0; k < m_cand; ++k) {
+        const size_t ck = (size_t)i * m_cand + k;
+        if (cand_mode[ck] == EB_VMODE_EMPTY) continue;
+        const float* v = cand + ck * 4;
+        const float vl = cand_lw ? cand_lw[ck * 2] : EGO_L;
+        const float vw = cand_lw ? cand_lw[ck * 2 + 1] : EGO_W;
+        if (__builtin_fabsf(v[0] - x) < 10.0f && __builtin_fabsf(v[1] - y) < 10.0f) {
+            const float s_lw = (vl - vw) / 2;
+            float ss, sc;
+            sincos_det(v[3] / 180.0f * PI_F, ss, sc);
+            const float sx0 = v[0] + sc * s_lw, sy0 = v[1] + ss * s_lw, sx1 = v[0] - sc * s_lw, sy1 = v[1] - ss * s_lw;
+            const float thr = sq((vw + EGO_W) / 2 + 0.5f);
+            if (sq(ex0 - sx0) + sq(ey0 - sy0) < thr) collision = true;
+            else if (sq(ex0 - sx1) + sq(ey0 - sy1) < thr) collision = true;
+            else if (sq(ex1 - sx1) + sq(ey1 - sy1) < thr) collision = true;
+            else if (sq(ex1 - sx0) + sq(ey1 - sy0) < thr) collision = true;
+        }
+    }
+    // corner points (E2E:171-176, UTL:120-157) through judge_feasible
+    float rs, rc;
+    sincos_det(-phi * PI_F / 180.0f, rs, rc);
+    bool feasible = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float cx = (q < 2 ? EGO_L : -EGO_L) / 2, cy = ((q & 1) ? -EGO_W : EGO_W) / 2;
+        const float tx = cx * rc + cy * rs;
+        const float ty = -cx * rs + cy * rc;
+        const float X = tx - (-x), Y = ty - (-y);
+        feasible = feasible && judge_feasible(X, Y, task);
+    }
+    const float miu_r = params[4 * (size_t)i + 3];
+    const float r_bound = miu_r * 9.81f / (__builtin_fabsf(v_x) + 1e-8f);   // E2E:167
+    const float delta_y = obs[(size_t)D * i + 6];                            // E2E:224
+    bool goal;
+    if (task == TASK_LEFT) goal = x < -HALF_CROSS - 10.0f && 0.0f < y && y < 3.0f * LANE_W;
+    else if (task == TASK_RIGHT) goal = x > HALF_CROSS + 10.0f && -3.0f * LANE_W < y && y < 0.0f;
+    else goal = y > HALF_CROSS + 10.0f && 0.0f < x && x < 3.0f * LANE_W;
+    uint8_t code;
+    if (collision) code = EB_DONE_COLLISION;
+    else if (!feasible) code = EB_DONE_BREAK_ROAD;
+    else if (__builtin_fabsf(delta_y) > 15.0f) code = EB_DONE_DEVIATE;
+    else if (!(-r_bound < r && r < r_bound)) code = EB_DONE_STABILITY;
+    else if (v_light && v_light[i] != 0 && y > -HALF_CROSS && task != TASK_RIGHT) code = EB_DONE_RED_LIGHT;
+    else if (goal) code = EB_DONE_GOOD;
+    else code = EB_DONE_NOT_YET;
+    done_code[i] = code;
+}
+
+hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const float* params, const float* obs,
+                             int m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
+                             const uint8_t* v_light, uint8_t* done_code, hipStream_t s) {
+    hipLaunchKernelGGL(judge_done_kernel, dim3((n_env + 127) / 128), dim3(128), 0, s, task, n_env, D, ego, params,
+                       obs, m_cand, cand, cand_mode, cand_lw, v_light, done_code);
+    return hipGetLastError();
+}
+
+}  // namespace eb

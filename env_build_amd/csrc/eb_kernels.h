@@ -1,0 +1,67 @@
+// eb_kernels.h — host-visible launch interface between eb_capi.hip and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eb_device.h"
+
+namespace eb {
+
+constexpr int ROLLOUT_THREADS = 256;
+
+struct VehModes {
+    uint8_t turn[64];   // TURN_* per slot (predict_for_a_mode, DAM:416-421)
+    uint8_t mode[64];   // EB_VMODE_* per slot
+};
+
+struct RolloutArgs {
+    const float* obs_in;
+    const float* actions;
+    const int* ref_idx;
+    float* obs_out;
+    float* out5;
+    float* scaled_actions;
+    const float2* red_all;     // all paths' stride-10 (x,y) tables, back to back
+    const float* rad_all;      // 3 x 32 block radii of the pruned search (closest_index_pruned)
+    PathTables pt;
+    int red_off[3];            // offset of path k inside the staged LDS table (training mode)
+    int red_base;              // first entry of red_all to stage
+    int red_total;             // entries to stage (all paths in training mode, one path otherwise)
+    int red_total_pad;         // rounded up to an even count (16-byte LDS carve)
+    int n_env, obs_dim, n_veh, n_future;
+    int n_env_blocks;          // blocks [0, n_env_blocks) run the per-env role (256 envs each)
+    int envs_per_vblock;       // whole envs per vehicle-role block: max(1, 256 / n_veh)
+    unsigned nv_magic;         // ceil(2^32 / n_veh): item / n_veh == umulhi(item, nv_magic)
+    int path_id, training;
+    int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
+    int do_rewards;            // 0: compute_next_obses only
+    int ablate;                // profiling aid (EB_ABLATE): 1 skip search, 2 skip vehicle math, 4 skip per-env math
+    uint8_t turn[64];
+};
+
+size_t rollout_lds_bytes(int red_total_pad);
+hipError_t launch_rollout(int task, const RolloutArgs& A, int grid, size_t lds, hipStream_t s);
+hipError_t launch_f_xu(int n, const float* st, const float* ac, float tau, float* nx, float* pr, hipStream_t s);
+hipError_t launch_action_transform(int n, const float* in, float* out, hipStream_t s);
+hipError_t launch_rewards(int task, int n_env, int D, int n_future, int NV, const float* obs, const float* act,
+                          float* out5, float* d16, hipStream_t s);
+hipError_t launch_tracking(int task, int n, const PathTables& pt, const float* xs, const float* ys, const float* phis,
+                           const float* vs, const int* ref_idx, int path_id, int n_future, float* out,
+                           int* out_index, float* out_points, hipStream_t s);
+hipError_t launch_veh_predict(int n_env, int NV, const VehModes& modes, const float* veh, float* out, hipStream_t s);
+hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const PathTables& pt, const VehModes& modes,
+                     const float* obs, const float* actions, const int* ref_idx, int path_id, int training,
+                     float one_m_lam, float* out, hipStream_t s);
+
+// real-env step pieces (eb_env_kernels.hip)
+hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, float* next_ego, float* params,
+                               hipStream_t s);
+hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
+                          const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
+                          const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag, float* obs_out,
+                          hipStream_t s);
+hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const float* params, const float* obs,
+                             int m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
+                             const uint8_t* v_light, uint8_t* done_code, hipStream_t s);
+
+}  // namespace eb

@@ -18,8 +18,8 @@
  *     thread-local message.  No exceptions / aborts cross the ABI.
  *   - the caller owns every data buffer; a handle owns only its path tables / mode table.
  *   - a handle is bound to one device and is not thread-safe; distinct handles are independent.
- *   - launches are asynchronous on `stream` (a hipStream_t; NULL = the handle's own stream);
- *     eb_sync() blocks until the handle's work is done.
+ *   - launches are asynchronous on `stream` (a hipStream_t; NULL = the HIP null stream);
+ *     eb_sync() blocks until all work on the handle's device is done.
  *   - all floating point is IEEE fp32, evaluated op-for-op in the reference's order with no FMA
  *     contraction; sin/cos/atan use the deterministic kernels documented in DESIGN.md so that
  *     the HIP path and the oracle agree bit-for-bit.

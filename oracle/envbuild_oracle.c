@@ -545,7 +545,8 @@ static void next_obs_row(const eb_handle h, const float* obs, const float* act, 
     for (int j = 0; j < c->n_veh; ++j) veh_predict_one(veh + 4 * j, h->turn[j], out + 6 + T + 4 * j); /* DAM:355 */
 }
 
-static int check_rollout(eb_handle h, const int32_t* ref_idx, int path_id, const char* who) {
+static int check_rollout(eb_handle h, int n_env, const int32_t* ref_idx, int path_id, const char* who) {
+    (void)n_env;
     int rc = check_paths(h, who);
     if (rc) return rc;
     rc = check_modes(h);
@@ -559,7 +560,8 @@ static int check_rollout(eb_handle h, const int32_t* ref_idx, int path_id, const
 int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, void* stream) {
     (void)stream;
-    int rc = check_rollout(h, ref_idx, path_id, "eb_compute_next_obses: null handle");
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_compute_next_obses: null handle");
     if (rc) return rc;
     if (n_env < 0 || !obs || !actions || !obs_out) return fail(EB_EINVAL, "eb_compute_next_obses: bad argument");
     const int D = obs_dim(&h->cfg);
@@ -577,7 +579,8 @@ int eb_rollout_step(eb_handle h, int32_t n_env, const float* obs_in, const float
                     const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                     float* scaled_actions, void* stream) {
     (void)stream;
-    int rc = check_rollout(h, ref_idx, path_id, "eb_rollout_step: null handle");
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_step: null handle");
     if (rc) return rc;
     if (n_env < 0 || !obs_in || !actions || !obs_out || !out5) return fail(EB_EINVAL, "eb_rollout_step: bad argument");
     const int D = obs_dim(&h->cfg);
@@ -620,7 +623,8 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
 int eb_ss(eb_handle h, int32_t n_env, const float* obs, const float* actions, const int32_t* ref_idx,
           int32_t path_id, double lam, float* out, void* stream) {
     (void)stream;
-    int rc = check_rollout(h, ref_idx, path_id, "eb_ss: null handle");
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_ss: null handle");
     if (rc) return rc;
     if (n_env < 0 || !obs || !actions || !out) return fail(EB_EINVAL, "eb_ss: bad argument");
     const eb_config* c = &h->cfg;

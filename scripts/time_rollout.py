@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Profiling aid: kernel-only timing of eb_rollout_step on cuda:0 (HIP events on the launch stream)."""
+import argparse, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from env_build_amd.dynamics_and_models import EnvironmentModel
+from env_build_amd.synthetic import make_rollout_inputs
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--task', default='left'); ap.add_argument('--n-env', type=int, default=65536)
+ap.add_argument('--n-veh', type=int, default=32); ap.add_argument('--mode', default='training')
+ap.add_argument('--iters', type=int, default=200)
+a = ap.parse_args()
+dev = torch.device('cuda', 0)
+inp = make_rollout_inputs(a.task, a.n_env, a.n_veh, 25, seed=0)
+m = EnvironmentModel(a.task, 0, mode=a.mode, n_veh=a.n_veh, device=dev)
+ego = torch.from_numpy(inp['ego']).to(dev); ref = torch.from_numpy(inp['ref_idx']).to(dev)
+if a.mode != 'training': m.ref_path.set_path(1)
+trk = m.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(),
+                                               ego[:, 0].contiguous(), 0, ref_indexes=ref if a.mode == 'training' else None).t
+obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
+tape = torch.from_numpy(inp['actions']).to(dev)
+bufs = [torch.empty_like(obs0), torch.empty_like(obs0)]; out5 = torch.empty((25, 5, a.n_env), device=dev)
+p = lambda t: C.c_void_p(t.data_ptr())
+st = torch.cuda.current_stream(); sp = C.c_void_p(st.cuda_stream)
+fn = m.api.lib.eb_rollout_step
+def step(i):
+    t = i % 25
+    src = obs0 if t == 0 else bufs[(t - 1) & 1]
+    rc = fn(m.handle, a.n_env, p(src), p(tape[t]), p(ref) if a.mode == 'training' else None, 1, p(bufs[t & 1]), p(out5[t]), None, sp)
+    assert rc == 0, m.api.lib.eb_last_error()
+for i in range(50): step(i)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(st)
+for i in range(a.iters): step(i)
+e1.record(st); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / a.iters
+alg = (104 + 32 * a.n_veh) * a.n_env
+print('ablate=%s task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
+      % (os.environ.get('EB_ABLATE', '0'), a.task, a.n_env, a.n_veh, a.mode, us, a.n_env / us / 1e3, alg / us / 1e3, alg / us / 1e3 / 80))

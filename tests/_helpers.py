@@ -44,7 +44,9 @@ def i32(a):
 
 
 class HostModel(object):
-    """One eb_handle on host memory (used with the oracle library)."""
+    """One eb_handle driven with NumPy arrays.  With the oracle library the arrays are passed as
+    host pointers; DeviceModel (below) stages them through torch CUDA tensors for the HIP library.
+    Both issue exactly the same C-ABI calls."""
 
     def __init__(self, api, task, n_veh=None, n_future=0, mode='training', modes=None):
         self.api, self.task = api, task
@@ -65,6 +67,7 @@ class HostModel(object):
             modes = native if self.n_veh == len(native) else tiled_mode_list(task, self.n_veh)
         ids = np.array([_capi.VMODE_ID[m] for m in modes], np.uint8)
         api.set_veh_modes(self.h, _p(ids), len(ids))
+        self.stream = None
 
     def __del__(self):
         try:
@@ -72,98 +75,138 @@ class HostModel(object):
         except Exception:
             pass
 
-    def f_xu(self, states, actions, tau):
-        states, actions = f32(states), f32(actions)
-        n = len(states)
-        nxt, par = np.empty((n, 6), np.float32), np.empty((n, 4), np.float32)
-        self.api.f_xu(self.h, n, _p(states), _p(actions), float(tau), _p(nxt), _p(par), None)
-        return nxt, par
+    # ---- staging hooks (overridden by DeviceModel) ----
+    def _in(self, a, dtype=np.float32):
+        return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+    def _out(self, shape, dtype=np.float32):
+        return np.empty(shape, dtype)
+
+    def _ptr(self, a):
+        return _p(a)
+
+    def _ret(self, a):
+        return a
+
+    # ---- one method per C-ABI entry point ----
+    def f_xu(self, states, actions, tau, want_params=True):
+        st, ac = self._in(states), self._in(actions)
+        n = len(st)
+        nxt, par = self._out((n, 6)), (self._out((n, 4)) if want_params else None)
+        self.api.f_xu(self.h, n, self._ptr(st), self._ptr(ac), float(tau), self._ptr(nxt), self._ptr(par), self.stream)
+        return self._ret(nxt), (self._ret(par) if want_params else None)
 
     def action_transform(self, actions):
-        actions = f32(actions)
-        out = np.empty_like(actions)
-        self.api.action_transform(self.h, len(actions), _p(actions), _p(out), None)
-        return out
+        ac = self._in(actions)
+        out = self._out(ac.shape)
+        self.api.action_transform(self.h, len(ac), self._ptr(ac), self._ptr(out), self.stream)
+        return self._ret(out)
 
     def compute_rewards(self, obs, actions, want_dict=True):
-        obs, actions = f32(obs), f32(actions)
-        n = len(obs)
-        out5 = np.empty((5, n), np.float32)
-        d16 = np.empty((16, n), np.float32) if want_dict else None
-        self.api.compute_rewards(self.h, n, _p(obs), _p(actions), _p(out5), _p(d16), None)
-        return out5, d16
+        ob, ac = self._in(obs), self._in(actions)
+        n = len(ob)
+        out5 = self._out((5, n))
+        d16 = self._out((16, n)) if want_dict else None
+        self.api.compute_rewards(self.h, n, self._ptr(ob), self._ptr(ac), self._ptr(out5), self._ptr(d16), self.stream)
+        return self._ret(out5), (self._ret(d16) if want_dict else None)
 
     def compute_next_obses(self, obs, actions, ref_idx=None, path_id=0):
-        obs, actions, ref_idx = f32(obs), f32(actions), i32(ref_idx)
-        out = np.empty_like(obs)
-        self.api.compute_next_obses(self.h, len(obs), _p(obs), _p(actions), _p(ref_idx), int(path_id), _p(out), None)
-        return out
+        ob, ac, ri = self._in(obs), self._in(actions), self._in(ref_idx, np.int32)
+        out = self._out(ob.shape)
+        self.api.compute_next_obses(self.h, len(ob), self._ptr(ob), self._ptr(ac), self._ptr(ri), int(path_id), self._ptr(out), self.stream)
+        return self._ret(out)
 
     def rollout_step(self, obs, actions, ref_idx=None, path_id=0):
-        obs, actions, ref_idx = f32(obs), f32(actions), i32(ref_idx)
-        n = len(obs)
-        out, out5, sc = np.empty_like(obs), np.empty((5, n), np.float32), np.empty((n, 2), np.float32)
-        self.api.rollout_step(self.h, n, _p(obs), _p(actions), _p(ref_idx), int(path_id), _p(out), _p(out5), _p(sc), None)
-        return out, out5, sc
+        ob, ac, ri = self._in(obs), self._in(actions), self._in(ref_idx, np.int32)
+        n = len(ob)
+        out, out5, sc = self._out(ob.shape), self._out((5, n)), self._out((n, 2))
+        self.api.rollout_step(self.h, n, self._ptr(ob), self._ptr(ac), self._ptr(ri), int(path_id), self._ptr(out), self._ptr(out5), self._ptr(sc), self.stream)
+        return self._ret(out), self._ret(out5), self._ret(sc)
 
     def rollout_tape(self, obs, tape, ref_idx=None, path_id=0):
-        obs, tape, ref_idx = f32(obs), f32(tape), i32(ref_idx)
-        H, n = tape.shape[0], len(obs)
-        work, out, out5 = np.empty_like(obs), np.empty_like(obs), np.empty((H, 5, n), np.float32)
-        self.api.rollout_tape(self.h, n, H, _p(obs), _p(tape), _p(ref_idx), int(path_id), _p(work), _p(out), _p(out5), None)
-        return out, out5
+        ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
+        H, n = tp.shape[0], len(ob)
+        work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
+        self.api.rollout_tape(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work), self._ptr(out), self._ptr(out5), self.stream)
+        return self._ret(out), self._ret(out5)
 
     def find_closest_point(self, xs, ys, ref_idx=None, path_id=0):
-        xs, ys, ref_idx = f32(xs), f32(ys), i32(ref_idx)
-        n = len(xs)
-        idx, pts = np.empty(n, np.int32), np.empty((3, n), np.float32)
-        self.api.find_closest_point(self.h, n, _p(xs), _p(ys), _p(ref_idx), int(path_id), _p(idx), _p(pts), None)
-        return idx, pts
+        x, y, ri = self._in(xs), self._in(ys), self._in(ref_idx, np.int32)
+        n = len(x)
+        idx, pts = self._out((n,), np.int32), self._out((3, n))
+        self.api.find_closest_point(self.h, n, self._ptr(x), self._ptr(y), self._ptr(ri), int(path_id), self._ptr(idx), self._ptr(pts), self.stream)
+        return self._ret(idx), self._ret(pts)
 
     def tracking_error(self, xs, ys, phis, vs, n_future, ref_idx=None, path_id=0):
-        xs, ys, phis, vs, ref_idx = f32(xs), f32(ys), f32(phis), f32(vs), i32(ref_idx)
-        n = len(xs)
-        out = np.empty((n, 3 * (n_future + 1)), np.float32)
-        self.api.tracking_error(self.h, n, _p(xs), _p(ys), _p(phis), _p(vs), _p(ref_idx), int(path_id), int(n_future), _p(out), None)
-        return out
+        x, y, ph, v, ri = self._in(xs), self._in(ys), self._in(phis), self._in(vs), self._in(ref_idx, np.int32)
+        n = len(x)
+        out = self._out((n, 3 * (n_future + 1)))
+        self.api.tracking_error(self.h, n, self._ptr(x), self._ptr(y), self._ptr(ph), self._ptr(v), self._ptr(ri), int(path_id), int(n_future), self._ptr(out), self.stream)
+        return self._ret(out)
 
     def veh_predict(self, veh):
-        veh = f32(veh)
-        out = np.empty_like(veh)
-        self.api.veh_predict(self.h, len(veh), _p(veh), _p(out), None)
-        return out
+        v = self._in(veh)
+        out = self._out(v.shape)
+        self.api.veh_predict(self.h, len(v), self._ptr(v), self._ptr(out), self.stream)
+        return self._ret(out)
 
     def ss(self, obs, actions, ref_idx=None, path_id=0, lam=0.1):
-        obs, actions, ref_idx = f32(obs), f32(actions), i32(ref_idx)
-        out = np.empty(len(obs), np.float32)
-        self.api.ss(self.h, len(obs), _p(obs), _p(actions), _p(ref_idx), int(path_id), float(lam), _p(out), None)
-        return out
+        ob, ac, ri = self._in(obs), self._in(actions), self._in(ref_idx, np.int32)
+        out = self._out((len(ob),))
+        self.api.ss(self.h, len(ob), self._ptr(ob), self._ptr(ac), self._ptr(ri), int(path_id), float(lam), self._ptr(out), self.stream)
+        return self._ret(out)
 
     def env_ego_step(self, ego, actions):
-        ego, actions = f32(ego), f32(actions)
-        n = len(ego)
-        nxt, par = np.empty((n, 6), np.float32), np.empty((n, 4), np.float32)
-        self.api.env_ego_step(self.h, n, _p(ego), _p(actions), _p(nxt), _p(par), None)
-        return nxt, par
+        eg, ac = self._in(ego), self._in(actions)
+        n = len(eg)
+        nxt, par = self._out((n, 6)), self._out((n, 4))
+        self.api.env_ego_step(self.h, n, self._ptr(eg), self._ptr(ac), self._ptr(nxt), self._ptr(par), self.stream)
+        return self._ret(nxt), self._ret(par)
 
     def get_obs(self, ego, cand, cand_mode, light_flag, ref_idx=None, path_id=0):
-        ego, cand, ref_idx = f32(ego), f32(cand), i32(ref_idx)
-        cand_mode = np.ascontiguousarray(cand_mode, np.uint8)
-        light_flag = np.ascontiguousarray(light_flag, np.uint8)
-        n, m = len(ego), cand.shape[1]
-        out = np.empty((n, self.D), np.float32)
-        self.api.get_obs(self.h, n, _p(ego), _p(ref_idx), int(path_id), m, _p(cand), _p(cand_mode), _p(light_flag), _p(out), None)
-        return out
+        eg, cd, ri = self._in(ego), self._in(cand), self._in(ref_idx, np.int32)
+        cm, lf = self._in(cand_mode, np.uint8), self._in(light_flag, np.uint8)
+        n, m = len(eg), cd.shape[1]
+        out = self._out((n, self.D))
+        self.api.get_obs(self.h, n, self._ptr(eg), self._ptr(ri), int(path_id), m, self._ptr(cd), self._ptr(cm), self._ptr(lf), self._ptr(out), self.stream)
+        return self._ret(out)
 
     def judge_done(self, ego, params, obs, cand, cand_mode, cand_lw, v_light):
-        ego, params, obs, cand = f32(ego), f32(params), f32(obs), f32(cand)
-        cand_lw = None if cand_lw is None else f32(cand_lw)
-        cand_mode = np.ascontiguousarray(cand_mode, np.uint8)
-        v_light = np.ascontiguousarray(v_light, np.uint8)
-        n, m = len(ego), cand.shape[1]
-        out = np.empty(n, np.uint8)
-        self.api.judge_done(self.h, n, _p(ego), _p(params), _p(obs), m, _p(cand), _p(cand_mode), _p(cand_lw), _p(v_light), _p(out), None)
-        return out
+        eg, pr, ob, cd = self._in(ego), self._in(params), self._in(obs), self._in(cand)
+        lw, cm, vl = self._in(cand_lw), self._in(cand_mode, np.uint8), self._in(v_light, np.uint8)
+        n, m = len(eg), cd.shape[1]
+        out = self._out((n,), np.uint8)
+        self.api.judge_done(self.h, n, self._ptr(eg), self._ptr(pr), self._ptr(ob), m, self._ptr(cd), self._ptr(cm), self._ptr(lw), self._ptr(vl), self._ptr(out), self.stream)
+        return self._ret(out)
+
+
+class DeviceModel(HostModel):
+    """Same calls against libenvbuild_hip.so: inputs are copied to cuda:0 with torch (plumbing
+    only), outputs allocated there, results copied back for comparison."""
+
+    def __init__(self, task, **kw):
+        import torch
+        self.torch = torch
+        self.dev = torch.device('cuda', 0)
+        HostModel.__init__(self, _capi.hip_api(), task, **kw)
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    _TD = {np.dtype(np.float32): 'float32', np.dtype(np.int32): 'int32', np.dtype(np.uint8): 'uint8'}
+
+    def _in(self, a, dtype=np.float32):
+        if a is None:
+            return None
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.dev)
+
+    def _out(self, shape, dtype=np.float32):
+        return self.torch.empty(tuple(shape), dtype=getattr(self.torch, self._TD[np.dtype(dtype)]), device=self.dev)
+
+    def _ptr(self, t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _ret(self, t):
+        self.torch.cuda.synchronize()
+        return t.cpu().numpy()
 
 
 def max_err(a, b, rtol):
