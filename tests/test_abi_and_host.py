@@ -1,0 +1,161 @@
+"""CPU (-m "not gpu"): the C-ABI libraries load and export every symbol include/envbuild.h
+declares (no compute calls on the HIP library without a GPU), the ctypes prototypes cover the
+header, argument validation / error reporting, and the host-side helpers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from env_build_amd import _capi, build as eb_build
+from env_build_amd import endtoend_env_utils as U
+from env_build_amd.synthetic import assemble_obs, make_rollout_inputs
+from tests._helpers import ROOT, HostModel, oracle_lib
+
+HEADER = os.path.join(ROOT, 'include', 'envbuild.h')
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(eb_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_declares_what_ctypes_binds():
+    syms = header_symbols()
+    assert len(syms) >= 20
+    assert sorted(_capi.PROTOTYPES) == syms
+
+
+def test_hip_library_builds_loads_and_exports_every_symbol():
+    lib_path = eb_build.build()            # hipcc --offload-arch=gfx950 (cross-compiles without a GPU)
+    assert os.path.isfile(lib_path)
+    import torch  # noqa: F401  (binds the HIP runtime torch ships before ours, as the product does)
+    lib = C.CDLL(lib_path)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    lib.eb_backend.restype = C.c_char_p
+    assert lib.eb_backend() == b'hip'
+    assert lib.eb_abi_version() == _capi.EB_ABI_VERSION
+
+
+def test_hip_library_contains_gfx950_code_object():
+    lib_path = eb_build.build()
+    blob = open(lib_path, 'rb').read()
+    assert b'gfx950' in blob and b'rollout_step_kernel' in blob
+
+
+def test_hip_backend_refuses_to_run_without_a_gpu():
+    """No CPU fallback: on a box without a GPU eb_create fails loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible')
+    api = _capi.hip_api()
+    with pytest.raises((_capi.EbError, ValueError)) as e:
+        api.create('left', 8, 0, _capi.MODE_TRAINING)
+    assert 'no HIP device' in str(e.value) or 'HIP' in str(e.value)
+    from env_build_amd.dynamics_and_models import EnvironmentModel
+    with pytest.raises(_capi.EbError):
+        EnvironmentModel('left')
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'env_build_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'libenvbuild_oracle' not in text and 'oracle_lib' not in text, f
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+
+
+def test_oracle_exports_and_error_paths():
+    api = oracle_lib()
+    for name in header_symbols():
+        assert hasattr(api.lib, name), name
+    with pytest.raises(ValueError):
+        api.create('left', 0, 0, _capi.MODE_TRAINING)          # n_veh out of range
+    with pytest.raises(ValueError):
+        api.create('left', 65, 0, _capi.MODE_TRAINING)
+    with pytest.raises(ValueError):
+        api.create(7, 8, 0, _capi.MODE_TRAINING)               # bad task
+    h = api.create('left', 8, 0, _capi.MODE_TRAINING)
+    z = np.zeros((4, 41), np.float32)
+    a = np.zeros((4, 2), np.float32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    with pytest.raises(_capi.EbError):                          # paths / modes not set -> EB_ESTATE
+        api.rollout_step(h, 4, p(z), p(a), None, 0, p(z.copy()), p(np.zeros((5, 4), np.float32)), None, None)
+    api.destroy(h)
+
+
+def test_oracle_empty_and_bad_ref_index():
+    host = HostModel(oracle_lib(), 'left')
+    out, o5, sc = host.rollout_step(np.zeros((0, host.D), np.float32), np.zeros((0, 2), np.float32),
+                                    np.zeros((0,), np.int32))
+    assert out.shape == (0, host.D) and o5.shape == (5, 0)
+    with pytest.raises(ValueError):    # training mode without ref_indexes
+        host.rollout_step(np.zeros((4, host.D), np.float32), np.zeros((4, 2), np.float32), None)
+    inp = make_rollout_inputs('left', 16, 8, 1, seed=0)
+    inp['ref_idx'][::2] = 9            # rows with an out-of-range path keep zero tracking (DAM:342, 352)
+    trk = host.tracking_error(inp['ego'][:, 3], inp['ego'][:, 4], inp['ego'][:, 5], inp['ego'][:, 0], 0,
+                              ref_idx=inp['ref_idx'])
+    assert np.all(trk[::2] == 0) and np.all(trk[1::2, 2] == inp['ego'][1::2, 0] - 8)
+
+
+def test_oracle_linearity_free_properties():
+    """Size-independent properties the domain offers: rewards do not depend on far-away vehicles;
+    veh_predict keeps speed; a straight-mode vehicle keeps heading; tape == stepwise."""
+    host = HostModel(oracle_lib(), 'straight', n_veh=16)
+    inp = make_rollout_inputs('straight', 300, 16, 4, seed=2)
+    trk = host.tracking_error(inp['ego'][:, 3], inp['ego'][:, 4], inp['ego'][:, 5], inp['ego'][:, 0], 0,
+                              ref_idx=inp['ref_idx'])
+    obs = assemble_obs(inp['ego'], trk, inp['veh'])
+    act = host.action_transform(inp['actions'][0])
+    o5, _ = host.compute_rewards(obs, act)
+    far = obs.copy()
+    veh = far[:, 9:].reshape(300, 16, 4)
+    d = np.hypot(veh[:, :, 0] - far[:, None, 3], veh[:, :, 1] - far[:, None, 4])
+    veh[d > 7.0, 0] += 500.0           # > 3.5 + 2*1.4 m away: contributes exact zeros
+    o5b, _ = host.compute_rewards(far, act)
+    assert np.array_equal(o5, o5b)
+    nxt = host.veh_predict(inp['veh']).reshape(300, 16, 4)
+    assert np.array_equal(nxt[:, :, 2], inp['veh'].reshape(300, 16, 4)[:, :, 2])
+    modes = U.tiled_mode_list('straight', 16)
+    straight_slots = [j for j, m in enumerate(modes) if m in ('du', 'ud')]
+    np.testing.assert_allclose(nxt[:, straight_slots, 3], inp['veh'].reshape(300, 16, 4)[:, straight_slots, 3],
+                               rtol=1e-6, atol=1e-4)
+    a, o5s = host.rollout_tape(obs, inp['actions'], inp['ref_idx'])
+    b = obs
+    for t in range(4):
+        b, o5t, _ = host.rollout_step(b, inp['actions'][t], inp['ref_idx'])
+        assert np.array_equal(o5t, o5s[t])
+    assert np.array_equal(a, b)
+
+
+def test_constants_and_mode_tables():
+    assert (U.L, U.W, U.LANE_WIDTH, U.LANE_NUMBER, U.CROSSROAD_SIZE, U.EXPECTED_V) == (4.8, 2.0, 3.75, 3, 50, 8.)
+    assert U.VEH_NUM == dict(left=8, straight=9, right=5)
+    assert U.VEHICLE_MODE_LIST['left'] == ['dl', 'dl', 'du', 'du', 'ud', 'ud', 'ul', 'ul']
+    assert U.VEHICLE_MODE_LIST['right'] == ['dr', 'ur', 'ur', 'lr', 'lr']
+    assert len(U.ROUTE2MODE) == 12 and all(U.ROUTE2MODE[U.MODE2ROUTE[m]] == m for m in _capi.VMODES)
+    assert U.tiled_mode_list('right', 7) == ['dr', 'ur', 'ur', 'lr', 'lr', 'dr', 'ur']
+    assert U.deal_with_phi(190) == -170 and U.deal_with_phi(-180) == 180 and U.deal_with_phi(540) == 180
+    x, y, d = U.rotate_coordination(1.0, 0.0, 0.0, 90.0)
+    assert abs(x) < 1e-12 and abs(y + 1.0) < 1e-12 and d == -90.0
+    assert U.judge_feasible(1.0, -30.0, 'left') and not U.judge_feasible(4.0, -30.0, 'left')
+    assert U.judge_feasible(5.0, 30.0, 'straight') and not U.judge_feasible(-1.0, 30.0, 'straight')
+    assert U.judge_feasible(30.0, -5.0, 'right') and not U.judge_feasible(30.0, 1.0, 'right')
+    assert U.judge_feasible(-24.0, 24.0, 'right')
+
+
+def test_synthetic_inputs_are_seeded_and_shaped():
+    a = make_rollout_inputs('left', 64, 32, 5, seed=3)
+    b = make_rollout_inputs('left', 64, 32, 5, seed=3)
+    c = make_rollout_inputs('left', 64, 32, 5, seed=4)
+    for k in ('ego', 'veh', 'ref_idx', 'actions'):
+        assert np.array_equal(a[k], b[k])
+    assert not np.array_equal(a['ego'], c['ego'])
+    assert a['ego'].shape == (64, 6) and a['veh'].shape == (64, 128) and a['actions'].shape == (5, 64, 2)
+    assert a['ref_idx'].dtype == np.int32 and set(a['ref_idx'].tolist()) <= {0, 1, 2}
+    assert a['modes'] == U.tiled_mode_list('left', 32)
