@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched model rollout (EnvironmentModel.rollout_out) on MI355X.
 
-A "step" is one rollout_out call over the whole batch: B env-steps.  Workload at N GPUs:
+A "step" is one rollout_out pass over the whole batch = B env-steps.  Workload at N GPUs:
 BASELINE.json configs[2] per GPU (N_env = 65 536, N_veh = 32, horizon 25, task `left`, training
-mode, fp32), i.e. weak scaling — every rank owns an independent shard of envs, there is no
-data-path collective, and the only exchange is one all-gather (RCCL) of the per-rank episodic-return
-summary at the end of every 25-step horizon (inside the timed region).
+mode, fp32) — weak scaling: every rank owns an independent shard of envs, there is no data-path
+collective; the only exchange is one all-gather (RCCL) of the 8-float episodic-return summary at the
+end of every 25-step horizon, inside the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+The K timed steps run as K // 25 replays of a 25-launch hipGraph (eb_plan_*, one kernel launch per
+rollout step — the policy-in-the-loop form, not a fused open-loop kernel) plus K % 25 eager
+eb_rollout_step launches.  Rank 0 prints ONE JSON line with two extra objects:
   roofline     — algorithmic bytes per launch (104 + 32*N_veh per env-step) divided
-                 by the rollout kernel's average launch duration measured with HIP events on the
-                 launch stream, against the 8 TB/s HBM peak;
-  cpu_baseline — the CPU oracle (oracle/, plain C port of the reference path, OpenMP over envs) timed
+                 by the rollout kernel's average launch duration, measured with HIP event pairs
+                 (eb_event_*) on the launch stream around every graph replay — so the figure includes
+                 the inter-kernel gaps — against the 8 TB/s HBM peak;
+  cpu_baseline — the CPU oracle (oracle/, plain-C port of the reference path, OpenMP over envs) timed
                  on this box's host cores on a bounded sample of the same workload.  The oracle is
-                 only the thing timed here, never part of the GPU path.
+                 only the thing timed there, never part of the GPU path.
 """
 import argparse
 import ctypes as C
@@ -32,22 +35,33 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 TASK, N_ENV, N_VEH, HORIZON = 'left', 65536, 32, 25
-ALG_BYTES_PER_ENV_STEP = 104 + 32 * N_VEH        # fp32, SURVEY.md §8(d): 1128 B at N_veh = 32
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec
+MAX_EVENT_PAIRS = 256
 
 
-def cpu_baseline(inp, obs0, budget_s=12.0):
-    """Oracle timed on host cores: bounded sample (B_cpu envs x HORIZON steps, repeated until the
-    budget is used), all cores via OpenMP and then 1 core (the reference pins TF to 1 thread)."""
+def alg_bytes_per_env_step(n_veh):
+    return 104 + 32 * n_veh                      # fp32, SURVEY.md §8(d): 1128 B at N_veh = 32
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(inp, obs0, n_veh, budget_s=16.0):
+    """Oracle timed on host cores: bounded sample (8192 envs x HORIZON steps, repeated until the
+    budget is used) on all usable cores via OpenMP, then on 1 core (the reference pins TF to 1 thread)."""
     from tests._helpers import HostModel, oracle_lib
     api = oracle_lib()
     api.lib.eb_oracle_set_threads.restype = C.c_int
     api.lib.eb_oracle_set_threads.argtypes = [C.c_int]
     b_cpu = 8192
-    host = HostModel(api, TASK, n_veh=N_VEH)
+    host = HostModel(api, TASK, n_veh=n_veh)
     obs, act, ref = obs0[:b_cpu].copy(), inp['actions'][:, :b_cpu].copy(), inp['ref_idx'][:b_cpu].copy()
     res = {}
-    for label, threads in (('all', os.cpu_count() or 1), ('one', 1)):
+    for label, threads in (('all', host_cores()), ('one', 1)):
         used = api.lib.eb_oracle_set_threads(int(threads))
         host.rollout_tape(obs, act[:2], ref)   # warm-up
         n_steps, t0 = 0, time.perf_counter()
@@ -58,27 +72,31 @@ def cpu_baseline(inp, obs0, budget_s=12.0):
                 break
         dt = time.perf_counter() - t0
         res[label] = (b_cpu * n_steps / dt, used, n_steps)
-    v_all, cores, n_steps = res['all']
-    return {'value': v_all, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'value_1core': res['one'][0],
-            'sample': '%d envs x %d steps (N_veh=%d, same seeded inputs), oracle/envbuild_oracle.c, '
-                      'OpenMP over envs; 1-core figure is the reference-faithful setting (TF pinned to 1 thread)'
-                      % (b_cpu, n_steps, N_VEH)}
+    best = 'all' if res['all'][0] >= res['one'][0] else 'one'
+    return {'value': res[best][0], 'unit': 'env-steps/s', 'cores': res[best][1], 'kind': 'port',
+            'value_1core': res['one'][0], 'value_allcores': res['all'][0], 'allcores': res['all'][1],
+            'sample': '%d envs x %d steps on %d threads / x %d steps on 1 thread (N_veh=%d, same seeded inputs), '
+                      'oracle/envbuild_oracle.c, OpenMP over envs; the 1-thread figure is the reference-faithful '
+                      'setting (the reference pins TF to 1 thread)'
+                      % (b_cpu, res['all'][2], res['all'][1], res['one'][2], n_veh)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=500)
-    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--n-env', type=int, default=N_ENV, help='envs per GPU (default: configs[2])')
+    ap.add_argument('--n-veh', type=int, default=N_VEH)
+    ap.add_argument('--eager', action='store_true', help='one host launch per step instead of hipGraph replays')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    n_env, n_veh = args.n_env, args.n_veh
 
     import torch
     import torch.distributed as dist
-    from env_build_amd import _capi
     from env_build_amd.dynamics_and_models import EnvironmentModel
-    from env_build_amd.synthetic import make_rollout_inputs, assemble_obs
+    from env_build_amd.synthetic import make_rollout_inputs
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -91,96 +109,133 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
 
-    # ---- synthetic shard of this rank (seed = rank: independent envs per GPU) ----
-    inp = make_rollout_inputs(TASK, N_ENV, N_VEH, HORIZON, seed=rank)
-    model = EnvironmentModel(TASK, num_future_data=0, mode='training', n_veh=N_VEH, device=dev)
+    # ---- synthetic shard of this rank (seed = rank: independent envs per GPU), resident in HBM ----
+    inp = make_rollout_inputs(TASK, n_env, n_veh, HORIZON, seed=rank)
+    model = EnvironmentModel(TASK, num_future_data=0, mode='training', n_veh=n_veh, device=dev)
     ego = torch.from_numpy(inp['ego']).to(dev)
+    ref_idx = torch.from_numpy(inp['ref_idx']).to(dev)
     trk = model.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(),
                                                        ego[:, 5].contiguous(), ego[:, 0].contiguous(), 0,
-                                                       ref_indexes=torch.from_numpy(inp['ref_idx']).to(dev)).t
+                                                       ref_indexes=ref_idx).t
     obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
-    ref_idx = torch.from_numpy(inp['ref_idx']).to(dev)
     tape = torch.from_numpy(inp['actions']).to(dev)                      # [H, B, 2]
-    bufs = [torch.empty_like(obs0), torch.empty_like(obs0)]
-    out5 = torch.empty((HORIZON, 5, N_ENV), dtype=torch.float32, device=dev)
-    summary_all = torch.zeros((world, 6), dtype=torch.float32, device=dev)
+    work, final = torch.empty_like(obs0), torch.empty_like(obs0)
+    out5 = torch.empty((HORIZON, 5, n_env), dtype=torch.float32, device=dev)
+    summary = torch.zeros((8,), dtype=torch.float32, device=dev)
+    summary_all = torch.zeros((world, 8), dtype=torch.float32, device=dev)
 
     api, h = model.api, model.handle
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
-    step_fn = api.lib.eb_rollout_step
-    tape_p = [p(tape[t]) for t in range(HORIZON)]
-    out5_p = [p(out5[t]) for t in range(HORIZON)]
-    obs0_p, buf_p, ref_p = p(obs0), [p(bufs[0]), p(bufs[1])], p(ref_idx)
+    plan = C.c_void_p()
+    api.plan_create(h, n_env, HORIZON, p(obs0), p(tape), p(ref_idx), 0, p(work), p(final), p(out5), None, C.byref(plan))
+    lib = api.lib
+    # the eager form ping-pongs exactly as eb_rollout_tape does, so that step 24 lands in `final`
+    dst = [final if (HORIZON - 1 - t) % 2 == 0 else work for t in range(HORIZON)]
+    src = [obs0] + dst[:-1]
+    eager_args = [(h, n_env, p(src[t]), p(tape[t]), p(ref_idx), 0, p(dst[t]), p(out5[t]), None, sp) for t in range(HORIZON)]
 
-    def one_step(i):
-        """step i of the job: horizon-periodic, reading obs0 at the start of each horizon."""
-        t = i % HORIZON
-        src = obs0_p if t == 0 else buf_p[(t - 1) & 1]
-        rc = step_fn(h, N_ENV, src, tape_p[t], ref_p, 0, buf_p[t & 1], out5_p[t], None, sp)
-        if rc != 0:
-            api.check(rc)
-        if t == HORIZON - 1:
-            # episodic-return summary of this shard: sum reward, sum punish_train, sum punish_real,
-            # #envs with a real collision/road penalty, mean |delta_y|, max |delta_y| of the final obs
-            s = out5.sum(dim=(0, 2))
-            fin = bufs[t & 1][:, 6].abs()
-            mine = torch.stack([s[0], s[1], s[2], (out5[:, 2] > 0).any(0).sum().float(), fin.mean(), fin.max()])
-            if world > 1:
-                dist.all_gather_into_tensor(summary_all.view(-1), mine)
+    def eager_steps(t0, t1):
+        for t in range(t0, t1):
+            rc = lib.eb_rollout_step(*eager_args[t])
+            if rc != 0:
+                api.check(rc)
+
+    def end_of_horizon():
+        # episodic-return summary of this shard (two small kernels), then the only inter-GPU exchange
+        api.episode_summary(h, n_env, HORIZON, p(out5), p(final), p(summary), sp)
+        if world > 1:
+            dist.all_gather_into_tensor(summary_all.view(-1), summary)
+        else:
+            summary_all[0].copy_(summary, non_blocking=True)
+
+    n_pairs = min(MAX_EVENT_PAIRS, max(1, args.steps // HORIZON))
+    ev = []
+    for _ in range(2 * n_pairs):
+        e = C.c_void_p()
+        api.event_create(h, C.byref(e))
+        ev.append(e)
+
+    def run(n_steps, timed):
+        full, rem = divmod(n_steps, HORIZON)
+        for k in range(full):
+            marks = timed and k < n_pairs
+            if marks:
+                lib.eb_event_record(ev[2 * k], sp)
+            if args.eager:
+                eager_steps(0, HORIZON)
             else:
-                summary_all[0].copy_(mine)
+                rc = lib.eb_plan_launch(plan, sp)
+                if rc != 0:
+                    api.check(rc)
+            if marks:
+                lib.eb_event_record(ev[2 * k + 1], sp)
+            end_of_horizon()
+        eager_steps(0, rem)
+        return full
 
-    for i in range(args.warmup):
-        one_step(i)
+    run(args.warmup, False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps):
-        one_step(i)
-    ev1.record(stream)
+    full = run(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
 
+    ms = C.c_float()
+    ev_ms, n_marked = 0.0, min(full, n_pairs)
+    for k in range(n_marked):
+        api.event_elapsed_ms(ev[2 * k], ev[2 * k + 1], C.byref(ms))
+        ev_ms += ms.value
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
     if rank == 0:
-        value = N_ENV * world * args.steps / dt_max
-        launch_s = ev_ms * 1e-3 / args.steps       # HIP events on the launch stream, per rollout launch
-        achieved = ALG_BYTES_PER_ENV_STEP * N_ENV / launch_s / 1e9
+        value = n_env * world * args.steps / dt_max
+        alg = alg_bytes_per_env_step(n_veh) * n_env
+        if n_marked:
+            launch_s = ev_ms * 1e-3 / (n_marked * HORIZON)   # HIP events on the launch stream, per rollout launch
+        else:
+            launch_s = dt_max / args.steps                   # fewer than 25 steps: whole-region wall time
+        achieved = alg / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')   # written from a separate --pmc run
+        if os.path.isfile(tpath) and n_env == N_ENV and n_veh == N_VEH:
+            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        cfg = 'configs[2]' if (n_env, n_veh) == (N_ENV, N_VEH) else 'custom'
         line = {
             'metric': 'env-steps/s (batched rollout) at N_env x N_veh; achieved HBM GB/s vs peak',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt_max * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[2]: N_env=65536 per GPU, N_veh=32, horizon=25, task=left, '
-                                   'mode=training, closed-loop rollout_out (one launch per step)',
-                       'n_env_per_gpu': N_ENV, 'n_veh': N_VEH, 'horizon': HORIZON,
-                       'parallelism': 'env-shard x%d, all-gather of the episodic summary per horizon' % world},
+            'config': {'workload': '%s: N_env=%d per GPU, N_veh=%d, horizon=%d, task=%s, mode=training, '
+                                   'closed-loop rollout_out (one kernel launch per step, %s)'
+                                   % (cfg, n_env, n_veh, HORIZON, TASK,
+                                      'eager' if args.eager else '25-launch hipGraph replays'),
+                       'n_env_per_gpu': n_env, 'n_veh': n_veh, 'horizon': HORIZON,
+                       'parallelism': 'env-shard x%d, all-gather of the 8-float episodic summary per horizon' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'eb::rollout_step_kernel<0>', 'alg_bytes_per_launch': ALG_BYTES_PER_ENV_STEP * N_ENV,
-                         'avg_launch_us': launch_s * 1e6},
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'eb::rollout_step_kernel<0>', 'alg_bytes_per_launch': alg,
+                         'avg_launch_us': launch_s * 1e6, 'launches_timed': n_marked * HORIZON},
             'summary': [float(x) for x in summary_all[0].tolist()],
         }
         if not args.no_cpu_baseline:
-            obs0_h = obs0.cpu().numpy()
-            line['cpu_baseline'] = cpu_baseline(inp, obs0_h)
+            line['cpu_baseline'] = cpu_baseline(inp, obs0.cpu().numpy(), n_veh)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
+    for e in ev:
+        api.event_destroy(e)
+    api.plan_destroy(plan)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

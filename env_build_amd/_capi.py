@@ -44,6 +44,14 @@ PROTOTYPES = {
     'eb_compute_next_obses': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P]),
     'eb_rollout_step': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'eb_episode_summary': (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
+    'eb_plan_create': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, C.POINTER(_P)]),
+    'eb_plan_launch': (C.c_int, [_P, _P]),
+    'eb_plan_destroy': (C.c_int, [_P]),
+    'eb_event_create': (C.c_int, [_P, C.POINTER(_P)]),
+    'eb_event_record': (C.c_int, [_P, _P]),
+    'eb_event_elapsed_ms': (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    'eb_event_destroy': (C.c_int, [_P]),
     'eb_find_closest_point': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
     'eb_tracking_error': (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     'eb_veh_predict': (C.c_int, [_P, _I, _P, _P, _P]),

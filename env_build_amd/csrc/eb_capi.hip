@@ -43,6 +43,7 @@ struct eb_handle_s {
     float* d_tables;          // one allocation: x|y|phi per path, then the stride-10 (x,y) tables
     float2* d_red_all;
     float* d_rad_all;         // 3 x 32 block radii for the pruned closest-point search
+    double* d_partials;       // SUMMARY_MAX_PARTS x 6 doubles: stage-1 partials of eb_episode_summary
     int n_cu;                 // compute units of the device (persistent grid size)
     int red_off[3];
     int red_total;
@@ -82,6 +83,8 @@ int eb_create(const eb_config* cfg, eb_handle* out) {
         if (e != hipSuccess) { delete h; return fail_hip("hipGetDeviceProperties", e); }
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    e = hipMalloc(reinterpret_cast<void**>(&h->d_partials), sizeof(double) * 6 * eb::SUMMARY_MAX_PARTS);
+    if (e != hipSuccess) { delete h; return fail_hip("hipMalloc(summary partials)", e); }
     *out = h;
     return EB_OK;
 }
@@ -91,6 +94,7 @@ int eb_destroy(eb_handle h) {
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
     if (h->d_tables) hipFree(h->d_tables);
+    if (h->d_partials) hipFree(h->d_partials);
     delete h;
     return EB_OK;
 }
@@ -413,6 +417,116 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
     EB_HIP(hipSetDevice(h->cfg.device));
     EB_HIP(eb::launch_judge_done(h->cfg.task, n_env, obs_dim(h->cfg), ego, params, obs, m_cand, cand, cand_mode,
                                  cand_lw, v_light, done_code, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float* out5_steps, const float* obs_final,
+                       float* out8, void* stream) {
+    if (!h || n_env < 0 || horizon < 0 || !out8 || (n_env > 0 && horizon > 0 && !out5_steps) || (n_env > 0 && !obs_final))
+        return fail(EB_EINVAL, "eb_episode_summary: bad argument");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_summary(n_env, horizon, obs_dim(h->cfg), out5_steps, obs_final, h->d_partials,
+                              eb::SUMMARY_MAX_PARTS, out8, pick(h, stream)));
+    return EB_OK;
+}
+
+}  // extern "C"
+
+struct eb_plan_s {
+    eb_handle h;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+struct eb_event_s {
+    hipEvent_t ev;
+    int device;
+};
+
+extern "C" {
+
+int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
+                   const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
+                   float* summary8, eb_plan* out) {
+    if (!out) return fail(EB_EINVAL, "eb_plan_create: null argument");
+    *out = nullptr;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_plan_create: null handle");
+    if (rc) return rc;
+    if (n_env < 1 || horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps)
+        return fail(EB_EINVAL, "eb_plan_create: bad argument (n_env >= 1, horizon >= 1, non-null buffers)");
+    if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
+        return fail(EB_EINVAL, "eb_plan_create: obs_in, obs_work and obs_out must be distinct buffers");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t cs = nullptr;
+    EB_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { hipStreamDestroy(cs); return fail_hip("hipStreamBeginCapture", e); }
+    rc = eb_rollout_tape(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs);
+    if (rc == EB_OK && summary8) rc = eb_episode_summary(h, n_env, horizon, out5_steps, obs_out, summary8, cs);
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(cs, &graph);
+    hipStreamDestroy(cs);
+    if (rc != EB_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) return fail_hip("hipStreamEndCapture", e);
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { hipGraphDestroy(graph); return fail_hip("hipGraphInstantiate", e); }
+    eb_plan p = new (std::nothrow) eb_plan_s();
+    if (!p) { hipGraphExecDestroy(exec); hipGraphDestroy(graph); return fail(EB_ENOMEM, "eb_plan_create: out of memory"); }
+    p->h = h; p->graph = graph; p->exec = exec;
+    *out = p;
+    return EB_OK;
+}
+
+int eb_plan_launch(eb_plan p, void* stream) {
+    if (!p) return fail(EB_EINVAL, "eb_plan_launch: null plan");
+    EB_HIP(hipSetDevice(p->h->cfg.device));
+    EB_HIP(hipGraphLaunch(p->exec, (hipStream_t)stream));
+    return EB_OK;
+}
+
+int eb_plan_destroy(eb_plan p) {
+    if (!p) return EB_OK;
+    hipSetDevice(p->h->cfg.device);
+    hipDeviceSynchronize();
+    if (p->exec) hipGraphExecDestroy(p->exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    delete p;
+    return EB_OK;
+}
+
+int eb_event_create(eb_handle h, eb_event* out) {
+    if (!h || !out) return fail(EB_EINVAL, "eb_event_create: null argument");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    hipEvent_t ev;
+    EB_HIP(hipEventCreate(&ev));
+    eb_event e = new (std::nothrow) eb_event_s();
+    if (!e) { hipEventDestroy(ev); return fail(EB_ENOMEM, "eb_event_create: out of memory"); }
+    e->ev = ev; e->device = h->cfg.device;
+    *out = e;
+    return EB_OK;
+}
+
+int eb_event_record(eb_event e, void* stream) {
+    if (!e) return fail(EB_EINVAL, "eb_event_record: null event");
+    EB_HIP(hipSetDevice(e->device));
+    EB_HIP(hipEventRecord(e->ev, (hipStream_t)stream));
+    return EB_OK;
+}
+
+int eb_event_elapsed_ms(eb_event start, eb_event stop, float* ms) {
+    if (!start || !stop || !ms) return fail(EB_EINVAL, "eb_event_elapsed_ms: null argument");
+    EB_HIP(hipSetDevice(stop->device));
+    EB_HIP(hipEventSynchronize(stop->ev));
+    EB_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return EB_OK;
+}
+
+int eb_event_destroy(eb_event e) {
+    if (!e) return EB_OK;
+    hipSetDevice(e->device);
+    hipEventDestroy(e->ev);
+    delete e;
     return EB_OK;
 }
 

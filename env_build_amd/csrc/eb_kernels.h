@@ -53,6 +53,10 @@ hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const Pat
                      const float* obs, const float* actions, const int* ref_idx, int path_id, int training,
                      float one_m_lam, float* out, hipStream_t s);
 
+constexpr int SUMMARY_MAX_PARTS = 1024;   // blocks of the stage-1 summary reduction (handle scratch: 6 doubles each)
+hipError_t launch_summary(int n_env, int horizon, int D, const float* out5_steps, const float* obs_final,
+                          double* partials, int max_parts, float* out8, hipStream_t s);
+
 // real-env step pieces (eb_env_kernels.hip)
 hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, float* next_ego, float* params,
                                hipStream_t s);

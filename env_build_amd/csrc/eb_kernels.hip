@@ -622,4 +622,96 @@ hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const Pat
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// episodic-return summary of a shard (eb_episode_summary): two launches, fixed reduction order
+// ------------------------------------------------------------------------------------------------
+// Stage 1: thread i walks env i, i + G*256, ... and, per env, the `horizon` step records of
+// out5_steps [H, 5, B] (consecutive lanes read consecutive envs: coalesced), accumulating in float64;
+// wave shuffle + LDS tree gives one 6-double partial per block.  Stage 2: one block folds the
+// partials in block order.  No atomics, so the result does not depend on scheduling.
+constexpr int SUM_THREADS = 256;
+
+struct Sum6 { double r, pt, pr, cnt, ady, mdy; };
+
+EB_DEV Sum6 sum6_combine(const Sum6& a, const Sum6& b) {
+    Sum6 o;
+    o.r = a.r + b.r; o.pt = a.pt + b.pt; o.pr = a.pr + b.pr; o.cnt = a.cnt + b.cnt; o.ady = a.ady + b.ady;
+    o.mdy = a.mdy > b.mdy ? a.mdy : b.mdy;
+    return o;
+}
+
+EB_DEV Sum6 sum6_block_reduce(Sum6 v, Sum6* s_part) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Sum6 o;
+        o.r = __shfl_down(v.r, off, 64); o.pt = __shfl_down(v.pt, off, 64); o.pr = __shfl_down(v.pr, off, 64);
+        o.cnt = __shfl_down(v.cnt, off, 64); o.ady = __shfl_down(v.ady, off, 64); o.mdy = __shfl_down(v.mdy, off, 64);
+        v = sum6_combine(v, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_part[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SUM_THREADS / 64; ++w) v = sum6_combine(v, s_part[w]);
+    }
+    return v;   // valid in thread 0
+}
+
+__global__ __launch_bounds__(SUM_THREADS) void summary_partial_kernel(int n_env, int horizon, int D,
+                                                                       const float* __restrict__ out5_steps,
+                                                                       const float* __restrict__ obs_final,
+                                                                       double* __restrict__ partials) {
+    __shared__ Sum6 s_part[SUM_THREADS / 64];
+    Sum6 acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const size_t n = (size_t)n_env;
+    for (int i = blockIdx.x * SUM_THREADS + threadIdx.x; i < n_env; i += gridDim.x * SUM_THREADS) {
+        bool any = false;
+        for (int t = 0; t < horizon; ++t) {
+            const float* o5 = out5_steps + (size_t)t * 5 * n;
+            const float pr = o5[2 * n + i];
+            acc.r += (double)o5[i];
+            acc.pt += (double)o5[n + i];
+            acc.pr += (double)pr;
+            any = any || pr > 0.0f;
+        }
+        const double dy = (double)__builtin_fabsf(obs_final[(size_t)i * D + 6]);
+        acc.cnt += any ? 1.0 : 0.0;
+        acc.ady += dy;
+        acc.mdy = dy > acc.mdy ? dy : acc.mdy;
+    }
+    const Sum6 b = sum6_block_reduce(acc, s_part);
+    if (threadIdx.x == 0) {
+        double* p = partials + 6 * (size_t)blockIdx.x;
+        p[0] = b.r; p[1] = b.pt; p[2] = b.pr; p[3] = b.cnt; p[4] = b.ady; p[5] = b.mdy;
+    }
+}
+
+__global__ __launch_bounds__(SUM_THREADS) void summary_final_kernel(int n_part, int n_env, int horizon,
+                                                                     const double* __restrict__ partials,
+                                                                     float* __restrict__ out8) {
+    __shared__ Sum6 s_part[SUM_THREADS / 64];
+    Sum6 acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < n_part; b += SUM_THREADS) {
+        const double* p = partials + 6 * (size_t)b;
+        Sum6 v = {p[0], p[1], p[2], p[3], p[4], p[5]};
+        acc = sum6_combine(acc, v);
+    }
+    const Sum6 r = sum6_block_reduce(acc, s_part);
+    if (threadIdx.x == 0) {
+        out8[0] = (float)r.r; out8[1] = (float)r.pt; out8[2] = (float)r.pr; out8[3] = (float)r.cnt;
+        out8[4] = (float)r.ady; out8[5] = (float)r.mdy; out8[6] = (float)n_env; out8[7] = (float)horizon;
+    }
+}
+
+hipError_t launch_summary(int n_env, int horizon, int D, const float* out5_steps, const float* obs_final,
+                          double* partials, int max_parts, float* out8, hipStream_t s) {
+    int g = (n_env + SUM_THREADS - 1) / SUM_THREADS;
+    g = g < 1 ? 1 : (g > max_parts ? max_parts : g);
+    hipLaunchKernelGGL(summary_partial_kernel, dim3(g), dim3(SUM_THREADS), 0, s, n_env, horizon, D, out5_steps,
+                       obs_final, partials);
+    hipLaunchKernelGGL(summary_final_kernel, dim3(1), dim3(SUM_THREADS), 0, s, g, n_env, horizon, partials, out8);
+    return hipGetLastError();
+}
+
 }  // namespace eb

@@ -147,6 +147,40 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
                     const float* action_tape, const int32_t* ref_idx, int32_t path_id,
                     float* obs_work, float* obs_out, float* out5_steps, void* stream);
 
+/* Episodic-return summary of one shard of envs after a rollout of `horizon` steps — the only
+ * quantity north_star exchanges between GPUs (one all-gather of this vector per rollout; the
+ * reference's callers accumulate the same sums step by step, hier_decision.py:96).
+ *   out5_steps [horizon, 5, n_env] as written by eb_rollout_tape / eb_plan_launch;
+ *   obs_final  [n_env, D] the obs after the last step.
+ *   out8[0] = sum rewards, [1] = sum punish_term_for_training, [2] = sum real_punish_term (all over
+ *   steps and envs, accumulated in float64, rounded once), [3] = number of envs with
+ *   real_punish_term > 0 at any step, [4] = sum |delta_y| of obs_final, [5] = max |delta_y|,
+ *   [6] = n_env, [7] = horizon.  Deterministic (fixed reduction order). */
+#define EB_SUMMARY_LEN 8
+int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float* out5_steps,
+                       const float* obs_final, float* out8, void* stream);
+
+/* A rollout plan = eb_rollout_tape over FIXED buffers, recorded once and replayed: the HIP library
+ * captures the `horizon` launches (plus the episodic summary when summary8 != NULL) into a
+ * hipGraph, so that a replay costs one host call instead of `horizon`.  Buffer contents may
+ * change between launches, addresses and sizes may not.  The plan borrows every buffer; destroy it
+ * before the handle. */
+typedef struct eb_plan_s* eb_plan;
+int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in,
+                   const float* action_tape, const int32_t* ref_idx, int32_t path_id,
+                   float* obs_work, float* obs_out, float* out5_steps, float* summary8,
+                   eb_plan* out);
+int eb_plan_launch(eb_plan p, void* stream);
+int eb_plan_destroy(eb_plan p);
+
+/* Stream-ordered timing marks for benchmarks (hipEvent pairs on the launch stream).
+ * eb_event_elapsed_ms blocks until `stop` has completed.  The oracle uses the host clock. */
+typedef struct eb_event_s* eb_event;
+int eb_event_create(eb_handle h, eb_event* out);
+int eb_event_record(eb_event e, void* stream);
+int eb_event_elapsed_ms(eb_event start, eb_event stop, float* ms);
+int eb_event_destroy(eb_event e);
+
 /* ReferencePath.find_closest_point (DAM:702-715), ratio = 10.  out_index: [n] int32 (already
  * multiplied by ratio); out_points: 3 arrays of n floats (x, y, phi).  ref_idx nullable ->
  * path_id for every row. */

@@ -22,12 +22,14 @@
  *  - python-float constants are rounded to fp32 at the op where they meet a tensor, in the
  *    reference's evaluation order.
  */
+#define _POSIX_C_SOURCE 200809L
 #include "../include/envbuild.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -899,6 +901,100 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
         else code = EB_DONE_NOT_YET;
         done_code[i] = code;
     }
+    return EB_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* episodic summary, rollout plans, timing marks (no reference counterpart; include/envbuild.h) */
+/* ------------------------------------------------------------------------------------------ */
+int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float* out5_steps,
+                       const float* obs_final, float* out8, void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || horizon < 0 || !out8 || (n_env > 0 && horizon > 0 && !out5_steps) || (n_env > 0 && !obs_final))
+        return fail(EB_EINVAL, "eb_episode_summary: bad argument");
+    const int D = obs_dim(&h->cfg);
+    double r = 0, pt = 0, pr = 0, cnt = 0, ady = 0, mdy = 0;
+    for (int i = 0; i < n_env; ++i) {
+        int any = 0;
+        for (int t = 0; t < horizon; ++t) {
+            const float* o5 = out5_steps + (size_t)t * 5 * n_env;
+            r += (double)o5[i];
+            pt += (double)o5[(size_t)n_env + i];
+            pr += (double)o5[2 * (size_t)n_env + i];
+            any |= o5[2 * (size_t)n_env + i] > 0.0f;
+        }
+        double dy = (double)fabsf(obs_final[(size_t)i * D + 6]);
+        cnt += any;
+        ady += dy;
+        if (dy > mdy) mdy = dy;
+    }
+    out8[0] = (float)r; out8[1] = (float)pt; out8[2] = (float)pr; out8[3] = (float)cnt;
+    out8[4] = (float)ady; out8[5] = (float)mdy; out8[6] = (float)n_env; out8[7] = (float)horizon;
+    return EB_OK;
+}
+
+struct eb_plan_s {
+    eb_handle h;
+    int32_t n_env, horizon, path_id;
+    const float *obs_in, *tape;
+    const int32_t* ref_idx;
+    float *obs_work, *obs_out, *out5_steps, *summary8;
+};
+
+int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in,
+                   const float* action_tape, const int32_t* ref_idx, int32_t path_id,
+                   float* obs_work, float* obs_out, float* out5_steps, float* summary8, eb_plan* out) {
+    if (!out) return fail(EB_EINVAL, "eb_plan_create: null argument");
+    *out = NULL;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_plan_create: null handle");
+    if (rc) return rc;
+    if (n_env < 1 || horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps)
+        return fail(EB_EINVAL, "eb_plan_create: bad argument (n_env >= 1, horizon >= 1, non-null buffers)");
+    if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
+        return fail(EB_EINVAL, "eb_plan_create: obs_in, obs_work and obs_out must be distinct buffers");
+    eb_plan p = (eb_plan)calloc(1, sizeof *p);
+    if (!p) return fail(EB_ENOMEM, "eb_plan_create: out of memory");
+    p->h = h; p->n_env = n_env; p->horizon = horizon; p->path_id = path_id; p->obs_in = obs_in;
+    p->tape = action_tape; p->ref_idx = ref_idx; p->obs_work = obs_work; p->obs_out = obs_out;
+    p->out5_steps = out5_steps; p->summary8 = summary8;
+    *out = p;
+    return EB_OK;
+}
+
+int eb_plan_launch(eb_plan p, void* stream) {
+    if (!p) return fail(EB_EINVAL, "eb_plan_launch: null plan");
+    int rc = eb_rollout_tape(p->h, p->n_env, p->horizon, p->obs_in, p->tape, p->ref_idx, p->path_id,
+                             p->obs_work, p->obs_out, p->out5_steps, stream);
+    if (rc == EB_OK && p->summary8)
+        rc = eb_episode_summary(p->h, p->n_env, p->horizon, p->out5_steps, p->obs_out, p->summary8, stream);
+    return rc;
+}
+
+int eb_plan_destroy(eb_plan p) {
+    free(p);
+    return EB_OK;
+}
+
+struct eb_event_s { struct timespec ts; };
+
+int eb_event_create(eb_handle h, eb_event* out) {
+    if (!h || !out) return fail(EB_EINVAL, "eb_event_create: null argument");
+    *out = (eb_event)calloc(1, sizeof **out);
+    return *out ? EB_OK : fail(EB_ENOMEM, "eb_event_create: out of memory");
+}
+int eb_event_record(eb_event e, void* stream) {
+    (void)stream;
+    if (!e) return fail(EB_EINVAL, "eb_event_record: null event");
+    clock_gettime(CLOCK_MONOTONIC, &e->ts);
+    return EB_OK;
+}
+int eb_event_elapsed_ms(eb_event start, eb_event stop, float* ms) {
+    if (!start || !stop || !ms) return fail(EB_EINVAL, "eb_event_elapsed_ms: null argument");
+    *ms = (float)((stop->ts.tv_sec - start->ts.tv_sec) * 1e3 + (stop->ts.tv_nsec - start->ts.tv_nsec) * 1e-6);
+    return EB_OK;
+}
+int eb_event_destroy(eb_event e) {
+    free(e);
     return EB_OK;
 }
 

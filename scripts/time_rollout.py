@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling aid: kernel-only timing of eb_rollout_step on cuda:0 (HIP events on the launch stream)."""
-import argparse, ctypes as C, os, sys
+import argparse, ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -33,10 +33,14 @@ def step(i):
 for i in range(50): step(i)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter()
 e0.record(st)
 for i in range(a.iters): step(i)
+t1 = time.perf_counter()
 e1.record(st); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) * 1e3 / a.iters
+t2 = time.perf_counter()
+print('wall: enqueue %.2f us/step, enqueue+drain %.2f us/step; torch events %.2f us/step' % ((t1 - t0) * 1e6 / a.iters, (t2 - t0) * 1e6 / a.iters, e0.elapsed_time(e1) * 1e3 / a.iters))
+us = (t2 - t0) * 1e6 / a.iters
 alg = (104 + 32 * a.n_veh) * a.n_env
 print('ablate=%s task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
       % (os.environ.get('EB_ABLATE', '0'), a.task, a.n_env, a.n_veh, a.mode, us, a.n_env / us / 1e3, alg / us / 1e3, alg / us / 1e3 / 80))

@@ -130,6 +130,29 @@ class HostModel(object):
         self.api.rollout_tape(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work), self._ptr(out), self._ptr(out5), self.stream)
         return self._ret(out), self._ret(out5)
 
+    def episode_summary(self, out5_steps, obs_final):
+        o5, ob = self._in(out5_steps), self._in(obs_final)
+        out8 = self._out((8,))
+        self.api.episode_summary(self.h, o5.shape[2], o5.shape[0], self._ptr(o5), self._ptr(ob), self._ptr(out8), self.stream)
+        return self._ret(out8)
+
+    def plan_run(self, obs, tape, ref_idx=None, path_id=0, replays=2, with_summary=True):
+        """eb_plan_create + `replays` x eb_plan_launch + destroy -> (obs_out, out5 [H,5,n], summary8)."""
+        ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
+        H, n = tp.shape[0], len(ob)
+        work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
+        s8 = self._out((8,)) if with_summary else None
+        plan = C.c_void_p()
+        self.api.plan_create(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work),
+                             self._ptr(out), self._ptr(out5), self._ptr(s8), C.byref(plan))
+        try:
+            for _ in range(replays):
+                self.api.plan_launch(plan, self.stream)
+            res = self._ret(out), self._ret(out5), (self._ret(s8) if with_summary else None)
+        finally:
+            self.api.plan_destroy(plan)
+        return res
+
     def find_closest_point(self, xs, ys, ref_idx=None, path_id=0):
         x, y, ri = self._in(xs), self._in(ys), self._in(ref_idx, np.int32)
         n = len(x)

@@ -159,3 +159,29 @@ def test_synthetic_inputs_are_seeded_and_shaped():
     assert a['ego'].shape == (64, 6) and a['veh'].shape == (64, 128) and a['actions'].shape == (5, 64, 2)
     assert a['ref_idx'].dtype == np.int32 and set(a['ref_idx'].tolist()) <= {0, 1, 2}
     assert a['modes'] == U.tiled_mode_list('left', 32)
+
+
+def test_oracle_plan_summary_and_events():
+    host = HostModel(oracle_lib(), 'left', n_veh=16)
+    inp = make_rollout_inputs('left', 130, 16, 5, seed=9)
+    trk = host.tracking_error(inp['ego'][:, 3], inp['ego'][:, 4], inp['ego'][:, 5], inp['ego'][:, 0], 0,
+                              ref_idx=inp['ref_idx'])
+    obs = assemble_obs(inp['ego'], trk, inp['veh'])
+    out_a, o5_a = host.rollout_tape(obs, inp['actions'], inp['ref_idx'])
+    out_b, o5_b, s8 = host.plan_run(obs, inp['actions'], inp['ref_idx'])
+    assert np.array_equal(out_a, out_b) and np.array_equal(o5_a, o5_b)
+    np.testing.assert_allclose(s8[0], o5_a[:, 0].astype(np.float64).sum(), rtol=1e-6)
+    np.testing.assert_allclose(s8[1], o5_a[:, 1].astype(np.float64).sum(), rtol=1e-6)
+    np.testing.assert_allclose(s8[2], o5_a[:, 2].astype(np.float64).sum(), rtol=1e-6)
+    assert s8[3] == (o5_a[:, 2] > 0).any(0).sum()
+    np.testing.assert_allclose(s8[4], np.abs(out_a[:, 6]).astype(np.float64).sum(), rtol=1e-6)
+    assert s8[5] == np.abs(out_a[:, 6]).max() and s8[6] == 130 and s8[7] == 5
+    api = host.api
+    e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+    api.event_create(host.h, C.byref(e0)); api.event_create(host.h, C.byref(e1))
+    api.event_record(e0, None); api.event_record(e1, None)
+    api.event_elapsed_ms(e0, e1, C.byref(ms))
+    assert 0.0 <= ms.value < 1000.0
+    api.event_destroy(e0); api.event_destroy(e1)
+    with pytest.raises(ValueError):
+        api.plan_create(host.h, 0, 5, None, None, None, 0, None, None, None, None, C.byref(C.c_void_p()))

@@ -94,6 +94,44 @@ def test_rollout_tape_equals_stepwise_and_oracle():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('task,N,B,H', [('left', 32, 2049, 25), ('right', 5, 100, 3), ('straight', 64, 777, 7)])
+def test_plan_graph_replay_and_summary(task, N, B, H):
+    """hipGraph-captured rollout (eb_plan_*) == eb_rollout_tape == the oracle; the episodic summary
+    matches the oracle's float64 sums."""
+    host, dev = _pair(task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, H, seed=21)
+    obs0 = _initial_obs(host, inp)
+    out_h, o5_h, s8_h = host.plan_run(obs0, inp['actions'], inp['ref_idx'])
+    out_d, o5_d, s8_d = dev.plan_run(obs0, inp['actions'], inp['ref_idx'], replays=3)
+    out_t, o5_t = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    assert np.array_equal(out_d, out_h) and np.array_equal(out_d, out_t)
+    assert np.array_equal(o5_d, o5_t)
+    np.testing.assert_allclose(o5_d, o5_h, rtol=PEN_RTOL, atol=0)
+    # summary of the DEVICE's own out5 against the oracle's float64 reduction of the same numbers
+    s8_ref = host.episode_summary(o5_d, out_d)
+    np.testing.assert_allclose(s8_d, s8_ref, rtol=1e-6, atol=0)
+    assert s8_d[3] == s8_ref[3] and s8_d[5] == s8_ref[5] and s8_d[6] == B and s8_d[7] == H
+    np.testing.assert_allclose(s8_d, s8_h, rtol=1e-5, atol=0)
+    assert np.array_equal(dev.episode_summary(o5_d, out_d), s8_d)
+
+
+def test_event_marks_measure_stream_time():
+    import ctypes as C
+    host, dev = _pair('left', n_veh=32)
+    inp = make_rollout_inputs('left', 8192, 32, 2, seed=1)
+    obs0 = _initial_obs(host, inp)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    dev.api.event_create(dev.h, C.byref(e0)); dev.api.event_create(dev.h, C.byref(e1))
+    dev.api.event_record(e0, dev.stream)
+    for _ in range(20):
+        dev.rollout_step(obs0, inp['actions'][0], inp['ref_idx'])
+    dev.api.event_record(e1, dev.stream)
+    ms = C.c_float()
+    dev.api.event_elapsed_ms(e0, e1, C.byref(ms))
+    assert 0.0 < ms.value < 5000.0
+    dev.api.event_destroy(e0); dev.api.event_destroy(e1)
+
+
 @pytest.mark.parametrize('task', TASKS)
 def test_single_ops_bit_exact(task):
     N = VEH_NUM[task]
