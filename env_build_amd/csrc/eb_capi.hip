@@ -44,6 +44,7 @@ struct eb_handle_s {
     float2* d_red_all;
     float* d_rad_all;         // 3 x 32 block radii for the pruned closest-point search
     double* d_partials;       // SUMMARY_MAX_PARTS x 6 doubles: stage-1 partials of eb_episode_summary
+    eb::PathTables* d_pt;     // device copy of pt (+ slot turns) read by the rollout kernel
     int n_cu;                 // compute units of the device (persistent grid size)
     int red_off[3];
     int red_total;
@@ -51,8 +52,17 @@ struct eb_handle_s {
     int modes_set;
 };
 
+// the kernel-visible copy of the tables: refreshed whenever paths or slot modes change
+static hipError_t upload_tables(eb_handle_s* h);
+
 static int obs_dim(const eb_config& c) { return 6 + 3 * (c.n_future + 1) + 4 * c.n_veh; }
 static hipStream_t pick(eb_handle, void* stream) { return (hipStream_t)stream; }   // NULL = the HIP null stream
+
+static hipError_t upload_tables(eb_handle_s* h) {
+    for (int k = 0; k < 3; ++k) h->pt.red_off[k] = h->red_off[k];
+    std::memcpy(h->pt.turn, h->modes.turn, sizeof h->pt.turn);
+    return hipMemcpy(h->d_pt, &h->pt, sizeof h->pt, hipMemcpyHostToDevice);
+}
 
 extern "C" {
 
@@ -85,6 +95,8 @@ int eb_create(const eb_config* cfg, eb_handle* out) {
     }
     e = hipMalloc(reinterpret_cast<void**>(&h->d_partials), sizeof(double) * 6 * eb::SUMMARY_MAX_PARTS);
     if (e != hipSuccess) { delete h; return fail_hip("hipMalloc(summary partials)", e); }
+    e = hipMalloc(reinterpret_cast<void**>(&h->d_pt), sizeof(eb::PathTables));
+    if (e != hipSuccess) { hipFree(h->d_partials); delete h; return fail_hip("hipMalloc(tables)", e); }
     *out = h;
     return EB_OK;
 }
@@ -95,6 +107,7 @@ int eb_destroy(eb_handle h) {
     hipDeviceSynchronize();
     if (h->d_tables) hipFree(h->d_tables);
     if (h->d_partials) hipFree(h->d_partials);
+    if (h->d_pt) hipFree(h->d_pt);
     delete h;
     return EB_OK;
 }
@@ -177,6 +190,7 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     }
     h->pt.n_paths = n_paths;
     h->red_total = (int)red_total;
+    EB_HIP(upload_tables(h));
     return EB_OK;
 }
 
@@ -194,6 +208,9 @@ int eb_set_veh_modes(eb_handle h, const uint8_t* mode_id, int32_t n) {
         }
     }
     h->modes_set = 1;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(hipDeviceSynchronize());
+    EB_HIP(upload_tables(h));
     return EB_OK;
 }
 
@@ -253,10 +270,9 @@ static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const
     A.obs_in = obs_in; A.actions = actions; A.ref_idx = ref_idx; A.obs_out = obs_out; A.out5 = out5;
     A.scaled_actions = scaled_actions;
     A.red_all = h->d_red_all;
-    A.pt = h->pt;
+    A.dt = h->d_pt;
     A.training = h->cfg.mode == EB_MODE_TRAINING;
     if (A.training) {
-        for (int k = 0; k < 3; ++k) A.red_off[k] = h->red_off[k];
         A.red_base = 0;
         A.red_total = h->red_total;
     } else {
@@ -268,7 +284,14 @@ static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const
     A.nv_magic = (unsigned)((0x100000000ull + (unsigned)NV - 1) / (unsigned)NV);
     A.rad_all = h->d_rad_all;
     A.n_env_blocks = (n_env + eb::ROLLOUT_THREADS - 1) / eb::ROLLOUT_THREADS;
-    A.envs_per_vblock = std::min(64, std::max(1, eb::ROLLOUT_THREADS / NV));   // s_ego / s_mask hold 64 envs
+    // vehicle-role tile: whole envs, at most 64 of them and at most 1024 records (4 per thread)
+    int E = std::max(1, std::min(eb::ROLLOUT_TILE_ENVS, eb::ROLLOUT_TILE_RECS / NV));
+    {
+        static const int force_e = std::getenv("EB_TILE_ENVS") ? std::atoi(std::getenv("EB_TILE_ENVS")) : 0;   // tuning aid
+        if (force_e >= 1 && force_e <= E) E = force_e;
+    }
+    A.envs_per_tile = E;
+    A.recs_per_thread = (E * NV + eb::ROLLOUT_THREADS - 1) / eb::ROLLOUT_THREADS;
     A.path_id = path_id;
     A.actions_raw = actions_raw;
     A.do_rewards = do_rewards;
@@ -276,9 +299,16 @@ static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const
         static const int ablate = std::getenv("EB_ABLATE") ? std::atoi(std::getenv("EB_ABLATE")) : 0;   // profiling aid
         A.ablate = ablate;
     }
-    std::memcpy(A.turn, h->modes.turn, sizeof A.turn);
     const size_t lds = eb::rollout_lds_bytes(A.red_total_pad);
-    const int grid = A.n_env_blocks + (n_env + A.envs_per_vblock - 1) / A.envs_per_vblock;
+    const int n_tiles = (n_env + E - 1) / E;
+    const int grid = A.n_env_blocks + n_tiles;
+    // the XCD-aware tile order needs whole groups: 256 % E == 0, and a tile count that fills 8 XCDs evenly
+    A.tiles_per_group = eb::ROLLOUT_THREADS / E;
+    A.xcd_remap = (eb::ROLLOUT_THREADS % E == 0) && (n_tiles % (8 * A.tiles_per_group) == 0);
+    {
+        static const int no_remap = std::getenv("EB_NO_XCD_REMAP") ? 1 : 0;   // tuning aid
+        if (no_remap) A.xcd_remap = 0;
+    }
     EB_HIP(eb::launch_rollout(h->cfg.task, A, grid, lds, s));
     return EB_OK;
 }

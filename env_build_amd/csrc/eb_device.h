@@ -252,6 +252,8 @@ struct PathTables {
     int len[3];
     int red_len[3];
     int n_paths;
+    int red_off[3];         // first entry of path k in the concatenated stride-10 table
+    uint8_t turn[64];       // TURN_* per vehicle slot (filled by eb_set_veh_modes)
 };
 
 // path used by row i: ref_idx[i] when given, else path_id; out of range -> -1 (zeros, DAM:342, 352)

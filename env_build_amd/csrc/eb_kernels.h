@@ -8,6 +8,9 @@
 namespace eb {
 
 constexpr int ROLLOUT_THREADS = 256;
+constexpr int ROLLOUT_TILE_ENVS = 64;       // vehicle role: max whole envs per tile
+constexpr int ROLLOUT_TILE_RECS = 1024;     // vehicle role: max records per tile (4 per thread)
+constexpr int EB_MAX_VEH_SLOTS = 64;
 
 struct VehModes {
     uint8_t turn[64];   // TURN_* per slot (predict_for_a_mode, DAM:416-421)
@@ -23,20 +26,21 @@ struct RolloutArgs {
     float* scaled_actions;
     const float2* red_all;     // all paths' stride-10 (x,y) tables, back to back
     const float* rad_all;      // 3 x 32 block radii of the pruned search (closest_index_pruned)
-    PathTables pt;
-    int red_off[3];            // offset of path k inside the staged LDS table (training mode)
+    const PathTables* dt;      // device copy of the handle's tables (pointers, lengths, offsets, slot turns)
     int red_base;              // first entry of red_all to stage
     int red_total;             // entries to stage (all paths in training mode, one path otherwise)
     int red_total_pad;         // rounded up to an even count (16-byte LDS carve)
     int n_env, obs_dim, n_veh, n_future;
     int n_env_blocks;          // blocks [0, n_env_blocks) run the per-env role (256 envs each)
-    int envs_per_vblock;       // whole envs per vehicle-role block: max(1, 256 / n_veh)
+    int envs_per_tile;         // vehicle role: whole envs per tile, <= 64 and envs_per_tile * n_veh <= 1024
+    int recs_per_thread;       // vehicle role: ceil(envs_per_tile * n_veh / 256) <= 4
+    int xcd_remap;             // 1: vehicle tiles are reordered so that a 256-env group stays on one XCD
+    int tiles_per_group;       // vehicle tiles per env-role block (256 / envs_per_tile) when xcd_remap
     unsigned nv_magic;         // ceil(2^32 / n_veh): item / n_veh == umulhi(item, nv_magic)
     int path_id, training;
     int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
     int do_rewards;            // 0: compute_next_obses only
     int ablate;                // profiling aid (EB_ABLATE): 1 skip search, 2 skip vehicle math, 4 skip per-env math
-    uint8_t turn[64];
 };
 
 size_t rollout_lds_bytes(int red_total_pad);

@@ -1,0 +1,75 @@
+// Microbenchmark (profiling aid, not product): what does a plain copy of an obs-sized buffer reach on
+// this GPU?  Variants: aligned float4 grid-stride, 4-byte-misaligned float4, one-load-per-thread.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ void copy_stride(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+template <int U>
+__global__ void copy_stride_u(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * step < n4; i += U * step) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = in[i + u * step];
+#pragma unroll
+        for (int u = 0; u < U; ++u) out[i + u * step] = v[u];
+    }
+    for (; i < n4; i += step) out[i] = in[i];
+}
+__global__ void copy_one(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n4) out[i] = in[i];
+}
+__global__ void copy_misaligned(const float* __restrict__ in, float* __restrict__ out, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        *reinterpret_cast<f4u*>(out + 4 * i + 1) = *reinterpret_cast<const f4u*>(in + 4 * i + 1);
+}
+__global__ void read_only(const float4* __restrict__ in, float* __restrict__ out, size_t n4) {
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) { float4 v = in[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 123.456f) out[0] = acc;
+}
+__global__ void write_only(float4* __restrict__ out, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+int main(int argc, char** argv) {
+    const size_t rows = argc > 1 ? atol(argv[1]) : 65536, D = 137;
+    const size_t n = rows * D, n4 = n / 4, bytes = n * 4;
+    float* buf[3];
+    for (int i = 0; i < 3; ++i) { CK(hipMalloc(&buf[i], bytes + 64)); CK(hipMemset(buf[i], 0, bytes + 64)); }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 500;
+    auto run = [&](const char* name, auto launch, double traffic) {
+        for (int i = 0; i < 20; ++i) launch(i);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) launch(i);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters;
+        printf("%-44s %8.2f us  %7.0f GB/s\n", name, us, traffic / us / 1e3);
+    };
+    // ping-pong like the rollout: step t reads buf[t&1] writes buf[(t+1)&1]
+    for (int grid : {1024, 2048, 4096, 8192}) {
+        char nm[96]; snprintf(nm, 96, "copy grid-stride aligned, grid=%d", grid);
+        run(nm, [&](int i) { hipLaunchKernelGGL(copy_stride, dim3(grid), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    }
+    run("copy unroll4 grid=1024", [&](int i) { hipLaunchKernelGGL(copy_stride_u<4>, dim3(1024), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("copy unroll4 grid=2048", [&](int i) { hipLaunchKernelGGL(copy_stride_u<4>, dim3(2048), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("copy unroll8 grid=1024", [&](int i) { hipLaunchKernelGGL(copy_stride_u<8>, dim3(1024), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("copy one-load-per-thread", [&](int i) { hipLaunchKernelGGL(copy_one, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("copy misaligned(+4B) grid=2048", [&](int i) { hipLaunchKernelGGL(copy_misaligned, dim3(2048), dim3(256), 0, 0, (const float*)buf[i & 1], buf[(i + 1) & 1], n4 - 1); }, 2.0 * bytes);
+    run("read only grid=2048", [&](int i) { hipLaunchKernelGGL(read_only, dim3(2048), dim3(256), 0, 0, (const float4*)buf[i & 1], buf[2], n4); }, 1.0 * bytes);
+    run("write only grid=2048", [&](int i) { hipLaunchKernelGGL(write_only, dim3(2048), dim3(256), 0, 0, (float4*)buf[i & 1], n4); }, 1.0 * bytes);
+    run("copy same src->dst each time grid=2048", [&](int i) { hipLaunchKernelGGL(copy_stride, dim3(2048), dim3(256), 0, 0, (const float4*)buf[0], (float4*)buf[1], n4); }, 2.0 * bytes);
+    return 0;
+}
