@@ -415,6 +415,7 @@ template <int TASK>
 __global__ __launch_bounds__(ROLLOUT_THREADS, 8) void rollout_step_kernel(const RolloutArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x < A.n_env_blocks) {
+        if (A.ablate & 16) return;
         __builtin_amdgcn_s_setprio(3);
         env_role<TASK>(A, smem);
     } else {
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(ROLLOUT_THREADS, 8) void rollout_step_kernel(const 
         // vehicle tiles.  Put both on the same XCD: vehicle block i = x + 8*y takes tile
         // tpg * (x + 8 * (y / tpg)) + y % tpg, i.e. a tile of group G = x (mod 8) — the XCD of env block G.
         int i = (int)blockIdx.x - A.n_env_blocks;
+        if (A.ablate & 8) return;
         if (A.xcd_remap) {
             const int tpg = A.tiles_per_group, x = i & 7, y = i >> 3;
             i = tpg * (x + 8 * (y / tpg)) + y % tpg;
