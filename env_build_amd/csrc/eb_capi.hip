@@ -43,6 +43,8 @@ struct eb_handle_s {
     float* d_tables;          // one allocation: x|y|phi per path, then the stride-10 (x,y) tables
     float2* d_red_all;
     float* d_rad_all;         // 3 x 32 block radii for the pruned closest-point search
+    float* d_phi10_all;       // stride-10 headings, indexed like d_red_all
+    uint32_t* d_cells;        // closest-point cell grid (PathTables::cells)
     double* d_partials;       // SUMMARY_MAX_PARTS x 6 doubles: stage-1 partials of eb_episode_summary
     eb::PathTables* d_pt;     // device copy of pt (+ slot turns) read by the rollout kernel
     int n_cu;                 // compute units of the device (persistent grid size)
@@ -57,6 +59,61 @@ static hipError_t upload_tables(eb_handle_s* h);
 
 static int obs_dim(const eb_config& c) { return 6 + 3 * (c.n_future + 1) + 4 * c.n_veh; }
 static hipStream_t pick(eb_handle, void* stream) { return (hipStream_t)stream; }   // NULL = the HIP null stream
+
+// Closest-point cell grid.  For every 0.5 m cell C of a grid around the paths and every path k, the
+// index range [lo, hi] of the stride-10 table outside of which no point can be the closest one for
+// any position p in C:  with c the cell centre, hd its half diagonal and m = min_r |c - P_r|,
+//   D*(p) <= |p - P_rmin| <= m + hd   and   |p - P_r| >= |c - P_r| - hd,
+// so every r with |c - P_r| > m + 2 hd is strictly farther than the winner; [lo, hi] is the envelope of
+// the others, widened by 0.01 m of slack — three orders of magnitude above the fp32 rounding of the
+// kernel's cell assignment and of its dist^2 values at these coordinates (<= 1e-5 m).  The kernel
+// scans [lo, hi] in index order with the reference's fp32 expression and a strict '<', which is the
+// reference's full-scan argmin (first minimum) restricted to a range that provably contains it.
+static int build_cell_grid(eb_handle_s* h, const float* hred, int n_paths) {
+    const double cell = 1.0 / (double)eb::CELL_INV, margin = 10.0;
+    double x0 = 1e30, x1 = -1e30, y0 = 1e30, y1 = -1e30;
+    for (int k = 0; k < n_paths; ++k) {
+        const float* r = hred + 2 * (size_t)h->red_off[k];
+        for (int i = 0; i < h->pt.red_len[k]; ++i) {
+            if (!std::isfinite(r[2 * i]) || !std::isfinite(r[2 * i + 1])) return fail(EB_EINVAL, "eb_set_paths: non-finite path point");
+            x0 = std::min(x0, (double)r[2 * i]); x1 = std::max(x1, (double)r[2 * i]);
+            y0 = std::min(y0, (double)r[2 * i + 1]); y1 = std::max(y1, (double)r[2 * i + 1]);
+        }
+    }
+    x0 = std::floor(x0 - margin); y0 = std::floor(y0 - margin);
+    int nx = (int)std::ceil((x1 + margin - x0) / cell), ny = (int)std::ceil((y1 + margin - y0) / cell);
+    nx = std::min(nx, 1024); ny = std::min(ny, 1024);   // positions outside the grid take the pruned full search
+    const double hd = cell * std::sqrt(2.0) / 2.0, win = 2.0 * hd + 0.01;
+    std::vector<uint32_t> cells((size_t)n_paths * nx * ny);
+    std::vector<double> d;
+    for (int k = 0; k < n_paths; ++k) {
+        const float* r = hred + 2 * (size_t)h->red_off[k];
+        const int n = h->pt.red_len[k];
+        d.resize(n);
+        for (int iy = 0; iy < ny; ++iy)
+            for (int ix = 0; ix < nx; ++ix) {
+                const double cx = x0 + (ix + 0.5) * cell, cy = y0 + (iy + 0.5) * cell;
+                double m = 1e300;
+                for (int i = 0; i < n; ++i) {
+                    const double dx = cx - (double)r[2 * i], dy = cy - (double)r[2 * i + 1];
+                    d[i] = dx * dx + dy * dy;
+                    m = std::min(m, d[i]);
+                }
+                const double lim = (std::sqrt(m) + win) * (std::sqrt(m) + win);
+                int lo = 0, hi = n - 1;
+                while (d[lo] > lim) ++lo;
+                while (d[hi] > lim) --hi;
+                cells[((size_t)k * ny + iy) * nx + ix] = (uint32_t)lo | ((uint32_t)hi << 16);
+            }
+    }
+    if (h->d_cells) { hipFree(h->d_cells); h->d_cells = nullptr; }
+    EB_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_cells), cells.size() * sizeof(uint32_t)));
+    EB_HIP(hipMemcpy(h->d_cells, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->pt.cells = h->d_cells;
+    h->pt.gx0 = (float)x0; h->pt.gy0 = (float)y0;   // integers: exact in fp32
+    h->pt.gnx = nx; h->pt.gny = ny;
+    return EB_OK;
+}
 
 static hipError_t upload_tables(eb_handle_s* h) {
     for (int k = 0; k < 3; ++k) h->pt.red_off[k] = h->red_off[k];
@@ -106,6 +163,7 @@ int eb_destroy(eb_handle h) {
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
     if (h->d_tables) hipFree(h->d_tables);
+    if (h->d_cells) hipFree(h->d_cells);
     if (h->d_partials) hipFree(h->d_partials);
     if (h->d_pt) hipFree(h->d_pt);
     delete h;
@@ -132,7 +190,7 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     for (int k = 0; k < n_paths; ++k)
         if ((lens[k] + 9) / 10 > 512) return fail(EB_EINVAL, "eb_set_paths: path longer than 5120 points (32 search blocks)");
     // host staging: [x | y | phi] full resolution, then float2 stride-10 tables
-    std::vector<float> host(3 * total + 2 * red_total + 4 + 96 + 8);
+    std::vector<float> host(3 * total + 2 * red_total + 4 + 96 + 8 + red_total + 8 + 8, 0.0f);
     float* hx = host.data();
     float* hy = hx + total;
     float* hp = hy + total;
@@ -172,11 +230,21 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
             hrad[32 * k + b] = (float)(std::sqrt(r2) * (1.0 + 1e-6) + 1e-4);
         }
     }
-    const size_t bytes = rad_byte_off + 96 * sizeof(float);
+    // stride-10 headings (phi of the point the search returns), same indexing as the (x, y) table; both
+    // tables are readable 4 entries past their end (the range scan loads 4 points at a time)
+    const size_t phi10_byte_off = rad_byte_off + 96 * sizeof(float);
+    float* hphi10 = reinterpret_cast<float*>(reinterpret_cast<char*>(host.data()) + phi10_byte_off);
+    off = 0; roff = 0;
+    for (int k = 0; k < n_paths; ++k) {
+        for (int i = 0; i < lens[k]; i += 10) hphi10[roff++] = phis[off + i];
+        off += (size_t)lens[k];
+    }
+    const size_t bytes = phi10_byte_off + (red_total + 8) * sizeof(float);
     EB_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tables), bytes));
     EB_HIP(hipMemcpy(h->d_tables, host.data(), bytes, hipMemcpyHostToDevice));
     h->d_red_all = reinterpret_cast<float2*>(reinterpret_cast<char*>(h->d_tables) + red_byte_off);
     h->d_rad_all = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_tables) + rad_byte_off);
+    h->d_phi10_all = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_tables) + phi10_byte_off);
     std::memset(&h->pt, 0, sizeof h->pt);
     off = 0;
     for (int k = 0; k < n_paths; ++k) {
@@ -190,6 +258,8 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     }
     h->pt.n_paths = n_paths;
     h->red_total = (int)red_total;
+    int rc = build_cell_grid(h, hred, n_paths);
+    if (rc) return rc;
     EB_HIP(upload_tables(h));
     return EB_OK;
 }
@@ -261,9 +331,47 @@ int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float
     return EB_OK;
 }
 
+static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* obs_in, const float* actions,
+                         const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
+                         float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s) {
+    const int NV = h->cfg.n_veh;
+    eb::FusedArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.obs_in = obs_in; A.actions = actions; A.ref_idx = ref_idx; A.obs_out = obs_out; A.out5 = out5;
+    A.scaled_actions = scaled_actions;
+    A.dt = h->d_pt;
+    A.xy10 = reinterpret_cast<const float*>(h->d_red_all);
+    A.phi10 = h->d_phi10_all;
+    A.rad_all = h->d_rad_all;
+    A.cells = h->d_cells;
+    A.gx0 = h->pt.gx0; A.gy0 = h->pt.gy0; A.gnx = h->pt.gnx; A.gny = h->pt.gny;
+    for (int k = 0; k < 3; ++k) { A.red_off[k] = h->red_off[k]; A.red_len[k] = h->pt.red_len[k]; }
+    A.n_paths = h->pt.n_paths;
+    A.n_env = n_env; A.obs_dim = obs_dim(h->cfg); A.n_veh = NV; A.n_future = h->cfg.n_future;
+    A.nv_magic = (unsigned)((0x100000000ull + (unsigned)NV - 1) / (unsigned)NV);
+    A.envs_per_tile = std::max(1, std::min(64, eb::fused_tile_records(variant) / NV));
+    A.path_id = path_id;
+    A.training = h->cfg.mode == EB_MODE_TRAINING;
+    A.actions_raw = actions_raw;
+    A.do_rewards = do_rewards;
+    {
+        static const int ablate = std::getenv("EB_ABLATE") ? std::atoi(std::getenv("EB_ABLATE")) : 0;   // profiling aid
+        A.ablate = ablate;
+    }
+    const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
+    EB_HIP(eb::launch_rollout_fused(h->cfg.task, variant, A, grid, s));
+    return EB_OK;
+}
+
 static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                           float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s) {
+    {
+        static const int variant = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : 0;   // tuning aid: -1 = two-role kernel
+        if (variant >= 0)
+            return rollout_fused(h, variant, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
+                                 actions_raw, do_rewards, s);
+    }
     const int NV = h->cfg.n_veh;
     eb::RolloutArgs A;
     std::memset(&A, 0, sizeof A);

@@ -7,7 +7,7 @@
 //
 // sin/cos/atan are branch-light Cephes-scheme fp32 kernels (3-term Cody-Waite + minimax
 // polynomials, <= 2 ulp): cheaper than ocml's large-argument paths, and — because they use only
-// IEEE add/mul/div/rint — reproducible bit-for-bit by the CPU oracle.
+// IEEE add/mul/div/fma/rint — reproducible bit-for-bit by the CPU oracle.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,22 +64,23 @@ EB_DEV float deg2rad(float d) { return div_const<C180>(d * PI_F); }  // x * np.p
 EB_DEV float rad2deg(float r) { return div_const<CPi>(r * 180.0f); } // x * 180 / np.pi   (DAM:81)
 
 EB_DEV void sincos_det(float x, float& s_out, float& c_out) {
-    float kf = __builtin_rintf(x * 0.636619747f);
-    int k = (int)kf;
-    float r = x - kf * 1.5703125f;
-    r = r - kf * 4.83751296997070312e-4f;
-    r = r - kf * 7.54978995489188216e-8f;
-    float z = r * r;
-    float ps = -1.9515295891e-4f;
-    ps = ps * z + 8.3321608736e-3f;
-    ps = ps * z - 1.6666654611e-1f;
-    float s = r + r * z * ps;
-    float pc = 2.443315711809948e-5f;
-    pc = pc * z - 1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    float c = 1.0f - 0.5f * z + z * z * pc;
-    float a = (k & 1) ? c : s;
-    float b = (k & 1) ? -s : c;
+    // k = nearest integer to x / (pi/2); r = x - k*pi/2 by 3-term Cody-Waite with fused steps;
+    // minimax polynomials on |r| <= pi/4 in Horner form with fused multiply-adds.  fmaf is correctly
+    // rounded on both sides, so oracle/envbuild_oracle.c:eb_sincosf reproduces every bit.
+    const float kf = __builtin_rintf(x * 0.636619747f);
+    const int k = (int)kf;
+    float r = __builtin_fmaf(-kf, 1.5703125f, x);
+    r = __builtin_fmaf(-kf, 4.83751296997070312e-4f, r);
+    r = __builtin_fmaf(-kf, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    const float a = (k & 1) ? c : s;
+    const float b = (k & 1) ? -s : c;
     s_out = (k & 2) ? -a : a;
     c_out = (k & 2) ? -b : b;
 }
@@ -254,13 +255,96 @@ struct PathTables {
     int n_paths;
     int red_off[3];         // first entry of path k in the concatenated stride-10 table
     uint8_t turn[64];       // TURN_* per vehicle slot (filled by eb_set_veh_modes)
+    // closest-point cell grid (one geometry for all paths of the handle): cell (ix, iy) of path k at
+    // cells[(k * gny + iy) * gnx + ix] = lo | hi << 16 — the stride-10 index range that holds the
+    // closest table point of EVERY position inside the 0.5 m cell (built by eb_set_paths)
+    const uint32_t* cells;
+    float gx0, gy0;         // lower-left corner of the grid
+    int gnx, gny;
 };
+constexpr float CELL_INV = 2.0f;   // 1 / cell size (0.5 m): exact in fp32
 
 // path used by row i: ref_idx[i] when given, else path_id; out of range -> -1 (zeros, DAM:342, 352)
 EB_DEV int row_path(const PathTables& pt, const int* ref_idx, int path_id, int i) {
     const int p = ref_idx ? ref_idx[i] : path_id;
     return (p >= 0 && p < pt.n_paths) ? p : -1;
 }
+
+// ---- closest point, one lane per env ---------------------------------------------------------------
+// EXACTLY the index the reference's full scan + argmin returns (DAM:702-715) while visiting ~1/5 of
+// the table.  The stride-10 table is cut into blocks of 16 consecutive points; for block b the host
+// stored a radius R_b >= max_r |P_r - c_b| around the block's centre point c_b = P_min(16b+8, n-1).
+//   1. M = min_b |p - c_b|  (every c_b is itself a table point, so the true minimum D* <= M);
+//   2. block b can hold a point with |p - P_r| <= M only if |p - c_b| - R_b <= M; blocks failing
+//      |p - c_b| <= M + R_b + 0.01 are skipped — the 0.01 m slack is ~100x the fp32 rounding of
+//      these distances, so every skipped point's fp32 dist^2 is strictly above the winner's;
+//   3. the surviving blocks are scanned in index order with the reference's fp32 expression and a
+//      strict '<' (first minimum).
+// NaN / inf coordinates end with index 0, as the full scan does.
+EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, float px, float py) {
+    const int nb = (n + 15) >> 4;
+    float m2 = __builtin_inff();
+    for (int b = 0; b < nb; ++b) {
+        const float2 q = red[min(16 * b + 8, n - 1)];
+        m2 = __builtin_fminf(m2, sq(px - q.x) + sq(py - q.y));
+    }
+    const float m = __builtin_amdgcn_sqrtf(m2);   // approximate is enough: only feeds the slack test
+    unsigned cand = 0u;
+    for (int b = 0; b < nb; ++b) {
+        const float2 q = red[min(16 * b + 8, n - 1)];
+        const float d2 = sq(px - q.x) + sq(py - q.y);
+        const float thr = m + rad[b] + 0.01f;
+        cand |= (d2 <= thr * thr) ? (1u << b) : 0u;
+    }
+    float best = __builtin_inff();
+    int bi = 0;
+    while (cand) {
+        const int b = __builtin_ctz(cand);
+        cand &= cand - 1u;
+        const int r1 = min(16 * b + 16, n);
+        for (int r = 16 * b; r < r1; ++r) {
+            const float2 t = red[r];
+            const float d = sq(px - t.x) + sq(py - t.y);   // DAM:712
+            if (d < best) { best = d; bi = r; }             // first minimum, DAM:714
+        }
+    }
+    return bi;
+}
+
+// predict_for_a_mode (DAM:405-427) with the slot's turn divisor taken from a table: tc = (c, 1/c,
+// sign, enabled) = (26.875, ., +1, 1) for dl rd ur lu, (15.625, ., -1, 1) for dr ru ul ld, (1, 1, 0, 0)
+// otherwise.  EXACT = false uses the 3-op exact constant divisions and reports through `tiny`
+// whether any dividend was a non-zero magnitude below 2^-101 (where only the true division is
+// exact); EXACT = true is the same arithmetic with IEEE divisions.  sn / cs return sin / cos of the
+// record's CURRENT heading (also the circle-centre offsets of DAM:221-224).
+template <bool EXACT>
+EB_DEV float4 predict_record(float x, float y, float v, float phi, const float4 tc, unsigned& tiny, float& sn,
+                             float& cs) {
+    const float t1 = phi * PI_F;
+    const float phi_rad = EXACT ? t1 / 180.0f : div_fast(t1, 180.0f, 1.0f / 180.0f);   // DAM:407
+    sincos_det(phi_rad, sn, cs);
+    const bool middle = (x > -HALF_CROSS && x < HALF_CROSS) && (y > -HALF_CROSS && y < HALF_CROSS);   // DAM:409-410
+    const float v10 = EXACT ? v / 10.0f : div_fast(v, 10.0f, 1.0f / 10.0f);
+    const float dx = v10 * cs, dy = v10 * sn;                                            // DAM:413-414
+    const float u = (EXACT ? v / tc.x : div_fast(v, tc.x, tc.y)) * tc.z;                 // +-(v / radius)
+    const float u10 = EXACT ? u / 10.0f : div_fast(u, 10.0f, 1.0f / 10.0f);
+    const float dphi = (middle && tc.w != 0.0f) ? u10 : 0.0f;                            // DAM:416-421
+    float nphi = phi_rad + dphi;                                                         // DAM:423
+    if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                             // DAM:424
+    if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                                           // DAM:425
+    const float t2 = nphi * 180.0f;
+    const float nphi_deg = EXACT ? t2 / PI_F : div_fast(t2, PI_F, 1.0f / PI_F);          // DAM:426
+    if (!EXACT) {
+        // non-zero and below 2^-101 <=> (bits << 1) - 1 < 2 * 0x0D000000 - 1 (unsigned)
+        const unsigned a = (__builtin_bit_cast(unsigned, t1) << 1) - 1u;
+        const unsigned b = (__builtin_bit_cast(unsigned, v) << 1) - 1u;
+        const unsigned c = (__builtin_bit_cast(unsigned, t2) << 1) - 1u;
+        const unsigned d = (__builtin_bit_cast(unsigned, u) << 1) - 1u;
+        tiny = min(min(a, b), min(c, d)) < 2u * 0x0D000000u - 1u;
+    }
+    return make_float4(x + dx, y + dy, v, nphi_deg);                                     // DAM:422-427
+}
+
 
 EB_DEV float wrap_deal_with_phi(float phi) {  // UTL:232-237
     while (phi > 180.0f) phi -= 360.0f;

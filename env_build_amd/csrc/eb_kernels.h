@@ -43,6 +43,34 @@ struct RolloutArgs {
     int ablate;                // profiling aid (EB_ABLATE): 1 skip search, 2 skip vehicle math, 4 skip per-env math
 };
 
+// ---- fused rollout step (eb_rollout.hip): one block = one env wave + RW record waves ----
+struct FusedArgs {
+    const float* obs_in;
+    const float* actions;
+    const int* ref_idx;
+    float* obs_out;
+    float* out5;
+    float* scaled_actions;
+    const PathTables* dt;      // full tables (look-ahead points when n_future > 0) and the slot turns
+    const float* xy10;         // all paths' stride-10 (x, y) pairs back to back, readable 4 entries past the end
+    const float* phi10;        // their headings, same indexing
+    const float* rad_all;      // 3 x 32 block radii of the pruned search (positions outside the cell grid)
+    const uint32_t* cells;     // closest-point cell grid, PathTables::cells
+    float gx0, gy0;
+    int gnx, gny;
+    int red_off[3], red_len[3], n_paths;
+    int n_env, obs_dim, n_veh, n_future;
+    int envs_per_tile;         // whole envs per block: <= 64 and envs_per_tile * n_veh <= RW * 64 * RPT
+    unsigned nv_magic;         // ceil(2^32 / n_veh): item / n_veh == umulhi(item, nv_magic)
+    int path_id, training;
+    int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
+    int do_rewards;            // 0: compute_next_obses only
+    int ablate;                // profiling aid (EB_ABLATE)
+};
+// variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 3 x 6 (1152), 2 = 4 x 4 (1024)
+int fused_tile_records(int variant);
+hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s);
+
 size_t rollout_lds_bytes(int red_total_pad);
 hipError_t launch_rollout(int task, const RolloutArgs& A, int grid, size_t lds, hipStream_t s);
 hipError_t launch_f_xu(int n, const float* st, const float* ac, float tau, float* nx, float* pr, hipStream_t s);

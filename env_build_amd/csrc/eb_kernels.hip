@@ -81,43 +81,30 @@ EB_DEV void tracking_from_index(const PathTables& pt, int p, int idx, float ex, 
 //      four penalty outputs.
 // HBM-bound; no MFMA (nothing here is a dense contraction).
 
-// ---- closest point, one lane per env ---------------------------------------------------------------
-// EXACTLY the index the reference's full scan + argmin returns (DAM:702-715) while visiting ~1/5 of
-// the table.  The stride-10 table is cut into blocks of 16 consecutive points; for block b the host
-// stored a radius R_b >= max_r |P_r - c_b| around the block's centre point c_b = P_min(16b+8, n-1).
-//   1. M = min_b |p - c_b|  (every c_b is itself a table point, so the true minimum D* <= M);
-//   2. block b can hold a point with |p - P_r| <= M only if |p - c_b| - R_b <= M; blocks failing
-//      |p - c_b| <= M + R_b + 0.01 are skipped — the 0.01 m slack is ~100x the fp32 rounding of
-//      these distances, so every skipped point's fp32 dist^2 is strictly above the winner's;
-//   3. the surviving blocks are scanned in index order with the reference's fp32 expression and a
-//      strict '<' (first minimum).
-// NaN / inf coordinates end with index 0, as the full scan does.
-EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, float px, float py) {
-    const int nb = (n + 15) >> 4;
-    float m2 = __builtin_inff();
-    for (int b = 0; b < nb; ++b) {
-        const float2 q = red[min(16 * b + 8, n - 1)];
-        m2 = __builtin_fminf(m2, sq(px - q.x) + sq(py - q.y));
-    }
-    const float m = __builtin_amdgcn_sqrtf(m2);   // approximate is enough: only feeds the slack test
-    unsigned cand = 0u;
-    for (int b = 0; b < nb; ++b) {
-        const float2 q = red[min(16 * b + 8, n - 1)];
-        const float d2 = sq(px - q.x) + sq(py - q.y);
-        const float thr = m + rad[b] + 0.01f;
-        cand |= (d2 <= thr * thr) ? (1u << b) : 0u;
-    }
+// ---- closest point through the cell grid (PathTables::cells) --------------------------------------
+// The cell of (px, py) names the index range [lo, hi] that holds the reference's argmin for every
+// position in the cell (eb_capi.hip:build_cell_grid); scanning it in index order with the reference's
+// fp32 expression and a strict '<' returns the index of the full scan (DAM:702-715) after ~6-10
+// evaluations instead of ~370.  Positions outside the grid (or NaN) take closest_reduced_index.
+// `red` must be readable up to 3 entries past hi (the staged table is padded).
+EB_DEV int closest_cell_index(const PathTables& pt, int p, const float2* red, const float* rad, int n,
+                              float px, float py) {
+    const float fx = (px - pt.gx0) * CELL_INV, fy = (py - pt.gy0) * CELL_INV;
+    const int nx = pt.gnx, ny = pt.gny;
+    if (!(fx >= 0.0f && fx < (float)nx && fy >= 0.0f && fy < (float)ny))
+        return closest_reduced_index(red, rad, n, px, py);
+    const unsigned c = pt.cells[(p * ny + (int)fy) * nx + (int)fx];
+    const int lo = (int)(c & 0xffffu), hi = (int)(c >> 16);
     float best = __builtin_inff();
-    int bi = 0;
-    while (cand) {
-        const int b = __builtin_ctz(cand);
-        cand &= cand - 1u;
-        const int r1 = min(16 * b + 16, n);
-        for (int r = 16 * b; r < r1; ++r) {
-            const float2 t = red[r];
-            const float d = sq(px - t.x) + sq(py - t.y);   // DAM:712
-            if (d < best) { best = d; bi = r; }             // first minimum, DAM:714
-        }
+    int bi = 0;   // all-NaN distances keep index 0, as the full scan does
+    for (int r = lo; r <= hi; r += 4) {
+        const float2 q0 = red[r], q1 = red[r + 1], q2 = red[r + 2], q3 = red[r + 3];
+        const float d0 = sq(px - q0.x) + sq(py - q0.y), d1 = sq(px - q1.x) + sq(py - q1.y);   // DAM:712
+        const float d2 = sq(px - q2.x) + sq(py - q2.y), d3 = sq(px - q3.x) + sq(py - q3.y);
+        if (d0 < best) { best = d0; bi = r; }                                                   // first minimum, DAM:714
+        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; }
+        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; }
+        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; }
     }
     return bi;
 }
@@ -133,7 +120,7 @@ EB_DEV void env_role(const RolloutArgs& A, unsigned char* smem) {
     const int D = A.obs_dim;
     const int T = 3 * (A.n_future + 1);
     float2* s_red = reinterpret_cast<float2*>(smem);                       // red_total_pad entries
-    float* s_rad = reinterpret_cast<float*>(s_red + A.red_total_pad);      // 3 x 32 block radii
+    float* s_rad = reinterpret_cast<float*>(s_red + A.red_total_pad + 4);  // 3 x 32 block radii (4 pad entries before)
     float* s_head = s_rad + 96;                                            // 256 x 9 head words
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * ENVS_PER_EBLOCK;
@@ -168,6 +155,7 @@ EB_DEV void env_role(const RolloutArgs& A, unsigned char* smem) {
             }
         }
         if (tid < 96) s_rad[tid] = A.rad_all[tid];
+        if (tid < 4) s_red[A.red_total_pad + tid] = make_float2(0.0f, 0.0f);   // read (masked) by the 4-wide range scan
 #pragma unroll
         for (int u = 0; u < 9; ++u) s_head[tid + u * RT] = hv[u];
     }
@@ -206,7 +194,7 @@ EB_DEV void env_role(const RolloutArgs& A, unsigned char* smem) {
         float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
         if (p >= 0) {
             const float2* red = s_red + (A.training ? A.dt->red_off[p] : 0);
-            const int bi = (A.ablate & 1) ? 0 : closest_reduced_index(red, s_rad + 32 * p, A.dt->red_len[p], nx[3], nx[4]);
+            const int bi = (A.ablate & 1) ? 0 : closest_cell_index(*A.dt, p, red, s_rad + 32 * p, A.dt->red_len[p], nx[3], nx[4]);
             const int idx = bi * 10;                                        // DAM:714
             const float2 r = red[bi];                                       // == path[idx]: idx < len always
             const float rphi = A.dt->phi[p][idx];
@@ -240,40 +228,6 @@ EB_DEV void env_role(const RolloutArgs& A, unsigned char* smem) {
         if (i < nE * 9) tout[e * D + c] = s_head[i];
     }
 }
-
-// predict_for_a_mode (DAM:405-427) with the slot's turn divisor taken from a table: tc = (c, 1/c,
-// sign, enabled) = (26.875, ., +1, 1) for dl rd ur lu, (15.625, ., -1, 1) for dr ru ul ld, (1, 1, 0, 0)
-// otherwise.  EXACT = false uses the 3-op exact constant divisions and reports through `tiny`
-// whether any dividend was a non-zero magnitude below 2^-101 (where only the true division is
-// exact); EXACT = true is the same arithmetic with IEEE divisions.
-template <bool EXACT>
-EB_DEV float4 predict_record(float x, float y, float v, float phi, const float4 tc, unsigned& tiny) {
-    const float t1 = phi * PI_F;
-    const float phi_rad = EXACT ? t1 / 180.0f : div_fast(t1, 180.0f, 1.0f / 180.0f);   // DAM:407
-    float sn, cs;
-    sincos_det(phi_rad, sn, cs);
-    const bool middle = (x > -HALF_CROSS && x < HALF_CROSS) && (y > -HALF_CROSS && y < HALF_CROSS);   // DAM:409-410
-    const float v10 = EXACT ? v / 10.0f : div_fast(v, 10.0f, 1.0f / 10.0f);
-    const float dx = v10 * cs, dy = v10 * sn;                                            // DAM:413-414
-    const float u = (EXACT ? v / tc.x : div_fast(v, tc.x, tc.y)) * tc.z;                 // +-(v / radius)
-    const float u10 = EXACT ? u / 10.0f : div_fast(u, 10.0f, 1.0f / 10.0f);
-    const float dphi = (middle && tc.w != 0.0f) ? u10 : 0.0f;                            // DAM:416-421
-    float nphi = phi_rad + dphi;                                                         // DAM:423
-    if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                             // DAM:424
-    if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                                           // DAM:425
-    const float t2 = nphi * 180.0f;
-    const float nphi_deg = EXACT ? t2 / PI_F : div_fast(t2, PI_F, 1.0f / PI_F);          // DAM:426
-    if (!EXACT) {
-        // non-zero and below 2^-101 <=> (bits << 1) - 1 < 2 * 0x0D000000 - 1 (unsigned)
-        const unsigned a = (__builtin_bit_cast(unsigned, t1) << 1) - 1u;
-        const unsigned b = (__builtin_bit_cast(unsigned, v) << 1) - 1u;
-        const unsigned c = (__builtin_bit_cast(unsigned, t2) << 1) - 1u;
-        const unsigned d = (__builtin_bit_cast(unsigned, u) << 1) - 1u;
-        tiny = min(min(a, b), min(c, d)) < 2u * 0x0D000000u - 1u;
-    }
-    return make_float4(x + dx, y + dy, v, nphi_deg);                                     // DAM:422-427
-}
-
 
 // LDS of a vehicle-role block (fixed offsets, all multiples of 16)
 struct VehSmem {
@@ -352,8 +306,9 @@ EB_DEV void veh_role(const RolloutArgs& A, unsigned char* smem, int tile) {
                                 : t == TURN_RIGHT ? make_float4(15.625f, 1.0f / 15.625f, -1.0f, 1.0f)
                                                   : make_float4(1.0f, 1.0f, 0.0f, 0.0f);
                 unsigned tiny = 0u;
-                float4 nv = predict_record<false>(rec[k].x, rec[k].y, rec[k].z, rec[k].w, tc, tiny);
-                if (__builtin_expect(tiny != 0u, 0)) nv = predict_record<true>(rec[k].x, rec[k].y, rec[k].z, rec[k].w, tc, tiny);
+                float psn, pcs;
+                float4 nv = predict_record<false>(rec[k].x, rec[k].y, rec[k].z, rec[k].w, tc, tiny, psn, pcs);
+                if (__builtin_expect(tiny != 0u, 0)) nv = predict_record<true>(rec[k].x, rec[k].y, rec[k].z, rec[k].w, tc, tiny, psn, pcs);
                 f4u o;
                 o.x = nv.x; o.y = nv.y; o.z = nv.z; o.w = nv.w;
                 *reinterpret_cast<f4u*>(tout + off) = o;
@@ -434,7 +389,7 @@ __global__ __launch_bounds__(ROLLOUT_THREADS, 8) void rollout_step_kernel(const 
 }
 
 size_t rollout_lds_bytes(int red_total_pad) {
-    const size_t env = (size_t)red_total_pad * 8 + 96 * 4 + (size_t)RT * 9 * 4;
+    const size_t env = (size_t)(red_total_pad + 4) * 8 + 96 * 4 + (size_t)RT * 9 * 4;
     const size_t veh = VehSmem::BYTES;
     return env > veh ? env : veh;
 }

@@ -17,8 +17,8 @@
  * uses rtol 1e-5 (+ a stated atol) rather than bit equality.
  *
  * Deliberate choices (all documented in DESIGN.md):
- *  - sin/cos/atan are the deterministic Cephes-style fp32 kernels below (only IEEE + - * / and
- *    rint), NOT libm, so the HIP kernels can reproduce them bit-for-bit.
+ *  - sin/cos/atan are the deterministic Cephes-style fp32 kernels below (only IEEE + - * / fma
+ *    and rint), NOT libm's, so the HIP kernels can reproduce them bit-for-bit.
  *  - python-float constants are rounded to fp32 at the op where they meet a tensor, in the
  *    reference's evaluation order.
  */
@@ -63,22 +63,21 @@ static const float EXP_V = 8.0f;                    /* EXPECTED_V, UTL:18 */
 /* deterministic fp32 transcendental kernels (Cephes single-precision scheme)                  */
 /* ------------------------------------------------------------------------------------------ */
 static void eb_sincosf(float x, float* s_out, float* c_out) {
-    /* k = nearest integer to x / (pi/2); r = x - k*pi/2 by 3-term Cody-Waite (exact products
-     * for |k| < 2^12); minimax polynomials on |r| <= pi/4. */
+    /* k = nearest integer to x / (pi/2); r = x - k*pi/2 by 3-term Cody-Waite with fused steps;
+     * minimax polynomials on |r| <= pi/4, Horner with explicit fmaf (correctly rounded with or
+     * without hardware FMA, so the HIP kernels' v_fma_f32 sequence gives the same bits). */
     float kf = nearbyintf(x * 0.636619747f);
     int k = (int)kf;
-    float r = x - kf * 1.5703125f;
-    r = r - kf * 4.83751296997070312e-4f;
-    r = r - kf * 7.54978995489188216e-8f;
+    float r = fmaf(-kf, 1.5703125f, x);
+    r = fmaf(-kf, 4.83751296997070312e-4f, r);
+    r = fmaf(-kf, 7.54978995489188216e-8f, r);
     float z = r * r;
-    float ps = -1.9515295891e-4f;
-    ps = ps * z + 8.3321608736e-3f;
-    ps = ps * z - 1.6666654611e-1f;
-    float s = r + r * z * ps;
-    float pc = 2.443315711809948e-5f;
-    pc = pc * z - 1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    float c = 1.0f - 0.5f * z + z * z * pc;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float s = fmaf(r * z, ps, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
     switch (k & 3) {
         case 0: *s_out = s; *c_out = c; break;
         case 1: *s_out = c; *c_out = -s; break;
