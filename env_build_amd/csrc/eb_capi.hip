@@ -52,6 +52,8 @@ struct eb_handle_s {
     int red_total;
     eb::VehModes modes;
     int modes_set;
+    long long* trace;         // profiling aid, see eb_debug_set_trace
+    int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
 };
 
 // the kernel-visible copy of the tables: refreshed whenever paths or slot modes change
@@ -144,6 +146,7 @@ int eb_create(const eb_config* cfg, eb_handle* out) {
     if (!h) return fail(EB_ENOMEM, "eb_create: out of memory");
     std::memset(h, 0, sizeof *h);
     h->cfg = *cfg;
+    h->tile_variant = -1;
     {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, cfg->device);
@@ -358,6 +361,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         static const int ablate = std::getenv("EB_ABLATE") ? std::atoi(std::getenv("EB_ABLATE")) : 0;   // profiling aid
         A.ablate = ablate;
     }
+    A.trace = h->trace;
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
     EB_HIP(eb::launch_rollout_fused(h->cfg.task, variant, A, grid, s));
     return EB_OK;
@@ -366,59 +370,18 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
 static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                           float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s) {
-    {
-        static const int variant = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : 0;   // tuning aid: -1 = two-role kernel
-        if (variant >= 0)
-            return rollout_fused(h, variant, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
-                                 actions_raw, do_rewards, s);
+    static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
+    int variant = h->tile_variant >= 0 ? h->tile_variant : forced;
+    if (variant < 0 || variant > 2) {
+        // the largest tile that still gives every CU two blocks; small batches take small tiles
+        variant = 2;
+        for (int v = 0; v < 2; ++v) {
+            const int e = std::max(1, std::min(64, eb::fused_tile_records(v) / h->cfg.n_veh));
+            if ((n_env + e - 1) / e >= 2 * h->n_cu) { variant = v; break; }
+        }
     }
-    const int NV = h->cfg.n_veh;
-    eb::RolloutArgs A;
-    std::memset(&A, 0, sizeof A);
-    A.obs_in = obs_in; A.actions = actions; A.ref_idx = ref_idx; A.obs_out = obs_out; A.out5 = out5;
-    A.scaled_actions = scaled_actions;
-    A.red_all = h->d_red_all;
-    A.dt = h->d_pt;
-    A.training = h->cfg.mode == EB_MODE_TRAINING;
-    if (A.training) {
-        A.red_base = 0;
-        A.red_total = h->red_total;
-    } else {
-        A.red_base = h->red_off[path_id];
-        A.red_total = h->pt.red_len[path_id];
-    }
-    A.red_total_pad = (A.red_total + 1) & ~1;
-    A.n_env = n_env; A.obs_dim = obs_dim(h->cfg); A.n_veh = NV; A.n_future = h->cfg.n_future;
-    A.nv_magic = (unsigned)((0x100000000ull + (unsigned)NV - 1) / (unsigned)NV);
-    A.rad_all = h->d_rad_all;
-    A.n_env_blocks = (n_env + eb::ROLLOUT_THREADS - 1) / eb::ROLLOUT_THREADS;
-    // vehicle-role tile: whole envs, at most 64 of them and at most 1024 records (4 per thread)
-    int E = std::max(1, std::min(eb::ROLLOUT_TILE_ENVS, eb::ROLLOUT_TILE_RECS / NV));
-    {
-        static const int force_e = std::getenv("EB_TILE_ENVS") ? std::atoi(std::getenv("EB_TILE_ENVS")) : 0;   // tuning aid
-        if (force_e >= 1 && force_e <= E) E = force_e;
-    }
-    A.envs_per_tile = E;
-    A.recs_per_thread = (E * NV + eb::ROLLOUT_THREADS - 1) / eb::ROLLOUT_THREADS;
-    A.path_id = path_id;
-    A.actions_raw = actions_raw;
-    A.do_rewards = do_rewards;
-    {
-        static const int ablate = std::getenv("EB_ABLATE") ? std::atoi(std::getenv("EB_ABLATE")) : 0;   // profiling aid
-        A.ablate = ablate;
-    }
-    const size_t lds = eb::rollout_lds_bytes(A.red_total_pad);
-    const int n_tiles = (n_env + E - 1) / E;
-    const int grid = A.n_env_blocks + n_tiles;
-    // the XCD-aware tile order needs whole groups: 256 % E == 0, and a tile count that fills 8 XCDs evenly
-    A.tiles_per_group = eb::ROLLOUT_THREADS / E;
-    A.xcd_remap = (eb::ROLLOUT_THREADS % E == 0) && (n_tiles % (8 * A.tiles_per_group) == 0);
-    {
-        static const int no_remap = std::getenv("EB_NO_XCD_REMAP") ? 1 : 0;   // tuning aid
-        if (no_remap) A.xcd_remap = 0;
-    }
-    EB_HIP(eb::launch_rollout(h->cfg.task, A, grid, lds, s));
-    return EB_OK;
+    return rollout_fused(h, variant, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
+                         actions_raw, do_rewards, s);
 }
 
 int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
@@ -555,6 +518,23 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
     EB_HIP(hipSetDevice(h->cfg.device));
     EB_HIP(eb::launch_judge_done(h->cfg.task, n_env, obs_dim(h->cfg), ego, params, obs, m_cand, cand, cand_mode,
                                  cand_lw, v_light, done_code, pick(h, stream)));
+    return EB_OK;
+}
+
+// Profiling aid (not part of include/envbuild.h): device buffer of [n_waves][8] int64 that the rollout kernel
+// fills with per-wave wall-clock marks (100 MHz) — scripts/trace_rollout.py.  NULL switches it off.
+int eb_debug_set_trace(eb_handle h, long long* device_buf) {
+    if (!h) return fail(EB_EINVAL, "eb_debug_set_trace: null handle");
+    h->trace = device_buf;
+    return EB_OK;
+}
+
+// Test / tuning aid (not part of include/envbuild.h): force the rollout kernel's tile shape — 0: 2048-record
+// tiles (4 record waves x 8 records per lane), 1: 1024 (4 x 4), 2: 256 (1 x 4); -1: pick by batch size.
+// Every shape computes the same bits; the tests run all of them at small sizes.
+int eb_debug_set_tile(eb_handle h, int variant) {
+    if (!h || variant < -1 || variant > 2) return fail(EB_EINVAL, "eb_debug_set_tile: bad argument");
+    h->tile_variant = variant;
     return EB_OK;
 }
 

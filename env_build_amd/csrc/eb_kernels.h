@@ -7,40 +7,11 @@
 
 namespace eb {
 
-constexpr int ROLLOUT_THREADS = 256;
-constexpr int ROLLOUT_TILE_ENVS = 64;       // vehicle role: max whole envs per tile
-constexpr int ROLLOUT_TILE_RECS = 1024;     // vehicle role: max records per tile (4 per thread)
 constexpr int EB_MAX_VEH_SLOTS = 64;
 
 struct VehModes {
     uint8_t turn[64];   // TURN_* per slot (predict_for_a_mode, DAM:416-421)
     uint8_t mode[64];   // EB_VMODE_* per slot
-};
-
-struct RolloutArgs {
-    const float* obs_in;
-    const float* actions;
-    const int* ref_idx;
-    float* obs_out;
-    float* out5;
-    float* scaled_actions;
-    const float2* red_all;     // all paths' stride-10 (x,y) tables, back to back
-    const float* rad_all;      // 3 x 32 block radii of the pruned search (closest_index_pruned)
-    const PathTables* dt;      // device copy of the handle's tables (pointers, lengths, offsets, slot turns)
-    int red_base;              // first entry of red_all to stage
-    int red_total;             // entries to stage (all paths in training mode, one path otherwise)
-    int red_total_pad;         // rounded up to an even count (16-byte LDS carve)
-    int n_env, obs_dim, n_veh, n_future;
-    int n_env_blocks;          // blocks [0, n_env_blocks) run the per-env role (256 envs each)
-    int envs_per_tile;         // vehicle role: whole envs per tile, <= 64 and envs_per_tile * n_veh <= 1024
-    int recs_per_thread;       // vehicle role: ceil(envs_per_tile * n_veh / 256) <= 4
-    int xcd_remap;             // 1: vehicle tiles are reordered so that a 256-env group stays on one XCD
-    int tiles_per_group;       // vehicle tiles per env-role block (256 / envs_per_tile) when xcd_remap
-    unsigned nv_magic;         // ceil(2^32 / n_veh): item / n_veh == umulhi(item, nv_magic)
-    int path_id, training;
-    int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
-    int do_rewards;            // 0: compute_next_obses only
-    int ablate;                // profiling aid (EB_ABLATE): 1 skip search, 2 skip vehicle math, 4 skip per-env math
 };
 
 // ---- fused rollout step (eb_rollout.hip): one block = one env wave + RW record waves ----
@@ -66,13 +37,12 @@ struct FusedArgs {
     int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
     int do_rewards;            // 0: compute_next_obses only
     int ablate;                // profiling aid (EB_ABLATE)
+    long long* trace;          // profiling aid (eb_debug_set_trace): [n_waves][8] s_memrealtime marks, or NULL
 };
-// variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 3 x 6 (1152), 2 = 4 x 4 (1024)
+// variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 4 x 4 (1024), 2 = 1 x 4 (256)
 int fused_tile_records(int variant);
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s);
 
-size_t rollout_lds_bytes(int red_total_pad);
-hipError_t launch_rollout(int task, const RolloutArgs& A, int grid, size_t lds, hipStream_t s);
 hipError_t launch_f_xu(int n, const float* st, const float* ac, float tau, float* nx, float* pr, hipStream_t s);
 hipError_t launch_action_transform(int n, const float* in, float* out, hipStream_t s);
 hipError_t launch_rewards(int task, int n_env, int D, int n_future, int NV, const float* obs, const float* act,

@@ -5,23 +5,23 @@
 //
 //   env wave (wave 0, one lane per env) — the per-env chain, ~450 VALU ops on 36 + 36 bytes:
 //     load the 9-word head (ego 6 + tracking 3), the action and the path id; sin/cos of the ego heading;
-//     put (x, y, sin, cos) of the CURRENT pose into LDS for the record waves            -- barrier 1 --
+//     put (x, y, sin, cos) of the CURRENT pose into LDS for the record waves             -- hand-off 1 --
 //     reward terms (DAM:198-207, 297-298), bicycle-model step (DAM:386-392), closest point of the NEXT
-//     pose through the cell grid, tracking error (DAM:334-353, 735-770), head store      -- barrier 2 --
+//     pose through the cell grid (tables in L2), tracking error (DAM:334-353, 735-770), head store
+//                                                                                        -- hand-off 2 --
 //     per-env penalty sums in vehicle order (DAM:218), road walls (DAM:231-295), the four penalty outputs.
 //
 //   record waves (waves 1..RW, one lane per (env, vehicle) record, RPT records per lane; every 16-byte
-//   record load is issued before anything else, consecutive lanes on consecutive records -> coalesced
-//   HBM streams):                                                                         -- barrier 1 --
+//   record load is issued up front, consecutive lanes on consecutive records -> coalesced HBM streams):
+//     per record: predict (DAM:405-427), store — nothing here depends on the env wave    -- hand-off 1 --
 //     per record: centre distance to the ego from LDS; records inside 6.364 m are pushed on the wave's
-//     own LDS queue with their (x, y, sin, cos) (ballot prefix, no atomics) — every other record adds
-//     exact zeros to the penalty sums (DAM:228-229); predict (DAM:405-427); store.
-//     Then the queue, compacted one record per lane: four circle-pair distances (DAM:218-229) ->
-//     per-record partial sums + a bit in the env's 64-bit slot mask in LDS               -- barrier 2 --
+//     own LDS queue (ballot prefix, no atomics) — every other record adds exact zeros to the penalty
+//     sums (DAM:228-229).  Then the queue, compacted one record per lane: four circle-pair distances
+//     (DAM:218-229) -> per-record partial sums + a bit in the env's 64-bit slot mask     -- hand-off 2 --
 //
-// The record waves never wait for the env wave's chain; the barriers only order LDS traffic
-// (s_waitcnt lgkmcnt(0) + s_barrier: outstanding HBM loads/stores stay in flight across them).
-// HBM-bound: 104 + 32 n_veh algorithmic bytes per env-step; no MFMA (nothing here is a dense contraction).
+// The hand-offs are LDS flags (see lds_publish / lds_wait_until), not barriers: neither role ever waits for
+// the other's HBM traffic.  HBM-bound: 104 + 32 n_veh algorithmic bytes per env-step; no MFMA (nothing here
+// is a dense contraction).
 #include "eb_device.h"
 #include "eb_kernels.h"
 
@@ -31,36 +31,61 @@ namespace eb {
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access, 4-byte aligned
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));                 // register pair for v_pk_*_f32
+EB_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // LDS-only workgroup barrier: orders this wave's LDS traffic, leaves global loads/stores in flight
 EB_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The two hand-offs between the roles are LDS flags, not barriers: a barrier would hold the env wave until
+// every record wave has its HBM data, and the record waves until the env wave's chain is through.
+// (All waves of a block are resident together, so polling cannot deadlock.)
+EB_DEV void lds_publish(int* flag, int value) {   // everything this wave wrote to LDS before is visible first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *reinterpret_cast<volatile int*>(flag) = value;
+}
+EB_DEV void lds_wait_until(int* flag, int value) {
+    while (*reinterpret_cast<volatile int*>(flag) != value) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+}
 
-constexpr int QCAP = 128;   // per-wave near-record queue (flushed whenever 64 entries are waiting)
+// profiling aid: mark slot `i` of this wave's trace row with the 100 MHz wall clock (lane 0 only)
+#define EB_MARK(A, row, i) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + (i)] = wall_clock64(); } while (0)
+
+// per-wave near-record queue: drained at the end, and after every second record step if more than 64 entries
+// are waiting by then (so at most 64 + 2 * 64 ever are).  4 blocks of 2048 records must fit a CU's LDS with
+// room to spare: blocks above ~32 KB were seen to run 3 per CU, i.e. a second round of blocks.
+constexpr int QCAP = 192;
 
 // ---- closest point of (px, py) on path p (DAM:702-715), tables in global memory (L1/L2 resident) ----
 // The cell of the position names the index range [lo, hi] that provably holds the reference's argmin for
 // every position inside the cell (eb_capi.hip:build_cell_grid); scanning it in index order with the
 // reference's fp32 expression and a strict '<' returns the index of the full scan after ~6-10 evaluations
 // instead of ~370.  Positions outside the grid (or NaN) take the pruned full search.
-EB_DEV int closest_cell_index(const FusedArgs& A, int p, int roff, float px, float py) {
+// Returns the table index and the table point itself (x, y, heading).
+EB_DEV int closest_cell_index(const FusedArgs& A, int p, int roff, float px, float py, float& rx, float& ry, float& rphi) {
     const float* xy = A.xy10 + 2 * roff;
+    const float* ph = A.phi10 + roff;
     const float fx = (px - A.gx0) * CELL_INV, fy = (py - A.gy0) * CELL_INV;
     if (!(fx >= 0.0f && fx < (float)A.gnx && fy >= 0.0f && fy < (float)A.gny)) {
         const int n = p == 0 ? A.red_len[0] : p == 1 ? A.red_len[1] : A.red_len[2];
-        return closest_reduced_index(reinterpret_cast<const float2*>(xy), A.rad_all + 32 * p, n, px, py);
+        const int bi = closest_reduced_index(reinterpret_cast<const float2*>(xy), A.rad_all + 32 * p, n, px, py);
+        rx = xy[2 * bi]; ry = xy[2 * bi + 1]; rphi = ph[bi];
+        return bi;
     }
     const unsigned c = A.cells[(p * A.gny + (int)fy) * A.gnx + (int)fx];
     const int lo = (int)(c & 0xffffu), hi = (int)(c >> 16);
     float best = __builtin_inff();
     int bi = 0;
+    rx = xy[0]; ry = xy[1]; rphi = ph[0];   // index 0 unless a distance compares below +inf, as in the full scan
     for (int r = lo; r <= hi; r += 4) {
         const f4u q01 = *reinterpret_cast<const f4u*>(xy + 2 * r), q23 = *reinterpret_cast<const f4u*>(xy + 2 * r + 4);
+        const f4u h = *reinterpret_cast<const f4u*>(ph + r);
         const float d0 = sq(px - q01.x) + sq(py - q01.y), d1 = sq(px - q01.z) + sq(py - q01.w);   // DAM:712
         const float d2 = sq(px - q23.x) + sq(py - q23.y), d3 = sq(px - q23.z) + sq(py - q23.w);
-        if (d0 < best) { best = d0; bi = r; }                                                       // first minimum, DAM:714
-        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; }
-        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; }
-        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; }
+        if (d0 < best) { best = d0; bi = r; rx = q01.x; ry = q01.y; rphi = h.x; }                  // first minimum, DAM:714
+        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; rx = q01.z; ry = q01.w; rphi = h.y; }
+        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; rx = q23.x; ry = q23.y; rphi = h.z; }
+        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; rx = q23.z; ry = q23.w; rphi = h.w; }
     }
     return bi;
 }
@@ -69,11 +94,12 @@ template <int RW, int RPT>
 struct FusedSmem {
     static constexpr int ITEMS = RW * 64 * RPT;
     float4 ego[64];                       // (x, y, sin phi, cos phi) of the current ego pose
-    float4 tc[64];                        // per slot: (turn radius c, 1/c, sign, enabled), DAM:416-421
+    unsigned char turn[64];               // per slot: TURN_* (every record wave writes the same codes, reads its own)
     unsigned long long mask[64];          // per env: slots with a non-zero penalty sum
     float2 pen[ITEMS];                    // per record: (3.5 m sum, 2.5 m sum), DAM:228-229
-    float4 qd[RW][QCAP];                  // per record wave: queued near records (x, y, sin phi, cos phi)
-    unsigned short qi[RW][QCAP];          // and their item ids
+    float4 qd[RW][QCAP];                  // per record wave: queued near records (x, y, phi, item id)
+    int ego_ready;                        // set by the env wave once ego[] and mask[] are written
+    int waves_done;                       // record waves that have published their partial sums
 };
 
 // ---- env wave -------------------------------------------------------------------------------------
@@ -95,12 +121,8 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
         const int pr = A.ref_idx[ge];
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
-    if (lane < NV) {   // slot turn constants for the record waves (predict_for_a_mode, DAM:416-421)
-        const int t = A.dt->turn[lane];
-        S.tc[lane] = t == TURN_LEFT ? make_float4(26.875f, 1.0f / 26.875f, 1.0f, 1.0f)
-                   : t == TURN_RIGHT ? make_float4(15.625f, 1.0f / 15.625f, -1.0f, 1.0f)
-                                     : make_float4(1.0f, 1.0f, 0.0f, 0.0f);
-    }
+    const int trow = blockIdx.x * (RW + 1);
+    EB_MARK(A, trow, 0);                                                    // loads issued
     const float st[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
     const float phi_rad = deg2rad(st[5]);
     float es, ec;
@@ -108,8 +130,9 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
     if (A.do_rewards) {
         S.ego[lane] = make_float4(st[3], st[4], es, ec);
         S.mask[lane] = 0ull;
+        lds_publish(&S.ego_ready, 1);                                       // ---- hand-off 1 ----
+        EB_MARK(A, trow, 1);                                                // head arrived, ego published
     }
-    lds_barrier();                                                          // ---- barrier 1 ----
 
     float steer, a_x;
     if (A.actions_raw) action_transform(araw.x, araw.y, steer, a_x);        // DAM:120
@@ -125,16 +148,20 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
                      5.0f * punish_steer + 0.05f * punish_a_x;              // DAM:297-298
     }
     float nx[6];
+    if (A.ablate & 4) { for (int c = 0; c < 6; ++c) nx[c] = st[c]; }
+    else {
     f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);                  // DAM:387
     nx[0] = __builtin_fminf(__builtin_fmaxf(nx[0], 0.0f), 35.0f);           // DAM:390
+    }
     // tracking error of the next pose on the env's path (DAM:334-353)
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
-    if (p >= 0) {
+    if (p >= 0 && !(A.ablate & 4)) {
         const int roff = p == 0 ? A.red_off[0] : p == 1 ? A.red_off[1] : A.red_off[2];
-        const int bi = (A.ablate & 1) ? 0 : closest_cell_index(A, p, roff, nx[3], nx[4]);
-        const f2u r = *reinterpret_cast<const f2u*>(A.xy10 + 2 * (roff + bi));   // == path[bi * 10]: bi * 10 < len always
-        const float rphi = A.phi10[roff + bi];
-        t0 = two2one<TASK>(nx[3], nx[4], r.x, r.y);                         // DAM:758
+        EB_MARK(A, trow, 2);                                                // bicycle step done
+        float rx = 0.0f, ry = 0.0f, rphi = 0.0f;                            // == path[bi * 10]: bi * 10 < len always
+        const int bi = (A.ablate & 1) ? 0 : closest_cell_index(A, p, roff, nx[3], nx[4], rx, ry, rphi);
+        t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                           // DAM:758
+        if (A.trace) { asm volatile("" :: "v"(t0)); EB_MARK(A, trow, 3); }  // closest point found
         t1 = deal_with_phi_diff(nx[5] - rphi);                              // DAM:759
         t2 = nx[0] - EXP_V;                                                 // DAM:760
         if (A.n_future > 0 && act) {                                        // DAM:717-724, 763-768
@@ -160,8 +187,10 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
         *reinterpret_cast<f4u*>(hout + 4) = f4u{nx[4], nx[5], t0, t1};
         hout[8] = t2;
     }
+    EB_MARK(A, trow, 4);                                                    // head stored
     if (!A.do_rewards) return;
-    lds_barrier();                                                          // ---- barrier 2 ----
+    lds_wait_until(&S.waves_done, RW);                                      // ---- hand-off 2 ----
+    EB_MARK(A, trow, 5);                                                    // record waves done
 
     // per env: penalty sums in vehicle order + road walls (DAM:231-295, 299-300)
     if (act) {
@@ -183,20 +212,22 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
         A.out5[3 * n + ge] = a25;
         A.out5[4 * n + ge] = road_r;
     }
+    EB_MARK(A, trow, 6);                                                    // end
 }
 
 // ---- record waves -----------------------------------------------------------------------------------
-// one queue pass: entries [0, n) of this wave's queue, one per lane: DAM:218-229
+// one queue pass: entries [base, base + n) of this wave's queue, one per lane: DAM:218-229
 template <int RW, int RPT>
-EB_DEV void queue_pass(const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int n) {
+EB_DEV void queue_pass(const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int base, int n) {
     if (lane < n) {
-        const float4 v = S.qd[w][lane];
-        const int item = S.qi[w][lane];
+        const float4 v = S.qd[w][base + lane];                              // (x, y, phi, item id)
+        const int item = __float_as_int(v.w);
         const int e2 = (int)__umulhi((unsigned)item, A.nv_magic), j2 = item - e2 * A.n_veh;
         const float4 eg = S.ego[e2];
-        float t35[4], t25[4];
+        float t35[4], t25[4], vs, vc;
         const float4 pts = make_float4(eg.x + LWS * eg.w, eg.y + LWS * eg.z, eg.x - LWS * eg.w, eg.y - LWS * eg.z);
-        veh2veh_terms(pts, v.x, v.y, v.z, v.w, t35, t25);
+        sincos_det(deg2rad(v.z), vs, vc);                                   // DAM:221
+        veh2veh_terms(pts, v.x, v.y, vs, vc, t35, t25);
         const float p35 = ((t35[0] + t35[1]) + t35[2]) + t35[3];
         const float p25 = ((t25[0] + t25[1]) + t25[2]) + t25[3];
         if (p35 != 0.0f) {   // p25 != 0 implies p35 != 0
@@ -206,7 +237,65 @@ EB_DEV void queue_pass(const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lan
     }
 }
 
-template <int TASK, int RW, int RPT>
+// predict_for_a_mode (DAM:405-427) on one record with the independent fp32 ops issued in pairs
+// (v_pk_mul/add/fma_f32: two IEEE fp32 results per instruction, each rounded exactly like its scalar
+// twin in eb_device.h:predict_record, so the bits are the same):
+//   (v, phi*pi) -> (v/10, phi_rad)      one 3-op exact constant division for both
+//   sin / cos polynomials                both Horner chains in one register pair
+//   (dx, dy), (x + dx, y + dy)           one multiply, one add
+// The heading chain (turn rate, wrap, back to degrees) is sequential and stays scalar.
+template <bool EXACT>
+EB_DEV f4u predict_record_pk(const f4u rec, const float4 tc, unsigned& tiny) {
+    const v2f xy = {rec.x, rec.y}, vp = {rec.z, rec.w};
+    const v2f vt = vp * v2f{1.0f, PI_F};                                     // (v, phi * np.pi), DAM:407
+    v2f vr;                                                                  // (v / 10, phi_rad), DAM:407, 413
+    if (EXACT) {
+        vr = v2f{vt.x / 10.0f, vt.y / 180.0f};
+    } else {
+        const v2f c = {10.0f, 180.0f}, rc = {1.0f / 10.0f, 1.0f / 180.0f};
+        const v2f q = vt * rc;
+        vr = fma2(fma2(-q, c, vt), rc, q);
+    }
+    const float v = rec.z, v10 = vr.x, phi_rad = vr.y;
+    // sincos_det(phi_rad), same operations as eb_device.h
+    const float kf = __builtin_rintf(phi_rad * 0.636619747f);
+    const int k = (int)kf;
+    float r = __builtin_fmaf(-kf, 1.5703125f, phi_rad);
+    r = __builtin_fmaf(-kf, 4.83751296997070312e-4f, r);
+    r = __builtin_fmaf(-kf, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const v2f zz = {z, z};
+    v2f pl = fma2(v2f{-1.9515295891e-4f, 2.443315711809948e-5f}, zz, v2f{8.3321608736e-3f, -1.388731625493765e-3f});
+    pl = fma2(pl, zz, v2f{-1.6666654611e-1f, 4.166664568298827e-2f});
+    const float t = __builtin_fmaf(-0.5f, z, 1.0f);
+    const v2f sc = fma2(v2f{r, z} * zz, pl, v2f{r, t});                      // (sin r, cos r)
+    const float a = (k & 1) ? sc.y : sc.x;
+    const float b = (k & 1) ? -sc.x : sc.y;
+    const float sn = (k & 2) ? -a : a, cs = (k & 2) ? -b : b;
+    const v2f nxy = xy + v2f{v10, v10} * v2f{cs, sn};                        // DAM:413-414, 422
+    const bool middle = (rec.x > -HALF_CROSS && rec.x < HALF_CROSS) && (rec.y > -HALF_CROSS && rec.y < HALF_CROSS);   // DAM:409-410
+    const float u = (EXACT ? v / tc.x : div_fast(v, tc.x, tc.y)) * tc.z;    // +-(v / radius)
+    const float u10 = EXACT ? u / 10.0f : div_fast(u, 10.0f, 1.0f / 10.0f);
+    const float dphi = (middle && tc.w != 0.0f) ? u10 : 0.0f;                // DAM:416-421
+    float nphi = phi_rad + dphi;                                             // DAM:423
+    if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                 // DAM:424
+    if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                               // DAM:425
+    const float t2 = nphi * 180.0f;
+    const float nphi_deg = EXACT ? t2 / PI_F : div_fast(t2, PI_F, 1.0f / PI_F);   // DAM:426
+    if (!EXACT) {
+        // the 3-op divisions are exact unless a dividend is non-zero and below 2^-101: (bits << 1) - 1 < 2 * 0x0D000000 - 1
+        const unsigned g0 = (__builtin_bit_cast(unsigned, vt.y) << 1) - 1u;
+        const unsigned g1 = (__builtin_bit_cast(unsigned, v) << 1) - 1u;
+        const unsigned g2 = (__builtin_bit_cast(unsigned, t2) << 1) - 1u;
+        const unsigned g3 = (__builtin_bit_cast(unsigned, u) << 1) - 1u;
+        tiny = min(min(g0, g1), min(g2, g3)) < 2u * 0x0D000000u - 1u;
+    }
+    return f4u{nxy.x, nxy.y, v, nphi_deg};                                   // DAM:422-427
+}
+
+// FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
+// fixed step, so slot constants are fetched once and addresses advance by a uniform stride.
+template <int TASK, int RW, int RPT, bool FAST>
 EB_DEV void record_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
     constexpr int RL = RW * 64;                     // record lanes per block
     const int rtid = threadIdx.x - 64, w = rtid >> 6, lane = rtid & 63;
@@ -214,104 +303,148 @@ EB_DEV void record_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int n
     const int items = nE * NV;
     const float* tin = A.obs_in + (size_t)e0 * D;
     float* tout = A.obs_out + (size_t)e0 * D;
+    const int e_first = (int)__umulhi((unsigned)rtid, A.nv_magic), j_first = rtid - e_first * NV;
+    const int epk = RL / NV;                                  // FAST: envs per k step
+    const int off_first = 4 * rtid + (e_first + 1) * HD, off_step = 4 * RL + epk * HD;
+    // record k of this lane: item id, env (tile-local), float offset of the record in the tile (== e*D + HD + 4*j)
+    auto item_of = [&](int k) { return k * RL + rtid; };
+    auto env_of = [&](int k) { return FAST ? e_first + k * epk : (int)__umulhi((unsigned)item_of(k), A.nv_magic); };
+    auto off_of = [&](int k) { return FAST ? off_first + k * off_step : 4 * item_of(k) + (env_of(k) + 1) * HD; };
 
+    // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then every record
+    const int turn_code = A.dt->turn[lane];
     f4u rec[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        // lanes past the tile's last record re-read that record (branch-free loads; never stored)
-        const int item = min(k * RL + rtid, items - 1);
-        const int e = (int)__umulhi((unsigned)item, A.nv_magic);
-        rec[k] = *reinterpret_cast<const f4u*>(tin + 4 * item + (e + 1) * HD);   // == e*D + HD + 4*j
+        // lanes past the tile's last record re-read the tile's last record (branch-free loads; never stored)
+        const int off = item_of(k) < items ? off_of(k) : 4 * (items - 1) + nE * HD;
+        rec[k] = *reinterpret_cast<const f4u*>(tin + off);
     }
-    lds_barrier();                                                          // ---- barrier 1 ----
+    const int trow = blockIdx.x * (RW + 1) + 1 + w;
+    EB_MARK(A, trow, 0);                                                    // loads issued
+    // slot turn constants (predict_for_a_mode, DAM:416-421): (turn radius c, 1/c, sign, enabled)
+    auto turn_consts = [](int t) {
+        return t == TURN_LEFT ? make_float4(26.875f, 1.0f / 26.875f, 1.0f, 1.0f)
+             : t == TURN_RIGHT ? make_float4(15.625f, 1.0f / 15.625f, -1.0f, 1.0f)
+                               : make_float4(1.0f, 1.0f, 0.0f, 0.0f);
+    };
+    S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
+    const float4 tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
 
-    int qn = 0;
+    // ---- predict + store ----
+    auto predict_all = [&]() {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int item = k * RL + rtid;
-        const bool valid = item < items;
-        const int e = (int)__umulhi((unsigned)item, A.nv_magic), j = item - e * NV;
-        float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-        float sn = 0.0f, cs = 1.0f;
-        if (valid) {
-            const float4 tc = S.tc[j];
-            unsigned tiny = 0u;
-            nv = predict_record<false>(rec[k].x, rec[k].y, rec[k].z, rec[k].w, tc, tiny, sn, cs);
-            if (__builtin_expect(tiny != 0u, 0)) nv = predict_record<true>(rec[k].x, rec[k].y, rec[k].z, rec[k].w, tc, tiny, sn, cs);
-            *reinterpret_cast<f4u*>(tout + 4 * item + (e + 1) * HD) = f4u{nv.x, nv.y, nv.z, nv.w};
+        for (int k = 0; k < RPT; ++k) {
+            if (item_of(k) < items) {
+                const float4 tc = FAST ? tc_lane : turn_consts(S.turn[item_of(k) - env_of(k) * NV]);
+                unsigned tiny = 0u;
+                f4u nv = predict_record_pk<false>(rec[k], tc, tiny);
+                if (__builtin_expect(tiny != 0u, 0)) nv = predict_record_pk<true>(rec[k], tc, tiny);
+                *reinterpret_cast<f4u*>(tout + off_of(k)) = nv;
+            }
+            if (k == 0) EB_MARK(A, trow, 1);                                // first record stored
+            if (k == RPT - 1) EB_MARK(A, trow, 2);                          // last record stored
+            __builtin_amdgcn_sched_barrier(0);   // one record at a time: keeps the live set at the loaded records + one record's temporaries
         }
-        if (A.do_rewards) {
-            // A circle pair can only be closer than 3.5 m when the two vehicle centres are within
-            // 3.5 + 2*1.4 = 6.3 m; records inside 6.364 m (slack >> fp32 rounding) are queued, every
-            // other record contributes exact zeros to the penalty sums (DAM:228-229).
+    };
+    predict_all();
+    if (!A.do_rewards) return;
+
+    // ---- near-ego records -> this wave's queue -> circle-pair distances ----
+    // A circle pair can only be closer than 3.5 m when the two vehicle centres are within 3.5 + 2*1.4 = 6.3 m;
+    // records inside 6.364 m (slack >> fp32 rounding) are queued, every other record contributes exact zeros
+    // to the penalty sums (DAM:228-229).
+    lds_wait_until(&S.ego_ready, 1);                                        // ---- hand-off 1: ego poses are in LDS ----
+    EB_MARK(A, trow, 3);                                                    // ego seen
+    int qn = 0;
+    auto drain = [&]() {
+        for (int base = 0; base < qn; base += 64) queue_pass<RW, RPT>(A, S, w, lane, base, min(64, qn - base));
+        qn = 0;
+    };
+    if (!(A.ablate & 8)) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
             bool near = false;
-            if (valid) {
-                const float4 eg = S.ego[e];
-                near = sq(rec[k].x - eg.x) + sq(rec[k].y - eg.y) < 40.5f;
+            if (item_of(k) < items) {
+                const float4 eg = S.ego[env_of(k)];
+                const v2f d = v2f{rec[k].x, rec[k].y} - v2f{eg.x, eg.y};
+                const v2f d2 = d * d;
+                near = d2.x + d2.y < 40.5f;
             }
             const unsigned long long b = __ballot(near);
             if (b) {
                 if (near) {
                     const int pos = qn + __popcll(b & ((1ull << lane) - 1ull));
-                    S.qd[w][pos] = make_float4(rec[k].x, rec[k].y, sn, cs);
-                    S.qi[w][pos] = (unsigned short)item;
+                    S.qd[w][pos] = make_float4(rec[k].x, rec[k].y, rec[k].w, __int_as_float(item_of(k)));
                 }
                 qn += __popcll(b);
-                if (qn >= 64) {   // flush one full pass, move the remainder (< 64 entries) to the front
-                    queue_pass<RW, RPT>(A, S, w, lane, 64);
-                    const int rem = qn - 64;
-                    float4 td = make_float4(0.f, 0.f, 0.f, 0.f);
-                    unsigned short ti = 0;
-                    if (lane < rem) { td = S.qd[w][64 + lane]; ti = S.qi[w][64 + lane]; }
-                    if (lane < rem) { S.qd[w][lane] = td; S.qi[w][lane] = ti; }
-                    qn = rem;
-                }
             }
+            if ((k & 1) && k != RPT - 1 && qn > 64) drain();   // see QCAP
         }
-        __builtin_amdgcn_sched_barrier(0);   // one record at a time: keeps the live set at the loaded records + one record's temporaries
     }
-    if (!A.do_rewards) return;
-    if (qn > 0) queue_pass<RW, RPT>(A, S, w, lane, qn);
-    lds_barrier();                                                          // ---- barrier 2 ----
+    EB_MARK(A, trow, 4);                                                    // near tests done
+    if (!(A.ablate & 16)) drain();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // ---- hand-off 2: partial sums are in LDS ----
+    if (lane == 0) atomicAdd(&S.waves_done, 1);
+    EB_MARK(A, trow, 5);                                                    // end
 }
 
-// waves per SIMD the tile shape is sized for (bounds the VGPR budget): 2048-record tiles -> 4 blocks x 5
-// waves per CU at the headline size; the smaller tiles fill all 8 wave slots of a SIMD
-template <int RW, int RPT>
-constexpr int fused_waves_per_simd() { return RW * RPT >= 32 ? 5 : 8; }
-
-template <int TASK, int RW, int RPT>
-__global__ __launch_bounds__((RW + 1) * 64, (fused_waves_per_simd<RW, RPT>())) void rollout_fused_kernel(const FusedArgs A) {
+template <int TASK, int RW, int RPT, bool FAST>
+EB_DEV void fused_body(const FusedArgs& A) {
     __shared__ FusedSmem<RW, RPT> S;
     const int e0 = blockIdx.x * A.envs_per_tile;
     const int nE = min(A.envs_per_tile, A.n_env - e0);
+    if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
+    lds_barrier();   // the only barrier: at launch, before any wave has something to wait for
     if (threadIdx.x < 64) {
         __builtin_amdgcn_s_setprio(2);
         env_wave<TASK, RW, RPT>(A, S, e0, nE);
     } else {
-        record_wave<TASK, RW, RPT>(A, S, e0, nE);
+        record_wave<TASK, RW, RPT, FAST>(A, S, e0, nE);
     }
 }
 
-int fused_tile_records(int variant) { return variant == 0 ? 4 * 64 * 8 : variant == 1 ? 3 * 64 * 6 : 4 * 64 * 4; }
-
-template <int RW, int RPT>
-static hipError_t launch_v(int task, const FusedArgs& A, int grid, hipStream_t s) {
-    const dim3 g(grid), b((RW + 1) * 64);
-    switch (task) {
-        case TASK_LEFT: hipLaunchKernelGGL((rollout_fused_kernel<TASK_LEFT, RW, RPT>), g, b, 0, s, A); break;
-        case TASK_STRAIGHT: hipLaunchKernelGGL((rollout_fused_kernel<TASK_STRAIGHT, RW, RPT>), g, b, 0, s, A); break;
-        default: hipLaunchKernelGGL((rollout_fused_kernel<TASK_RIGHT, RW, RPT>), g, b, 0, s, A); break;
+// One kernel per tile shape, with the VGPR budget spelled out.  2048-record tiles run 4 blocks x 5 waves per
+// CU at the headline size = 5 waves per SIMD on average, but a block's 5 waves land 2-1-1-1 on the SIMDs from
+// a varying start, so one SIMD can be asked for a 6th: budget for 6 (80 VGPRs) or that block waits a whole
+// round.  The smaller tiles fill all 8 wave slots of a SIMD (64 VGPRs).
+#define EB_FUSED_KERNEL(NAME, RW, RPT, WAVES, VGPRS)                                                     \
+    template <int TASK, bool FAST>                                                                       \
+    __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
+        const FusedArgs A) {                                                                             \
+        fused_body<TASK, RW, RPT, FAST>(A);                                                              \
     }
-    return hipGetLastError();
+EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
+EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 8, 64)
+EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 8, 64)
+
+int fused_tile_records(int variant) {
+    switch (variant) {
+        case 0: return 4 * 64 * 8;
+        case 1: return 4 * 64 * 4;
+        default: return 1 * 64 * 4;
+    }
 }
+
+#define EB_LAUNCH_TASK(KERNEL, FAST_)                                                                          \
+    switch (task) {                                                                                            \
+        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_>), g, b, 0, s, A); break;                  \
+        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_>), g, b, 0, s, A); break;          \
+        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_>), g, b, 0, s, A); break;                        \
+    }
+#define EB_LAUNCH(KERNEL, RW)                                                                                  \
+    {                                                                                                          \
+        const dim3 g(grid), b((RW + 1) * 64);                                                                  \
+        if ((RW * 64) % A.n_veh == 0) { EB_LAUNCH_TASK(KERNEL, true) } else { EB_LAUNCH_TASK(KERNEL, false) }  \
+    }
 
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s) {
     switch (variant) {
-        case 0: return launch_v<4, 8>(task, A, grid, s);
-        case 1: return launch_v<3, 6>(task, A, grid, s);
-        default: return launch_v<4, 4>(task, A, grid, s);
+        case 0: EB_LAUNCH(rollout_fused_4x8, 4) break;
+        case 1: EB_LAUNCH(rollout_fused_4x4, 4) break;
+        default: EB_LAUNCH(rollout_fused_1x4, 1) break;
     }
+    return hipGetLastError();
 }
 
 }  // namespace eb

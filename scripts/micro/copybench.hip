@@ -23,6 +23,24 @@ __global__ void copy_stride_u(const float4* __restrict__ in, float4* __restrict_
     }
     for (; i < n4; i += step) out[i] = in[i];
 }
+__global__ void copy_nt_store(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n4) { float4 v = in[i]; __builtin_nontemporal_store(v.x, &out[i].x); __builtin_nontemporal_store(v.y, &out[i].y); __builtin_nontemporal_store(v.z, &out[i].z); __builtin_nontemporal_store(v.w, &out[i].w); }
+}
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ void copy_nt_store4(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n4) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n4) { f4v v = in[i]; __builtin_nontemporal_store(v, &out[i]); }
+}
+__global__ void copy_nt_both4(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n4) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n4) { f4v v = __builtin_nontemporal_load(&in[i]); __builtin_nontemporal_store(v, &out[i]); }
+}
+__global__ void copy_nt_load4(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n4) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n4) { f4v v = __builtin_nontemporal_load(&in[i]); out[i] = v; }
+}
+__global__ void empty_kernel(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {}
 __global__ void copy_one(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n4) out[i] = in[i];
@@ -67,6 +85,12 @@ int main(int argc, char** argv) {
     run("copy unroll4 grid=2048", [&](int i) { hipLaunchKernelGGL(copy_stride_u<4>, dim3(2048), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("copy unroll8 grid=1024", [&](int i) { hipLaunchKernelGGL(copy_stride_u<8>, dim3(1024), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("copy one-load-per-thread", [&](int i) { hipLaunchKernelGGL(copy_one, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("nt store (4 x dword)", [&](int i) { hipLaunchKernelGGL(copy_nt_store, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("nt store dwordx4", [&](int i) { hipLaunchKernelGGL(copy_nt_store4, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("nt load dwordx4", [&](int i) { hipLaunchKernelGGL(copy_nt_load4, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("nt load + nt store dwordx4", [&](int i) { hipLaunchKernelGGL(copy_nt_both4, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("empty kernel same grid", [&](int i) { hipLaunchKernelGGL(empty_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("empty kernel grid=1024x320", [&](int i) { hipLaunchKernelGGL(empty_kernel, dim3(1024), dim3(320), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("copy misaligned(+4B) grid=2048", [&](int i) { hipLaunchKernelGGL(copy_misaligned, dim3(2048), dim3(256), 0, 0, (const float*)buf[i & 1], buf[(i + 1) & 1], n4 - 1); }, 2.0 * bytes);
     run("read only grid=2048", [&](int i) { hipLaunchKernelGGL(read_only, dim3(2048), dim3(256), 0, 0, (const float4*)buf[i & 1], buf[2], n4); }, 1.0 * bytes);
     run("write only grid=2048", [&](int i) { hipLaunchKernelGGL(write_only, dim3(2048), dim3(256), 0, 0, (float4*)buf[i & 1], n4); }, 1.0 * bytes);

@@ -6,8 +6,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get('Kernel_Name', '')
-        if 'rollout_step' not in k: continue
-        acc['rollout_step'][r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'rollout_' not in k: continue
+        acc['rollout'][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k)
     for c in sorted(d):

@@ -214,6 +214,12 @@ class DeviceModel(HostModel):
         HostModel.__init__(self, _capi.hip_api(), task, **kw)
         self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def set_tile(self, variant):
+        """Force the rollout kernel's tile shape (eb_debug_set_tile; -1 = pick by batch size)."""
+        fn = self.api.lib.eb_debug_set_tile
+        fn.argtypes, fn.restype = [C.c_void_p, C.c_int], C.c_int
+        self.api.check(fn(self.h, int(variant)))
+
     _TD = {np.dtype(np.float32): 'float32', np.dtype(np.int32): 'int32', np.dtype(np.uint8): 'uint8'}
 
     def _in(self, a, dtype=np.float32):

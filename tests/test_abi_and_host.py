@@ -43,7 +43,7 @@ def test_hip_library_builds_loads_and_exports_every_symbol():
 def test_hip_library_contains_gfx950_code_object():
     lib_path = eb_build.build()
     blob = open(lib_path, 'rb').read()
-    assert b'gfx950' in blob and b'rollout_step_kernel' in blob
+    assert b'gfx950' in blob and b'rollout_fused_4x8' in blob
 
 
 def test_hip_backend_refuses_to_run_without_a_gpu():

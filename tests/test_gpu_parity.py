@@ -63,6 +63,91 @@ def test_rollout_25_steps_bit_exact(task, n_veh, mode):
         _check_out5(o5_d, o5_h, 'step %d' % t)
 
 
+@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('task,N', [('left', 32), ('straight', 9), ('right', 64), ('left', 16), ('right', 5)])
+def test_every_tile_shape_computes_the_same_bits(task, N, tile):
+    """The headline tile (2048 records) is only picked by batch size from 32 768 envs up; force each tile
+    shape on a small ragged batch (slot counts that do and do not divide the record lanes)."""
+    B, H = 777, 6
+    host, dev = _pair(task, n_veh=N)
+    dev.set_tile(tile)
+    inp = make_rollout_inputs(task, B, N, H, seed=100 + N + tile)
+    obs_h = obs_d = _initial_obs(host, inp)
+    for t in range(H):
+        obs_h, o5_h, _ = host.rollout_step(obs_h, inp['actions'][t], inp['ref_idx'])
+        obs_d, o5_d, _ = dev.rollout_step(obs_d, inp['actions'][t], inp['ref_idx'])
+        assert np.array_equal(obs_d, obs_h), 'step %d' % t
+        _check_out5(o5_d, o5_h, 'step %d' % t)
+    nxt = dev.compute_next_obses(obs_d, inp['actions'][0] * 0.3, inp['ref_idx'])   # the no-reward form of the kernel
+    assert np.array_equal(nxt, host.compute_next_obses(obs_h, inp['actions'][0] * 0.3, inp['ref_idx']))
+
+
+@pytest.mark.parametrize('tile', [0, 2])
+@pytest.mark.parametrize('N', [32, 9])
+def test_crowded_and_remote_scenes(N, tile):
+    """Edge scenes of the penalty path and the closest-point search:
+       * every vehicle within a few metres of the ego -> every record is queued (the queue drains mid-tile);
+       * egos far outside the closest-point cell grid (and on its border) -> the pruned full search;
+       * stopped vehicles, zero / tiny headings and speeds -> the exact-division fallback."""
+    task, B = 'left', 300
+    host, dev = _pair(task, n_veh=N)
+    dev.set_tile(tile)
+    inp = make_rollout_inputs(task, B, N, 4, seed=77)
+    rng = np.random.default_rng(5)
+    veh = inp['veh'].reshape(B, N, 4).copy()
+    ego = inp['ego'].copy()
+    veh[:100, :, 0] = ego[:100, None, 3] + rng.uniform(-4, 4, (100, N))      # crowded
+    veh[:100, :, 1] = ego[:100, None, 4] + rng.uniform(-4, 4, (100, N))
+    ego[100:150, 3] = rng.uniform(-400, 400, 50)                                # remote egos
+    ego[100:150, 4] = rng.uniform(-400, 400, 50)
+    ego[150:160, 3] = np.float32(-75.0) + np.arange(10, dtype=np.float32) * np.float32(1e-6)   # grid border
+    veh[160:200, :, 2] = 0.0                                                     # stopped
+    veh[200:220, :, 3] = 0.0
+    veh[220:240, :, 3] = np.float32(1e-38)
+    veh[240:260, :, 2] = np.float32(3e-39)                                       # denormal speed
+    veh[260:280, :, 3] = -0.0
+    inp['ego'], inp['veh'] = ego, veh.reshape(B, 4 * N)
+    obs_h = obs_d = _initial_obs(host, inp)
+    for t in range(4):
+        obs_h, o5_h, _ = host.rollout_step(obs_h, inp['actions'][t], inp['ref_idx'])
+        obs_d, o5_d, _ = dev.rollout_step(obs_d, inp['actions'][t], inp['ref_idx'])
+        assert np.array_equal(obs_d.view(np.uint32), obs_h.view(np.uint32)), 'step %d' % t
+        _check_out5(o5_d, o5_h, 'step %d' % t)
+        if t == 0:
+            assert (o5_d[1][:100] > 0).all()     # the crowded envs do touch the 3.5 m margin
+
+
+def test_headline_size_against_oracle_on_sampled_envs():
+    """BASELINE configs[2] (65 536 envs x 32 vehicles, the 2048-record tile chosen by batch size): envs are
+    independent, so the oracle replays a sample of rows (first / last tile, tile borders, random rows) and
+    must agree bit for bit; plus size-independent properties of the whole batch."""
+    task, B, N, H = 'left', 65536, 32, 3
+    host, dev = _pair(task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, H, seed=0)
+    rng = np.random.default_rng(1)
+    rows = np.unique(np.concatenate([np.arange(0, 130), np.arange(B - 130, B), np.arange(63, B, 4096), np.arange(64, B, 4096),
+                                     rng.integers(0, B, 600)]))
+    ego, ref = inp['ego'], inp['ref_idx']
+    trk = host.tracking_error(ego[rows, 3], ego[rows, 4], ego[rows, 5], ego[rows, 0], 0, ref_idx=ref[rows])
+    obs_d = assemble_obs(ego, np.zeros((B, 3), np.float32), inp['veh'])
+    obs_d[rows, 6:9] = trk
+    obs_h = obs_d[rows].copy()
+    for t in range(H):
+        obs_prev = obs_d
+        obs_d, o5_d, _ = dev.rollout_step(obs_d, inp['actions'][t], ref)
+        obs_h, o5_h, _ = host.rollout_step(obs_h, inp['actions'][t][rows], ref[rows])
+        assert np.array_equal(obs_d[rows], obs_h), 'step %d' % t
+        _check_out5(o5_d[:, rows], o5_h, 'step %d' % t)
+        # whole batch: vehicle speed is carried over unchanged (DAM:422), headings stay in (-180, 180] (DAM:424-426),
+        # penalties are non-negative sums of squares, nothing is NaN
+        v_in, v_out = obs_prev[:, 9:].reshape(B, N, 4), obs_d[:, 9:].reshape(B, N, 4)
+        assert np.array_equal(v_in[:, :, 2], v_out[:, :, 2])
+        assert (v_out[:, :, 3] > -180.001).all() and (v_out[:, :, 3] <= 180.001).all()
+        assert np.isfinite(obs_d).all() and np.isfinite(o5_d).all()
+        assert (o5_d[1:] >= 0).all() and (o5_d[0] <= 0).all()
+        assert (o5_d[1] >= o5_d[2] - 1e-6).all()          # the 3.5 m training margin dominates the 2.5 m real one
+
+
 @pytest.mark.parametrize('task', TASKS)
 def test_rollout_future_points_and_bad_ref_index(task):
     N, B = 8, 333
