@@ -207,7 +207,7 @@ def main():
             launch_s = dt_max / args.steps                   # fewer than 25 steps: whole-region wall time
         achieved = alg / launch_s / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')   # written from a separate --pmc run
+        tpath = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')   # from a separate --pmc run (scripts/pmc_traffic.sh)
         if os.path.isfile(tpath) and n_env == N_ENV and n_veh == N_VEH:
             traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
         cfg = 'configs[2]' if (n_env, n_veh) == (N_ENV, N_VEH) else 'custom'
@@ -224,7 +224,7 @@ def main():
                        'parallelism': 'env-shard x%d, all-gather of the 8-float episodic summary per horizon' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'eb::rollout_step_kernel<0>', 'alg_bytes_per_launch': alg,
+                         'kernel': 'eb::rollout_fused_4x8<0, true>', 'alg_bytes_per_launch': alg,
                          'avg_launch_us': launch_s * 1e6, 'launches_timed': n_marked * HORIZON},
             'summary': [float(x) for x in summary_all[0].tolist()],
         }

@@ -1,0 +1,364 @@
+"""Drop-in counterpart of the reference's endtoend.py Gym env — CrossroadEnd2end — with the arithmetic
+of step / reset running in HIP kernels on an MI355X (E2E = /root/reference/endtoend.py).
+
+Same constructor arguments, methods and attributes as the reference (E2E:44-507): `reset(**kwargs) ->
+obs`, `step(action) -> (obs, reward, done, info)`, `seed`, `close`, `set_traj`, `_get_obs(exit_)`,
+`compute_reward(obs, action)`, `action_space`, `obs`, `action`, `ego_dynamics`, `all_vehicles`, `v_light`,
+`done_type`, `reward_info`, `ref_path`, `env_model`, `dynamics`, `veh_num`.  Two additions:
+
+  * `n_env` (default 1): a BATCH of independent single-ego envs advanced by one set of kernel launches
+    per step.  With n_env == 1 every return value has the reference's shape and type (obs float32 [D],
+    reward np.float32, done int, info dict); with n_env > 1 they are device arrays of leading size B
+    (obs [B, D], reward [B], done uint8 [B]) and `done_type` is a list.
+  * the traffic source.  The reference co-simulates with SUMO over TraCI (traffic.py; out of scope,
+    SURVEY.md §2 #6).  Here the surrounding vehicles are a fixed pool of `n_cand` candidates per env
+    advanced with the model's own prediction step (EnvironmentModel.veh_predict, DAM:394-427 — the same
+    arithmetic the reference's 5/20-step safety shield trusts) and re-entered at their lane's start when
+    they leave the map.  As in the reference's `multi_display=True` mode (multi_ego.py:46-48, 94-96),
+    `all_vehicles`, `ego_dynamics` and `v_light` can also be injected by hand before `_get_obs(exit_)`.
+
+Per step (E2E:132-144): action scaling (E2E:133) -> reward on the CURRENT obs (E2E:134, DAM:186-320) ->
+ego bicycle-model step, v_x floored at 0, phi wrapped (E2E:135, 269-283) -> traffic step -> observation
+= ego | tracking error | filtered / sorted / padded vehicles (E2E:140, 285-464) -> done code by the
+reference's priority collision > road > deviation > stability > red light > goal (E2E:141, 200-256,
+TRF:263-295, UTL:73-104).  Every one of these is a C-ABI call into libenvbuild_hip.so; torch only owns
+the device buffers.  There is no CPU path.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _capi
+from .dynamics_and_models import (DevArray, EnvironmentModel, ReferencePath, VehicleDynamics, _Handle, _default_device,
+                                  _dev, _ptr, _stream)
+from .endtoend_env_utils import (CROSSROAD_SIZE, EXPECTED_V, L, LANE_NUMBER, LANE_WIDTH, VEH_NUM, VEHICLE_MODE_DICT,
+                                 VEHICLE_MODE_LIST, W, rotate_and_shift_coordination)
+
+__all__ = ['CrossroadEnd2end', 'Box']
+
+
+class Box(object):
+    """The slice of gym.spaces.Box the reference's callers use (E2E:64, 89)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32, seed=None):
+        self.low, self.high, self.shape, self.dtype = float(low), float(high), tuple(shape), dtype
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self):
+        return self._rng.uniform(self.low, self.high, self.shape).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+# exit-relative edge names of the reference's route classifier (E2E:345-348)
+_NAME_SETTINGS = dict(D=dict(do='1o', di='1i', ro='2o', ri='2i', uo='3o', ui='3i', lo='4o', li='4i'),
+                      R=dict(do='2o', di='2i', ro='3o', ri='3i', uo='4o', ui='4i', lo='1o', li='1i'),
+                      U=dict(do='3o', di='3i', ro='4o', ri='4i', uo='1o', ui='1i', lo='2o', li='2i'),
+                      L=dict(do='4o', di='4i', ro='1o', ri='1i', uo='2o', ui='2i', lo='3o', li='3i'))
+_MODE_EDGES = dict(dl=('do', 'li'), du=('do', 'ui'), dr=('do', 'ri'), rd=('ro', 'di'), rl=('ro', 'li'), ru=('ro', 'ui'),
+                   ur=('uo', 'ri'), ud=('uo', 'di'), ul=('uo', 'li'), lu=('lo', 'ui'), lr=('lo', 'ri'), ld=('lo', 'di'))
+
+
+def classify_route(route, exit_='D'):
+    """(start, end) edge names -> vehicle mode under the exit-relative naming (E2E:352-385), or None."""
+    names = _NAME_SETTINGS[exit_]
+    for mode, (s, e) in _MODE_EDGES.items():
+        if route[0] == names[s] and route[1] == names[e]:
+            return mode
+    return None
+
+
+def _lane_entry(mode):
+    """(x, y, phi, along-lane unit vector) where a vehicle of `mode` enters the map: the lanes the fill
+    values of E2E:439-447 are parked on."""
+    h = CROSSROAD_SIZE / 2
+    lane = {'l': 0.5, 'u': 1.5, 'r': LANE_NUMBER - 0.5}
+    s, e = mode[0], mode[1]
+    if s == 'd':
+        return LANE_WIDTH * lane[e], -(h + 35.), 90., (0., 1.)
+    if s == 'u':
+        off = {'r': 0.5, 'd': 1.5, 'l': LANE_NUMBER - 0.5}[e]
+        return -LANE_WIDTH * off, (h + 35.), -90., (0., -1.)
+    if s == 'r':
+        off = {'d': 0.5, 'l': 1.5, 'u': LANE_NUMBER - 0.5}[e]
+        return (h + 35.), LANE_WIDTH * off, 180., (-1., 0.)
+    off = {'u': 0.5, 'r': 1.5, 'd': LANE_NUMBER - 0.5}[e]
+    return -(h + 35.), -LANE_WIDTH * off, 0., (1., 0.)
+
+
+class CrossroadEnd2end(object):
+    def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
+                 device=None, respawn=True, **kwargs):
+        if training_task not in ('left', 'straight', 'right'):
+            raise ValueError("training_task must be 'left', 'straight' or 'right'")
+        self.device = device if device is not None else _default_device()
+        self.n_env = int(n_env)
+        if self.n_env < 1:
+            raise ValueError('n_env must be >= 1')
+        self.dynamics = VehicleDynamics(self.device)                                   # E2E:51
+        self.interested_vehs = None
+        self.training_task = training_task
+        self.ref_path = ReferencePath(self.training_task, device=self.device, **kwargs)   # E2E:54
+        self.detected_vehicles = None
+        self.all_vehicles = None
+        self.ego_dynamics = None
+        self.num_future_data = num_future_data
+        self.env_model = EnvironmentModel(training_task, num_future_data, device=self.device)   # E2E:59
+        self.init_state = {}
+        self.action_number = 2
+        self.exp_v = EXPECTED_V
+        self.ego_l, self.ego_w = L, W
+        self.action_space = Box(low=-1, high=1, shape=(self.action_number,), dtype=np.float32)   # E2E:64
+        self.seed()
+        self.v_light = 0
+        self.step_length = 100  # ms
+        self.step_time = self.step_length / 1000.0
+        self.obs = None
+        self.action = None
+        self.veh_mode_dict = VEHICLE_MODE_DICT[self.training_task]
+        self.veh_num = VEH_NUM[self.training_task]
+        self.virtual_red_light_vehicle = False
+        self.done_type = 'not_done_yet'
+        self.reward_info = None
+        self.ego_info_dim = 6
+        self.per_tracking_info_dim = 3
+        self.per_veh_info_dim = 4
+        self.mode = mode
+        self.multi_display = multi_display
+        self.respawn = respawn
+        self.obs_dim = 6 + 3 * (num_future_data + 1) + 4 * self.veh_num
+        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)
+
+        # handles: the model's (native slot list: rewards, obs construction, done) and one over the candidate pool
+        self.api, self._h = self.env_model.api, self.env_model.handle
+        native = VEHICLE_MODE_LIST[self.training_task]
+        self.cand_modes = list(native) * 2 if n_cand is None else [native[i % len(native)] for i in range(int(n_cand))]
+        self.n_cand = len(self.cand_modes)
+        if not 1 <= self.n_cand <= 64:
+            raise ValueError('n_cand must be in 1..64')
+        self._traffic = _Handle(self.training_task, self.n_cand, 0, _capi.MODE_SELECTING, self.device,
+                                modes=self.cand_modes, with_paths=False)
+        B, M, dev = self.n_env, self.n_cand, self.device
+        self._ego = torch.zeros((B, 6), dtype=torch.float32, device=dev)
+        self._params = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        self._cand = torch.zeros((B, M, 4), dtype=torch.float32, device=dev)
+        self._cand_mode = torch.tensor([_capi.VMODE_ID[m] for m in self.cand_modes], dtype=torch.uint8,
+                                       device=dev).repeat(B, 1).contiguous()
+        self._v_light = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._virtual = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._ref_idx = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._obs = torch.zeros((B, self.obs_dim), dtype=torch.float32, device=dev)
+        self._entry = torch.tensor([_lane_entry(m)[:3] for m in self.cand_modes], dtype=torch.float32, device=dev)
+        self._entry_dir = torch.tensor([_lane_entry(m)[3] for m in self.cand_modes], dtype=torch.float32, device=dev)
+        self._injected = False
+        self.init_state = self._reset_init_state()
+        if not multi_display:                                                           # E2E:84-93
+            self.reset()
+            self.step(self.action_space.sample() if B == 1 else
+                      np.stack([self.action_space.sample() for _ in range(B)]))
+            self.reset()
+
+    # -- gym plumbing ---------------------------------------------------------------------------
+    def seed(self, seed=None):  # E2E:95-97
+        self.np_random = np.random.default_rng(seed)
+        self._gen = torch.Generator(device='cpu')
+        self._gen.manual_seed(int(self.np_random.integers(0, 2 ** 31 - 1)))
+        return [seed]
+
+    def close(self):  # E2E:129-130
+        self._traffic = None
+
+    def set_traj(self, trajectory):  # E2E:793-795
+        self.ref_path = trajectory
+
+    def render(self, mode='human'):  # E2E:509-791 is a matplotlib view: out of scope
+        raise NotImplementedError('CrossroadEnd2end.render (matplotlib view) is out of scope')
+
+    # -- helpers --------------------------------------------------------------------------------
+    def _sp(self):
+        return _stream(self.device)
+
+    def _ret(self, t):
+        """reference-shaped value for n_env == 1, device array otherwise"""
+        return t[0].detach().cpu().numpy() if self.n_env == 1 else DevArray(t)
+
+    # -- reset ----------------------------------------------------------------------------------
+    def _reset_init_state(self):  # E2E:472-499, per env
+        span = {'left': 900 + 500, 'straight': 1200 + 500, 'right': 420 + 500}[self.training_task]
+        B = self.n_env
+        ref = np.full((B,), int(self.ref_path.ref_index), np.int32) if B == 1 else \
+            self.np_random.integers(0, len(self.ref_path.path_list), B).astype(np.int32)
+        index = (self.np_random.random(B) * span).astype(np.int64) + 700                # E2E:474-478
+        v = (EXPECTED_V * self.np_random.random(B)).astype(np.float32)                  # E2E:482
+        ego = np.zeros((B, 6), np.float32)
+        for k, path in enumerate(self.ref_path.path_list):
+            rows = ref == k
+            i = np.clip(index[rows], 0, len(path[0]) - 1)                               # indexs2points, DAM:727-728
+            ego[rows, 3], ego[rows, 4], ego[rows, 5] = path[0][i], path[1][i], path[2][i]
+        ego[:, 0] = v
+        route = {'left': 'dl', 'straight': 'du', 'right': 'dr'}[self.training_task]
+        self._init_ego, self._init_ref = ego, ref
+        return dict(ego=dict(v_x=ego[0, 0], v_y=0, r=0, x=ego[0, 3], y=ego[0, 4], phi=ego[0, 5], l=self.ego_l,
+                             w=self.ego_w, routeID=route))
+
+    def _spawn_traffic(self, rows=None):
+        """(Re)place candidates at a random distance along their entry lane (the SUMO flows' role)."""
+        B, M = self.n_env, self.n_cand
+        u = torch.rand((B, M), generator=self._gen).to(self.device)
+        spd = (torch.rand((B, M), generator=self._gen) * EXPECTED_V).to(self.device)
+        along = u * 60.0                                                                # up to the stop line + junction
+        fresh = torch.stack([self._entry[:, 0] + along * self._entry_dir[:, 0],
+                             self._entry[:, 1] + along * self._entry_dir[:, 1], spd,
+                             self._entry[:, 2].expand(B, M)], 2)
+        if rows is None:
+            self._cand.copy_(fresh)
+        else:
+            self._cand.copy_(torch.where(rows.unsqueeze(2), fresh, self._cand))
+
+    def reset(self, **kwargs):  # E2E:99-127
+        if kwargs or self.ref_path is None:
+            self.ref_path = ReferencePath(self.training_task, device=self.device, **kwargs)
+        elif self.n_env == 1:
+            self.ref_path = ReferencePath(self.training_task, device=self.device)
+        self.init_state = self._reset_init_state()
+        self._ego.copy_(torch.from_numpy(self._init_ego))
+        self._ref_idx.copy_(torch.from_numpy(self._init_ref))
+        miu = self.dynamics.vehicle_params['miu']
+        self._params.copy_(torch.tensor([0., 0., miu, miu], dtype=torch.float32).repeat(self.n_env, 1))   # E2E:110-113
+        self._spawn_traffic()
+        self._v_light.zero_()
+        if self.mode == 'training':                                                     # E2E:120-126
+            self._virtual.copy_(torch.from_numpy((self.np_random.random(self.n_env) > 0.9).astype(np.uint8)))
+        else:
+            self._virtual.zero_()
+        self.virtual_red_light_vehicle = bool(self._virtual[0].item()) if self.n_env == 1 else None
+        self._injected = False
+        self._publish_state()
+        self.obs = self._get_obs()
+        self.action = None
+        self.reward_info = None
+        self.done_type = 'not_done_yet' if self.n_env == 1 else ['not_done_yet'] * self.n_env
+        return self.obs
+
+    # -- reference-shaped views of the device state (n_env == 1) ---------------------------------
+    def _publish_state(self):
+        if self.n_env != 1:
+            self.ego_dynamics = self.all_vehicles = None
+            return
+        ego = self._ego[0].cpu().numpy()
+        par = self._params[0].cpu().numpy()
+        self.ego_dynamics = self._get_ego_dynamics(ego, par)
+        cand = self._cand[0].cpu().numpy()
+        names = _NAME_SETTINGS['D']
+        self.all_vehicles = [dict(x=float(c[0]), y=float(c[1]), v=float(c[2]), phi=float(c[3]), l=L, w=W,
+                                  route=(names[_MODE_EDGES[m][0]], names[_MODE_EDGES[m][1]]))
+                             for c, m in zip(cand, self.cand_modes)]
+        self.v_light = int(self._v_light[0].item())
+
+    def _get_ego_dynamics(self, next_ego_state, next_ego_params):  # E2E:150-183 (host floats, as in the reference)
+        out = dict(v_x=next_ego_state[0], v_y=next_ego_state[1], r=next_ego_state[2], x=next_ego_state[3],
+                   y=next_ego_state[4], phi=next_ego_state[5], l=self.ego_l, w=self.ego_w,
+                   alpha_f=next_ego_params[0], alpha_r=next_ego_params[1], miu_f=next_ego_params[2],
+                   miu_r=next_ego_params[3])
+        p = self.dynamics.vehicle_params
+        alpha_f_bound, alpha_r_bound = 3 * out['miu_f'] * p['F_zf'] / p['C_f'], 3 * out['miu_r'] * p['F_zr'] / p['C_r']
+        r_bound = out['miu_r'] * p['g'] / (abs(out['v_x']) + 1e-8)
+        l, w, x, y, phi = out['l'], out['w'], out['x'], out['y'], out['phi']
+        corners = tuple(rotate_and_shift_coordination(sx * l / 2, sy * w / 2, 0, -x, -y, -phi)[:2]
+                        for sx, sy in ((1, 1), (1, -1), (-1, 1), (-1, -1)))
+        out.update(dict(alpha_f_bound=alpha_f_bound, alpha_r_bound=alpha_r_bound, r_bound=r_bound, Corner_point=corners))
+        return out
+
+    def _absorb_injected(self, exit_):
+        """multi_display seam (multi_ego.py:94-96): the caller assigned ego_dynamics / all_vehicles / v_light."""
+        if self.n_env != 1 or self.ego_dynamics is None or self.all_vehicles is None:
+            return None, None
+        ed = self.ego_dynamics
+        ego = torch.tensor([[ed['v_x'], ed['v_y'], ed['r'], ed['x'], ed['y'], ed['phi']]], dtype=torch.float32)
+        vs = [(v, classify_route(v['route'], exit_)) for v in self.all_vehicles if v.get('route') is not None]
+        vs = [(v, m) for v, m in vs if m is not None]
+        cand = torch.tensor([[v['x'], v['y'], v['v'], v['phi']] for v, _ in vs], dtype=torch.float32).reshape(1, -1, 4)
+        cmode = torch.tensor([[_capi.VMODE_ID[m] for _, m in vs]], dtype=torch.uint8).reshape(1, -1)
+        self._ego.copy_(ego)
+        self._v_light.fill_(1 if self.v_light else 0)
+        return cand.to(self.device), cmode.to(self.device)
+
+    # -- observation (E2E:285-303, 329-464) -------------------------------------------------------
+    def _get_obs(self, exit_='D'):
+        cand, cmode = self._cand, self._cand_mode
+        if self.n_env == 1 and (self.multi_display or exit_ != 'D'):
+            inj = self._absorb_injected(exit_)
+            if inj[0] is not None:
+                cand, cmode = inj
+        light = ((self._v_light != 0) | (self._virtual != 0)).to(torch.uint8)          # E2E:387-388
+        m = cand.shape[1]
+        ri = self._ref_idx
+        if self.n_env == 1:
+            ri = torch.tensor([int(self.ref_path.ref_index)], dtype=torch.int32, device=self.device)
+        self.api.get_obs(self._h, self.n_env, _ptr(self._ego), _ptr(ri), 0, m, _ptr(cand.contiguous()),
+                         _ptr(cmode.contiguous()), _ptr(light), _ptr(self._obs), self._sp())
+        return self._ret(self._obs.clone())
+
+    # -- step (E2E:132-144) -----------------------------------------------------------------------
+    def _action_transformation_for_end2end(self, action):  # E2E:258-267
+        act = _dev(np.asarray(action, np.float32).reshape(self.n_env, 2) if not isinstance(action, (torch.Tensor, DevArray))
+                   else action, self.device).reshape(self.n_env, 2).contiguous()
+        out = torch.empty_like(act)
+        self.api.action_transform(self._h, self.n_env, _ptr(act), _ptr(out), self._sp())
+        return out
+
+    def compute_reward(self, obs, action):  # E2E:501-507: reward only, plus the dict of 16 terms
+        obs_t = _dev(obs, self.device).reshape(self.n_env, self.obs_dim).contiguous()
+        act_t = _dev(action, self.device).reshape(self.n_env, 2).contiguous()
+        reward, _, _, _, _, reward_dict = self.env_model.compute_rewards(obs_t, act_t)
+        if self.n_env == 1:
+            return reward.numpy()[0], {k: v.numpy()[0] for k, v in reward_dict.items()}
+        return reward, reward_dict
+
+    def _get_next_ego_state(self, trans_action):  # E2E:269-283
+        act = _dev(trans_action, self.device).reshape(self.n_env, 2).contiguous()
+        nxt, par = torch.empty_like(self._ego), torch.empty_like(self._params)
+        self.api.env_ego_step(self._h, self.n_env, _ptr(self._ego), _ptr(act), _ptr(nxt), _ptr(par), self._sp())
+        return nxt, par
+
+    def _traffic_step(self):
+        """SUMO's role (TRF:220-238): advance every candidate by the model's prediction step."""
+        flat = self._cand.reshape(self.n_env, 4 * self.n_cand)
+        out = torch.empty_like(flat)
+        self.api.veh_predict(self._traffic.h, self.n_env, _ptr(flat), _ptr(out), self._sp())
+        self._cand = out.reshape(self.n_env, self.n_cand, 4)
+        if self.respawn:
+            lim = CROSSROAD_SIZE / 2 + 40.
+            gone = (self._cand[:, :, 0].abs() > lim) | (self._cand[:, :, 1].abs() > lim)
+            self._spawn_traffic(gone)
+
+    def _judge_done(self):  # E2E:200-256 -> (done_type, done)
+        code = torch.empty((self.n_env,), dtype=torch.uint8, device=self.device)
+        self.api.judge_done(self._h, self.n_env, _ptr(self._ego), _ptr(self._params), _ptr(self._obs), self.n_cand,
+                            _ptr(self._cand.contiguous()), _ptr(self._cand_mode), None, _ptr(self._v_light), _ptr(code),
+                            self._sp())
+        self.done_code = code
+        if self.n_env == 1:
+            c = int(code[0].item())
+            return _capi.DONE_NAMES[c], int(c != 0)
+        return [_capi.DONE_NAMES[int(c)] for c in code.cpu().numpy()], DevArray((code != 0).to(torch.uint8))
+
+    def step(self, action):
+        act = self._action_transformation_for_end2end(action)                           # E2E:133
+        self.action = act[0].cpu().numpy() if self.n_env == 1 else DevArray(act)
+        reward, self.reward_info = self.compute_reward(self._obs, act)                  # E2E:134 (on the current obs)
+        self._ego, self._params = self._get_next_ego_state(act)                         # E2E:135
+        self._traffic_step()                                                            # E2E:137-138
+        self._publish_state()                                                           # E2E:136, 139
+        self.obs = self._get_obs()                                                      # E2E:140
+        self.done_type, done = self._judge_done()                                       # E2E:141
+        self.reward_info.update({'final_rew': reward})                                  # E2E:142
+        all_info = dict(all_vehicles=self.all_vehicles, ego_dynamics=self.ego_dynamics, v_light=self.v_light)
+        all_info.update({'reward_info': self.reward_info,
+                         'ref_index': self.ref_path.ref_index if self.n_env == 1 else DevArray(self._ref_idx)})   # E2E:143
+        return self.obs, reward, done, all_info

@@ -59,7 +59,8 @@ __global__ void write_only(float4* __restrict__ out, size_t n4) {
 }
 
 int main(int argc, char** argv) {
-    const size_t rows = argc > 1 ? atol(argv[1]) : 65536, D = 137;
+    const bool calib = argc > 1 && argv[1][0] == 'c';   // "calib": only the one-load-per-thread copy, 40 launches (PMC calibration)
+    const size_t rows = (argc > 1 && !calib) ? atol(argv[1]) : 65536, D = 137;
     const size_t n = rows * D, n4 = n / 4, bytes = n * 4;
     float* buf[3];
     for (int i = 0; i < 3; ++i) { CK(hipMalloc(&buf[i], bytes + 64)); CK(hipMemset(buf[i], 0, bytes + 64)); }
@@ -76,6 +77,11 @@ int main(int argc, char** argv) {
         const double us = ms * 1e3 / iters;
         printf("%-44s %8.2f us  %7.0f GB/s\n", name, us, traffic / us / 1e3);
     };
+    if (calib) {
+        for (int i = 0; i < 40; ++i) hipLaunchKernelGGL(copy_one, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4);
+        CK(hipDeviceSynchronize());
+        return 0;
+    }
     // ping-pong like the rollout: step t reads buf[t&1] writes buf[(t+1)&1]
     for (int grid : {1024, 2048, 4096, 8192}) {
         char nm[96]; snprintf(nm, 96, "copy grid-stride aligned, grid=%d", grid);

@@ -1,0 +1,14 @@
+#!/bin/bash
+# HBM traffic of the rollout kernel from the L2 memory-side counters, per MI355X_MICROARCH.md §HBM:
+# FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (with --kernel-trace only), calibrated on a plain float4
+# copy of an obs-sized buffer (known bytes, same 16-byte-per-lane access width), gfx950 FETCH_SIZE x2.
+# Usage (GPU box, repo root): bash scripts/pmc_traffic.sh <tag>   -> gpurun_out/<tag>/pmc_traffic.json
+TAG=${1:-pmc}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -o p -- python bench.py --steps 50 --warmup 25 --no-cpu-baseline > $OUT/bench_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/copy_$c -o p -- scripts/micro/copybench calib > $OUT/copy_$c.log 2>&1
+done
+python scripts/pmc_traffic.py $OUT | tee $OUT/pmc_traffic.txt

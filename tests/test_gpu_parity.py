@@ -275,3 +275,127 @@ def test_golden_rollouts_on_gpu(name):
         np.testing.assert_allclose(o5, g['out5'][t], rtol=1e-5, atol=1e-4)
         if t in keep:
             np.testing.assert_allclose(obs, g['obs_steps'][keep.index(t)], rtol=1e-5, atol=1e-4)
+
+
+# ---- env-side kernels (endtoend.py): eb_env_ego_step / eb_get_obs / eb_judge_done -------------------------
+from env_build_amd import _capi  # noqa: E402
+from env_build_amd.endtoend_env_utils import VEHICLE_MODE_LIST  # noqa: E402
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_g6_env_logic_on_gpu(task):
+    """The reference-generated env-logic fixture (filter / sort / pad, the seven done outcomes, collision hits
+    and misses) replayed on the GPU: integer masks and copied floats bit-exact."""
+    g = golden('g6_env_logic_%s' % task)
+    dev = DeviceModel(task, mode='training')
+    light_flag = ((g['v_light'] != 0) | (g['virtual'] != 0)).astype(np.uint8)
+    obs = dev.get_obs(g['ego'], g['cand'], g['cand_mode'], light_flag, ref_idx=g['ref_index'])
+    assert np.array_equal(obs[:, :6], g['obs'][:, :6])
+    np.testing.assert_allclose(obs[:, 6:9], g['obs'][:, 6:9], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(obs[:, 9:], g['obs'][:, 9:])
+    done = dev.judge_done(g['ego'], g['params'], g['obs'], g['cand'], g['cand_mode'], g['cand_lw'], g['v_light'])
+    assert np.array_equal(done, g['done_code'])
+    assert np.array_equal(done == 1, g['collision'] != 0)
+
+
+def test_g7_config1_single_env_200_steps_on_gpu():
+    """BASELINE configs[0] on the GPU: one env, 8 vehicles, 200 steps, against the reference's trace."""
+    g = golden('g7_config1_left')
+    modes = [str(m) for m in g['modes']]
+    dev = DeviceModel('left', mode='selecting')
+    H = g['actions'].shape[0]
+    ref = np.array([int(g['ref_index'])], np.int32)
+    ego, veh, obs = g['ego'][0:1].copy(), g['veh'][0].copy(), g['obs'][0:1].copy()
+    cmode = np.array([[_capi.VMODE_ID[m] for m in modes]], np.uint8)
+    for t in range(H):
+        act = dev.action_transform(g['actions'][t:t + 1])
+        out5, _ = dev.compute_rewards(obs, act)
+        ego, params = dev.env_ego_step(ego, act)
+        veh = dev.veh_predict(veh.reshape(1, -1)).reshape(-1, 4)
+        obs = dev.get_obs(ego, veh[None], cmode, np.zeros(1, np.uint8), ref_idx=ref)
+        done = dev.judge_done(ego, params, obs, veh[None], cmode, None, np.zeros(1, np.uint8))
+        np.testing.assert_allclose(out5[0, 0], g['reward'][t], rtol=1e-5, atol=1e-5, err_msg='t=%d' % t)
+        np.testing.assert_allclose(obs[0], g['obs'][t + 1], rtol=1e-5, atol=2e-4, err_msg='t=%d' % t)
+        assert done[0] == g['done_code'][t], 't=%d' % t
+
+
+def _random_scene(task, B, M, seed):
+    rng = np.random.default_rng(seed)
+    inp = make_rollout_inputs(task, B, 8, 1, seed=seed)
+    ego = inp['ego'].copy()
+    ego[:, 1] = rng.normal(0, 0.3, B); ego[:, 2] = rng.normal(0, 0.4, B)
+    ego[::9, 3] += rng.uniform(-12, 12, len(ego[::9]))          # some egos off the road
+    cand = np.stack([rng.uniform(-60, 60, (B, M)), rng.uniform(-60, 60, (B, M)), rng.uniform(0, 9, (B, M)),
+                     rng.uniform(-180, 180, (B, M))], 2).astype(np.float32)
+    near = rng.random((B, M)) < 0.01                              # some candidates on top of the ego
+    cand[near, 0] = (ego[:, 3][:, None] + rng.uniform(-4, 4, (B, M)))[near]
+    cand[near, 1] = (ego[:, 4][:, None] + rng.uniform(-4, 4, (B, M)))[near]
+    cmode = rng.integers(0, 12, (B, M)).astype(np.uint8)
+    cmode[rng.random((B, M)) < 0.1] = _capi.VMODE_EMPTY
+    lw = np.stack([rng.uniform(3.5, 6, (B, M)), rng.uniform(1.6, 2.6, (B, M))], 2).astype(np.float32)
+    light = (rng.random(B) < 0.3).astype(np.uint8)
+    act = np.stack([rng.uniform(-.42, .42, B), rng.uniform(-3.2, 1.7, B)], 1).astype(np.float32)
+    return ego, cand, cmode, lw, light, act, inp['ref_idx']
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_env_kernels_random_scenes_bit_exact(task):
+    B, M = 700, 23
+    host, dev = _pair(task, n_veh=VEH_NUM[task])
+    ego, cand, cmode, lw, light, act, ref = _random_scene(task, B, M, 31)
+    (e_h, p_h), (e_d, p_d) = host.env_ego_step(ego, act), dev.env_ego_step(ego, act)
+    assert np.array_equal(e_h, e_d) and np.array_equal(p_h, p_d)
+    o_h = host.get_obs(e_h, cand, cmode, light, ref_idx=ref)
+    o_d = dev.get_obs(e_h, cand, cmode, light, ref_idx=ref)
+    assert np.array_equal(o_h, o_d)
+    for lw_ in (lw, None):
+        d_h = host.judge_done(e_h, p_h, o_h, cand, cmode, lw_, light)
+        d_d = dev.judge_done(e_h, p_h, o_h, cand, cmode, lw_, light)
+        assert np.array_equal(d_h, d_d)
+    assert len(set(d_h.tolist())) >= 3      # several outcomes occur
+    # no candidates at all: every slot takes its fill value (E2E:439-447)
+    z_h = host.get_obs(e_h, cand[:, :0], cmode[:, :0], light, ref_idx=ref)
+    z_d = dev.get_obs(e_h, cand[:, :0], cmode[:, :0], light, ref_idx=ref)
+    assert np.array_equal(z_h, z_d)
+
+
+@pytest.mark.parametrize('task,n_env', [('left', 1), ('straight', 1), ('right', 64), ('left', 300)])
+def test_crossroad_env_facade_matches_oracle_composition(task, n_env):
+    """CrossroadEnd2end.step / reset (the reference's Gym surface) against the same composition made of oracle
+    calls on the env's own traffic state: obs, reward and done code identical at every step."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    env = CrossroadEnd2end(task, n_env=n_env, mode='training')
+    env.seed(3)
+    obs = env.reset()
+    host = HostModel(oracle_lib(), task, mode='training')
+    traffic = HostModel(oracle_lib(), task, n_veh=env.n_cand, modes=env.cand_modes)
+    D = 9 + 4 * VEH_NUM[task]
+    assert (obs.shape == (D,) and obs.dtype == np.float32) if n_env == 1 else obs.shape == (n_env, D)
+    rng = np.random.default_rng(0)
+    cmode = env._cand_mode.cpu().numpy()
+    for t in range(12):
+        ego0, cand0 = env._ego.cpu().numpy(), env._cand.cpu().numpy()
+        obs0, ref = env._obs.cpu().numpy(), env._ref_idx.cpu().numpy()
+        if n_env == 1:
+            ref = np.array([env.ref_path.ref_index], np.int32)
+        light = ((env._v_light != 0) | (env._virtual != 0)).cpu().numpy().astype(np.uint8)
+        action = rng.uniform(-1, 1, (n_env, 2)).astype(np.float32)
+        obs, reward, done, info = env.step(action[0] if n_env == 1 else action)
+        act = host.action_transform(action)
+        o5, d16 = host.compute_rewards(obs0, act)
+        ego1, par1 = host.env_ego_step(ego0, act)
+        cand1 = traffic.veh_predict(cand0.reshape(n_env, -1)).reshape(n_env, -1, 4)
+        gone = (np.abs(cand1[:, :, 0]) > 65) | (np.abs(cand1[:, :, 1]) > 65)
+        cand_env = env._cand.cpu().numpy()
+        assert np.array_equal(cand_env[~gone], cand1[~gone])              # re-entered vehicles are the env's own business
+        obs1 = host.get_obs(ego1, cand_env, cmode, light, ref_idx=ref)
+        done1 = host.judge_done(ego1, par1, obs1, cand_env, cmode, None, env._v_light.cpu().numpy())
+        if n_env == 1:
+            assert isinstance(done, int) and np.asarray(reward).shape == () and 'reward_info' in info
+            assert np.array_equal(obs, obs1[0]) and reward == o5[0, 0] and done == int(done1[0] != 0)
+            assert env.done_type == _capi.DONE_NAMES[int(done1[0])]
+            assert set(info['reward_info']) >= {'punish_steer', 'veh2road4real', 'final_rew'}
+            assert len(env.all_vehicles) == env.n_cand and abs(env.ego_dynamics['x'] - ego1[0, 3]) < 1e-6
+        else:
+            assert np.array_equal(obs.numpy(), obs1) and np.array_equal(reward.numpy(), o5[0])
+            assert np.array_equal(env.done_code.cpu().numpy(), done1)
