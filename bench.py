@@ -97,6 +97,7 @@ def main():
     import torch.distributed as dist
     from env_build_amd.dynamics_and_models import EnvironmentModel
     from env_build_amd.synthetic import make_rollout_inputs
+    from env_build_amd.sharding import combine_summaries, gather_summaries
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -122,7 +123,7 @@ def main():
     work, final = torch.empty_like(obs0), torch.empty_like(obs0)
     out5 = torch.empty((HORIZON, 5, n_env), dtype=torch.float32, device=dev)
     summary = torch.zeros((8,), dtype=torch.float32, device=dev)
-    summary_all = torch.zeros((world, 8), dtype=torch.float32, device=dev)
+    gathered = [torch.zeros((world, 8), dtype=torch.float32, device=dev)]
 
     api, h = model.api, model.handle
     stream = torch.cuda.current_stream()
@@ -145,10 +146,7 @@ def main():
     def end_of_horizon():
         # episodic-return summary of this shard (two small kernels), then the only inter-GPU exchange
         api.episode_summary(h, n_env, HORIZON, p(out5), p(final), p(summary), sp)
-        if world > 1:
-            dist.all_gather_into_tensor(summary_all.view(-1), summary)
-        else:
-            summary_all[0].copy_(summary, non_blocking=True)
+        gathered[0] = gather_summaries(summary)      # env_build_amd/sharding.py: one all-gather of 8 floats per rank
 
     n_pairs = min(MAX_EVENT_PAIRS, max(1, args.steps // HORIZON))
     ev = []
@@ -226,7 +224,7 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'eb::rollout_fused_4x8<0, true>', 'alg_bytes_per_launch': alg,
                          'avg_launch_us': launch_s * 1e6, 'launches_timed': n_marked * HORIZON},
-            'summary': [float(x) for x in summary_all[0].tolist()],
+            'summary': [float(x) for x in combine_summaries(gathered[0]).tolist()],
         }
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(inp, obs0.cpu().numpy(), n_veh)

@@ -1,0 +1,47 @@
+"""Batch sharding of the rollout over the GPUs of one node.
+
+Every env row is independent in every function on the path (DAM:118-427 are row-wise over the batch), so
+the env axis is split contiguously — rank r owns rows [lo, hi) of obs / actions / ref_indexes and its own
+handle — and there is NO data-path collective.  The only exchange is one all-gather per rollout of the
+8-float episodic summary that eb_episode_summary produces for a shard (RCCL over xGMI on the GPU box:
+backend "nccl"; the CPU tests run the same code over gloo).  The message is 32 bytes per rank:
+latency-bound, off the critical path.
+
+Host logic only — no arithmetic of the path lives here."""
+import torch
+import torch.distributed as dist
+
+SUMMARY_LEN = 8   # EB_SUMMARY_LEN: [sum reward, sum punish_train, sum punish_real, #envs punished, sum |dy|, max |dy|, n_env, horizon]
+
+
+def shard_range(n_env_total, rank, world):
+    """Contiguous split of the env axis; the first (n_env_total % world) ranks take one extra row."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError('bad rank/world: %r/%r' % (rank, world))
+    base, extra = divmod(int(n_env_total), world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_summaries(summary8, group=None):
+    """All-gather of one shard summary -> [world, 8] on every rank (the only inter-GPU exchange)."""
+    if summary8.numel() != SUMMARY_LEN:
+        raise ValueError('summary must have %d floats' % SUMMARY_LEN)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return summary8.reshape(1, SUMMARY_LEN).clone()
+    world = dist.get_world_size(group)
+    out = torch.empty((world, SUMMARY_LEN), dtype=summary8.dtype, device=summary8.device)
+    dist.all_gather_into_tensor(out.view(-1), summary8.reshape(-1).contiguous(), group=group)
+    return out
+
+
+def combine_summaries(all8):
+    """[world, 8] shard summaries -> the summary of the whole batch (sums add, max takes the max, the horizon
+    is common).  Accumulated in float64, as eb_episode_summary does inside a shard."""
+    a = all8.to(torch.float64)
+    out = torch.empty((SUMMARY_LEN,), dtype=torch.float64, device=all8.device)
+    out[0:5] = a[:, 0:5].sum(0)
+    out[5] = a[:, 5].max()
+    out[6] = a[:, 6].sum()
+    out[7] = a[:, 7].max()
+    return out.to(all8.dtype)
