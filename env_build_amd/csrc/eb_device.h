@@ -33,9 +33,13 @@ EB_DEV float sq(float x) { return x * x; }
 
 // IEEE-exact x / C for a compile-time constant C in 3 VALU ops (Markstein: q = x*rc, one exact
 // residual, one correction) instead of the ~11-op v_div_scale/v_rcp/v_div_fmas/v_div_fixup sequence.
-// Verified EXHAUSTIVELY against x / C over all 2^32 bit patterns for the five divisors used here
-// (tests/test_exact_math.py on CPU, eb_selftest on the GPU): bit-identical for every
-// |x| >= 3.1e-32 up to FLT_MAX; smaller non-zero magnitudes take the true division.
+// Checked against x / C over all 2^32 bit patterns for the five divisors used here
+// (tests/test_exact_math.py: oracle/envbuild_oracle.c:eb_oracle_check_div_exact runs the same fma
+// arithmetic on the CPU): bit-identical except for three kinds of dividend, which take the true division —
+// non-zero magnitudes below 2^-101 (the residual underflows), -0.0 (the correction adds +0), +-inf (inf - inf).
+// -0.0, +-inf, NaN: v_cmp_class_f32 mask sNaN | qNaN | -inf | -0 | +inf
+EB_DEV bool div_special(float x) { return __builtin_amdgcn_classf(x, 0x227); }
+
 // the unguarded core, also used with per-lane (c, 1/c) pairs (predict_record)
 EB_DEV float div_fast(float x, float c, float rc) {
     const float q = x * rc;
@@ -48,7 +52,7 @@ EB_DEV float div_const(float x) {
     constexpr float c = C::value;
     constexpr float rc = 1.0f / C::value;
     const unsigned mag2 = __builtin_bit_cast(unsigned, x) << 1;   // |x| bits * 2
-    if (__builtin_expect(mag2 - 1u < 2u * 0x0D000000u - 1u, 0))  // 0 < |x| < 2^-101 (~3.9e-31)
+    if (__builtin_expect(mag2 - 1u < 2u * 0x0D000000u - 1u || div_special(x), 0))  // 0 < |x| < 2^-101 (~3.9e-31), -0, inf, NaN
         return x / c;
     const float q = x * rc;
     const float r = __builtin_fmaf(-q, c, x);
@@ -314,8 +318,8 @@ EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, flo
 // predict_for_a_mode (DAM:405-427) with the slot's turn divisor taken from a table: tc = (c, 1/c,
 // sign, enabled) = (26.875, ., +1, 1) for dl rd ur lu, (15.625, ., -1, 1) for dr ru ul ld, (1, 1, 0, 0)
 // otherwise.  EXACT = false uses the 3-op exact constant divisions and reports through `tiny`
-// whether any dividend was a non-zero magnitude below 2^-101 (where only the true division is
-// exact); EXACT = true is the same arithmetic with IEEE divisions.  sn / cs return sin / cos of the
+// whether any dividend was one of those only the true division gets right (non-zero below 2^-101, -0,
+// +-inf; see div_const); EXACT = true is the same arithmetic with IEEE divisions.  sn / cs return sin / cos of the
 // record's CURRENT heading (also the circle-centre offsets of DAM:221-224).
 template <bool EXACT>
 EB_DEV float4 predict_record(float x, float y, float v, float phi, const float4 tc, unsigned& tiny, float& sn,
@@ -340,7 +344,7 @@ EB_DEV float4 predict_record(float x, float y, float v, float phi, const float4 
         const unsigned b = (__builtin_bit_cast(unsigned, v) << 1) - 1u;
         const unsigned c = (__builtin_bit_cast(unsigned, t2) << 1) - 1u;
         const unsigned d = (__builtin_bit_cast(unsigned, u) << 1) - 1u;
-        tiny = min(min(a, b), min(c, d)) < 2u * 0x0D000000u - 1u;
+        tiny = (min(min(a, b), min(c, d)) < 2u * 0x0D000000u - 1u) || div_special(t1) || div_special(v) || div_special(t2);
     }
     return make_float4(x + dx, y + dy, v, nphi_deg);                                     // DAM:422-427
 }

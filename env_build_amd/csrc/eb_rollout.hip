@@ -283,12 +283,12 @@ EB_DEV f4u predict_record_pk(const f4u rec, const float4 tc, unsigned& tiny) {
     const float t2 = nphi * 180.0f;
     const float nphi_deg = EXACT ? t2 / PI_F : div_fast(t2, PI_F, 1.0f / PI_F);   // DAM:426
     if (!EXACT) {
-        // the 3-op divisions are exact unless a dividend is non-zero and below 2^-101: (bits << 1) - 1 < 2 * 0x0D000000 - 1
+        // the 3-op divisions are exact unless a dividend is non-zero and tiny, -0 or +-inf (eb_device.h:div_const).
+        // Tiny: (bits << 1) - 1 < 2 * T - 1 with the threshold raised to 2^-96 so that v covers u = v / c too.
         const unsigned g0 = (__builtin_bit_cast(unsigned, vt.y) << 1) - 1u;
         const unsigned g1 = (__builtin_bit_cast(unsigned, v) << 1) - 1u;
         const unsigned g2 = (__builtin_bit_cast(unsigned, t2) << 1) - 1u;
-        const unsigned g3 = (__builtin_bit_cast(unsigned, u) << 1) - 1u;
-        tiny = min(min(g0, g1), min(g2, g3)) < 2u * 0x0D000000u - 1u;
+        tiny = (min(g0, min(g1, g2)) < 2u * 0x0F800000u - 1u) || div_special(vt.y) || div_special(v) || div_special(t2);
     }
     return f4u{nxy.x, nxy.y, v, nphi_deg};                                   // DAM:422-427
 }

@@ -1017,3 +1017,40 @@ void eb_oracle_sincosf(const float* x, float* s, float* c, int n) {
 void eb_oracle_atanf(const float* x, float* y, int n) {
     for (int i = 0; i < n; ++i) y[i] = eb_atanf(x[i]);
 }
+
+/* Checks the kernels' 3-op constant division (eb_device.h:div_fast: q = x*rc, r = fma(-q, c, x), q + r*rc with
+ * rc = fl(1/c)) against IEEE x / c for every float bit pattern in [first, last] with stride `step`.  fmaf is
+ * correctly rounded here as v_fma_f32 is on the GPU, so this is the same arithmetic.  Returns the number of
+ * patterns that differ, ignoring the guarded dividends that take the true division in the kernels (non-zero
+ * |x| < 2^-101, -0.0, +-inf) and NaNs; *first_bad gets the first differing pattern.  With guard == 0 nothing is
+ * ignored except NaNs (used to show that the three guarded kinds are the only ones that differ). */
+long long eb_oracle_check_div_exact(float c, uint32_t first, uint32_t last, uint32_t step, int guard, uint32_t* first_bad) {
+    const float rc = 1.0f / c;
+    long long bad = 0;
+    uint32_t fb = 0xffffffffu;
+    const uint64_t n = ((uint64_t)last - first) / step + 1;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : bad) reduction(min : fb) schedule(static)
+#endif
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t bits = first + (uint32_t)(i * step);
+        float x;
+        memcpy(&x, &bits, 4);
+        if (x != x) continue;
+        const uint32_t mag2 = bits << 1;
+        if (guard && (mag2 - 1u < 2u * 0x0D000000u - 1u || bits == 0x80000000u || mag2 == 0xFF000000u)) continue;
+        const float q = x * rc;
+        const float r = fmaf(-q, c, x);
+        const float fast = fmaf(r, rc, q);
+        const float exact = x / c;
+        uint32_t a, b;
+        memcpy(&a, &fast, 4);
+        memcpy(&b, &exact, 4);
+        if (a != b && !(fast != fast && exact != exact)) {
+            ++bad;
+            if (bits < fb) fb = bits;
+        }
+    }
+    if (first_bad) *first_bad = fb;
+    return bad;
+}
