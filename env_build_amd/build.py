@@ -11,7 +11,8 @@ LIB = os.path.join(HERE, 'lib', 'libenvbuild_hip.so')
 SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip']
 HEADERS = ['eb_device.h', 'eb_kernels.h', os.path.join('..', '..', 'include', 'envbuild.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
-         '-fPIC', '-shared', '-Wno-unused-value']
+         '-fPIC', '-shared', '-Wno-unused-value', '-Wno-pass-failed',
+         '-mllvm', '-amdgpu-kernarg-preload-count=12']   # the rollout kernel's leading arguments arrive in SGPRs
 
 
 def needs_build():

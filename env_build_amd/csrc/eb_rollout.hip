@@ -48,6 +48,17 @@ EB_DEV void lds_wait_until(int* flag, int value) {
     asm volatile("" ::: "memory");
 }
 
+// The arguments every wave needs before it can issue its first HBM load travel as separate kernel parameters:
+// with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave instead of behind an s_load.
+// (The same-named members of FusedArgs are only read on the host side.)
+struct FusedHot {
+    const float* obs_in;
+    float* obs_out;
+    int n_env, obs_dim, n_veh, envs_per_tile;
+    unsigned nv_magic;
+    int do_rewards;
+};
+
 // profiling aid: mark slot `i` of this wave's trace row with the 100 MHz wall clock (lane 0 only)
 #define EB_MARK(A, row, i) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + (i)] = wall_clock64(); } while (0)
 
@@ -104,13 +115,13 @@ struct FusedSmem {
 
 // ---- env wave -------------------------------------------------------------------------------------
 template <int TASK, int RW, int RPT>
-EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
+EB_DEV void env_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
     const int lane = threadIdx.x;   // wave 0
-    const int D = A.obs_dim, NV = A.n_veh;
+    const int D = H.obs_dim, NV = H.n_veh;
     const bool act = lane < nE;
     const int e = act ? lane : 0, ge = e0 + e;
-    const float* hin = A.obs_in + (size_t)ge * D;
-    float* hout = A.obs_out + (size_t)ge * D;
+    const float* hin = H.obs_in + (size_t)ge * D;
+    float* hout = H.obs_out + (size_t)ge * D;
 
     // head (ego 6 | first tracking triple), action, path id
     const f4u h0 = *reinterpret_cast<const f4u*>(hin), h1 = *reinterpret_cast<const f4u*>(hin + 4);
@@ -127,7 +138,7 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
     const float phi_rad = deg2rad(st[5]);
     float es, ec;
     sincos_det(phi_rad, es, ec);                                            // DAM:211 and DAM:79-80
-    if (A.do_rewards) {
+    if (H.do_rewards) {
         S.ego[lane] = make_float4(st[3], st[4], es, ec);
         S.mask[lane] = 0ull;
         lds_publish(&S.ego_ready, 1);                                       // ---- hand-off 1 ----
@@ -138,7 +149,7 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
     if (A.actions_raw) action_transform(araw.x, araw.y, steer, a_x);        // DAM:120
     else { steer = araw.x; a_x = araw.y; }
     if (act && A.scaled_actions) *reinterpret_cast<f2u*>(A.scaled_actions + 2 * (size_t)ge) = f2u{steer, a_x};
-    if (act && A.do_rewards) {
+    if (act && H.do_rewards) {
         const float punish_steer = -sq(steer), punish_a_x = -sq(a_x);       // DAM:198-199
         const float punish_yaw_rate = -sq(st[2]);                           // DAM:202
         const float devi_y = -sq(h1.z);                                     // DAM:205
@@ -188,7 +199,7 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
         hout[8] = t2;
     }
     EB_MARK(A, trow, 4);                                                    // head stored
-    if (!A.do_rewards) return;
+    if (!H.do_rewards) return;
     lds_wait_until(&S.waves_done, RW);                                      // ---- hand-off 2 ----
     EB_MARK(A, trow, 5);                                                    // record waves done
 
@@ -206,7 +217,7 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
         float road_t = 0.0f, road_r = 0.0f;
         road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
         road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
-        const size_t n = (size_t)A.n_env;
+        const size_t n = (size_t)H.n_env;
         A.out5[n + ge] = a35 + road_t;       // DAM:299
         A.out5[2 * n + ge] = a25 + road_r;   // DAM:300
         A.out5[3 * n + ge] = a25;
@@ -218,11 +229,11 @@ EB_DEV void env_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) 
 // ---- record waves -----------------------------------------------------------------------------------
 // one queue pass: entries [base, base + n) of this wave's queue, one per lane: DAM:218-229
 template <int RW, int RPT>
-EB_DEV void queue_pass(const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int base, int n) {
+EB_DEV void queue_pass(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int base, int n) {
     if (lane < n) {
         const float4 v = S.qd[w][base + lane];                              // (x, y, phi, item id)
         const int item = __float_as_int(v.w);
-        const int e2 = (int)__umulhi((unsigned)item, A.nv_magic), j2 = item - e2 * A.n_veh;
+        const int e2 = (int)__umulhi((unsigned)item, H.nv_magic), j2 = item - e2 * H.n_veh;
         const float4 eg = S.ego[e2];
         float t35[4], t25[4], vs, vc;
         const float4 pts = make_float4(eg.x + LWS * eg.w, eg.y + LWS * eg.z, eg.x - LWS * eg.w, eg.y - LWS * eg.z);
@@ -296,19 +307,19 @@ EB_DEV f4u predict_record_pk(const f4u rec, const float4 tc, unsigned& tiny) {
 // FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
 // fixed step, so slot constants are fetched once and addresses advance by a uniform stride.
 template <int TASK, int RW, int RPT, bool FAST>
-EB_DEV void record_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
+EB_DEV void record_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
     constexpr int RL = RW * 64;                     // record lanes per block
     const int rtid = threadIdx.x - 64, w = rtid >> 6, lane = rtid & 63;
-    const int NV = A.n_veh, D = A.obs_dim, HD = D - 4 * NV;
+    const int NV = H.n_veh, D = H.obs_dim, HD = D - 4 * NV;
     const int items = nE * NV;
-    const float* tin = A.obs_in + (size_t)e0 * D;
-    float* tout = A.obs_out + (size_t)e0 * D;
-    const int e_first = (int)__umulhi((unsigned)rtid, A.nv_magic), j_first = rtid - e_first * NV;
+    const float* tin = H.obs_in + (size_t)e0 * D;
+    float* tout = H.obs_out + (size_t)e0 * D;
+    const int e_first = (int)__umulhi((unsigned)rtid, H.nv_magic), j_first = rtid - e_first * NV;
     const int epk = RL / NV;                                  // FAST: envs per k step
     const int off_first = 4 * rtid + (e_first + 1) * HD, off_step = 4 * RL + epk * HD;
     // record k of this lane: item id, env (tile-local), float offset of the record in the tile (== e*D + HD + 4*j)
     auto item_of = [&](int k) { return k * RL + rtid; };
-    auto env_of = [&](int k) { return FAST ? e_first + k * epk : (int)__umulhi((unsigned)item_of(k), A.nv_magic); };
+    auto env_of = [&](int k) { return FAST ? e_first + k * epk : (int)__umulhi((unsigned)item_of(k), H.nv_magic); };
     auto off_of = [&](int k) { return FAST ? off_first + k * off_step : 4 * item_of(k) + (env_of(k) + 1) * HD; };
 
     // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then every record
@@ -348,7 +359,7 @@ EB_DEV void record_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int n
         }
     };
     predict_all();
-    if (!A.do_rewards) return;
+    if (!H.do_rewards) return;
 
     // ---- near-ego records -> this wave's queue -> circle-pair distances ----
     // A circle pair can only be closer than 3.5 m when the two vehicle centres are within 3.5 + 2*1.4 = 6.3 m;
@@ -358,7 +369,7 @@ EB_DEV void record_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int n
     EB_MARK(A, trow, 3);                                                    // ego seen
     int qn = 0;
     auto drain = [&]() {
-        for (int base = 0; base < qn; base += 64) queue_pass<RW, RPT>(A, S, w, lane, base, min(64, qn - base));
+        for (int base = 0; base < qn; base += 64) queue_pass<RW, RPT>(H, A, S, w, lane, base, min(64, qn - base));
         qn = 0;
     };
     if (!(A.ablate & 8)) {
@@ -390,17 +401,17 @@ EB_DEV void record_wave(const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int n
 }
 
 template <int TASK, int RW, int RPT, bool FAST>
-EB_DEV void fused_body(const FusedArgs& A) {
+EB_DEV void fused_body(const FusedHot& H, const FusedArgs& A) {
     __shared__ FusedSmem<RW, RPT> S;
-    const int e0 = blockIdx.x * A.envs_per_tile;
-    const int nE = min(A.envs_per_tile, A.n_env - e0);
+    const int e0 = blockIdx.x * H.envs_per_tile;
+    const int nE = min(H.envs_per_tile, H.n_env - e0);
     if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
     lds_barrier();   // the only barrier: at launch, before any wave has something to wait for
     if (threadIdx.x < 64) {
         __builtin_amdgcn_s_setprio(2);
-        env_wave<TASK, RW, RPT>(A, S, e0, nE);
+        env_wave<TASK, RW, RPT>(H, A, S, e0, nE);
     } else {
-        record_wave<TASK, RW, RPT, FAST>(A, S, e0, nE);
+        record_wave<TASK, RW, RPT, FAST>(H, A, S, e0, nE);
     }
 }
 
@@ -411,8 +422,10 @@ EB_DEV void fused_body(const FusedArgs& A) {
 #define EB_FUSED_KERNEL(NAME, RW, RPT, WAVES, VGPRS)                                                     \
     template <int TASK, bool FAST>                                                                       \
     __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
-        const FusedArgs A) {                                                                             \
-        fused_body<TASK, RW, RPT, FAST>(A);                                                              \
+        const float* obs_in, float* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,       \
+        unsigned nv_magic, int do_rewards, const FusedArgs A) {                                          \
+        const FusedHot H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards};   \
+        fused_body<TASK, RW, RPT, FAST>(H, A);                                                           \
     }
 EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
 EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 8, 64)
@@ -426,11 +439,12 @@ int fused_tile_records(int variant) {
     }
 }
 
+#define EB_HOT_ARGS A.obs_in, A.obs_out, A.n_env, A.obs_dim, A.n_veh, A.envs_per_tile, A.nv_magic, A.do_rewards
 #define EB_LAUNCH_TASK(KERNEL, FAST_)                                                                          \
     switch (task) {                                                                                            \
-        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_>), g, b, 0, s, A); break;                  \
-        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_>), g, b, 0, s, A); break;          \
-        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_>), g, b, 0, s, A); break;                        \
+        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_>), g, b, 0, s, EB_HOT_ARGS, A); break;     \
+        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_>), g, b, 0, s, EB_HOT_ARGS, A); break; \
+        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_>), g, b, 0, s, EB_HOT_ARGS, A); break;           \
     }
 #define EB_LAUNCH(KERNEL, RW)                                                                                  \
     {                                                                                                          \
