@@ -50,9 +50,10 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(inp, obs0, n_veh, budget_s=16.0):
-    """Oracle timed on host cores: bounded sample (8192 envs x HORIZON steps, repeated until the
-    budget is used) on all usable cores via OpenMP, then on 1 core (the reference pins TF to 1 thread)."""
+def cpu_baseline(inp, obs0, n_veh, budget_s=18.0):
+    """Oracle timed on host cores on a bounded sample (8192 envs x HORIZON steps, repeated until the budget is
+    used): 1 thread (the reference pins TF to 1 thread) and OpenMP over envs on 8 / 32 / all usable cores
+    (a cgroup CPU quota can make "all" slower than 8, so every count is reported and the best one is `value`)."""
     from tests._helpers import HostModel, oracle_lib
     api = oracle_lib()
     api.lib.eb_oracle_set_threads.restype = C.c_int
@@ -60,25 +61,25 @@ def cpu_baseline(inp, obs0, n_veh, budget_s=16.0):
     b_cpu = 8192
     host = HostModel(api, TASK, n_veh=n_veh)
     obs, act, ref = obs0[:b_cpu].copy(), inp['actions'][:, :b_cpu].copy(), inp['ref_idx'][:b_cpu].copy()
+    counts = sorted(set([1] + [c for c in (8, 32) if c < host_cores()] + [host_cores()]))
     res = {}
-    for label, threads in (('all', host_cores()), ('one', 1)):
+    for threads in counts:
         used = api.lib.eb_oracle_set_threads(int(threads))
         host.rollout_tape(obs, act[:2], ref)   # warm-up
         n_steps, t0 = 0, time.perf_counter()
         while True:
             host.rollout_tape(obs, act, ref)
             n_steps += HORIZON
-            if time.perf_counter() - t0 > budget_s / 2:
+            if time.perf_counter() - t0 > budget_s / len(counts):
                 break
         dt = time.perf_counter() - t0
-        res[label] = (b_cpu * n_steps / dt, used, n_steps)
-    best = 'all' if res['all'][0] >= res['one'][0] else 'one'
-    return {'value': res[best][0], 'unit': 'env-steps/s', 'cores': res[best][1], 'kind': 'port',
-            'value_1core': res['one'][0], 'value_allcores': res['all'][0], 'allcores': res['all'][1],
-            'sample': '%d envs x %d steps on %d threads / x %d steps on 1 thread (N_veh=%d, same seeded inputs), '
-                      'oracle/envbuild_oracle.c, OpenMP over envs; the 1-thread figure is the reference-faithful '
-                      'setting (the reference pins TF to 1 thread)'
-                      % (b_cpu, res['all'][2], res['all'][1], res['one'][2], n_veh)}
+        res[used] = (b_cpu * n_steps / dt, n_steps)
+    best = max(res, key=lambda k: res[k][0])
+    return {'value': res[best][0], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
+            'value_1core': res[1][0], 'by_threads': {str(k): v[0] for k, v in res.items()},
+            'sample': '%d envs x %s steps on %s threads (N_veh=%d, same seeded inputs), oracle/envbuild_oracle.c, OpenMP '
+                      'over envs; the 1-thread figure is the reference-faithful setting (the reference pins TF to 1 thread)'
+                      % (b_cpu, '/'.join(str(v[1]) for v in res.values()), '/'.join(str(k) for k in res), n_veh)}
 
 
 def main():
