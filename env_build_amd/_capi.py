@@ -44,6 +44,8 @@ PROTOTYPES = {
     'eb_compute_next_obses': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P]),
     'eb_rollout_step': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'eb_rollout_step_f16': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'eb_rollout_tape_f16': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_episode_summary': (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
     'eb_plan_create': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, C.POINTER(_P)]),
     'eb_plan_launch': (C.c_int, [_P, _P]),

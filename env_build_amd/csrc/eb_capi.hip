@@ -334,12 +334,14 @@ int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float
     return EB_OK;
 }
 
+// obs_in / obs_out point at fp32 rows, or at binary16 rows when storage_f16 is set
 static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* obs_in, const float* actions,
                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
-                         float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s) {
+                         float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16) {
     const int NV = h->cfg.n_veh;
     eb::FusedArgs A;
     std::memset(&A, 0, sizeof A);
+    A.storage_f16 = storage_f16;
     A.obs_in = obs_in; A.actions = actions; A.ref_idx = ref_idx; A.obs_out = obs_out; A.out5 = out5;
     A.scaled_actions = scaled_actions;
     A.dt = h->d_pt;
@@ -369,7 +371,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
 
 static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
-                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s) {
+                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16 = 0) {
     static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
     int variant = h->tile_variant >= 0 ? h->tile_variant : forced;
     if (variant < 0 || variant > 2) {
@@ -381,7 +383,7 @@ static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const
         }
     }
     return rollout_fused(h, variant, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
-                         actions_raw, do_rewards, s);
+                         actions_raw, do_rewards, s, storage_f16);
 }
 
 int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
@@ -427,6 +429,37 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
         float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
         rc = rollout_common(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
                             out5_steps + (size_t)t * 5 * n_env, nullptr, 1, 1, s);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return EB_OK;
+}
+
+int eb_rollout_step_f16(eb_handle h, int32_t n_env, const uint16_t* obs_in, const float* actions, const int32_t* ref_idx,
+                        int32_t path_id, uint16_t* obs_out, float* out5, float* scaled_actions, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_step_f16: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs_in || !actions || !obs_out || !out5) return fail(EB_EINVAL, "eb_rollout_step_f16: bad argument");
+    if (obs_in == obs_out) return fail(EB_EINVAL, "eb_rollout_step_f16: in-place update is not supported");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    return rollout_common(h, n_env, reinterpret_cast<const float*>(obs_in), actions, ref_idx, path_id,
+                          reinterpret_cast<float*>(obs_out), out5, scaled_actions, 1, 1, pick(h, stream), 1);
+}
+
+int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint16_t* obs_in, const float* action_tape,
+                        const int32_t* ref_idx, int32_t path_id, uint16_t* obs_work, uint16_t* obs_out, float* out5_steps,
+                        void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    if (horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps)
+        return fail(EB_EINVAL, "eb_rollout_tape_f16: bad argument");
+    if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
+        return fail(EB_EINVAL, "eb_rollout_tape_f16: obs_in, obs_work and obs_out must be distinct buffers");
+    const uint16_t* cur = obs_in;
+    for (int t = 0; t < horizon; ++t) {   // ping-pong so that the last step lands in obs_out
+        uint16_t* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
+        int rc = eb_rollout_step_f16(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
+                                     out5_steps + (size_t)t * 5 * n_env, nullptr, stream);
         if (rc) return rc;
         cur = dst;
     }

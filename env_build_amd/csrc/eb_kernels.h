@@ -16,6 +16,7 @@ struct VehModes {
 
 // ---- fused rollout step (eb_rollout.hip): one block = one env wave + RW record waves ----
 struct FusedArgs {
+    int storage_f16;           // 0: obs rows are fp32; 1: IEEE binary16 (obs_in / obs_out then point at uint16 rows)
     const float* obs_in;
     const float* actions;
     const int* ref_idx;

@@ -34,6 +34,28 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));                 // register pair for v_pk_*_f32
 EB_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Storage of the obs rows: fp32 (the reference's layout) or IEEE binary16 (BASELINE configs[4]: state stored in
+// fp16, every operation and the reward accumulation in fp32, results rounded to nearest-even on the store).
+template <typename ST> struct Stored;
+template <> struct Stored<float> {
+    static EB_DEV f4u load4(const float* p) { return *reinterpret_cast<const f4u*>(p); }
+    static EB_DEV float load1(const float* p) { return *p; }
+    static EB_DEV void store4(float* p, f4u v) { *reinterpret_cast<f4u*>(p) = v; }
+    static EB_DEV void store1(float* p, float v) { *p = v; }
+};
+typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
+template <> struct Stored<_Float16> {
+    static EB_DEV f4u load4(const _Float16* p) {
+        const h4u h = *reinterpret_cast<const h4u*>(p);
+        return f4u{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    }
+    static EB_DEV float load1(const _Float16* p) { return (float)*p; }
+    static EB_DEV void store4(_Float16* p, f4u v) {
+        *reinterpret_cast<h4u*>(p) = h4u{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    }
+    static EB_DEV void store1(_Float16* p, float v) { *p = (_Float16)v; }
+};
+
 // LDS-only workgroup barrier: orders this wave's LDS traffic, leaves global loads/stores in flight
 EB_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // The two hand-offs between the roles are LDS flags, not barriers: a barrier would hold the env wave until
@@ -51,9 +73,10 @@ EB_DEV void lds_wait_until(int* flag, int value) {
 // The arguments every wave needs before it can issue its first HBM load travel as separate kernel parameters:
 // with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave instead of behind an s_load.
 // (The same-named members of FusedArgs are only read on the host side.)
+template <typename ST>
 struct FusedHot {
-    const float* obs_in;
-    float* obs_out;
+    const ST* obs_in;
+    ST* obs_out;
     int n_env, obs_dim, n_veh, envs_per_tile;
     unsigned nv_magic;
     int do_rewards;
@@ -114,18 +137,18 @@ struct FusedSmem {
 };
 
 // ---- env wave -------------------------------------------------------------------------------------
-template <int TASK, int RW, int RPT>
-EB_DEV void env_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
+template <int TASK, int RW, int RPT, typename ST>
+EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
     const int lane = threadIdx.x;   // wave 0
     const int D = H.obs_dim, NV = H.n_veh;
     const bool act = lane < nE;
     const int e = act ? lane : 0, ge = e0 + e;
-    const float* hin = H.obs_in + (size_t)ge * D;
-    float* hout = H.obs_out + (size_t)ge * D;
+    const ST* hin = H.obs_in + (size_t)ge * D;
+    ST* hout = H.obs_out + (size_t)ge * D;
 
     // head (ego 6 | first tracking triple), action, path id
-    const f4u h0 = *reinterpret_cast<const f4u*>(hin), h1 = *reinterpret_cast<const f4u*>(hin + 4);
-    const float h8 = hin[8];
+    const f4u h0 = Stored<ST>::load4(hin), h1 = Stored<ST>::load4(hin + 4);
+    const float h8 = Stored<ST>::load1(hin + 8);
     const f2u araw = *reinterpret_cast<const f2u*>(A.actions + 2 * (size_t)ge);
     int p = A.path_id;
     if (A.training) {
@@ -178,25 +201,25 @@ EB_DEV void env_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& 
         if (A.n_future > 0 && act) {                                        // DAM:717-724, 763-768
             const PathTables& pt = *A.dt;
             const int len = pt.len[p];
-            float* otrk = hout + 9;
+            ST* otrk = hout + 9;
             int cur = bi * 10;                                              // DAM:714
             for (int k = 0; k < A.n_future; ++k) {
                 cur += 80;
                 if (cur >= len - 2) cur = len - 2;
                 const int fi = clamp_index(cur, len);
-                otrk[3 * k] = pt.x[p][fi] - nx[3];
-                otrk[3 * k + 1] = pt.y[p][fi] - nx[4];
-                otrk[3 * k + 2] = deal_with_phi_diff(nx[5] - pt.phi[p][fi]);
+                Stored<ST>::store1(otrk + 3 * k, pt.x[p][fi] - nx[3]);
+                Stored<ST>::store1(otrk + 3 * k + 1, pt.y[p][fi] - nx[4]);
+                Stored<ST>::store1(otrk + 3 * k + 2, deal_with_phi_diff(nx[5] - pt.phi[p][fi]));
             }
         }
     } else if (A.n_future > 0 && act) {
-        float* otrk = hout + 9;
-        for (int c = 0; c < 3 * A.n_future; ++c) otrk[c] = 0.0f;            // DAM:342, 352
+        ST* otrk = hout + 9;
+        for (int c = 0; c < 3 * A.n_future; ++c) Stored<ST>::store1(otrk + c, 0.0f);   // DAM:342, 352
     }
     if (act) {
-        *reinterpret_cast<f4u*>(hout) = f4u{nx[0], nx[1], nx[2], nx[3]};
-        *reinterpret_cast<f4u*>(hout + 4) = f4u{nx[4], nx[5], t0, t1};
-        hout[8] = t2;
+        Stored<ST>::store4(hout, f4u{nx[0], nx[1], nx[2], nx[3]});
+        Stored<ST>::store4(hout + 4, f4u{nx[4], nx[5], t0, t1});
+        Stored<ST>::store1(hout + 8, t2);
     }
     EB_MARK(A, trow, 4);                                                    // head stored
     if (!H.do_rewards) return;
@@ -228,8 +251,8 @@ EB_DEV void env_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& 
 
 // ---- record waves -----------------------------------------------------------------------------------
 // one queue pass: entries [base, base + n) of this wave's queue, one per lane: DAM:218-229
-template <int RW, int RPT>
-EB_DEV void queue_pass(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int base, int n) {
+template <int RW, int RPT, typename ST>
+EB_DEV void queue_pass(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int base, int n) {
     if (lane < n) {
         const float4 v = S.qd[w][base + lane];                              // (x, y, phi, item id)
         const int item = __float_as_int(v.w);
@@ -306,14 +329,14 @@ EB_DEV f4u predict_record_pk(const f4u rec, const float4 tc, unsigned& tiny) {
 
 // FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
 // fixed step, so slot constants are fetched once and addresses advance by a uniform stride.
-template <int TASK, int RW, int RPT, bool FAST>
-EB_DEV void record_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
+template <int TASK, int RW, int RPT, bool FAST, typename ST>
+EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
     constexpr int RL = RW * 64;                     // record lanes per block
     const int rtid = threadIdx.x - 64, w = rtid >> 6, lane = rtid & 63;
     const int NV = H.n_veh, D = H.obs_dim, HD = D - 4 * NV;
     const int items = nE * NV;
-    const float* tin = H.obs_in + (size_t)e0 * D;
-    float* tout = H.obs_out + (size_t)e0 * D;
+    const ST* tin = H.obs_in + (size_t)e0 * D;
+    ST* tout = H.obs_out + (size_t)e0 * D;
     const int e_first = (int)__umulhi((unsigned)rtid, H.nv_magic), j_first = rtid - e_first * NV;
     const int epk = RL / NV;                                  // FAST: envs per k step
     const int off_first = 4 * rtid + (e_first + 1) * HD, off_step = 4 * RL + epk * HD;
@@ -329,7 +352,7 @@ EB_DEV void record_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT
     for (int k = 0; k < RPT; ++k) {
         // lanes past the tile's last record re-read the tile's last record (branch-free loads; never stored)
         const int off = item_of(k) < items ? off_of(k) : 4 * (items - 1) + nE * HD;
-        rec[k] = *reinterpret_cast<const f4u*>(tin + off);
+        rec[k] = Stored<ST>::load4(tin + off);
     }
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
     EB_MARK(A, trow, 0);                                                    // loads issued
@@ -351,7 +374,7 @@ EB_DEV void record_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT
                 unsigned tiny = 0u;
                 f4u nv = predict_record_pk<false>(rec[k], tc, tiny);
                 if (__builtin_expect(tiny != 0u, 0)) nv = predict_record_pk<true>(rec[k], tc, tiny);
-                *reinterpret_cast<f4u*>(tout + off_of(k)) = nv;
+                Stored<ST>::store4(tout + off_of(k), nv);
             }
             if (k == 0) EB_MARK(A, trow, 1);                                // first record stored
             if (k == RPT - 1) EB_MARK(A, trow, 2);                          // last record stored
@@ -369,7 +392,7 @@ EB_DEV void record_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT
     EB_MARK(A, trow, 3);                                                    // ego seen
     int qn = 0;
     auto drain = [&]() {
-        for (int base = 0; base < qn; base += 64) queue_pass<RW, RPT>(H, A, S, w, lane, base, min(64, qn - base));
+        for (int base = 0; base < qn; base += 64) queue_pass<RW, RPT, ST>(H, A, S, w, lane, base, min(64, qn - base));
         qn = 0;
     };
     if (!(A.ablate & 8)) {
@@ -400,8 +423,8 @@ EB_DEV void record_wave(const FusedHot& H, const FusedArgs& A, FusedSmem<RW, RPT
     EB_MARK(A, trow, 5);                                                    // end
 }
 
-template <int TASK, int RW, int RPT, bool FAST>
-EB_DEV void fused_body(const FusedHot& H, const FusedArgs& A) {
+template <int TASK, int RW, int RPT, bool FAST, typename ST>
+EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
     __shared__ FusedSmem<RW, RPT> S;
     const int e0 = blockIdx.x * H.envs_per_tile;
     const int nE = min(H.envs_per_tile, H.n_env - e0);
@@ -409,9 +432,9 @@ EB_DEV void fused_body(const FusedHot& H, const FusedArgs& A) {
     lds_barrier();   // the only barrier: at launch, before any wave has something to wait for
     if (threadIdx.x < 64) {
         __builtin_amdgcn_s_setprio(2);
-        env_wave<TASK, RW, RPT>(H, A, S, e0, nE);
+        env_wave<TASK, RW, RPT, ST>(H, A, S, e0, nE);
     } else {
-        record_wave<TASK, RW, RPT, FAST>(H, A, S, e0, nE);
+        record_wave<TASK, RW, RPT, FAST, ST>(H, A, S, e0, nE);
     }
 }
 
@@ -420,12 +443,12 @@ EB_DEV void fused_body(const FusedHot& H, const FusedArgs& A) {
 // a varying start, so one SIMD can be asked for a 6th: budget for 6 (80 VGPRs) or that block waits a whole
 // round.  The smaller tiles fill all 8 wave slots of a SIMD (64 VGPRs).
 #define EB_FUSED_KERNEL(NAME, RW, RPT, WAVES, VGPRS)                                                     \
-    template <int TASK, bool FAST>                                                                       \
+    template <int TASK, bool FAST, typename ST>                                                          \
     __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
-        const float* obs_in, float* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,       \
+        const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
         unsigned nv_magic, int do_rewards, const FusedArgs A) {                                          \
-        const FusedHot H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards};   \
-        fused_body<TASK, RW, RPT, FAST>(H, A);                                                           \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards}; \
+        fused_body<TASK, RW, RPT, FAST, ST>(H, A);                                                       \
     }
 EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
 EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 8, 64)
@@ -439,17 +462,20 @@ int fused_tile_records(int variant) {
     }
 }
 
-#define EB_HOT_ARGS A.obs_in, A.obs_out, A.n_env, A.obs_dim, A.n_veh, A.envs_per_tile, A.nv_magic, A.do_rewards
-#define EB_LAUNCH_TASK(KERNEL, FAST_)                                                                          \
-    switch (task) {                                                                                            \
-        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_>), g, b, 0, s, EB_HOT_ARGS, A); break;     \
-        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_>), g, b, 0, s, EB_HOT_ARGS, A); break; \
-        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_>), g, b, 0, s, EB_HOT_ARGS, A); break;           \
+#define EB_HOT_ARGS(ST) reinterpret_cast<const ST*>(A.obs_in), reinterpret_cast<ST*>(A.obs_out), A.n_env, A.obs_dim, A.n_veh, \
+                        A.envs_per_tile, A.nv_magic, A.do_rewards
+#define EB_LAUNCH_TASK(KERNEL, FAST_, ST)                                                                       \
+    switch (task) {                                                                                             \
+        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \
+        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \
+        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break;     \
     }
-#define EB_LAUNCH(KERNEL, RW)                                                                                  \
-    {                                                                                                          \
-        const dim3 g(grid), b((RW + 1) * 64);                                                                  \
-        if ((RW * 64) % A.n_veh == 0) { EB_LAUNCH_TASK(KERNEL, true) } else { EB_LAUNCH_TASK(KERNEL, false) }  \
+#define EB_LAUNCH_FAST(KERNEL, RW, ST)                                                                          \
+    if ((RW * 64) % A.n_veh == 0) { EB_LAUNCH_TASK(KERNEL, true, ST) } else { EB_LAUNCH_TASK(KERNEL, false, ST) }
+#define EB_LAUNCH(KERNEL, RW)                                                                                   \
+    {                                                                                                           \
+        const dim3 g(grid), b((RW + 1) * 64);                                                                   \
+        if (A.storage_f16) { EB_LAUNCH_FAST(KERNEL, RW, _Float16) } else { EB_LAUNCH_FAST(KERNEL, RW, float) }   \
     }
 
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s) {

@@ -308,9 +308,15 @@ class EnvironmentModel(object):  # DAM:90-427
     `n_veh` (vehicle slots per env; default = the task's native 8/9/5, other counts tile
     VEHICLE_MODE_LIST[task]) and `device`."""
 
-    def __init__(self, training_task, num_future_data=0, mode='training', n_veh=None, device=None):
+    def __init__(self, training_task, num_future_data=0, mode='training', n_veh=None, device=None,
+                 state_dtype='float32'):
         if training_task not in ('left', 'straight', 'right'):
             raise ValueError("training_task must be 'left', 'straight' or 'right'")
+        if state_dtype not in ('float32', 'float16'):
+            raise ValueError("state_dtype must be 'float32' or 'float16'")
+        # 'float16': self.obses is STORED as binary16 (BASELINE configs[4]); rollout_out widens each row to fp32,
+        # runs the same fp32 arithmetic, returns fp32 rewards / penalties and rounds the next obs to binary16
+        self.state_dtype = torch.float16 if state_dtype == 'float16' else torch.float32
         self.task = training_task
         self.mode = mode
         self.device = device if device is not None else _default_device()
@@ -338,22 +344,27 @@ class EnvironmentModel(object):  # DAM:90-427
         self._ref_idx_dev = None
 
     # -- state ------------------------------------------------------------------------------
-    def _obs(self, obses):
-        t = _dev(obses, self.device)
+    def _obs(self, obses, dtype=torch.float32):
+        t = _unwrap(obses)
+        if dtype == torch.float16:
+            t = (t if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(t))))
+            t = t.to(device=self.device, dtype=torch.float16).contiguous()
+        else:
+            t = _dev(t, self.device)
         if t.dim() != 2 or t.shape[1] != self.obs_dim:
             raise ValueError('obses must be [B, %d] for task=%s, n_veh=%d, num_future_data=%d; got %s'
                              % (self.obs_dim, self.task, self.veh_num, self.num_future_data, tuple(t.shape)))
         return t
 
     def reset(self, obses, ref_indexes=None):  # DAM:108-112
-        self.obses = DevArray(self._obs(obses))
+        self.obses = DevArray(self._obs(obses, self.state_dtype))
         self.ref_indexes = ref_indexes
         self._ref_idx_dev = None if ref_indexes is None else _dev(ref_indexes, self.device, torch.int32)
         self.actions = None
         self.reward_info = None
 
     def add_traj(self, obses, path_index):  # DAM:114-116
-        self.obses = DevArray(self._obs(obses))
+        self.obses = DevArray(self._obs(obses, self.state_dtype))
         self.ref_path.set_path(path_index)
 
     def _path_args(self):
@@ -369,15 +380,16 @@ class EnvironmentModel(object):  # DAM:90-427
 
     # -- the hot path -----------------------------------------------------------------------
     def rollout_out(self, actions):  # DAM:118-126
-        obs = self._obs(self.obses)
+        obs = self._obs(self.obses, self.state_dtype)
         act = _dev(actions, self.device)
         B = obs.shape[0]
         ri, pid = self._path_args()
         obs_out = torch.empty_like(obs)
         out5 = torch.empty((5, B), dtype=torch.float32, device=self.device)
         scaled = torch.empty((B, 2), dtype=torch.float32, device=self.device)
-        self.api.rollout_step(self.handle, B, _ptr(obs), _ptr(act), _ptr(ri), pid, _ptr(obs_out), _ptr(out5),
-                              _ptr(scaled), _stream(self.device))
+        step = self.api.rollout_step_f16 if self.state_dtype == torch.float16 else self.api.rollout_step
+        step(self.handle, B, _ptr(obs), _ptr(act), _ptr(ri), pid, _ptr(obs_out), _ptr(out5), _ptr(scaled),
+             _stream(self.device))
         self.actions = DevArray(scaled)
         self.obses = DevArray(obs_out)
         self._after_tracking()
@@ -388,14 +400,15 @@ class EnvironmentModel(object):  # DAM:90-427
         """Open-loop rollout over an action tape [H, B, 2] (the MPC callers' cost_function,
         mpc/main.py:470-479): H launches enqueued by one C call.  Returns (final obses,
         out5 [H, 5, B])."""
-        obs = self._obs(self.obses)
+        obs = self._obs(self.obses, self.state_dtype)
         tape = _dev(action_tape, self.device)
         H, B = tape.shape[0], obs.shape[0]
         ri, pid = self._path_args()
         work, out = torch.empty_like(obs), torch.empty_like(obs)
         out5 = torch.empty((H, 5, B), dtype=torch.float32, device=self.device)
-        self.api.rollout_tape(self.handle, B, H, _ptr(obs), _ptr(tape), _ptr(ri), pid, _ptr(work), _ptr(out),
-                              _ptr(out5), _stream(self.device))
+        tape_fn = self.api.rollout_tape_f16 if self.state_dtype == torch.float16 else self.api.rollout_tape
+        tape_fn(self.handle, B, H, _ptr(obs), _ptr(tape), _ptr(ri), pid, _ptr(work), _ptr(out), _ptr(out5),
+                _stream(self.device))
         self.obses = DevArray(out)
         self._after_tracking()
         return self.obses, DevArray(out5)

@@ -147,6 +147,20 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
                     const float* action_tape, const int32_t* ref_idx, int32_t path_id,
                     float* obs_work, float* obs_out, float* out5_steps, void* stream);
 
+/* fp16 state storage (BASELINE.json configs[4]: N_veh = 64, "fp16 state with fp32 reward accumulate").
+ * Same as eb_rollout_step / eb_rollout_tape with the obs rows stored as IEEE binary16 (uint16_t bit patterns,
+ * same column layout [ego 6 | tracking 3*(n_future+1) | veh 4*n_veh], row-major): every row is widened to
+ * fp32 on load, ALL arithmetic of DAM:118-427 runs in fp32 exactly as in the fp32 entry points, rewards and
+ * penalties are accumulated and returned in fp32, and the next obs is rounded to binary16 (round to nearest
+ * even) on the store.  actions, ref_idx, out5 and scaled_actions keep their 32-bit types.
+ * Algorithmic bytes per env-step: 68 + 16 * n_veh. */
+int eb_rollout_step_f16(eb_handle h, int32_t n_env, const uint16_t* obs_in, const float* actions,
+                        const int32_t* ref_idx, int32_t path_id, uint16_t* obs_out, float* out5,
+                        float* scaled_actions, void* stream);
+int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint16_t* obs_in,
+                        const float* action_tape, const int32_t* ref_idx, int32_t path_id,
+                        uint16_t* obs_work, uint16_t* obs_out, float* out5_steps, void* stream);
+
 /* Episodic-return summary of one shard of envs after a rollout of `horizon` steps — the only
  * quantity north_star exchanges between GPUs (one all-gather of this vector per rollout; the
  * reference's callers accumulate the same sums step by step, hier_decision.py:96).

@@ -618,6 +618,83 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
     return EB_OK;
 }
 
+/* fp16 state storage (BASELINE.json configs[4]): rows are widened to fp32 (exact), stepped by the fp32 code above and
+ * rounded to binary16, nearest-even, on the way out.  Software conversions: no F16C dependency. */
+static float half_to_float(uint16_t hbits) {
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16;
+    uint32_t e = (hbits >> 10) & 0x1Fu, m = hbits & 0x3FFu, bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else { /* subnormal: normalise */
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            bits = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((m & 0x3FFu) << 13);
+        }
+    } else if (e == 31) bits = sign | 0x7F800000u | (m << 13);
+    else bits = sign | ((e + 127 - 15) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+static uint16_t float_to_half(float f) { /* round to nearest even */
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    const uint32_t a = x & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (a > 0x7F800000u ? (0x200u | ((a >> 13) & 0x3FFu)) : 0u));
+    if (a >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);            /* >= 65520: rounds to inf */
+    if (a < 0x33000001u) return sign;                                    /* <= 2^-25: rounds to zero */
+    if (a < 0x38800000u) {                                               /* subnormal half */
+        const int shift = 113 - (int)(a >> 23);                          /* 1..24 */
+        const uint32_t mant = (a & 0x7FFFFFu) | 0x800000u;
+        uint32_t h = mant >> (shift + 13);
+        const uint32_t rem = mant & ((1u << (shift + 13)) - 1u), half = 1u << (shift + 12);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((a >> 23) - 112u) << 10 | ((a >> 13) & 0x3FFu);
+    const uint32_t rem = a & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;              /* carries into the exponent correctly */
+    return (uint16_t)(sign | h);
+}
+
+void eb_oracle_half_to_float(const uint16_t* in, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = half_to_float(in[i]); }
+void eb_oracle_float_to_half(const float* in, uint16_t* out, int n) { for (int i = 0; i < n; ++i) out[i] = float_to_half(in[i]); }
+
+int eb_rollout_step_f16(eb_handle h, int32_t n_env, const uint16_t* obs_in, const float* actions,
+                        const int32_t* ref_idx, int32_t path_id, uint16_t* obs_out, float* out5,
+                        float* scaled_actions, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    if (!h) return fail(EB_EINVAL, "eb_rollout_step_f16: null handle");
+    if (n_env < 0 || !obs_in || !obs_out) return fail(EB_EINVAL, "eb_rollout_step_f16: bad argument");
+    const size_t n = (size_t)n_env * (size_t)obs_dim(&h->cfg);
+    float* a = (float*)calloc(n ? n : 1, sizeof(float));
+    float* b = (float*)calloc(n ? n : 1, sizeof(float));
+    if (!a || !b) { free(a); free(b); return fail(EB_ENOMEM, "eb_rollout_step_f16: out of memory"); }
+    for (size_t i = 0; i < n; ++i) a[i] = half_to_float(obs_in[i]);
+    int rc = eb_rollout_step(h, n_env, a, actions, ref_idx, path_id, b, out5, scaled_actions, stream);
+    if (rc == EB_OK)
+        for (size_t i = 0; i < n; ++i) obs_out[i] = float_to_half(b[i]);
+    free(a); free(b);
+    return rc;
+}
+
+int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint16_t* obs_in,
+                        const float* action_tape, const int32_t* ref_idx, int32_t path_id,
+                        uint16_t* obs_work, uint16_t* obs_out, float* out5_steps, void* stream) {
+    if (horizon < 1 || !obs_work || !obs_out || !action_tape || !out5_steps)
+        return fail(EB_EINVAL, "eb_rollout_tape_f16: bad argument");
+    const uint16_t* cur = obs_in;
+    for (int t = 0; t < horizon; ++t) {
+        uint16_t* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
+        int rc = eb_rollout_step_f16(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
+                                     out5_steps + (size_t)t * 5 * n_env, NULL, stream);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return EB_OK;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* a12: EnvironmentModel.ss, DAM:134-184                                                       */
 /* ------------------------------------------------------------------------------------------ */

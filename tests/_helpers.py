@@ -123,6 +123,21 @@ class HostModel(object):
         self.api.rollout_step(self.h, n, self._ptr(ob), self._ptr(ac), self._ptr(ri), int(path_id), self._ptr(out), self._ptr(out5), self._ptr(sc), self.stream)
         return self._ret(out), self._ret(out5), self._ret(sc)
 
+    def rollout_step_f16(self, obs_u16, actions, ref_idx=None, path_id=0):
+        """fp16 state storage (eb_rollout_step_f16): obs as uint16 bit patterns of IEEE binary16."""
+        ob, ac, ri = self._in(np.ascontiguousarray(obs_u16).view(np.int16), np.int16), self._in(actions), self._in(ref_idx, np.int32)
+        n = len(ob)
+        out, out5, sc = self._out(ob.shape, np.int16), self._out((5, n)), self._out((n, 2))
+        self.api.rollout_step_f16(self.h, n, self._ptr(ob), self._ptr(ac), self._ptr(ri), int(path_id), self._ptr(out), self._ptr(out5), self._ptr(sc), self.stream)
+        return self._ret(out).view(np.uint16), self._ret(out5), self._ret(sc)
+
+    def rollout_tape_f16(self, obs_u16, tape, ref_idx=None, path_id=0):
+        ob, tp, ri = self._in(np.ascontiguousarray(obs_u16).view(np.int16), np.int16), self._in(tape), self._in(ref_idx, np.int32)
+        H, n = tp.shape[0], len(ob)
+        work, out, out5 = self._out(ob.shape, np.int16), self._out(ob.shape, np.int16), self._out((H, 5, n))
+        self.api.rollout_tape_f16(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work), self._ptr(out), self._ptr(out5), self.stream)
+        return self._ret(out).view(np.uint16), self._ret(out5)
+
     def rollout_tape(self, obs, tape, ref_idx=None, path_id=0):
         ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
         H, n = tp.shape[0], len(ob)
@@ -220,7 +235,8 @@ class DeviceModel(HostModel):
         fn.argtypes, fn.restype = [C.c_void_p, C.c_int], C.c_int
         self.api.check(fn(self.h, int(variant)))
 
-    _TD = {np.dtype(np.float32): 'float32', np.dtype(np.int32): 'int32', np.dtype(np.uint8): 'uint8'}
+    _TD = {np.dtype(np.float32): 'float32', np.dtype(np.int32): 'int32', np.dtype(np.uint8): 'uint8',
+           np.dtype(np.int16): 'int16'}
 
     def _in(self, a, dtype=np.float32):
         if a is None:

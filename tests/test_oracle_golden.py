@@ -180,3 +180,46 @@ def test_g7_config1_single_env_200_steps(oracle):
         np.testing.assert_allclose(obs[0], g['obs'][t + 1], rtol=RTOL, atol=2e-4, err_msg='t=%d' % t)
         n_done_mismatch += int(done[0] != g['done_code'][t])
     assert n_done_mismatch == 0
+
+
+# ---- G8: fp16 state storage (BASELINE configs[4]) -------------------------------------------------
+def _half_ulps(a_u16, b_u16):
+    """distance in binary16 steps between two arrays of half bit patterns (monotone integer mapping)"""
+    def key(u):
+        u = u.astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7FFF), u & 0x7FFF)
+    return np.abs(key(a_u16) - key(b_u16))
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_g8_fp16_state_storage(oracle, task):
+    """Every step fed from the fixture's fp16 rows: the fp32 outputs (rewards, penalties) agree with the
+    reference at 1e-5, the re-rounded fp16 state within one binary16 step (the fp32 results differ from the
+    reference's by <= a few fp32 ulp, which can tip a value across a rounding boundary; never more)."""
+    g = golden('g8_fp16_rollout_%s_N64' % task)
+    host = HostModel(oracle, task, n_veh=64, modes=[str(m) for m in g['modes']])
+    n_off = 0
+    for t in range(g['actions'].shape[0]):
+        out, o5, _ = host.rollout_step_f16(g['obs_in'][t], g['actions'][t], g['ref_idx'])
+        np.testing.assert_allclose(o5, g['out5'][t], rtol=RTOL, atol=1e-4)
+        d = _half_ulps(out, g['obs_out'][t])
+        assert d.max() <= 1, 't=%d' % t
+        n_off += int((d > 0).sum())
+    assert n_off <= 0.002 * g['obs_out'].size     # and only a handful do
+
+
+def test_fp16_storage_equals_fp32_path_on_fp16_inputs(oracle):
+    """Definition check: the fp16 entry point == widen, fp32 step, round to nearest even."""
+    host = HostModel(oracle, 'left', n_veh=64)
+    g = golden('g8_fp16_rollout_left_N64')
+    obs16 = g['obs_in'][0]
+    out16, o5_a, sc_a = host.rollout_step_f16(obs16, g['actions'][0], g['ref_idx'])
+    out32, o5_b, sc_b = host.rollout_step(obs16.view(np.float16).astype(np.float32), g['actions'][0], g['ref_idx'])
+    assert np.array_equal(out16, out32.astype(np.float16).view(np.uint16))
+    assert np.array_equal(o5_a, o5_b) and np.array_equal(sc_a, sc_b)
+    tape_out, tape_o5 = host.rollout_tape_f16(obs16, g['actions'][:3], g['ref_idx'])
+    o, o5s = obs16, []
+    for t in range(3):
+        o, o5, _ = host.rollout_step_f16(o, g['actions'][t], g['ref_idx'])
+        o5s.append(o5)
+    assert np.array_equal(tape_out, o) and np.array_equal(tape_o5, np.stack(o5s))
