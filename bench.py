@@ -227,7 +227,7 @@ def main():
                          'avg_launch_us': launch_s * 1e6, 'launches_timed': n_marked * HORIZON},
             'summary': [float(x) for x in combine_summaries(gathered[0]).tolist()],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
             line['cpu_baseline'] = cpu_baseline(inp, obs0.cpu().numpy(), n_veh)
         else:
             line['cpu_baseline'] = None

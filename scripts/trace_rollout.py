@@ -35,8 +35,20 @@ lib.eb_debug_set_trace(m.handle, p(tr))
 step(10); step(11)          # warm the marked code path
 torch.cuda.synchronize()
 tr.zero_(); torch.cuda.synchronize()
-step(12); torch.cuda.synchronize()
+# three back-to-back launches, each with its own mark buffer: the dead time between consecutive kernels
+trs = [torch.zeros_like(tr) for _ in range(3)]
+for k in range(3):
+    lib.eb_debug_set_trace(m.handle, p(trs[k])); step(12 + k)
+torch.cuda.synchronize()
 lib.eb_debug_set_trace(m.handle, None)
+spans = []
+for x in trs:
+    x = x.cpu().numpy(); used = x[x[:, 0] > 0]
+    spans.append((used[:, 0].min(), used.max()))
+for k in range(1, 3):
+    print('launch %d: first wave start .. last wave end = %.2f us; dead time since the previous kernel\'s last wave = %.2f us'
+          % (k, (spans[k][1] - spans[k][0]) / 100.0, (spans[k][0] - spans[k - 1][1]) / 100.0))
+tr = trs[1]
 t = tr.cpu().numpy()
 nb = int((t[:, 0] > 0).sum()) // W
 t = t[:nb * W].astype(np.float64)
@@ -50,3 +62,13 @@ for i, name in enumerate(['loads issued', 'ego published', 'bicycle step done', 
     print('env wave  %-22s %s' % (name, q(env[:, i])))
 for i, name in enumerate(['loads issued', 'first record stored', 'last record stored', 'ego seen', 'near tests done', 'end']):
     print('rec wave  %-22s %s' % (name, q(rec[:, i])))
+blk_start = np.nanmin(t[:, 0].reshape(nb, W), axis=1)
+blk_end = np.nanmax(t.reshape(nb, W * 8), axis=1)
+print('block start            %s' % q(blk_start))
+print('block end              %s' % q(blk_end))
+print('block duration         %s' % q(blk_end - blk_start))
+order = np.argsort(blk_start)
+for lo, hi in ((0, nb // 4), (nb // 4, nb // 2), (nb // 2, 3 * nb // 4), (3 * nb // 4, nb)):
+    sel = order[lo:hi]
+    print('  blocks by start quartile: start %.2f..%.2f  mean duration %.2f  mean end %.2f  (block ids %d..%d median %d)'
+          % (blk_start[sel].min(), blk_start[sel].max(), (blk_end - blk_start)[sel].mean(), blk_end[sel].mean(), sel.min(), sel.max(), int(np.median(sel))))
