@@ -85,8 +85,8 @@ struct FusedHot {
 // profiling aid: mark slot `i` of this wave's trace row with the 100 MHz wall clock (lane 0 only)
 #define EB_MARK(A, row, i) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + (i)] = wall_clock64(); } while (0)
 
-// per-wave near-record queue: drained at the end, and after every second record step if more than 64 entries
-// are waiting by then (so at most 64 + 2 * 64 ever are).  4 blocks of 2048 records must fit a CU's LDS with
+// per-wave near-record queue: normally one drain at the end; in a crowded tile the in-loop tests stop while 64
+// slots are still free and the rest is tested record by record with a drain before each (see record_wave).  4 blocks of 2048 records must fit a CU's LDS with
 // room to spare: blocks above ~32 KB were seen to run 3 per CU, i.e. a second round of blocks.
 constexpr int QCAP = 192;
 
@@ -131,7 +131,9 @@ struct FusedSmem {
     unsigned char turn[64];               // per slot: TURN_* (every record wave writes the same codes, reads its own)
     unsigned long long mask[64];          // per env: slots with a non-zero penalty sum
     float2 pen[ITEMS];                    // per record: (3.5 m sum, 2.5 m sum), DAM:228-229
-    float4 qd[RW][QCAP];                  // per record wave: queued near records (x, y, phi, item id)
+    v2f qxy[RW][QCAP];                    // per record wave: queued near records: (x, y),
+    float qphi[RW][QCAP];                 //   heading,
+    int qitem[RW][QCAP];                  //   item id
     int ego_ready;                        // set by the env wave once ego[] and mask[] are written
     int waves_done;                       // record waves that have published their partial sums
 };
@@ -254,8 +256,9 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
 template <int RW, int RPT, typename ST>
 EB_DEV void queue_pass(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int base, int n) {
     if (lane < n) {
-        const float4 v = S.qd[w][base + lane];                              // (x, y, phi, item id)
-        const int item = __float_as_int(v.w);
+        const v2f vxy = S.qxy[w][base + lane];
+        const float4 v = make_float4(vxy.x, vxy.y, S.qphi[w][base + lane], 0.0f);
+        const int item = S.qitem[w][base + lane];
         const int e2 = (int)__umulhi((unsigned)item, H.nv_magic), j2 = item - e2 * H.n_veh;
         const float4 eg = S.ego[e2];
         float t35[4], t25[4], vs, vc;
@@ -351,8 +354,9 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         // lanes past the tile's last record re-read the tile's last record (branch-free loads; never stored)
-        const int off = item_of(k) < items ? off_of(k) : 4 * (items - 1) + nE * HD;
-        rec[k] = Stored<ST>::load4(tin + off);
+        const bool valid = item_of(k) < items;
+        rec[k] = Stored<ST>::load4(tin + (valid ? off_of(k) : 4 * (items - 1) + nE * HD));
+        if (!valid) rec[k].x = 1e30f;            // never near an ego (and never stored)
     }
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
     EB_MARK(A, trow, 0);                                                    // loads issued
@@ -365,55 +369,78 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
     const float4 tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
 
-    // ---- predict + store ----
-    auto predict_all = [&]() {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            if (item_of(k) < items) {
-                const float4 tc = FAST ? tc_lane : turn_consts(S.turn[item_of(k) - env_of(k) * NV]);
-                unsigned tiny = 0u;
-                f4u nv = predict_record_pk<false>(rec[k], tc, tiny);
-                if (__builtin_expect(tiny != 0u, 0)) nv = predict_record_pk<true>(rec[k], tc, tiny);
-                Stored<ST>::store4(tout + off_of(k), nv);
-            }
-            if (k == 0) EB_MARK(A, trow, 1);                                // first record stored
-            if (k == RPT - 1) EB_MARK(A, trow, 2);                          // last record stored
-            __builtin_amdgcn_sched_barrier(0);   // one record at a time: keeps the live set at the loaded records + one record's temporaries
-        }
-    };
-    predict_all();
-    if (!H.do_rewards) return;
-
-    // ---- near-ego records -> this wave's queue -> circle-pair distances ----
+    // ---- near-ego records -> this wave's queue ----
     // A circle pair can only be closer than 3.5 m when the two vehicle centres are within 3.5 + 2*1.4 = 6.3 m;
     // records inside 6.364 m (slack >> fp32 rounding) are queued, every other record contributes exact zeros
     // to the penalty sums (DAM:228-229).
-    lds_wait_until(&S.ego_ready, 1);                                        // ---- hand-off 1: ego poses are in LDS ----
-    EB_MARK(A, trow, 3);                                                    // ego seen
     int qn = 0;
     auto drain = [&]() {
         for (int base = 0; base < qn; base += 64) queue_pass<RW, RPT, ST>(H, A, S, w, lane, base, min(64, qn - base));
         qn = 0;
     };
-    if (!(A.ablate & 8)) {
+    // (lanes past the tile's last record carry x = 1e30 in `r`, see the loads: never near)
+    auto near_test = [&](int item, int env, const f4u r) {
+        const float4 eg = S.ego[env];
+        const v2f d = v2f{r.x, r.y} - v2f{eg.x, eg.y};
+        const v2f d2 = d * d;
+        const bool near = d2.x + d2.y < 40.5f;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(near);
+        if (b) {
+            if (near) {
+                // queue slot = entries so far + near lanes below this one (v_mbcnt with the running count as its addend)
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)qn));
+                S.qxy[w][pos] = v2f{r.x, r.y};          // three plain LDS writes straight from the record's registers
+                S.qphi[w][pos] = r.w;
+                S.qitem[w][pos] = item;
+            }
+            qn += __popcll(b);
+        }
+    };
+    // The env wave's head is the first load of the block, so the ego poses are normally in LDS by the time this
+    // wave's records arrive: wait for them here (hand-off 1), then test each record as it is predicted — a record's
+    // registers are free again after its iteration and only the queue pass is left once the stores are out.
+    // Crowded tiles: once fewer than 64 queue slots are free the in-loop tests stop (k_late); the remaining records
+    // are re-read (L2) and tested after the loop, with the queue drained in between.
+    if (H.do_rewards) {
+        lds_wait_until(&S.ego_ready, 1);                                    // ---- hand-off 1: ego poses are in LDS ----
+        EB_MARK(A, trow, 3);                                                // ego seen
+    }
+    const bool test_near = H.do_rewards && !(A.ablate & 8);
+    int k_late = test_near ? RPT : 0;
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            bool near = false;
-            if (item_of(k) < items) {
-                const float4 eg = S.ego[env_of(k)];
-                const v2f d = v2f{rec[k].x, rec[k].y} - v2f{eg.x, eg.y};
-                const v2f d2 = d * d;
-                near = d2.x + d2.y < 40.5f;
-            }
-            const unsigned long long b = __ballot(near);
-            if (b) {
-                if (near) {
-                    const int pos = qn + __popcll(b & ((1ull << lane) - 1ull));
-                    S.qd[w][pos] = make_float4(rec[k].x, rec[k].y, rec[k].w, __int_as_float(item_of(k)));
-                }
-                qn += __popcll(b);
-            }
-            if ((k & 1) && k != RPT - 1 && qn > 64) drain();   // see QCAP
+    for (int k = 0; k < RPT; ++k) {
+        // Recompute this record's item id / env / offset from the lane's bases (an add each) instead of keeping the
+        // eight copies made for the loads alive through the whole loop: the empty asm hides the per-step constants.
+        int k_item = k * RL, k_env = k * epk, k_off = k * off_step;
+        asm volatile("" : "+s"(k_item), "+s"(k_env), "+s"(k_off));
+        const int item = k_item + rtid;
+        const int env = FAST ? e_first + k_env : (int)__umulhi((unsigned)item, H.nv_magic);
+        const int off = FAST ? off_first + k_off : 4 * item + (env + 1) * HD;
+        const bool valid = item < items;
+        if (k < k_late) {
+            near_test(item, valid ? env : 0, rec[k]);
+            if (qn > QCAP - 64) k_late = k + 1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (valid) {
+            const float4 tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
+            unsigned tiny = 0u;
+            f4u nv = predict_record_pk<false>(rec[k], tc, tiny);
+            if (__builtin_expect(tiny != 0u, 0)) nv = predict_record_pk<true>(rec[k], tc, tiny);
+            Stored<ST>::store4(tout + off, nv);
+        }
+        if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
+        if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
+        __builtin_amdgcn_sched_barrier(0);   // one record at a time: keeps the live set at the loaded records + one record's temporaries
+    }
+    if (!H.do_rewards) return;
+    if (test_near && k_late < RPT) {
+        for (int k = k_late; k < RPT; ++k) {       // not unrolled: rare path
+            drain();
+            const bool valid = item_of(k) < items;
+            f4u r = Stored<ST>::load4(tin + (valid ? off_of(k) : 4 * (items - 1) + nE * HD));
+            if (!valid) r.x = 1e30f;
+            near_test(item_of(k), valid ? env_of(k) : 0, r);
         }
     }
     EB_MARK(A, trow, 4);                                                    // near tests done
