@@ -420,7 +420,6 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         if (k < k_late) {
             near_test(item, valid ? env : 0, rec[k]);
             if (qn > QCAP - 64) k_late = k + 1;
-            __builtin_amdgcn_sched_barrier(0);
         }
         if (valid) {
             const float4 tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
@@ -431,7 +430,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         }
         if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
         if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
-        __builtin_amdgcn_sched_barrier(0);   // one record at a time: keeps the live set at the loaded records + one record's temporaries
+        if (k & 1) __builtin_amdgcn_sched_barrier(0);   // two records at a time: bounds the live set, leaves some ILP
     }
     if (!H.do_rewards) return;
     if (test_near && k_late < RPT) {
