@@ -54,6 +54,7 @@ struct eb_handle_s {
     int modes_set;
     long long* trace;         // profiling aid, see eb_debug_set_trace
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
+    int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
 };
 
 // the kernel-visible copy of the tables: refreshed whenever paths or slot modes change
@@ -337,7 +338,8 @@ int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float
 // obs_in / obs_out point at fp32 rows, or at binary16 rows when storage_f16 is set
 static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* obs_in, const float* actions,
                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
-                         float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16) {
+                         float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16,
+                         int tape_horizon = 0) {   // > 0: `actions` is a tape [H, n_env, 2], `out5` is [H, 5, n_env], one launch
     const int NV = h->cfg.n_veh;
     eb::FusedArgs A;
     std::memset(&A, 0, sizeof A);
@@ -365,13 +367,15 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     }
     A.trace = h->trace;
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
-    EB_HIP(eb::launch_rollout_fused(h->cfg.task, variant, A, grid, s));
+    if (tape_horizon > 0) EB_HIP(eb::launch_rollout_tape_fused(h->cfg.task, variant, A, tape_horizon, grid, s));
+    else EB_HIP(eb::launch_rollout_fused(h->cfg.task, variant, A, grid, s));
     return EB_OK;
 }
 
 static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
-                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16 = 0) {
+                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16 = 0,
+                          int tape_horizon = 0) {
     static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
     int variant = h->tile_variant >= 0 ? h->tile_variant : forced;
     if (variant < 0 || variant > 2) {
@@ -383,7 +387,7 @@ static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const
         }
     }
     return rollout_fused(h, variant, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
-                         actions_raw, do_rewards, s, storage_f16);
+                         actions_raw, do_rewards, s, storage_f16, tape_horizon);
 }
 
 int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
@@ -411,6 +415,36 @@ int eb_rollout_step(eb_handle h, int32_t n_env, const float* obs_in, const float
                           pick(h, stream));
 }
 
+// H launches of the per-step kernel, ping-ponging so that the last step lands in obs_out (what eb_plan_* records)
+static int rollout_tape_stepwise(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
+                                 const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out,
+                                 float* out5_steps, hipStream_t s, int storage_f16) {
+    const size_t row_bytes = (size_t)obs_dim(h->cfg) * (storage_f16 ? 2 : 4);
+    (void)row_bytes;
+    const float* cur = obs_in;
+    for (int t = 0; t < horizon; ++t) {
+        float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
+        int rc = rollout_common(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
+                                out5_steps + (size_t)t * 5 * n_env, nullptr, 1, 1, s, storage_f16);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return EB_OK;
+}
+
+// Open loop over a tape: ONE launch of the tape kernel (state in registers across the steps); bit-identical to the
+// H per-step launches (EB_TAPE_STEPWISE=1 forces those, for A/B checks).
+static int rollout_tape_any(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
+                            const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
+                            hipStream_t s, int storage_f16) {
+    static const int stepwise = std::getenv("EB_TAPE_STEPWISE") ? std::atoi(std::getenv("EB_TAPE_STEPWISE")) : 0;
+    if (stepwise || h->tape_stepwise)
+        return rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, s,
+                                     storage_f16);
+    return rollout_common(h, n_env, obs_in, action_tape, ref_idx, path_id, obs_out, out5_steps, nullptr, 1, 1, s, storage_f16,
+                          horizon);
+}
+
 int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                     const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
                     void* stream) {
@@ -423,16 +457,8 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
         return fail(EB_EINVAL, "eb_rollout_tape: obs_in, obs_work and obs_out must be distinct buffers");
     if (n_env == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
-    hipStream_t s = pick(h, stream);
-    const float* cur = obs_in;
-    for (int t = 0; t < horizon; ++t) {   // ping-pong so that the last step lands in obs_out
-        float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
-        rc = rollout_common(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
-                            out5_steps + (size_t)t * 5 * n_env, nullptr, 1, 1, s);
-        if (rc) return rc;
-        cur = dst;
-    }
-    return EB_OK;
+    return rollout_tape_any(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps,
+                            pick(h, stream), 0);
 }
 
 int eb_rollout_step_f16(eb_handle h, int32_t n_env, const uint16_t* obs_in, const float* actions, const int32_t* ref_idx,
@@ -451,19 +477,16 @@ int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint1
                         const int32_t* ref_idx, int32_t path_id, uint16_t* obs_work, uint16_t* obs_out, float* out5_steps,
                         void* stream) {
     if (h && n_env == 0) return EB_OK;
-    if (horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps)
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_tape_f16: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps)
         return fail(EB_EINVAL, "eb_rollout_tape_f16: bad argument");
     if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
         return fail(EB_EINVAL, "eb_rollout_tape_f16: obs_in, obs_work and obs_out must be distinct buffers");
-    const uint16_t* cur = obs_in;
-    for (int t = 0; t < horizon; ++t) {   // ping-pong so that the last step lands in obs_out
-        uint16_t* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
-        int rc = eb_rollout_step_f16(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
-                                     out5_steps + (size_t)t * 5 * n_env, nullptr, stream);
-        if (rc) return rc;
-        cur = dst;
-    }
-    return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    return rollout_tape_any(h, n_env, horizon, reinterpret_cast<const float*>(obs_in), action_tape, ref_idx, path_id,
+                            reinterpret_cast<float*>(obs_work), reinterpret_cast<float*>(obs_out), out5_steps,
+                            pick(h, stream), 1);
 }
 
 int eb_find_closest_point(eb_handle h, int32_t n, const float* xs, const float* ys, const int32_t* ref_idx,
@@ -571,6 +594,13 @@ int eb_debug_set_tile(eb_handle h, int variant) {
     return EB_OK;
 }
 
+// Test aid (not part of include/envbuild.h): 1 = eb_rollout_tape[_f16] as H per-step launches, 0 = one tape-kernel launch.
+int eb_debug_set_tape_stepwise(eb_handle h, int on) {
+    if (!h) return fail(EB_EINVAL, "eb_debug_set_tape_stepwise: null handle");
+    h->tape_stepwise = on ? 1 : 0;
+    return EB_OK;
+}
+
 int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float* out5_steps, const float* obs_final,
                        float* out8, void* stream) {
     if (!h || n_env < 0 || horizon < 0 || !out8 || (n_env > 0 && horizon > 0 && !out5_steps) || (n_env > 0 && !obs_final))
@@ -612,7 +642,8 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
     EB_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { hipStreamDestroy(cs); return fail_hip("hipStreamBeginCapture", e); }
-    rc = eb_rollout_tape(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs);
+    // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph
+    rc = rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs, 0);
     if (rc == EB_OK && summary8) rc = eb_episode_summary(h, n_env, horizon, out5_steps, obs_out, summary8, cs);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(cs, &graph);

@@ -31,33 +31,22 @@ enum { TURN_NONE = 0, TURN_LEFT = 1, TURN_RIGHT = 2 };
 
 EB_DEV float sq(float x) { return x * x; }
 
-// IEEE-exact x / C for a compile-time constant C in 3 VALU ops (Markstein: q = x*rc, one exact
-// residual, one correction) instead of the ~11-op v_div_scale/v_rcp/v_div_fmas/v_div_fixup sequence.
-// Checked against x / C over all 2^32 bit patterns for the five divisors used here
-// (tests/test_exact_math.py: oracle/envbuild_oracle.c:eb_oracle_check_div_exact runs the same fma
-// arithmetic on the CPU): bit-identical except for three kinds of dividend, which take the true division —
-// non-zero magnitudes below 2^-101 (the residual underflows), -0.0 (the correction adds +0), +-inf (inf - inf).
-// -0.0, +-inf, NaN: v_cmp_class_f32 mask sNaN | qNaN | -inf | -0 | +inf
-EB_DEV bool div_special(float x) { return __builtin_amdgcn_classf(x, 0x227); }
-
-// the unguarded core, also used with per-lane (c, 1/c) pairs (predict_record)
-EB_DEV float div_fast(float x, float c, float rc) {
-    const float q = x * rc;
-    const float r = __builtin_fmaf(-q, c, x);
-    return __builtin_fmaf(r, rc, q);
-}
-
+// IEEE-exact x / C for the five constant divisors of the path in 3 instructions and with no special cases:
+//     x / C  ==  (float)((double)x * (1.0 / (double)C))          v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64
+// The double product carries <= 2^-52 relative error, and a quotient of a 24-bit dividend by one of these
+// divisors is never that close to a rounding boundary of the fp32 grid (normal or subnormal), so the single
+// rounding of the conversion lands on the correctly rounded quotient; -0, +-inf, NaN and subnormals come out as
+// IEEE division gives them.  Verified against x / C for ALL 2^32 dividends and each divisor
+// (tests/test_exact_math.py; oracle/envbuild_oracle.c:eb_oracle_check_div_exact runs the same two operations on
+// the CPU, where they are IEEE too).  Replaces the ~11-op v_div_scale / v_rcp / v_div_fmas / v_div_fixup
+// sequence; an fp32-only 3-op form (q = x*rc, residual, correction) is a little cheaper but wrong for tiny
+// non-zero dividends, -0 and +-inf, which then need guards and a second code path.
 template <typename C>
 EB_DEV float div_const(float x) {
-    constexpr float c = C::value;
-    constexpr float rc = 1.0f / C::value;
-    const unsigned mag2 = __builtin_bit_cast(unsigned, x) << 1;   // |x| bits * 2
-    if (__builtin_expect(mag2 - 1u < 2u * 0x0D000000u - 1u || div_special(x), 0))  // 0 < |x| < 2^-101 (~3.9e-31), -0, inf, NaN
-        return x / c;
-    const float q = x * rc;
-    const float r = __builtin_fmaf(-q, c, x);
-    return __builtin_fmaf(r, rc, q);
+    constexpr double rc = 1.0 / (double)C::value;
+    return (float)((double)x * rc);
 }
+EB_DEV float div_by(float x, double rc) { return (float)((double)x * rc); }   // rc = 1.0 / (double)c for one of the five
 struct C180 { static constexpr float value = 180.0f; };
 struct CPi { static constexpr float value = 3.14159265358979323846f; };
 struct C10 { static constexpr float value = 10.0f; };
@@ -314,41 +303,6 @@ EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, flo
     }
     return bi;
 }
-
-// predict_for_a_mode (DAM:405-427) with the slot's turn divisor taken from a table: tc = (c, 1/c,
-// sign, enabled) = (26.875, ., +1, 1) for dl rd ur lu, (15.625, ., -1, 1) for dr ru ul ld, (1, 1, 0, 0)
-// otherwise.  EXACT = false uses the 3-op exact constant divisions and reports through `tiny`
-// whether any dividend was one of those only the true division gets right (non-zero below 2^-101, -0,
-// +-inf; see div_const); EXACT = true is the same arithmetic with IEEE divisions.  sn / cs return sin / cos of the
-// record's CURRENT heading (also the circle-centre offsets of DAM:221-224).
-template <bool EXACT>
-EB_DEV float4 predict_record(float x, float y, float v, float phi, const float4 tc, unsigned& tiny, float& sn,
-                             float& cs) {
-    const float t1 = phi * PI_F;
-    const float phi_rad = EXACT ? t1 / 180.0f : div_fast(t1, 180.0f, 1.0f / 180.0f);   // DAM:407
-    sincos_det(phi_rad, sn, cs);
-    const bool middle = (x > -HALF_CROSS && x < HALF_CROSS) && (y > -HALF_CROSS && y < HALF_CROSS);   // DAM:409-410
-    const float v10 = EXACT ? v / 10.0f : div_fast(v, 10.0f, 1.0f / 10.0f);
-    const float dx = v10 * cs, dy = v10 * sn;                                            // DAM:413-414
-    const float u = (EXACT ? v / tc.x : div_fast(v, tc.x, tc.y)) * tc.z;                 // +-(v / radius)
-    const float u10 = EXACT ? u / 10.0f : div_fast(u, 10.0f, 1.0f / 10.0f);
-    const float dphi = (middle && tc.w != 0.0f) ? u10 : 0.0f;                            // DAM:416-421
-    float nphi = phi_rad + dphi;                                                         // DAM:423
-    if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                             // DAM:424
-    if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                                           // DAM:425
-    const float t2 = nphi * 180.0f;
-    const float nphi_deg = EXACT ? t2 / PI_F : div_fast(t2, PI_F, 1.0f / PI_F);          // DAM:426
-    if (!EXACT) {
-        // non-zero and below 2^-101 <=> (bits << 1) - 1 < 2 * 0x0D000000 - 1 (unsigned)
-        const unsigned a = (__builtin_bit_cast(unsigned, t1) << 1) - 1u;
-        const unsigned b = (__builtin_bit_cast(unsigned, v) << 1) - 1u;
-        const unsigned c = (__builtin_bit_cast(unsigned, t2) << 1) - 1u;
-        const unsigned d = (__builtin_bit_cast(unsigned, u) << 1) - 1u;
-        tiny = (min(min(a, b), min(c, d)) < 2u * 0x0D000000u - 1u) || div_special(t1) || div_special(v) || div_special(t2);
-    }
-    return make_float4(x + dx, y + dy, v, nphi_deg);                                     // DAM:422-427
-}
-
 
 EB_DEV float wrap_deal_with_phi(float phi) {  // UTL:232-237
     while (phi > 180.0f) phi -= 360.0f;

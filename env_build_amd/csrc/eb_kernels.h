@@ -43,6 +43,8 @@ struct FusedArgs {
 // variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 4 x 4 (1024), 2 = 1 x 4 (256)
 int fused_tile_records(int variant);
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s);
+// open-loop rollout of `horizon` steps in one launch: A.actions = tape [horizon, n_env, 2], A.out5 = [horizon, 5, n_env]
+hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, int horizon, int grid, hipStream_t s);
 
 hipError_t launch_f_xu(int n, const float* st, const float* ac, float tau, float* nx, float* pr, hipStream_t s);
 hipError_t launch_action_transform(int n, const float* in, float* out, hipStream_t s);

@@ -42,6 +42,7 @@ template <> struct Stored<float> {
     static EB_DEV float load1(const float* p) { return *p; }
     static EB_DEV void store4(float* p, f4u v) { *reinterpret_cast<f4u*>(p) = v; }
     static EB_DEV void store1(float* p, float v) { *p = v; }
+    static EB_DEV float round(float v) { return v; }                    // what a store + load does to a value
 };
 typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
 template <> struct Stored<_Float16> {
@@ -54,6 +55,7 @@ template <> struct Stored<_Float16> {
         *reinterpret_cast<h4u*>(p) = h4u{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
     }
     static EB_DEV void store1(_Float16* p, float v) { *p = (_Float16)v; }
+    static EB_DEV float round(float v) { return (float)(_Float16)v; }
 };
 
 // LDS-only workgroup barrier: orders this wave's LDS traffic, leaves global loads/stores in flight
@@ -253,14 +255,14 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
 
 // ---- record waves -----------------------------------------------------------------------------------
 // one queue pass: entries [base, base + n) of this wave's queue, one per lane: DAM:218-229
-template <int RW, int RPT, typename ST>
-EB_DEV void queue_pass(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int w, int lane, int base, int n) {
+template <typename SM, typename ST>
+EB_DEV void queue_pass(const FusedHot<ST>& H, SM& S, const float4* ego, int w, int lane, int base, int n) {
     if (lane < n) {
         const v2f vxy = S.qxy[w][base + lane];
         const float4 v = make_float4(vxy.x, vxy.y, S.qphi[w][base + lane], 0.0f);
         const int item = S.qitem[w][base + lane];
         const int e2 = (int)__umulhi((unsigned)item, H.nv_magic), j2 = item - e2 * H.n_veh;
-        const float4 eg = S.ego[e2];
+        const float4 eg = ego[e2];
         float t35[4], t25[4], vs, vc;
         const float4 pts = make_float4(eg.x + LWS * eg.w, eg.y + LWS * eg.z, eg.x - LWS * eg.w, eg.y - LWS * eg.z);
         sincos_det(deg2rad(v.z), vs, vc);                                   // DAM:221
@@ -281,19 +283,20 @@ EB_DEV void queue_pass(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, 
 //   sin / cos polynomials                both Horner chains in one register pair
 //   (dx, dy), (x + dx, y + dy)           one multiply, one add
 // The heading chain (turn rate, wrap, back to degrees) is sequential and stays scalar.
-template <bool EXACT>
-EB_DEV f4u predict_record_pk(const f4u rec, const float4 tc, unsigned& tiny) {
-    const v2f xy = {rec.x, rec.y}, vp = {rec.z, rec.w};
-    const v2f vt = vp * v2f{1.0f, PI_F};                                     // (v, phi * np.pi), DAM:407
-    v2f vr;                                                                  // (v / 10, phi_rad), DAM:407, 413
-    if (EXACT) {
-        vr = v2f{vt.x / 10.0f, vt.y / 180.0f};
-    } else {
-        const v2f c = {10.0f, 180.0f}, rc = {1.0f / 10.0f, 1.0f / 180.0f};
-        const v2f q = vt * rc;
-        vr = fma2(fma2(-q, c, vt), rc, q);
-    }
-    const float v = rec.z, v10 = vr.x, phi_rad = vr.y;
+// slot turn constants (predict_for_a_mode, DAM:416-421): 1 / turn radius in double (for the exact division), the
+// sign of the heading rate, and whether the slot turns at all
+struct TurnC { double rc; float sign, enabled; };
+EB_DEV TurnC turn_consts(int t) {
+    return t == TURN_LEFT ? TurnC{1.0 / 26.875, 1.0f, 1.0f} : t == TURN_RIGHT ? TurnC{1.0 / 15.625, -1.0f, 1.0f}
+                                                                             : TurnC{1.0, 0.0f, 0.0f};
+}
+
+template <typename ST>
+EB_DEV f4u predict_record_pk(const f4u rec, const TurnC tc) {
+    const v2f xy = {rec.x, rec.y};
+    const float v = rec.z;
+    const float v10 = div_const<C10>(v);                                     // DAM:413
+    const float phi_rad = div_const<C180>(rec.w * PI_F);                     // DAM:407
     // sincos_det(phi_rad), same operations as eb_device.h
     const float kf = __builtin_rintf(phi_rad * 0.636619747f);
     const int k = (int)kf;
@@ -311,22 +314,13 @@ EB_DEV f4u predict_record_pk(const f4u rec, const float4 tc, unsigned& tiny) {
     const float sn = (k & 2) ? -a : a, cs = (k & 2) ? -b : b;
     const v2f nxy = xy + v2f{v10, v10} * v2f{cs, sn};                        // DAM:413-414, 422
     const bool middle = (rec.x > -HALF_CROSS && rec.x < HALF_CROSS) && (rec.y > -HALF_CROSS && rec.y < HALF_CROSS);   // DAM:409-410
-    const float u = (EXACT ? v / tc.x : div_fast(v, tc.x, tc.y)) * tc.z;    // +-(v / radius)
-    const float u10 = EXACT ? u / 10.0f : div_fast(u, 10.0f, 1.0f / 10.0f);
-    const float dphi = (middle && tc.w != 0.0f) ? u10 : 0.0f;                // DAM:416-421
+    const float u = div_by(v, tc.rc) * tc.sign;                              // +-(v / radius), DAM:417, 419
+    const float u10 = div_const<C10>(u);
+    const float dphi = (middle && tc.enabled != 0.0f) ? u10 : 0.0f;          // DAM:416-421
     float nphi = phi_rad + dphi;                                             // DAM:423
     if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                 // DAM:424
     if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                               // DAM:425
-    const float t2 = nphi * 180.0f;
-    const float nphi_deg = EXACT ? t2 / PI_F : div_fast(t2, PI_F, 1.0f / PI_F);   // DAM:426
-    if (!EXACT) {
-        // the 3-op divisions are exact unless a dividend is non-zero and tiny, -0 or +-inf (eb_device.h:div_const).
-        // Tiny: (bits << 1) - 1 < 2 * T - 1 with the threshold raised to 2^-96 so that v covers u = v / c too.
-        const unsigned g0 = (__builtin_bit_cast(unsigned, vt.y) << 1) - 1u;
-        const unsigned g1 = (__builtin_bit_cast(unsigned, v) << 1) - 1u;
-        const unsigned g2 = (__builtin_bit_cast(unsigned, t2) << 1) - 1u;
-        tiny = (min(g0, min(g1, g2)) < 2u * 0x0F800000u - 1u) || div_special(vt.y) || div_special(v) || div_special(t2);
-    }
+    const float nphi_deg = div_const<CPi>(nphi * 180.0f);                    // DAM:426
     return f4u{nxy.x, nxy.y, v, nphi_deg};                                   // DAM:422-427
 }
 
@@ -360,14 +354,8 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     }
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
     EB_MARK(A, trow, 0);                                                    // loads issued
-    // slot turn constants (predict_for_a_mode, DAM:416-421): (turn radius c, 1/c, sign, enabled)
-    auto turn_consts = [](int t) {
-        return t == TURN_LEFT ? make_float4(26.875f, 1.0f / 26.875f, 1.0f, 1.0f)
-             : t == TURN_RIGHT ? make_float4(15.625f, 1.0f / 15.625f, -1.0f, 1.0f)
-                               : make_float4(1.0f, 1.0f, 0.0f, 0.0f);
-    };
     S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
-    const float4 tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
+    const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
 
     // ---- near-ego records -> this wave's queue ----
     // A circle pair can only be closer than 3.5 m when the two vehicle centres are within 3.5 + 2*1.4 = 6.3 m;
@@ -375,7 +363,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     // to the penalty sums (DAM:228-229).
     int qn = 0;
     auto drain = [&]() {
-        for (int base = 0; base < qn; base += 64) queue_pass<RW, RPT, ST>(H, A, S, w, lane, base, min(64, qn - base));
+        for (int base = 0; base < qn; base += 64) queue_pass(H, S, S.ego, w, lane, base, min(64, qn - base));
         qn = 0;
     };
     // (lanes past the tile's last record carry x = 1e30 in `r`, see the loads: never near)
@@ -422,11 +410,8 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
             if (qn > QCAP - 64) k_late = k + 1;
         }
         if (valid) {
-            const float4 tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
-            unsigned tiny = 0u;
-            f4u nv = predict_record_pk<false>(rec[k], tc, tiny);
-            if (__builtin_expect(tiny != 0u, 0)) nv = predict_record_pk<true>(rec[k], tc, tiny);
-            Stored<ST>::store4(tout + off, nv);
+            const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
+            Stored<ST>::store4(tout + off, predict_record_pk<ST>(rec[k], tc));
         }
         if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
         if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
@@ -447,6 +432,209 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // ---- hand-off 2: partial sums are in LDS ----
     if (lane == 0) atomicAdd(&S.waves_done, 1);
     EB_MARK(A, trow, 5);                                                    // end
+}
+
+// ====================================================================================================
+// Open-loop rollout over an action tape in ONE launch (eb_rollout_tape; the MPC callers' cost_function,
+// mpc/main.py:470-479): the same two roles, with a tile's records and ego states kept in registers across the
+// H steps.  HBM is touched for the initial obs, the actions and out5 of every step, the table gathers and the
+// final obs: per env-step that is 28 + (72 + 32 N) / H bytes — the kernel is VALU-bound, not HBM-bound, and is
+// reported separately from the per-step kernel.  Arithmetic and order of operations are those of
+// the per-step kernel, so the results equal H calls of eb_rollout_step bit for bit (fp16 storage: every step's
+// state passes through Stored<ST>::round, i.e. the binary16 rounding a store + load would apply).
+// Hand-offs per step t: ego_ready = t + 1 (env wave -> record waves, ego poses double-buffered),
+// waves_done = RW * (t + 1) (record waves -> env wave).
+template <int RW, int RPT>
+struct TapeSmem {
+    static constexpr int ITEMS = RW * 64 * RPT;
+    float4 ego[2][64];
+    unsigned char turn[64];
+    unsigned long long mask[64];
+    float2 pen[ITEMS];
+    v2f qxy[RW][QCAP];
+    float qphi[RW][QCAP];
+    int qitem[RW][QCAP];
+    int ego_ready;
+    int waves_done;
+};
+
+template <int TASK, int RW, int RPT, typename ST>
+EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, int e0, int nE, int horizon) {
+    const int lane = threadIdx.x;   // wave 0
+    const int D = H.obs_dim, NV = H.n_veh;
+    const bool act = lane < nE;
+    const int e = act ? lane : 0, ge = e0 + e;
+    const ST* hin = H.obs_in + (size_t)ge * D;
+    ST* hout = H.obs_out + (size_t)ge * D;
+    const f4u h0 = Stored<ST>::load4(hin), h1 = Stored<ST>::load4(hin + 4);
+    float st[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
+    float trk[3] = {h1.z, h1.w, Stored<ST>::load1(hin + 8)};
+    int p = A.path_id;
+    if (A.training) {
+        const int pr = A.ref_idx[ge];
+        p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
+    }
+    const int roff = p == 1 ? A.red_off[1] : p == 2 ? A.red_off[2] : A.red_off[0];
+    const size_t n = (size_t)H.n_env;
+    f2u araw = *reinterpret_cast<const f2u*>(A.actions + 2 * (size_t)ge);
+    for (int t = 0; t < horizon; ++t) {
+        float* out5 = A.out5 + (size_t)t * 5 * n;
+        f2u araw_next = araw;
+        if (t + 1 < horizon) araw_next = *reinterpret_cast<const f2u*>(A.actions + 2 * ((size_t)(t + 1) * n + ge));   // prefetch
+        const float phi_rad = deg2rad(st[5]);
+        float es, ec;
+        sincos_det(phi_rad, es, ec);                                        // DAM:211 and DAM:79-80
+        S.ego[t & 1][lane] = make_float4(st[3], st[4], es, ec);
+        S.mask[lane] = 0ull;                       // the record waves are through with step t - 1 (waited for below)
+        lds_publish(&S.ego_ready, t + 1);                                   // ---- hand-off 1 ----
+        float steer, a_x;
+        action_transform(araw.x, araw.y, steer, a_x);                       // DAM:120
+        if (act) {
+            const float punish_steer = -sq(steer), punish_a_x = -sq(a_x);   // DAM:198-199
+            const float punish_yaw_rate = -sq(st[2]);                       // DAM:202
+            const float devi_y = -sq(trk[0]);                               // DAM:205
+            const float devi_phi = -sq(deg2rad(trk[1]));                    // DAM:206
+            const float devi_v = -sq(trk[2]);                               // DAM:207
+            out5[ge] = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                       5.0f * punish_steer + 0.05f * punish_a_x;            // DAM:297-298
+        }
+        float nx[6];
+        f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);              // DAM:387
+        nx[0] = __builtin_fminf(__builtin_fmaxf(nx[0], 0.0f), 35.0f);       // DAM:390
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+        int bi = 0;
+        if (p >= 0) {                                                       // DAM:334-353
+            float rx = 0.0f, ry = 0.0f, rphi = 0.0f;
+            bi = closest_cell_index(A, p, roff, nx[3], nx[4], rx, ry, rphi);
+            t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                       // DAM:758
+            t1 = deal_with_phi_diff(nx[5] - rphi);                          // DAM:759
+            t2 = nx[0] - EXP_V;                                             // DAM:760
+        }
+        if (t == horizon - 1 && act) {     // the final obs: head (+ look-ahead columns, which feed nothing on the way)
+            Stored<ST>::store4(hout, f4u{nx[0], nx[1], nx[2], nx[3]});
+            Stored<ST>::store4(hout + 4, f4u{nx[4], nx[5], t0, t1});
+            Stored<ST>::store1(hout + 8, t2);
+            ST* otrk = hout + 9;
+            if (p >= 0) {                                                   // DAM:717-724, 763-768
+                const PathTables& pt = *A.dt;
+                const int len = pt.len[p];
+                int cur = bi * 10;                                          // DAM:714
+                for (int k = 0; k < A.n_future; ++k) {
+                    cur += 80;
+                    if (cur >= len - 2) cur = len - 2;
+                    const int fi = clamp_index(cur, len);
+                    Stored<ST>::store1(otrk + 3 * k, pt.x[p][fi] - nx[3]);
+                    Stored<ST>::store1(otrk + 3 * k + 1, pt.y[p][fi] - nx[4]);
+                    Stored<ST>::store1(otrk + 3 * k + 2, deal_with_phi_diff(nx[5] - pt.phi[p][fi]));
+                }
+            } else {
+                for (int c = 0; c < 3 * A.n_future; ++c) Stored<ST>::store1(otrk + c, 0.0f);   // DAM:342, 352
+            }
+        }
+        lds_wait_until(&S.waves_done, RW * (t + 1));                        // ---- hand-off 2 ----
+        if (act) {                                                          // DAM:231-295, 299-300
+            float a35 = 0.0f, a25 = 0.0f;
+            unsigned long long m = S.mask[lane];
+            while (m) {
+                const int jj = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float2 ps = S.pen[lane * NV + jj];
+                a35 += ps.x;
+                a25 += ps.y;
+            }
+            float road_t = 0.0f, road_r = 0.0f;
+            road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
+            road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
+            out5[n + ge] = a35 + road_t;       // DAM:299
+            out5[2 * n + ge] = a25 + road_r;   // DAM:300
+            out5[3 * n + ge] = a25;
+            out5[4 * n + ge] = road_r;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) st[c] = Stored<ST>::round(nx[c]);
+        trk[0] = Stored<ST>::round(t0); trk[1] = Stored<ST>::round(t1); trk[2] = Stored<ST>::round(t2);
+        araw = araw_next;
+    }
+}
+
+template <int TASK, int RW, int RPT, bool FAST, typename ST>
+EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, int e0, int nE, int horizon) {
+    constexpr int RL = RW * 64;
+    const int rtid = threadIdx.x - 64, w = rtid >> 6, lane = rtid & 63;
+    const int NV = H.n_veh, D = H.obs_dim, HD = D - 4 * NV;
+    const int items = nE * NV;
+    const ST* tin = H.obs_in + (size_t)e0 * D;
+    ST* tout = H.obs_out + (size_t)e0 * D;
+    const int e_first = (int)__umulhi((unsigned)rtid, H.nv_magic), j_first = rtid - e_first * NV;
+    const int epk = RL / NV;
+    const int off_first = 4 * rtid + (e_first + 1) * HD, off_step = 4 * RL + epk * HD;
+    auto item_of = [&](int k) { return k * RL + rtid; };
+    auto env_of = [&](int k) { return FAST ? e_first + k * epk : (int)__umulhi((unsigned)item_of(k), H.nv_magic); };
+    auto off_of = [&](int k) { return FAST ? off_first + k * off_step : 4 * item_of(k) + (env_of(k) + 1) * HD; };
+    const int turn_code = A.dt->turn[lane];
+    f4u rec[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const bool valid = item_of(k) < items;
+        rec[k] = Stored<ST>::load4(tin + (valid ? off_of(k) : 4 * (items - 1) + nE * HD));
+        if (!valid) rec[k].x = 1e30f;            // never near an ego, never stored (stays that way: x + dx of 1e30)
+    }
+    S.turn[lane] = (unsigned char)turn_code;
+    const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
+    for (int t = 0; t < horizon; ++t) {
+        const float4* ego = S.ego[t & 1];
+        int qn = 0;
+        auto drain = [&]() {
+            for (int base = 0; base < qn; base += 64) queue_pass(H, S, ego, w, lane, base, min(64, qn - base));
+            qn = 0;
+        };
+        lds_wait_until(&S.ego_ready, t + 1);                                // ---- hand-off 1 ----
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int item = item_of(k), env = env_of(k);
+            const bool valid = item < items;
+            if (k > 0 && (k & 1) == 0 && qn > 64) drain();                  // at most 64 + 2 * 64 = QCAP entries ever wait
+            {
+                const float4 eg = ego[valid ? env : 0];
+                const v2f d = v2f{rec[k].x, rec[k].y} - v2f{eg.x, eg.y};
+                const v2f d2 = d * d;
+                const bool near = d2.x + d2.y < 40.5f;                      // DAM:228-229, see record_wave
+                const unsigned long long b = __builtin_amdgcn_ballot_w64(near);
+                if (b) {
+                    if (near) {
+                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)qn));
+                        S.qxy[w][pos] = v2f{rec[k].x, rec[k].y};
+                        S.qphi[w][pos] = rec[k].w;
+                        S.qitem[w][pos] = item;
+                    }
+                    qn += __popcll(b);
+                }
+            }
+            if (valid) {
+                const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
+                const f4u nv = predict_record_pk<ST>(rec[k], tc);
+                rec[k] = f4u{Stored<ST>::round(nv.x), Stored<ST>::round(nv.y), Stored<ST>::round(nv.z), Stored<ST>::round(nv.w)};
+            }
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        drain();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // ---- hand-off 2 ----
+        if (lane == 0) atomicAdd(&S.waves_done, 1);
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+        if (item_of(k) < items) Stored<ST>::store4(tout + off_of(k), rec[k]);
+}
+
+template <int TASK, int RW, int RPT, bool FAST, typename ST>
+EB_DEV void tape_body(const FusedHot<ST>& H, const FusedArgs& A, int horizon) {
+    __shared__ TapeSmem<RW, RPT> S;
+    const int e0 = blockIdx.x * H.envs_per_tile;
+    const int nE = min(H.envs_per_tile, H.n_env - e0);
+    if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
+    lds_barrier();
+    if (threadIdx.x < 64) env_wave_tape<TASK, RW, RPT, ST>(H, A, S, e0, nE, horizon);
+    else record_wave_tape<TASK, RW, RPT, FAST, ST>(H, A, S, e0, nE, horizon);
 }
 
 template <int TASK, int RW, int RPT, bool FAST, typename ST>
@@ -480,6 +668,18 @@ EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
 EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 8, 64)
 EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 8, 64)
 
+#define EB_TAPE_KERNEL(NAME, RW, RPT, WAVES)                                                             \
+    template <int TASK, bool FAST, typename ST>                                                          \
+    __global__ __launch_bounds__((RW + 1) * 64, WAVES) void NAME(                                        \
+        const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
+        unsigned nv_magic, int horizon, const FusedArgs A) {                                             \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1};        \
+        tape_body<TASK, RW, RPT, FAST, ST>(H, A, horizon);                                               \
+    }
+EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, 5)
+EB_TAPE_KERNEL(rollout_tape_4x4, 4, 4, 1)
+EB_TAPE_KERNEL(rollout_tape_1x4, 1, 4, 1)
+
 int fused_tile_records(int variant) {
     switch (variant) {
         case 0: return 4 * 64 * 8;
@@ -503,6 +703,32 @@ int fused_tile_records(int variant) {
         const dim3 g(grid), b((RW + 1) * 64);                                                                   \
         if (A.storage_f16) { EB_LAUNCH_FAST(KERNEL, RW, _Float16) } else { EB_LAUNCH_FAST(KERNEL, RW, float) }   \
     }
+
+#define EB_TAPE_ARGS(ST) reinterpret_cast<const ST*>(A.obs_in), reinterpret_cast<ST*>(A.obs_out), A.n_env, A.obs_dim, A.n_veh, \
+                         A.envs_per_tile, A.nv_magic, horizon
+#define EB_TAPE_TASK(KERNEL, FAST_, ST)                                                                         \
+    switch (task) {                                                                                             \
+        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, 0, s, EB_TAPE_ARGS(ST), A); break; \
+        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, ST>), g, b, 0, s, EB_TAPE_ARGS(ST), A); break; \
+        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, ST>), g, b, 0, s, EB_TAPE_ARGS(ST), A); break;    \
+    }
+#define EB_TAPE_FAST(KERNEL, RW, ST)                                                                            \
+    if ((RW * 64) % A.n_veh == 0) { EB_TAPE_TASK(KERNEL, true, ST) } else { EB_TAPE_TASK(KERNEL, false, ST) }
+#define EB_TAPE_LAUNCH(KERNEL, RW)                                                                              \
+    {                                                                                                           \
+        const dim3 g(grid), b((RW + 1) * 64);                                                                   \
+        if (A.storage_f16) { EB_TAPE_FAST(KERNEL, RW, _Float16) } else { EB_TAPE_FAST(KERNEL, RW, float) }       \
+    }
+
+// A.actions = the tape [horizon, n_env, 2], A.out5 = [horizon, 5, n_env]
+hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, int horizon, int grid, hipStream_t s) {
+    switch (variant) {
+        case 0: EB_TAPE_LAUNCH(rollout_tape_4x8, 4) break;
+        case 1: EB_TAPE_LAUNCH(rollout_tape_4x4, 4) break;
+        default: EB_TAPE_LAUNCH(rollout_tape_1x4, 1) break;
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s) {
     switch (variant) {

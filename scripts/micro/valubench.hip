@@ -24,6 +24,22 @@ __global__ void k_dep(float* out, float a, float b) {   // one dependent chain
     for (int i = 0; i < N; ++i) x0 = __builtin_fmaf(x0, a, b);
     if (x0 == 12345.f) out[0] = x0;
 }
+__global__ void k_divd(float* out, float a, float b) {   // x / c as (float)((double)x * (1/c)): cvt, v_mul_f64, cvt
+    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+    const double rc = 1.0 / (double)a;
+    for (int i = 0; i < N / 4; ++i) { x0 = (float)((double)x0 * rc) + b; x1 = (float)((double)x1 * rc) + b; x2 = (float)((double)x2 * rc) + b; x3 = (float)((double)x3 * rc) + b; }
+    if (x0 + x1 + x2 + x3 == 12345.f) out[0] = x0;
+}
+__global__ void k_divf(float* out, float a, float b) {   // 3-op exact form: mul, fma, fma
+    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+    const float rc = 1.0f / a;
+    for (int i = 0; i < N / 4; ++i) {
+        float q0 = x0 * rc, q1 = x1 * rc, q2 = x2 * rc, q3 = x3 * rc;
+        x0 = __builtin_fmaf(__builtin_fmaf(-q0, a, x0), rc, q0) + b; x1 = __builtin_fmaf(__builtin_fmaf(-q1, a, x1), rc, q1) + b;
+        x2 = __builtin_fmaf(__builtin_fmaf(-q2, a, x2), rc, q2) + b; x3 = __builtin_fmaf(__builtin_fmaf(-q3, a, x3), rc, q3) + b;
+    }
+    if (x0 + x1 + x2 + x3 == 12345.f) out[0] = x0;
+}
 __global__ void k_sqrt(float* out, float a, float b) {
     float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
     for (int i = 0; i < N / 4; ++i) { x0 = __builtin_sqrtf(x0 + a); x1 = __builtin_sqrtf(x1 + a); x2 = __builtin_sqrtf(x2 + a); x3 = __builtin_sqrtf(x3 + a); }
@@ -53,6 +69,8 @@ int main() {
         run("v_pk_fma_f32 x4 chains", k_pk, w, N);
         run("v_fma_f32 dependent", k_dep, w, N);
         run("v_sqrt_f32(+add) x4", k_sqrt, w, N);
+        run("div via f64 mul (+add) x4", k_divd, w, N);
+        run("div 3-op f32 (+add) x4", k_divf, w, N);
     }
     return 0;
 }

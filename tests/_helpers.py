@@ -229,6 +229,12 @@ class DeviceModel(HostModel):
         HostModel.__init__(self, _capi.hip_api(), task, **kw)
         self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def set_tape_stepwise(self, on):
+        """eb_rollout_tape as H per-step launches (True) or one tape-kernel launch (False, the default)."""
+        fn = self.api.lib.eb_debug_set_tape_stepwise
+        fn.argtypes, fn.restype = [C.c_void_p, C.c_int], C.c_int
+        self.api.check(fn(self.h, int(bool(on))))
+
     def set_tile(self, variant):
         """Force the rollout kernel's tile shape (eb_debug_set_tile; -1 = pick by batch size)."""
         fn = self.api.lib.eb_debug_set_tile

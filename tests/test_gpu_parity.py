@@ -484,3 +484,76 @@ def test_environment_model_fp16_state_facade():
         assert obses.dtype == __import__('torch').float16 and rewards.dtype == __import__('torch').float32
         assert np.array_equal(obses.numpy().view(np.uint16), o_h)
         assert np.array_equal(rewards.numpy(), o5_h[0])
+
+
+# ---- open-loop tape kernel (eb_rollout_tape: H steps in one launch, state in registers) -----------------------
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2])
+@pytest.mark.parametrize('task,N,nf,H', [('left', 32, 0, 25), ('straight', 9, 2, 7), ('right', 64, 0, 3), ('left', 16, 0, 1),
+                                         ('right', 5, 1, 12)])
+def test_tape_kernel_equals_stepwise_launches_and_oracle(task, N, nf, H, tile):
+    """One launch over the whole tape == H per-step launches (bit for bit, every output) == the oracle."""
+    B = 700
+    host, dev = _pair(task, n_veh=N, n_future=nf)
+    dev.set_tile(tile)
+    inp = make_rollout_inputs(task, B, N, H, seed=60 + N + H, n_future=nf)
+    inp['ref_idx'][::13] = 7          # rows without a path
+    obs0 = _initial_obs(host, inp)
+    out_f, o5_f = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    dev.set_tape_stepwise(True)
+    out_s, o5_s = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    dev.set_tape_stepwise(False)
+    out_h, o5_h = host.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    assert np.array_equal(out_f, out_s) and np.array_equal(o5_f, o5_s)
+    assert np.array_equal(out_f, out_h)
+    for t in range(H):
+        _check_out5(o5_f[t], o5_h[t], 'step %d' % t)
+
+
+@pytest.mark.parametrize('tile', [0, 2])
+def test_tape_kernel_crowded_remote_and_special_values(tile):
+    """the scenes of test_crowded_and_remote_scenes through the tape kernel: queue drains inside the step loop,
+    egos outside the cell grid, stopped / denormal / -0 / non-finite records carried in registers for 6 steps"""
+    task, B, N, H = 'left', 300, 32, 6
+    host, dev = _pair(task, n_veh=N)
+    dev.set_tile(tile)
+    inp = make_rollout_inputs(task, B, N, H, seed=78)
+    rng = np.random.default_rng(6)
+    veh, ego = inp['veh'].reshape(B, N, 4).copy(), inp['ego'].copy()
+    veh[:100, :, 0] = ego[:100, None, 3] + rng.uniform(-4, 4, (100, N))
+    veh[:100, :, 1] = ego[:100, None, 4] + rng.uniform(-4, 4, (100, N))
+    veh[:100, :, 2] = rng.uniform(0, 1.0, (100, N))                      # slow: they stay crowded
+    ego[100:150, 3] = rng.uniform(-400, 400, 50); ego[100:150, 4] = rng.uniform(-400, 400, 50)
+    veh[160:200, :, 2] = 0.0
+    veh[200:220, :, 3] = 0.0
+    veh[220:240, :, 3] = np.float32(1e-38)
+    veh[240:260, :, 2] = np.float32(3e-39)
+    veh[260:280, :, 0:2] = rng.uniform(-20, 20, (20, N, 2)); veh[260:280, :, 2] = 0.0; veh[260:280, :, 3] = -0.0
+    veh[290:294, :, 2] = np.inf
+    veh[294:297, :, 3] = -np.inf
+    veh[297:300, :, 3] = np.float32(2e38)
+    inp['ego'], inp['veh'] = ego, veh.reshape(B, 4 * N)
+    obs0 = _initial_obs(host, inp)
+    out_f, o5_f = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    out_h, o5_h = host.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    nan_h = np.isnan(out_h)
+    assert np.array_equal(nan_h, np.isnan(out_f))
+    assert np.array_equal(out_f.view(np.uint32)[~nan_h], out_h.view(np.uint32)[~nan_h])
+    for t in range(H):
+        ok = ~np.isnan(o5_h[t]).any(0)
+        assert np.array_equal(ok, ~np.isnan(o5_f[t]).any(0))
+        _check_out5(o5_f[t][:, ok], o5_h[t][:, ok], 'step %d' % t)
+    assert (o5_f[:, 1, :100] > 0).all()
+
+
+@pytest.mark.parametrize('N', [64, 9])
+def test_tape_kernel_fp16_storage(N):
+    """fp16 storage through the tape kernel: the state is re-rounded to binary16 after every step, as H stores would"""
+    task, B, H = 'straight', 400, 9
+    host, dev = _pair(task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, H, seed=90 + N)
+    obs16 = _initial_obs(host, inp).astype(np.float16).view(np.uint16)
+    a, a5 = dev.rollout_tape_f16(obs16, inp['actions'], inp['ref_idx'])
+    b, b5 = host.rollout_tape_f16(obs16, inp['actions'], inp['ref_idx'])
+    assert np.array_equal(a, b)
+    for t in range(H):
+        _check_out5(a5[t], b5[t], 'step %d' % t)
