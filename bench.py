@@ -91,6 +91,9 @@ def main():
     ap.add_argument('--n-veh', type=int, default=N_VEH)
     ap.add_argument('--eager', action='store_true', help='one host launch per step instead of hipGraph replays')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--open-loop', action='store_true',
+                    help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
+                         'state in registers — VALU-bound, not the HBM-bound closed-loop headline')
     args = ap.parse_args()
     n_env, n_veh = args.n_env, args.n_veh
 
@@ -138,6 +141,11 @@ def main():
     src = [obs0] + dst[:-1]
     eager_args = [(h, n_env, p(src[t]), p(tape[t]), p(ref_idx), 0, p(dst[t]), p(out5[t]), None, sp) for t in range(HORIZON)]
 
+    def tape_launch():
+        rc = lib.eb_rollout_tape(h, n_env, HORIZON, p(obs0), p(tape), p(ref_idx), 0, p(work), p(final), p(out5), sp)
+        if rc != 0:
+            api.check(rc)
+
     def eager_steps(t0, t1):
         for t in range(t0, t1):
             rc = lib.eb_rollout_step(*eager_args[t])
@@ -162,7 +170,9 @@ def main():
             marks = timed and k < n_pairs
             if marks:
                 lib.eb_event_record(ev[2 * k], sp)
-            if args.eager:
+            if args.open_loop:
+                tape_launch()
+            elif args.eager:
                 eager_steps(0, HORIZON)
             else:
                 rc = lib.eb_plan_launch(plan, sp)
@@ -210,21 +220,31 @@ def main():
         if os.path.isfile(tpath) and n_env == N_ENV and n_veh == N_VEH:
             traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
         cfg = 'configs[2]' if (n_env, n_veh) == (N_ENV, N_VEH) else 'custom'
+        kernel = 'eb::rollout_fused_4x8<0, true, float>'
+        form = 'closed-loop rollout_out (one kernel launch per step, %s)' % ('eager' if args.eager else '25-launch hipGraph replays')
+        if args.open_loop:
+            # one launch per 25-step tape; HBM sees the initial and final obs once, actions and outputs every step
+            alg = (28 * HORIZON + 72 + 32 * n_veh) * n_env
+            launch_s *= HORIZON
+            achieved = alg / launch_s / 1e9
+            traffic = None
+            kernel = 'eb::rollout_tape_4x8<0, true, float>'
+            form = ('OPEN-LOOP eb_rollout_tape (the whole %d-step action tape in one launch, records and ego state in registers; '
+                    'VALU-bound — reported apart from the closed-loop headline)' % HORIZON)
         line = {
             'metric': 'env-steps/s (batched rollout) at N_env x N_veh; achieved HBM GB/s vs peak',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt_max * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s: N_env=%d per GPU, N_veh=%d, horizon=%d, task=%s, mode=training, '
-                                   'closed-loop rollout_out (one kernel launch per step, %s)'
-                                   % (cfg, n_env, n_veh, HORIZON, TASK,
-                                      'eager' if args.eager else '25-launch hipGraph replays'),
+            'config': {'workload': '%s: N_env=%d per GPU, N_veh=%d, horizon=%d, task=%s, mode=training, %s'
+                                   % (cfg, n_env, n_veh, HORIZON, TASK, form),
                        'n_env_per_gpu': n_env, 'n_veh': n_veh, 'horizon': HORIZON,
                        'parallelism': 'env-shard x%d, all-gather of the 8-float episodic summary per horizon' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'eb::rollout_fused_4x8<0, true>', 'alg_bytes_per_launch': alg,
-                         'avg_launch_us': launch_s * 1e6, 'launches_timed': n_marked * HORIZON},
+                         'kernel': kernel, 'alg_bytes_per_launch': alg,
+                         'avg_launch_us': launch_s * 1e6,
+                         'launches_timed': n_marked * (1 if args.open_loop else HORIZON)},
             'summary': [float(x) for x in combine_summaries(gathered[0]).tolist()],
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only

@@ -589,37 +589,46 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
             qn = 0;
         };
         lds_wait_until(&S.ego_ready, t + 1);                                // ---- hand-off 1 ----
+        // near tests of step t on the records as they stand, then the queue, then hand-off 2 ...
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int item = item_of(k), env = env_of(k);
-            const bool valid = item < items;
+            int k_item = k * RL, k_env = k * epk;
+            asm volatile("" : "+s"(k_item), "+s"(k_env));
+            const int item = k_item + rtid;
+            const int env = FAST ? e_first + k_env : (int)__umulhi((unsigned)item, H.nv_magic);
             if (k > 0 && (k & 1) == 0 && qn > 64) drain();                  // at most 64 + 2 * 64 = QCAP entries ever wait
-            {
-                const float4 eg = ego[valid ? env : 0];
-                const v2f d = v2f{rec[k].x, rec[k].y} - v2f{eg.x, eg.y};
-                const v2f d2 = d * d;
-                const bool near = d2.x + d2.y < 40.5f;                      // DAM:228-229, see record_wave
-                const unsigned long long b = __builtin_amdgcn_ballot_w64(near);
-                if (b) {
-                    if (near) {
-                        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)qn));
-                        S.qxy[w][pos] = v2f{rec[k].x, rec[k].y};
-                        S.qphi[w][pos] = rec[k].w;
-                        S.qitem[w][pos] = item;
-                    }
-                    qn += __popcll(b);
+            const float4 eg = ego[item < items ? env : 0];
+            const v2f d = v2f{rec[k].x, rec[k].y} - v2f{eg.x, eg.y};
+            const v2f d2 = d * d;
+            const bool near = d2.x + d2.y < 40.5f;                          // DAM:228-229, see record_wave
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(near);
+            if (b) {
+                if (near) {
+                    const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)qn));
+                    S.qxy[w][pos] = v2f{rec[k].x, rec[k].y};
+                    S.qphi[w][pos] = rec[k].w;
+                    S.qitem[w][pos] = item;
                 }
+                qn += __popcll(b);
             }
-            if (valid) {
+        }
+        drain();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // ---- hand-off 2 ----
+        if (lane == 0) atomicAdd(&S.waves_done, 1);
+        // ... and the prediction, which needs nothing from the env wave, while that adds up step t and prepares t + 1
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            int k_item = k * RL, k_env = k * epk;
+            asm volatile("" : "+s"(k_item), "+s"(k_env));
+            const int item = k_item + rtid;
+            if (item < items) {
+                const int env = FAST ? e_first + k_env : (int)__umulhi((unsigned)item, H.nv_magic);
                 const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
                 const f4u nv = predict_record_pk<ST>(rec[k], tc);
                 rec[k] = f4u{Stored<ST>::round(nv.x), Stored<ST>::round(nv.y), Stored<ST>::round(nv.z), Stored<ST>::round(nv.w)};
             }
             if (k & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        drain();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // ---- hand-off 2 ----
-        if (lane == 0) atomicAdd(&S.waves_done, 1);
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
@@ -633,7 +642,10 @@ EB_DEV void tape_body(const FusedHot<ST>& H, const FusedArgs& A, int horizon) {
     const int nE = min(H.envs_per_tile, H.n_env - e0);
     if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
     lds_barrier();
-    if (threadIdx.x < 64) env_wave_tape<TASK, RW, RPT, ST>(H, A, S, e0, nE, horizon);
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_s_setprio(3);   // the env wave's per-step chain is the serial part of a step: it goes first
+        env_wave_tape<TASK, RW, RPT, ST>(H, A, S, e0, nE, horizon);
+    }
     else record_wave_tape<TASK, RW, RPT, FAST, ST>(H, A, S, e0, nE, horizon);
 }
 
@@ -676,7 +688,7 @@ EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 8, 64)
         const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1};        \
         tape_body<TASK, RW, RPT, FAST, ST>(H, A, horizon);                                               \
     }
-EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, 5)
+EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, 6)
 EB_TAPE_KERNEL(rollout_tape_4x4, 4, 4, 1)
 EB_TAPE_KERNEL(rollout_tape_1x4, 1, 4, 1)
 

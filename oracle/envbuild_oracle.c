@@ -1095,14 +1095,15 @@ void eb_oracle_atanf(const float* x, float* y, int n) {
     for (int i = 0; i < n; ++i) y[i] = eb_atanf(x[i]);
 }
 
-/* Checks the kernels' 3-op constant division (eb_device.h:div_fast: q = x*rc, r = fma(-q, c, x), q + r*rc with
- * rc = fl(1/c)) against IEEE x / c for every float bit pattern in [first, last] with stride `step`.  fmaf is
- * correctly rounded here as v_fma_f32 is on the GPU, so this is the same arithmetic.  Returns the number of
- * patterns that differ, ignoring the guarded dividends that take the true division in the kernels (non-zero
- * |x| < 2^-101, -0.0, +-inf) and NaNs; *first_bad gets the first differing pattern.  With guard == 0 nothing is
- * ignored except NaNs (used to show that the three guarded kinds are the only ones that differ). */
-long long eb_oracle_check_div_exact(float c, uint32_t first, uint32_t last, uint32_t step, int guard, uint32_t* first_bad) {
+/* Checks the kernels' constant division (eb_device.h:div_const: (float)((double)x * (1.0 / (double)c)), i.e.
+ * v_cvt_f64_f32, v_mul_f64, v_cvt_f32_f64) against IEEE x / c for every float bit pattern in [first, last] with
+ * stride `step`.  The same two IEEE operations run here on the CPU.  Returns the number of patterns whose result
+ * differs in any bit (NaN dividends are skipped: payloads are the FPU's business); *first_bad gets the first one.
+ * form == 1 checks the fp32-only 3-op form (q = x*rc, residual, correction) instead — kept to document why it
+ * is not used: it differs for -0.0, +-inf and non-zero magnitudes below 2^-101. */
+long long eb_oracle_check_div_exact(float c, uint32_t first, uint32_t last, uint32_t step, int form, uint32_t* first_bad) {
     const float rc = 1.0f / c;
+    const double rcd = 1.0 / (double)c;
     long long bad = 0;
     uint32_t fb = 0xffffffffu;
     const uint64_t n = ((uint64_t)last - first) / step + 1;
@@ -1114,11 +1115,13 @@ long long eb_oracle_check_div_exact(float c, uint32_t first, uint32_t last, uint
         float x;
         memcpy(&x, &bits, 4);
         if (x != x) continue;
-        const uint32_t mag2 = bits << 1;
-        if (guard && (mag2 - 1u < 2u * 0x0D000000u - 1u || bits == 0x80000000u || mag2 == 0xFF000000u)) continue;
-        const float q = x * rc;
-        const float r = fmaf(-q, c, x);
-        const float fast = fmaf(r, rc, q);
+        float fast;
+        if (form == 1) {
+            const float q = x * rc;
+            fast = fmaf(fmaf(-q, c, x), rc, q);
+        } else {
+            fast = (float)((double)x * rcd);
+        }
         const float exact = x / c;
         uint32_t a, b;
         memcpy(&a, &fast, 4);
