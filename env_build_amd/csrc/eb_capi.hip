@@ -355,7 +355,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     for (int k = 0; k < 3; ++k) { A.red_off[k] = h->red_off[k]; A.red_len[k] = h->pt.red_len[k]; }
     A.n_paths = h->pt.n_paths;
     A.n_env = n_env; A.obs_dim = obs_dim(h->cfg); A.n_veh = NV; A.n_future = h->cfg.n_future;
-    A.nv_magic = (unsigned)((0x100000000ull + (unsigned)NV - 1) / (unsigned)NV);
+    A.nv_magic = NV == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)NV - 1) / (unsigned)NV);   // 0: item / 1
     A.envs_per_tile = std::max(1, std::min(64, eb::fused_tile_records(variant) / NV));
     A.path_id = path_id;
     A.training = h->cfg.mode == EB_MODE_TRAINING;

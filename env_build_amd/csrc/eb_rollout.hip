@@ -84,6 +84,13 @@ struct FusedHot {
     int do_rewards;
 };
 
+// item / n_veh by the multiplicative inverse nv_magic = ceil(2^32 / n_veh) (exact for item < 65 536, checked; items stay
+// below 2048); n_veh == 1 has no 32-bit inverse and is flagged by nv_magic == 0
+template <typename ST>
+EB_DEV int env_of_item(const FusedHot<ST>& H, int item) {
+    return H.nv_magic ? (int)__umulhi((unsigned)item, H.nv_magic) : item;
+}
+
 // profiling aid: mark slot `i` of this wave's trace row with the 100 MHz wall clock (lane 0 only)
 #define EB_MARK(A, row, i) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + (i)] = wall_clock64(); } while (0)
 
@@ -261,7 +268,7 @@ EB_DEV void queue_pass(const FusedHot<ST>& H, SM& S, const float4* ego, int w, i
         const v2f vxy = S.qxy[w][base + lane];
         const float4 v = make_float4(vxy.x, vxy.y, S.qphi[w][base + lane], 0.0f);
         const int item = S.qitem[w][base + lane];
-        const int e2 = (int)__umulhi((unsigned)item, H.nv_magic), j2 = item - e2 * H.n_veh;
+        const int e2 = env_of_item(H, item), j2 = item - e2 * H.n_veh;
         const float4 eg = ego[e2];
         float t35[4], t25[4], vs, vc;
         const float4 pts = make_float4(eg.x + LWS * eg.w, eg.y + LWS * eg.z, eg.x - LWS * eg.w, eg.y - LWS * eg.z);
@@ -334,12 +341,12 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     const int items = nE * NV;
     const ST* tin = H.obs_in + (size_t)e0 * D;
     ST* tout = H.obs_out + (size_t)e0 * D;
-    const int e_first = (int)__umulhi((unsigned)rtid, H.nv_magic), j_first = rtid - e_first * NV;
+    const int e_first = env_of_item(H, rtid), j_first = rtid - e_first * NV;
     const int epk = RL / NV;                                  // FAST: envs per k step
     const int off_first = 4 * rtid + (e_first + 1) * HD, off_step = 4 * RL + epk * HD;
     // record k of this lane: item id, env (tile-local), float offset of the record in the tile (== e*D + HD + 4*j)
     auto item_of = [&](int k) { return k * RL + rtid; };
-    auto env_of = [&](int k) { return FAST ? e_first + k * epk : (int)__umulhi((unsigned)item_of(k), H.nv_magic); };
+    auto env_of = [&](int k) { return FAST ? e_first + k * epk : env_of_item(H, item_of(k)); };
     auto off_of = [&](int k) { return FAST ? off_first + k * off_step : 4 * item_of(k) + (env_of(k) + 1) * HD; };
 
     // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then every record
@@ -402,7 +409,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         int k_item = k * RL, k_env = k * epk, k_off = k * off_step;
         asm volatile("" : "+s"(k_item), "+s"(k_env), "+s"(k_off));
         const int item = k_item + rtid;
-        const int env = FAST ? e_first + k_env : (int)__umulhi((unsigned)item, H.nv_magic);
+        const int env = FAST ? e_first + k_env : env_of_item(H, item);
         const int off = FAST ? off_first + k_off : 4 * item + (env + 1) * HD;
         const bool valid = item < items;
         if (k < k_late) {
@@ -565,11 +572,11 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
     const int items = nE * NV;
     const ST* tin = H.obs_in + (size_t)e0 * D;
     ST* tout = H.obs_out + (size_t)e0 * D;
-    const int e_first = (int)__umulhi((unsigned)rtid, H.nv_magic), j_first = rtid - e_first * NV;
+    const int e_first = env_of_item(H, rtid), j_first = rtid - e_first * NV;
     const int epk = RL / NV;
     const int off_first = 4 * rtid + (e_first + 1) * HD, off_step = 4 * RL + epk * HD;
     auto item_of = [&](int k) { return k * RL + rtid; };
-    auto env_of = [&](int k) { return FAST ? e_first + k * epk : (int)__umulhi((unsigned)item_of(k), H.nv_magic); };
+    auto env_of = [&](int k) { return FAST ? e_first + k * epk : env_of_item(H, item_of(k)); };
     auto off_of = [&](int k) { return FAST ? off_first + k * off_step : 4 * item_of(k) + (env_of(k) + 1) * HD; };
     const int turn_code = A.dt->turn[lane];
     f4u rec[RPT];
@@ -595,7 +602,7 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
             int k_item = k * RL, k_env = k * epk;
             asm volatile("" : "+s"(k_item), "+s"(k_env));
             const int item = k_item + rtid;
-            const int env = FAST ? e_first + k_env : (int)__umulhi((unsigned)item, H.nv_magic);
+            const int env = FAST ? e_first + k_env : env_of_item(H, item);
             if (k > 0 && (k & 1) == 0 && qn > 64) drain();                  // at most 64 + 2 * 64 = QCAP entries ever wait
             const float4 eg = ego[item < items ? env : 0];
             const v2f d = v2f{rec[k].x, rec[k].y} - v2f{eg.x, eg.y};
@@ -622,7 +629,7 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
             asm volatile("" : "+s"(k_item), "+s"(k_env));
             const int item = k_item + rtid;
             if (item < items) {
-                const int env = FAST ? e_first + k_env : (int)__umulhi((unsigned)item, H.nv_magic);
+                const int env = FAST ? e_first + k_env : env_of_item(H, item);
                 const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
                 const f4u nv = predict_record_pk<ST>(rec[k], tc);
                 rec[k] = f4u{Stored<ST>::round(nv.x), Stored<ST>::round(nv.y), Stored<ST>::round(nv.z), Stored<ST>::round(nv.w)};

@@ -557,3 +557,36 @@ def test_tape_kernel_fp16_storage(N):
     assert np.array_equal(a, b)
     for t in range(H):
         _check_out5(a5[t], b5[t], 'step %d' % t)
+
+
+# ---- odd shapes ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('task,B,N,nf', [('left', 1, 8, 0), ('right', 2, 1, 0), ('straight', 63, 2, 8), ('left', 65, 33, 0),
+                                         ('right', 4097, 7, 1), ('straight', 130, 64, 0)])
+def test_odd_batch_and_slot_counts(task, B, N, nf):
+    """single env, one slot, slot counts that do not divide a wave, batches one past a tile: step and tape"""
+    host, dev = _pair(task, n_veh=N, n_future=nf)
+    inp = make_rollout_inputs(task, B, N, 4, seed=B + N, n_future=nf)
+    obs0 = _initial_obs(host, inp)
+    o_h, o5_h, _ = host.rollout_step(obs0, inp['actions'][0], inp['ref_idx'])
+    o_d, o5_d, _ = dev.rollout_step(obs0, inp['actions'][0], inp['ref_idx'])
+    assert np.array_equal(o_d, o_h)
+    _check_out5(o5_d, o5_h, 'step')
+    t_h, t5_h = host.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    t_d, t5_d = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    assert np.array_equal(t_d, t_h)
+    np.testing.assert_allclose(t5_d, t5_h, rtol=PEN_RTOL, atol=0)
+
+
+def test_sharded_batch_size_262144_rows_are_independent():
+    """BASELINE configs[3] is 262 144 envs split over 8 GPUs; on one GPU the same batch in one launch must give, row
+    for row, what eight 32 768-env shards give (no cross-row state anywhere on the path)."""
+    task, B, N = 'left', 262144, 32
+    dev = DeviceModel(task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, 1, seed=12)
+    obs0 = assemble_obs(inp['ego'], np.zeros((B, 3), np.float32), inp['veh'])
+    whole, whole5, _ = dev.rollout_step(obs0, inp['actions'][0], inp['ref_idx'])
+    from env_build_amd.sharding import shard_range
+    for r in (0, 3, 7):
+        lo, hi = shard_range(B, r, 8)
+        part, part5, _ = dev.rollout_step(obs0[lo:hi], inp['actions'][0][lo:hi], inp['ref_idx'][lo:hi])
+        assert np.array_equal(part, whole[lo:hi]) and np.array_equal(part5, whole5[:, lo:hi])
