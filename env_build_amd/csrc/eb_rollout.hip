@@ -484,6 +484,9 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
     const int roff = p == 1 ? A.red_off[1] : p == 2 ? A.red_off[2] : A.red_off[0];
     const size_t n = (size_t)H.n_env;
     f2u araw = *reinterpret_cast<const f2u*>(A.actions + 2 * (size_t)ge);
+    const int trow = blockIdx.x * (RW + 1);
+    long long waited = 0;
+    EB_MARK(A, trow, 0);
     for (int t = 0; t < horizon; ++t) {
         float* out5 = A.out5 + (size_t)t * 5 * n;
         f2u araw_next = araw;
@@ -538,7 +541,9 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
                 for (int c = 0; c < 3 * A.n_future; ++c) Stored<ST>::store1(otrk + c, 0.0f);   // DAM:342, 352
             }
         }
+        const long long w0 = A.trace ? wall_clock64() : 0;
         lds_wait_until(&S.waves_done, RW * (t + 1));                        // ---- hand-off 2 ----
+        if (A.trace) waited += wall_clock64() - w0;
         if (act) {                                                          // DAM:231-295, 299-300
             float a35 = 0.0f, a25 = 0.0f;
             unsigned long long m = S.mask[lane];
@@ -562,6 +567,8 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         trk[0] = Stored<ST>::round(t0); trk[1] = Stored<ST>::round(t1); trk[2] = Stored<ST>::round(t2);
         araw = araw_next;
     }
+    EB_MARK(A, trow, 1);
+    if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 2] = waited;
 }
 
 template <int TASK, int RW, int RPT, bool FAST, typename ST>
@@ -588,6 +595,9 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
     }
     S.turn[lane] = (unsigned char)turn_code;
     const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
+    const int trow = blockIdx.x * (RW + 1) + 1 + w;
+    long long waited = 0;
+    EB_MARK(A, trow, 0);
     for (int t = 0; t < horizon; ++t) {
         const float4* ego = S.ego[t & 1];
         int qn = 0;
@@ -595,7 +605,9 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
             for (int base = 0; base < qn; base += 64) queue_pass(H, S, ego, w, lane, base, min(64, qn - base));
             qn = 0;
         };
+        const long long w0 = A.trace ? wall_clock64() : 0;
         lds_wait_until(&S.ego_ready, t + 1);                                // ---- hand-off 1 ----
+        if (A.trace) waited += wall_clock64() - w0;
         // near tests of step t on the records as they stand, then the queue, then hand-off 2 ...
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -640,6 +652,8 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
         if (item_of(k) < items) Stored<ST>::store4(tout + off_of(k), rec[k]);
+    EB_MARK(A, trow, 1);
+    if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 2] = waited;
 }
 
 template <int TASK, int RW, int RPT, bool FAST, typename ST>

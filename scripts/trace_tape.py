@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Profiling aid: per-wave wall time and hand-off wait time of ONE eb_rollout_tape launch (tape kernel)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from env_build_amd.dynamics_and_models import EnvironmentModel
+from env_build_amd.synthetic import make_rollout_inputs
+B, N, H, W = 65536, 32, 25, 5
+dev = torch.device('cuda', 0)
+inp = make_rollout_inputs('left', B, N, H, seed=0)
+m = EnvironmentModel('left', 0, mode='training', n_veh=N, device=dev)
+ego = torch.from_numpy(inp['ego']).to(dev); ref = torch.from_numpy(inp['ref_idx']).to(dev)
+trk = m.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(), ego[:, 0].contiguous(), 0, ref_indexes=ref).t
+obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
+tape = torch.from_numpy(inp['actions']).to(dev)
+work, out = torch.empty_like(obs0), torch.empty_like(obs0); out5 = torch.empty((H, 5, B), device=dev)
+p = lambda t: C.c_void_p(t.data_ptr()); sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+lib = m.api.lib; lib.eb_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
+run = lambda: lib.eb_rollout_tape(m.handle, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), sp)
+for _ in range(3): assert run() == 0
+torch.cuda.synchronize()
+tr = torch.zeros((B * W // 8, 8), dtype=torch.int64, device=dev)
+lib.eb_debug_set_trace(m.handle, p(tr)); run(); torch.cuda.synchronize(); tr.zero_(); run(); torch.cuda.synchronize()
+lib.eb_debug_set_trace(m.handle, None)
+t = tr.cpu().numpy().astype(np.float64); nb = int((t[:, 0] > 0).sum()) // W; t = t[:nb * W]
+t0 = t[:, 0].min(); start, end, wait = (t[:, 0] - t0) / 100, (t[:, 1] - t0) / 100, t[:, 2] / 100
+q = lambda x: ' '.join('%7.2f' % v for v in np.percentile(x, [0, 10, 50, 90, 100]))
+env = np.arange(nb * W) % W == 0
+print('blocks %d, %d steps; us; percentiles 0 10 50 90 100' % (nb, H))
+for name, sel in (('env wave', env), ('rec wave', ~env)):
+    print('%s start %s' % (name, q(start[sel]))); print('%s end   %s' % (name, q(end[sel])))
+    print('%s life  %s' % (name, q((end - start)[sel]))); print('%s waiting at its hand-off (total over the steps) %s' % (name, q(wait[sel])))
+life = (end - start)[env]
+bid = np.arange(nb)
+print('mean block life by blockIdx %% 8 (XCD):', ' '.join('%.0f' % life[bid % 8 == x].mean() for x in range(8)))
+print('mean block life by blockIdx // 256:   ', ' '.join('%.0f' % life[bid // 256 == x].mean() for x in range(4)))
+print('mean block life by (blockIdx // 8) %% 32 (CU within XCD, if round-robin):', ' '.join('%.0f' % life[(bid // 8) % 32 == x].mean() for x in range(32)))
+srt = np.sort(life); print('life histogram deciles:', ' '.join('%.0f' % v for v in np.percentile(life, range(0, 101, 10))))
