@@ -97,3 +97,35 @@ def rotate_and_shift_coordination(orig_x, orig_y, orig_d, coordi_shift_x, coordi
     rx, ry, d = rotate_coordination(orig_x, orig_y, orig_d, coordi_rotate_d)
     tx, ty = shift_coordination(rx, ry, coordi_shift_x, coordi_shift_y)
     return tx, ty, d
+
+
+# ---- frames of the other exits (multi_ego.py:84-96 observes each ego in its own exit-relative frame) ----
+def transform_vehicles(vehicles, x, y, rotate_d):  # UTL:160-180 (cal_info_in_transform_coordination)
+    """Every vehicle dict re-expressed in the frame shifted by (x, y) and then rotated by rotate_d degrees
+    (positive = anticlockwise); speed, size and route are carried over."""
+    out = []
+    for veh in vehicles:
+        sx, sy = shift_coordination(veh['x'], veh['y'], x, y)
+        tx, ty, tphi = rotate_coordination(sx, sy, veh['phi'], rotate_d)
+        out.append(dict(veh, x=tx, y=ty, phi=tphi))
+    return out
+
+
+def transform_ego(ego_dynamics, x, y, rotate_d):  # UTL:183-196 (cal_ego_info_in_transform_coordination)
+    """The ego's pose and corner points in the shifted-then-rotated frame; updates and returns the dict, as
+    the reference does."""
+    heading = ego_dynamics['phi']
+    sx, sy = shift_coordination(ego_dynamics['x'], ego_dynamics['y'], x, y)
+    tx, ty, tphi = rotate_coordination(sx, sy, heading, rotate_d)
+    corners = []
+    for cx, cy in ego_dynamics['Corner_point']:
+        csx, csy = shift_coordination(cx, cy, x, y)
+        ctx, cty, _ = rotate_coordination(csx, csy, heading, rotate_d)
+        corners.append((ctx, cty))
+    ego_dynamics.update(dict(x=tx, y=ty, phi=tphi, Corner_point=corners))
+    return ego_dynamics
+
+
+# the reference's names
+cal_info_in_transform_coordination = transform_vehicles
+cal_ego_info_in_transform_coordination = transform_ego

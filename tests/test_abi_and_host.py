@@ -185,3 +185,23 @@ def test_oracle_plan_summary_and_events():
     api.event_destroy(e0); api.event_destroy(e1)
     with pytest.raises(ValueError):
         api.plan_create(host.h, 0, 5, None, None, None, 0, None, None, None, None, C.byref(C.c_void_p()))
+
+
+def test_exit_frame_transforms_match_reference_values():
+    """endtoend_env_utils.cal_info_in_transform_coordination / cal_ego_info_in_transform_coordination (UTL:160-196);
+    expected values produced by the reference's own functions (container run, rounded to 1e-9)."""
+    from env_build_amd import endtoend_env_utils as U
+    vehs = [dict(x=12.5, y=-3.25, v=4.0, phi=170.0, w=2., l=4.8, route=('2o', '4i')),
+            dict(x=-30.0, y=1.875, v=0.0, phi=-90.0, w=2.5, l=5., route=('3o', '1i'))]
+    expect = [(90, [(3.75, -9.5, 80.0), (8.875, 33.0, 180.0)], (-23.0, 2.0, 2.0), [(-21.0, 1.0), (-21.0, 3.0)]),
+              (-90, [(-3.75, 9.5, -100.0), (-8.875, -33.0, 0.0)], (23.0, -2.0, -178.0), [(21.0, -1.0), (21.0, -3.0)]),
+              (180, [(-9.5, -3.75, -10.0), (33.0, -8.875, 90.0)], (2.0, 23.0, -88.0), [(1.0, 21.0), (3.0, 21.0)]),
+              (37.5, [(9.819712092, -2.808158549, 132.5), (-20.777902547, 27.130138052, -127.5)],
+               (-15.588219548, -17.029603969, 54.5), [(-13.577343349, -16.051658717), (-15.16405003, -14.834135859)])]
+    for rot, ev, ee, ec in expect:
+        got = U.cal_info_in_transform_coordination(vehs, 3.0, -7.0, rot)
+        for g, e, v in zip(got, ev, vehs):
+            assert np.allclose((g['x'], g['y'], g['phi']), e, atol=2e-9) and g['v'] == v['v'] and g['route'] == v['route']
+        ego = U.cal_ego_info_in_transform_coordination(dict(x=1.0, y=-30.0, phi=92.0, Corner_point=[(2., -28.), (0., -28.)]),
+                                                       3., -7., rot)
+        assert np.allclose((ego['x'], ego['y'], ego['phi']), ee, atol=2e-9) and np.allclose(ego['Corner_point'], ec, atol=2e-9)
