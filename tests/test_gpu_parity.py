@@ -590,3 +590,33 @@ def test_sharded_batch_size_262144_rows_are_independent():
         lo, hi = shard_range(B, r, 8)
         part, part5, _ = dev.rollout_step(obs0[lo:hi], inp['actions'][0][lo:hi], inp['ref_idx'][lo:hi])
         assert np.array_equal(part, whole[lo:hi]) and np.array_equal(part5, whole5[:, lo:hi])
+
+
+def test_batched_safety_shield_matches_per_row_reference_logic():
+    """env_build_amd.shield.is_safe (hier_decision.py:89-97 for a whole batch): the same verdict and penalty as
+    stepping the oracle with the same closed-loop policy"""
+    import torch
+    from env_build_amd.dynamics_and_models import DevArray, EnvironmentModel
+    from env_build_amd.shield import is_safe, safe_shield
+    task, B, N = 'left', 600, 8
+    host = HostModel(oracle_lib(), task, n_veh=N, mode='selecting')
+    inp = make_rollout_inputs(task, B, N, 1, seed=15)
+    inp['ref_idx'][:] = 1
+    obs0 = _initial_obs(host, inp)
+
+    def policy(obs):               # a fixed linear feedback on the tracking errors, as a stand-in for run_batch
+        o = obs.torch() if isinstance(obs, DevArray) else torch.as_tensor(obs)
+        return torch.stack([(-0.05 * o[:, 6] - 0.01 * o[:, 7]).clamp(-1, 1), (-0.1 * o[:, 8]).clamp(-1, 1)], 1).contiguous()
+
+    model = EnvironmentModel(task, mode='selecting')
+    safe, punish = is_safe(model, policy, obs0, path_index=1, steps=5)
+    o, acc = obs0, np.zeros(B, np.float32)
+    for _ in range(5):
+        a = policy(torch.from_numpy(o)).numpy()
+        o, o5, _ = host.rollout_step(o, a, None, 1)
+        acc = acc + o5[3]
+    np.testing.assert_allclose(punish.numpy(), acc, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(safe.numpy(), ~(acc > 0)) and 0 < safe.numpy().sum() < B
+    act, started = safe_shield(model, policy, obs0, path_index=1)
+    assert np.array_equal(started.numpy(), ~safe.numpy())
+    assert np.array_equal(act.numpy()[started.numpy()], np.tile(np.float32([0., -1.]), (int(started.numpy().sum()), 1)))
