@@ -40,6 +40,15 @@ __global__ void copy_nt_load4(const f4v* __restrict__ in, f4v* __restrict__ out,
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n4) { f4v v = __builtin_nontemporal_load(&in[i]); out[i] = v; }
 }
+#define COPY_ASM_STORE(NAME, MODS)                                                                              \
+__global__ void NAME(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n4) {                            \
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;                                             \
+    if (i < n4) { f4v v = in[i]; f4v* p = out + i; asm volatile("global_store_dwordx4 %0, %1, off " MODS :: "v"(p), "v"(v) : "memory"); } \
+}
+COPY_ASM_STORE(copy_st_sc0, "sc0")
+COPY_ASM_STORE(copy_st_sc1, "sc1")
+COPY_ASM_STORE(copy_st_sc0sc1, "sc0 sc1")
+COPY_ASM_STORE(copy_st_ntsc1, "nt sc1")
 __global__ void empty_kernel(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {}
 __global__ void copy_one(const float4* __restrict__ in, float4* __restrict__ out, size_t n4) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -95,6 +104,10 @@ int main(int argc, char** argv) {
     run("nt store dwordx4", [&](int i) { hipLaunchKernelGGL(copy_nt_store4, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("nt load dwordx4", [&](int i) { hipLaunchKernelGGL(copy_nt_load4, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("nt load + nt store dwordx4", [&](int i) { hipLaunchKernelGGL(copy_nt_both4, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("store sc0", [&](int i) { hipLaunchKernelGGL(copy_st_sc0, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("store sc1", [&](int i) { hipLaunchKernelGGL(copy_st_sc1, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("store sc0 sc1", [&](int i) { hipLaunchKernelGGL(copy_st_sc0sc1, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
+    run("store nt sc1", [&](int i) { hipLaunchKernelGGL(copy_st_ntsc1, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const f4v*)buf[i & 1], (f4v*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("empty kernel same grid", [&](int i) { hipLaunchKernelGGL(empty_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("empty kernel grid=1024x320", [&](int i) { hipLaunchKernelGGL(empty_kernel, dim3(1024), dim3(320), 0, 0, (const float4*)buf[i & 1], (float4*)buf[(i + 1) & 1], n4); }, 2.0 * bytes);
     run("copy misaligned(+4B) grid=2048", [&](int i) { hipLaunchKernelGGL(copy_misaligned, dim3(2048), dim3(256), 0, 0, (const float*)buf[i & 1], buf[(i + 1) & 1], n4 - 1); }, 2.0 * bytes);
