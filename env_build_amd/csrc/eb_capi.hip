@@ -73,7 +73,7 @@ static hipStream_t pick(eb_handle, void* stream) { return (hipStream_t)stream; }
 // scans [lo, hi] in index order with the reference's fp32 expression and a strict '<', which is the
 // reference's full-scan argmin (first minimum) restricted to a range that provably contains it.
 static int build_cell_grid(eb_handle_s* h, const float* hred, int n_paths) {
-    const double cell = 1.0 / (double)eb::CELL_INV, margin = 10.0;
+    const double cell = 1.0 / (double)eb::CELL_INV, margin = 20.0;   // beyond that: the pruned full search
     double x0 = 1e30, x1 = -1e30, y0 = 1e30, y1 = -1e30;
     for (int k = 0; k < n_paths; ++k) {
         const float* r = hred + 2 * (size_t)h->red_off[k];

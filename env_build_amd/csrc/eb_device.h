@@ -274,20 +274,35 @@ EB_DEV int row_path(const PathTables& pt, const int* ref_idx, int path_id, int i
 //   3. the surviving blocks are scanned in index order with the reference's fp32 expression and a
 //      strict '<' (first minimum).
 // NaN / inf coordinates end with index 0, as the full scan does.
+// The table lives in global memory (L2): loads are issued in groups so that their latencies overlap.
 EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, float px, float py) {
-    const int nb = (n + 15) >> 4;
+    constexpr int G = 4;
+    const int nb = (n + 15) >> 4;                 // <= 32 blocks (eb_set_paths limits a path to 512 table points)
     float m2 = __builtin_inff();
-    for (int b = 0; b < nb; ++b) {
-        const float2 q = red[min(16 * b + 8, n - 1)];
-        m2 = __builtin_fminf(m2, sq(px - q.x) + sq(py - q.y));
+    for (int b0 = 0; b0 < nb; b0 += G) {
+        float2 q[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) q[u] = red[min(16 * min(b0 + u, nb - 1) + 8, n - 1)];   // past the end: the last centre again
+#pragma unroll
+        for (int u = 0; u < G; ++u) m2 = __builtin_fminf(m2, sq(px - q[u].x) + sq(py - q[u].y));
     }
     const float m = __builtin_amdgcn_sqrtf(m2);   // approximate is enough: only feeds the slack test
     unsigned cand = 0u;
-    for (int b = 0; b < nb; ++b) {
-        const float2 q = red[min(16 * b + 8, n - 1)];
-        const float d2 = sq(px - q.x) + sq(py - q.y);
-        const float thr = m + rad[b] + 0.01f;
-        cand |= (d2 <= thr * thr) ? (1u << b) : 0u;
+    for (int b0 = 0; b0 < nb; b0 += G) {
+        float2 q[G];
+        float rr[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int b = min(b0 + u, nb - 1);
+            q[u] = red[min(16 * b + 8, n - 1)];
+            rr[u] = rad[b];
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const float d2 = sq(px - q[u].x) + sq(py - q[u].y);
+            const float thr = m + rr[u] + 0.01f;
+            cand |= (b0 + u < nb && d2 <= thr * thr) ? (1u << (b0 + u)) : 0u;
+        }
     }
     float best = __builtin_inff();
     int bi = 0;
@@ -295,10 +310,15 @@ EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, flo
         const int b = __builtin_ctz(cand);
         cand &= cand - 1u;
         const int r1 = min(16 * b + 16, n);
-        for (int r = 16 * b; r < r1; ++r) {
-            const float2 t = red[r];
-            const float d = sq(px - t.x) + sq(py - t.y);   // DAM:712
-            if (d < best) { best = d; bi = r; }             // first minimum, DAM:714
+        for (int r0 = 16 * b; r0 < r1; r0 += G) {
+            float2 t[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) t[u] = red[min(r0 + u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const float d = sq(px - t[u].x) + sq(py - t[u].y);     // DAM:712
+                if (r0 + u < r1 && d < best) { best = d; bi = r0 + u; } // first minimum, DAM:714
+            }
         }
     }
     return bi;

@@ -677,6 +677,10 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
     const int nE = min(H.envs_per_tile, H.n_env - e0);
     if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
     lds_barrier();   // the only barrier: at launch, before any wave has something to wait for
+    // Occupancy pad for the 2048-record tile: 4 blocks x 5 waves per CU are 5 waves per SIMD when spread evenly.
+    // Holding 73-80 VGPRs caps a SIMD at 6 waves, which keeps the dispatcher from stacking 7 or 8 on one SIMD and 3
+    // on another (measured: 17.2 us with 58 VGPRs, 16.2 us with 77; a cap of exactly 5 makes some blocks wait a round).
+    if (RW * RPT >= 32) asm volatile("; keep v79 allocated" ::: "v79");
     if (threadIdx.x < 64) {
         __builtin_amdgcn_s_setprio(2);
         env_wave<TASK, RW, RPT, ST>(H, A, S, e0, nE);

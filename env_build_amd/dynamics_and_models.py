@@ -342,6 +342,9 @@ class EnvironmentModel(object):  # DAM:90-427
                            modes=self.veh_mode_list)
         self.api, self.handle = self._hd.api, self._hd.h
         self._ref_idx_dev = None
+        # the raw entry point of the hot call (the checked wrapper costs a Python closure per call)
+        self._step_fn = (self.api.lib.eb_rollout_step_f16 if self.state_dtype == torch.float16
+                         else self.api.lib.eb_rollout_step)
 
     # -- state ------------------------------------------------------------------------------
     def _obs(self, obses, dtype=torch.float32):
@@ -380,19 +383,27 @@ class EnvironmentModel(object):  # DAM:90-427
 
     # -- the hot path -----------------------------------------------------------------------
     def rollout_out(self, actions):  # DAM:118-126
-        obs = self._obs(self.obses, self.state_dtype)
-        act = _dev(actions, self.device)
+        obs = self.obses.t if type(self.obses) is DevArray else None
+        if obs is None or obs.dtype != self.state_dtype or obs.device != self.device or not obs.is_contiguous():
+            obs = self._obs(self.obses, self.state_dtype)
+        act = _unwrap(actions)
+        if not (isinstance(act, torch.Tensor) and act.dtype == torch.float32 and act.device == self.device
+                and act.is_contiguous()):
+            act = _dev(act, self.device)
         B = obs.shape[0]
         ri, pid = self._path_args()
         obs_out = torch.empty_like(obs)
         out5 = torch.empty((5, B), dtype=torch.float32, device=self.device)
         scaled = torch.empty((B, 2), dtype=torch.float32, device=self.device)
-        step = self.api.rollout_step_f16 if self.state_dtype == torch.float16 else self.api.rollout_step
-        step(self.handle, B, _ptr(obs), _ptr(act), _ptr(ri), pid, _ptr(obs_out), _ptr(out5), _ptr(scaled),
-             _stream(self.device))
+        rc = self._step_fn(self.handle, B, obs.data_ptr(), act.data_ptr(), ri.data_ptr() if ri is not None else None, pid,
+                           obs_out.data_ptr(), out5.data_ptr(), scaled.data_ptr(),
+                           torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            self.api.check(rc)
         self.actions = DevArray(scaled)
         self.obses = DevArray(obs_out)
-        self._after_tracking()
+        if self.mode == 'training':   # the reference's loop leaves ref_path.path on the last path, DAM:345-346
+            self.ref_path.path = self.ref_path.path_list[-1]
         return (self.obses, DevArray(out5[0]), DevArray(out5[1]), DevArray(out5[2]), DevArray(out5[3]),
                 DevArray(out5[4]))
 
