@@ -9,7 +9,7 @@ obs`, `step(action) -> (obs, reward, done, info)`, `seed`, `close`, `set_traj`, 
   * `n_env` (default 1): a BATCH of independent single-ego envs advanced by one set of kernel launches
     per step.  With n_env == 1 every return value has the reference's shape and type (obs float32 [D],
     reward np.float32, done int, info dict); with n_env > 1 they are device arrays of leading size B
-    (obs [B, D], reward [B], done uint8 [B]) and `done_type` is a list.
+    (obs [B, D], reward [B], done uint8 [B]) and `done_type` holds the uint8 done codes (`done_names()` spells them).
   * the traffic source.  The reference co-simulates with SUMO over TraCI (traffic.py; out of scope,
     SURVEY.md §2 #6).  Here the surrounding vehicles are a fixed pool of `n_cand` candidates per env
     advanced with the model's own prediction step (EnvironmentModel.veh_predict, DAM:394-427 — the same
@@ -166,7 +166,7 @@ class CrossroadEnd2end(object):
     # -- gym plumbing ---------------------------------------------------------------------------
     def seed(self, seed=None):  # E2E:95-97
         self.np_random = np.random.default_rng(seed)
-        self._gen = torch.Generator(device='cpu')
+        self._gen = torch.Generator(device=self.device)      # the traffic pool draws on the GPU: no per-step H2D copy
         self._gen.manual_seed(int(self.np_random.integers(0, 2 ** 31 - 1)))
         return [seed]
 
@@ -209,8 +209,8 @@ class CrossroadEnd2end(object):
     def _spawn_traffic(self, rows=None):
         """(Re)place candidates at a random distance along their entry lane (the SUMO flows' role)."""
         B, M = self.n_env, self.n_cand
-        u = torch.rand((B, M), generator=self._gen).to(self.device)
-        spd = (torch.rand((B, M), generator=self._gen) * EXPECTED_V).to(self.device)
+        u = torch.rand((B, M), generator=self._gen, device=self.device)
+        spd = torch.rand((B, M), generator=self._gen, device=self.device) * EXPECTED_V
         along = u * 60.0                                                                # up to the stop line + junction
         fresh = torch.stack([self._entry[:, 0] + along * self._entry_dir[:, 0],
                              self._entry[:, 1] + along * self._entry_dir[:, 1], spd,
@@ -242,7 +242,8 @@ class CrossroadEnd2end(object):
         self.obs = self._get_obs()
         self.action = None
         self.reward_info = None
-        self.done_type = 'not_done_yet' if self.n_env == 1 else ['not_done_yet'] * self.n_env
+        self.done_type = 'not_done_yet' if self.n_env == 1 else DevArray(torch.zeros((self.n_env,), dtype=torch.uint8,
+                                                                                  device=self.device))
         return self.obs
 
     # -- reference-shaped views of the device state (n_env == 1) ---------------------------------
@@ -335,7 +336,8 @@ class CrossroadEnd2end(object):
         if self.respawn:
             lim = CROSSROAD_SIZE / 2 + 40.
             gone = (self._cand[:, :, 0].abs() > lim) | (self._cand[:, :, 1].abs() > lim)
-            self._spawn_traffic(gone)
+            if self.n_env > 1 or bool(gone.any()):
+                self._spawn_traffic(gone)
 
     def _judge_done(self):  # E2E:200-256 -> (done_type, done)
         code = torch.empty((self.n_env,), dtype=torch.uint8, device=self.device)
@@ -346,7 +348,12 @@ class CrossroadEnd2end(object):
         if self.n_env == 1:
             c = int(code[0].item())
             return _capi.DONE_NAMES[c], int(c != 0)
-        return [_capi.DONE_NAMES[int(c)] for c in code.cpu().numpy()], DevArray((code != 0).to(torch.uint8))
+        # a batch keeps the uint8 codes on the device (EB_DONE_*; done_names() spells them out on request)
+        return DevArray(code), DevArray((code != 0).to(torch.uint8))
+
+    def done_names(self):
+        """done_type strings of the last step for every env of a batch (E2E:208-221)."""
+        return [_capi.DONE_NAMES[int(c)] for c in self.done_code.cpu().numpy()]
 
     def step(self, action):
         act = self._action_transformation_for_end2end(action)                           # E2E:133
