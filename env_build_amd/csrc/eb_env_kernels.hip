@@ -131,11 +131,18 @@ __global__ void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTable
     if (p < 0) { for (int c = 0; c < T; ++c) o[6 + c] = 0.0f; }
     else {
         // tracking_error_vector on the env's path, E2E:293-297
+        // closest table point: the cell grid names the index range that holds it (eb_capi.hip:build_cell_grid);
+        // outside the grid, the reference's full scan (DAM:702-715)
         const float2* red = pt.red[p];
-        const int n = pt.red_len[p];
+        int lo = 0, hi = pt.red_len[p] - 1;
+        const float fx = (ex - pt.gx0) * CELL_INV, fy = (ey - pt.gy0) * CELL_INV;
+        if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) {
+            const unsigned c = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
+            lo = (int)(c & 0xffffu); hi = (int)(c >> 16);
+        }
         float best = __builtin_inff();
         int bi = 0;
-        for (int r = 0; r < n; ++r) {
+        for (int r = lo; r <= hi; ++r) {
             const float2 q = red[r];
             const float d = sq(ex - q.x) + sq(ey - q.y);
             if (d < best) { best = d; bi = r; }
