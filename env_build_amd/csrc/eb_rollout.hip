@@ -93,6 +93,9 @@ EB_DEV int env_of_item(const FusedHot<ST>& H, int item) {
 
 // profiling aid: mark slot `i` of this wave's trace row with the 100 MHz wall clock (lane 0 only)
 #define EB_MARK(A, row, i) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + (i)] = wall_clock64(); } while (0)
+// slot 7 of a wave's trace row: where it ran — HW_REG_XCC_ID << 32 | HW_REG_HW_ID (simd [5:4], cu [11:8], sh [12], se [15:13])
+#define EB_MARK_PLACE(A, row) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + 7] = \
+    ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
 
 // per-wave near-record queue: normally one drain at the end; in a crowded tile the in-loop tests stop while 64
 // slots are still free and the rest is tested record by record with a drain before each (see record_wave).  4 blocks of 2048 records must fit a CU's LDS with
@@ -168,6 +171,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     }
     const int trow = blockIdx.x * (RW + 1);
     EB_MARK(A, trow, 0);                                                    // loads issued
+    EB_MARK_PLACE(A, trow);
     const float st[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
     const float phi_rad = deg2rad(st[5]);
     float es, ec;
@@ -361,6 +365,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     }
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
     EB_MARK(A, trow, 0);                                                    // loads issued
+    EB_MARK_PLACE(A, trow);
     S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
     const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
 

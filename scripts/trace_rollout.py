@@ -72,3 +72,17 @@ for lo, hi in ((0, nb // 4), (nb // 4, nb // 2), (nb // 2, 3 * nb // 4), (3 * nb
     sel = order[lo:hi]
     print('  blocks by start quartile: start %.2f..%.2f  mean duration %.2f  mean end %.2f  (block ids %d..%d median %d)'
           % (blk_start[sel].min(), blk_start[sel].max(), (blk_end - blk_start)[sel].mean(), blk_end[sel].mean(), sel.min(), sel.max(), int(np.median(sel))))
+# placement: waves per SIMD (slot 7 = XCC_ID << 32 | HW_ID)
+raw = tr.cpu().numpy()[:nb * W, 7]
+hw = raw & 0xffffffff; xcc = (raw >> 32) & 0xf
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+key_cu = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+import collections
+per_simd = collections.Counter(zip(key_cu.tolist(), simd.tolist()))
+per_cu = collections.Counter(key_cu.tolist())
+print('CUs used: %d; waves per CU: %s' % (len(per_cu), dict(collections.Counter(per_cu.values()))))
+print('waves per SIMD histogram:', dict(sorted(collections.Counter(per_simd.values()).items())), '(%d SIMDs with waves)' % len(per_simd))
+envw = np.arange(nb * W) % W == 0
+print('env waves per SIMD histogram:', dict(sorted(collections.Counter(collections.Counter(zip(key_cu[envw].tolist(), simd[envw].tolist())).values()).items())))
+blk_simd = simd.reshape(nb, W)
+print('SIMD of the waves of the first blocks:', blk_simd[:6].tolist())
