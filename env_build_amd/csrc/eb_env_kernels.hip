@@ -16,8 +16,9 @@ namespace eb {
 struct V4 { float x, y, v, phi; };
 
 // a14: _get_next_ego_state, E2E:269-283
-__global__ void env_ego_step_kernel(int n, const float* __restrict__ ego, const float* __restrict__ actions,
-                                    float* __restrict__ next_ego, float* __restrict__ params) {
+// (ego and next_ego may be the same buffer: eb_env_step updates the state in place)
+__global__ void env_ego_step_kernel(int n, const float* ego, const float* __restrict__ actions,
+                                    float* next_ego, float* __restrict__ params) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float st[6], nx[6], pr[4];

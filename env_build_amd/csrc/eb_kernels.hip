@@ -191,8 +191,8 @@ hipError_t launch_tracking(int task, int n, const PathTables& pt, const float* x
 }
 
 // veh_predict (DAM:394-427), one thread per (env, vehicle) record
-__global__ void veh_predict_kernel(int n_rec, int NV, VehModes modes, const float* __restrict__ veh,
-                                   float* __restrict__ out) {
+// (veh and out may be the same buffer: eb_env_step advances the traffic pool in place)
+__global__ void veh_predict_kernel(int n_rec, int NV, VehModes modes, const float* veh, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
     const float4 v = reinterpret_cast<const float4*>(veh)[i];

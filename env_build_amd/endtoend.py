@@ -356,16 +356,47 @@ class CrossroadEnd2end(object):
         return [_capi.DONE_NAMES[int(c)] for c in self.done_code.cpu().numpy()]
 
     def step(self, action):
-        act = self._action_transformation_for_end2end(action)                           # E2E:133
-        self.action = act[0].cpu().numpy() if self.n_env == 1 else DevArray(act)
-        reward, self.reward_info = self.compute_reward(self._obs, act)                  # E2E:134 (on the current obs)
-        self._ego, self._params = self._get_next_ego_state(act)                         # E2E:135
-        self._traffic_step()                                                            # E2E:137-138
+        """E2E:132-144 through ONE C-ABI call (eb_env_step): action scaling -> reward on the current obs -> ego step ->
+        traffic step -> observation -> done code; afterwards the traffic pool re-enters the vehicles that left the map
+        (the observation saw the pool as this step left it, the way the reference sees SUMO's state of the step)."""
+        B, dev = self.n_env, self.device
+        raw = _dev(np.asarray(action, np.float32).reshape(B, 2) if not isinstance(action, (torch.Tensor, DevArray))
+                   else action, dev).reshape(B, 2).contiguous()
+        act = torch.empty_like(raw)
+        out5 = torch.empty((5, B), dtype=torch.float32, device=dev)
+        d16 = torch.empty((16, B), dtype=torch.float32, device=dev)
+        obs_out = torch.empty_like(self._obs)
+        code = torch.empty((B,), dtype=torch.uint8, device=dev)
+        light = ((self._v_light != 0) | (self._virtual != 0)).to(torch.uint8)          # E2E:387-388
+        ri = self._ref_idx
+        if B == 1:
+            ri = torch.tensor([int(self.ref_path.ref_index)], dtype=torch.int32, device=dev)
+        self._cand = self._cand.contiguous()
+        self.api.env_step(self._h, self._traffic.h, B, _ptr(self._obs), _ptr(raw), _ptr(ri), 0, _ptr(self._ego),
+                          _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(light),
+                          _ptr(self._v_light), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out), _ptr(code), self._sp())
+        self._obs, self.done_code = obs_out, code
+        if self.respawn:
+            lim = CROSSROAD_SIZE / 2 + 40.
+            gone = (self._cand[:, :, 0].abs() > lim) | (self._cand[:, :, 1].abs() > lim)
+            if B > 1 or bool(gone.any()):
+                self._spawn_traffic(gone)
         self._publish_state()                                                           # E2E:136, 139
-        self.obs = self._get_obs()                                                      # E2E:140
-        self.done_type, done = self._judge_done()                                       # E2E:141
+        keys = EnvironmentModel.REWARD_KEYS
+        if B == 1:
+            self.action = act[0].cpu().numpy()
+            self.obs = obs_out[0].cpu().numpy()
+            reward = out5[0].cpu().numpy()[0]
+            d16h = d16[:, 0].cpu().numpy()
+            self.reward_info = {k: d16h[i] for i, k in enumerate(keys)}                # E2E:505-507
+            c = int(code[0].item())
+            self.done_type, done = _capi.DONE_NAMES[c], int(c != 0)                     # E2E:141
+        else:
+            self.action, self.obs, reward = DevArray(act), DevArray(obs_out), DevArray(out5[0])
+            self.reward_info = {k: DevArray(d16[i]) for i, k in enumerate(keys)}
+            self.done_type, done = DevArray(code), DevArray((code != 0).to(torch.uint8))
         self.reward_info.update({'final_rew': reward})                                  # E2E:142
         all_info = dict(all_vehicles=self.all_vehicles, ego_dynamics=self.ego_dynamics, v_light=self.v_light)
         all_info.update({'reward_info': self.reward_info,
-                         'ref_index': self.ref_path.ref_index if self.n_env == 1 else DevArray(self._ref_idx)})   # E2E:143
+                         'ref_index': self.ref_path.ref_index if B == 1 else DevArray(self._ref_idx)})   # E2E:143
         return self.obs, reward, done, all_info

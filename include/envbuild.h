@@ -243,6 +243,19 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
                   const float* obs, int32_t m_cand, const float* cand, const uint8_t* cand_mode,
                   const float* cand_lw, const uint8_t* v_light, uint8_t* done_code, void* stream);
 
+
+/* CrossroadEnd2end.step (E2E:132-144) for a batch of envs, as one call: action scaling (E2E:133) -> reward on the
+ * CURRENT obs (E2E:134; out5 / out_dict16 (nullable) as in eb_compute_rewards) -> ego step (E2E:135, eb_env_ego_step) -> traffic step ->
+ * observation (E2E:140, eb_get_obs) -> done code (E2E:141, eb_judge_done).  The reference advances the traffic with
+ * SUMO (TRF:220-238); here `traffic` is a second handle whose n_veh slots are the m_cand candidates of every env
+ * (its slot modes = their modes) and the candidates move by the model's own prediction step (eb_veh_predict).
+ * In-place state: ego [n_env,6], cand [n_env, m_cand, 4]; params [n_env,4] is written.  obs [n_env,D] is the
+ * current observation (input), obs_out the next one; they must differ.  Equivalent to the six calls in that order. */
+int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
+                const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
+                const uint8_t* cand_mode, const uint8_t* light_flag, const uint8_t* v_light,
+                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1074,6 +1074,25 @@ int eb_event_destroy(eb_event e) {
     return EB_OK;
 }
 
+/* a13: CrossroadEnd2end.step as one call, E2E:132-144 */
+int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
+                const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
+                const uint8_t* cand_mode, const uint8_t* light_flag, const uint8_t* v_light,
+                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream) {
+    if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
+    if (n_env < 0 || !obs || !actions || !ego || !params || !scaled_actions || !out5 || !obs_out || !done_code || obs == obs_out)
+        return fail(EB_EINVAL, "eb_env_step: bad argument");
+    if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_step: the traffic handle must have n_veh == m_cand");
+    if (n_env == 0) return EB_OK;
+    int rc = eb_action_transform(h, n_env, actions, scaled_actions, stream);                     /* E2E:133 */
+    if (!rc) rc = eb_compute_rewards(h, n_env, obs, scaled_actions, out5, out_dict16, stream);      /* E2E:134 */
+    if (!rc) rc = eb_env_ego_step(h, n_env, ego, scaled_actions, ego, params, stream);           /* E2E:135 */
+    if (!rc) rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                            /* TRF:220-238's role */
+    if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, stream);   /* E2E:140 */
+    if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, NULL, v_light, done_code, stream);   /* E2E:141 */
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* helpers for the CPU-baseline leg of bench.py                                                */
 /* ------------------------------------------------------------------------------------------ */

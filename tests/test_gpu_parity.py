@@ -369,6 +369,51 @@ def test_env_kernels_random_scenes_bit_exact(task):
     assert np.array_equal(z_h, z_d)
 
 
+@pytest.mark.parametrize('task', TASKS)
+def test_env_step_composite_equals_the_six_calls(task):
+    """eb_env_step == action_transform, compute_rewards, env_ego_step, veh_predict, get_obs, judge_done in that order,
+    on both libraries (bit for bit against the oracle's composite too)."""
+    import ctypes as C
+    B, M = 500, 14
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    ego, cand, _, _, light, _, ref = _random_scene(task, B, M, 44)
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    raw = np.random.default_rng(2).uniform(-1.2, 1.2, (B, 2)).astype(np.float32)
+    outs = []
+    for Model in (HostModel, DeviceModel):
+        args = (oracle_lib(),) if Model is HostModel else ()
+        m, tr = Model(*args, task, mode='training'), Model(*args, task, n_veh=M, modes=modes)
+        obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
+        # the six calls
+        act = m.action_transform(raw)
+        o5, d16 = m.compute_rewards(obs0, act)
+        ego1, par1 = m.env_ego_step(ego, act)
+        cand1 = tr.veh_predict(cand.reshape(B, -1)).reshape(B, M, 4)
+        obs1 = m.get_obs(ego1, cand1, cmode, light, ref_idx=ref)
+        done1 = m.judge_done(ego1, par1, obs1, cand1, cmode, None, light)
+        # the composite (state updated in place)
+        e_io, c_io = m._in(ego.copy()), m._in(cand.copy())       # updated in place: never the test's own arrays
+        ob, rw, ri = m._in(obs0), m._in(raw), m._in(ref, np.int32)
+        cm, lf = m._in(cmode, np.uint8), m._in(light, np.uint8)
+        par, sc, out5, dd = m._out((B, 4)), m._out((B, 2)), m._out((5, B)), m._out((16, B))
+        obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
+        m.api.env_step(m.h, tr.h, B, m._ptr(ob), m._ptr(rw), m._ptr(ri), 0, m._ptr(e_io), m._ptr(par), M, m._ptr(c_io),
+                       m._ptr(cm), m._ptr(lf), m._ptr(lf), m._ptr(sc), m._ptr(out5), m._ptr(dd), m._ptr(obs_o), m._ptr(code), m.stream)
+        got = [m._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code)]
+        want = [act, o5, d16, ego1, par1, cand1, obs1, done1]
+        for g, w in zip(got, want):
+            assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w)
+        outs.append(got)
+    for a, b in zip(*outs):
+        if a.dtype == np.float32 and a.shape == (5, B):
+            _check_out5(b, a, 'composite')
+        elif a.shape == (16, B):
+            np.testing.assert_allclose(b, a, rtol=PEN_RTOL, atol=0)
+        else:
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize('task,n_env', [('left', 1), ('straight', 1), ('right', 64), ('left', 300)])
 def test_crossroad_env_facade_matches_oracle_composition(task, n_env):
     """CrossroadEnd2end.step / reset (the reference's Gym surface) against the same composition made of oracle
@@ -398,8 +443,8 @@ def test_crossroad_env_facade_matches_oracle_composition(task, n_env):
         gone = (np.abs(cand1[:, :, 0]) > 65) | (np.abs(cand1[:, :, 1]) > 65)
         cand_env = env._cand.cpu().numpy()
         assert np.array_equal(cand_env[~gone], cand1[~gone])              # re-entered vehicles are the env's own business
-        obs1 = host.get_obs(ego1, cand_env, cmode, light, ref_idx=ref)
-        done1 = host.judge_done(ego1, par1, obs1, cand_env, cmode, None, env._v_light.cpu().numpy())
+        obs1 = host.get_obs(ego1, cand1, cmode, light, ref_idx=ref)        # the step observes the pool before re-entry
+        done1 = host.judge_done(ego1, par1, obs1, cand1, cmode, None, env._v_light.cpu().numpy())
         if n_env == 1:
             assert isinstance(done, int) and np.asarray(reward).shape == () and 'reward_info' in info
             assert np.array_equal(obs, obs1[0]) and reward == o5[0, 0] and done == int(done1[0] != 0)
