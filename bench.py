@@ -101,7 +101,7 @@ def main():
     import torch.distributed as dist
     from env_build_amd.dynamics_and_models import EnvironmentModel
     from env_build_amd.synthetic import make_rollout_inputs
-    from env_build_amd.sharding import combine_summaries, gather_summaries
+    from env_build_amd.sharding import combine_summaries, gather_summaries_async
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -110,7 +110,8 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('EB_BENCH_FORCE_DIST') == '1'   # the latter: exercise the RCCL calls on one GPU
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
 
@@ -126,8 +127,11 @@ def main():
     tape = torch.from_numpy(inp['actions']).to(dev)                      # [H, B, 2]
     work, final = torch.empty_like(obs0), torch.empty_like(obs0)
     out5 = torch.empty((HORIZON, 5, n_env), dtype=torch.float32, device=dev)
-    summary = torch.zeros((8,), dtype=torch.float32, device=dev)
+    # two summary buffers: the all-gather of rollout k overlaps the kernels of rollout k+1 (own RCCL stream)
+    summaries = [torch.zeros((8,), dtype=torch.float32, device=dev) for _ in range(2)]
+    in_flight = [None, None]
     gathered = [torch.zeros((world, 8), dtype=torch.float32, device=dev)]
+    n_rollouts = [0]
 
     api, h = model.api, model.handle
     stream = torch.cuda.current_stream()
@@ -154,8 +158,19 @@ def main():
 
     def end_of_horizon():
         # episodic-return summary of this shard (two small kernels), then the only inter-GPU exchange
-        api.episode_summary(h, n_env, HORIZON, p(out5), p(final), p(summary), sp)
-        gathered[0] = gather_summaries(summary)      # env_build_amd/sharding.py: one all-gather of 8 floats per rank
+        slot = n_rollouts[0] & 1
+        n_rollouts[0] += 1
+        if in_flight[slot] is not None:
+            gathered[0] = in_flight[slot].result()   # the gather of two rollouts ago: long finished
+        api.episode_summary(h, n_env, HORIZON, p(out5), p(final), p(summaries[slot]), sp)
+        in_flight[slot] = gather_summaries_async(summaries[slot])   # env_build_amd/sharding.py: 8 floats per rank
+
+    def drain_gathers():
+        order = [n_rollouts[0] & 1, (n_rollouts[0] + 1) & 1]       # oldest first
+        for slot in order:
+            if in_flight[slot] is not None:
+                gathered[0] = in_flight[slot].result()
+                in_flight[slot] = None
 
     n_pairs = min(MAX_EVENT_PAIRS, max(1, args.steps // HORIZON))
     ev = []
@@ -182,17 +197,18 @@ def main():
                 lib.eb_event_record(ev[2 * k + 1], sp)
             end_of_horizon()
         eager_steps(0, rem)
+        drain_gathers()
         return full
 
     run(args.warmup, False)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     full = run(args.steps, True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -203,7 +219,7 @@ def main():
         api.event_elapsed_ms(ev[2 * k], ev[2 * k + 1], C.byref(ms))
         ev_ms += ms.value
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
@@ -255,7 +271,7 @@ def main():
     for e in ev:
         api.event_destroy(e)
     api.plan_destroy(plan)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -273,10 +273,13 @@ hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const Pat
 // ------------------------------------------------------------------------------------------------
 // episodic-return summary of a shard (eb_episode_summary): two launches, fixed reduction order
 // ------------------------------------------------------------------------------------------------
-// Stage 1: thread i walks env i, i + G*256, ... and, per env, the `horizon` step records of
-// out5_steps [H, 5, B] (consecutive lanes read consecutive envs: coalesced), accumulating in float64;
-// wave shuffle + LDS tree gives one 6-double partial per block.  Stage 2: one block folds the
-// partials in block order.  No atomics, so the result does not depend on scheduling.
+// Stage 1: a block owns 64 envs at a time; its four waves split the `horizon` step records of
+// out5_steps [H, 5, B] (wave w takes steps w, w+4, ...: every load is 64 consecutive floats, four steps
+// in flight per lane), accumulating in float64.  The per-env "punished at any step" flags meet in LDS,
+// wave 0 adds the |delta_y| terms, and a shuffle + LDS tree leaves one 6-double partial per block.
+// Stage 2: one block folds the partials in block order.  No atomics: the result depends on the grid
+// size only, never on scheduling.  (A single launch with a last-block ticket was measured slower: the
+// device-scope ticket atomics of ~1000 blocks serialise for longer than the second launch costs.)
 constexpr int SUM_THREADS = 256;
 
 struct Sum6 { double r, pt, pr, cnt, ady, mdy; };
@@ -310,22 +313,47 @@ __global__ __launch_bounds__(SUM_THREADS) void summary_partial_kernel(int n_env,
                                                                        const float* __restrict__ obs_final,
                                                                        double* __restrict__ partials) {
     __shared__ Sum6 s_part[SUM_THREADS / 64];
+    __shared__ unsigned char s_any[SUM_THREADS / 64][64];
+    constexpr int NW = SUM_THREADS / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     Sum6 acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const size_t n = (size_t)n_env;
-    for (int i = blockIdx.x * SUM_THREADS + threadIdx.x; i < n_env; i += gridDim.x * SUM_THREADS) {
+    for (int base = blockIdx.x * 64; base < n_env; base += gridDim.x * 64) {
+        const int i = base + lane;
+        const bool live = i < n_env;
+        const int ic = live ? i : n_env - 1;
+        float dyv = 0.0f;
+        if (wave == 0) dyv = obs_final[(size_t)ic * D + 6];          // strided: issued first, used last
         bool any = false;
-        for (int t = 0; t < horizon; ++t) {
-            const float* o5 = out5_steps + (size_t)t * 5 * n;
-            const float pr = o5[2 * n + i];
-            acc.r += (double)o5[i];
-            acc.pt += (double)o5[n + i];
-            acc.pr += (double)pr;
-            any = any || pr > 0.0f;
+        double r = 0.0, pt = 0.0, prs = 0.0;
+        constexpr int U = 4;                                          // steps in flight per lane (3 loads each)
+        for (int t0 = wave; t0 < horizon; t0 += U * NW) {
+            float a[U], b[U], c[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * NW;
+                const float* o5 = out5_steps + (size_t)(t < horizon ? t : horizon - 1) * 5 * n;
+                a[u] = o5[ic]; b[u] = o5[n + ic]; c[u] = o5[2 * n + ic];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (t0 + u * NW < horizon) {
+                    r += (double)a[u]; pt += (double)b[u]; prs += (double)c[u];
+                    any = any || c[u] > 0.0f;
+                }
         }
-        const double dy = (double)__builtin_fabsf(obs_final[(size_t)i * D + 6]);
-        acc.cnt += any ? 1.0 : 0.0;
-        acc.ady += dy;
-        acc.mdy = dy > acc.mdy ? dy : acc.mdy;
+        if (live) { acc.r += r; acc.pt += pt; acc.pr += prs; }
+        s_any[wave][lane] = any ? 1 : 0;
+        __syncthreads();
+        if (wave == 0 && live) {
+            bool a = false;
+            for (int w = 0; w < NW; ++w) a = a || s_any[w][lane] != 0;
+            const double dy = (double)__builtin_fabsf(dyv);
+            acc.cnt += a ? 1.0 : 0.0;
+            acc.ady += dy;
+            acc.mdy = dy > acc.mdy ? dy : acc.mdy;
+        }
+        __syncthreads();
     }
     const Sum6 b = sum6_block_reduce(acc, s_part);
     if (threadIdx.x == 0) {
@@ -338,22 +366,22 @@ __global__ __launch_bounds__(SUM_THREADS) void summary_final_kernel(int n_part, 
                                                                      const double* __restrict__ partials,
                                                                      float* __restrict__ out8) {
     __shared__ Sum6 s_part[SUM_THREADS / 64];
-    Sum6 acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < n_part; b += SUM_THREADS) {
-        const double* p = partials + 6 * (size_t)b;
-        Sum6 v = {p[0], p[1], p[2], p[3], p[4], p[5]};
-        acc = sum6_combine(acc, v);
+    Sum6 tot = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = threadIdx.x; k < n_part; k += SUM_THREADS) {
+        const double* p = partials + 6 * (size_t)k;
+        const Sum6 x = {p[0], p[1], p[2], p[3], p[4], p[5]};
+        tot = sum6_combine(tot, x);
     }
-    const Sum6 r = sum6_block_reduce(acc, s_part);
+    const Sum6 f = sum6_block_reduce(tot, s_part);
     if (threadIdx.x == 0) {
-        out8[0] = (float)r.r; out8[1] = (float)r.pt; out8[2] = (float)r.pr; out8[3] = (float)r.cnt;
-        out8[4] = (float)r.ady; out8[5] = (float)r.mdy; out8[6] = (float)n_env; out8[7] = (float)horizon;
+        out8[0] = (float)f.r; out8[1] = (float)f.pt; out8[2] = (float)f.pr; out8[3] = (float)f.cnt;
+        out8[4] = (float)f.ady; out8[5] = (float)f.mdy; out8[6] = (float)n_env; out8[7] = (float)horizon;
     }
 }
 
 hipError_t launch_summary(int n_env, int horizon, int D, const float* out5_steps, const float* obs_final,
                           double* partials, int max_parts, float* out8, hipStream_t s) {
-    int g = (n_env + SUM_THREADS - 1) / SUM_THREADS;
+    int g = (n_env + 63) / 64;
     g = g < 1 ? 1 : (g > max_parts ? max_parts : g);
     hipLaunchKernelGGL(summary_partial_kernel, dim3(g), dim3(SUM_THREADS), 0, s, n_env, horizon, D, out5_steps,
                        obs_final, partials);

@@ -27,12 +27,40 @@ def gather_summaries(summary8, group=None):
     """All-gather of one shard summary -> [world, 8] on every rank (the only inter-GPU exchange)."""
     if summary8.numel() != SUMMARY_LEN:
         raise ValueError('summary must have %d floats' % SUMMARY_LEN)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return summary8.reshape(1, SUMMARY_LEN).clone()
     world = dist.get_world_size(group)
     out = torch.empty((world, SUMMARY_LEN), dtype=summary8.dtype, device=summary8.device)
     dist.all_gather_into_tensor(out.view(-1), summary8.reshape(-1).contiguous(), group=group)
     return out
+
+
+class PendingGather:
+    """An all-gather in flight (gather_summaries_async).  result() orders the caller's stream after the
+    collective (no host wait on RCCL) and hands back the [world, 8] tensor."""
+    def __init__(self, work, out, keep):
+        self._work, self._out, self._keep = work, out, keep
+
+    def result(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._out
+
+
+def gather_summaries_async(summary8, group=None):
+    """gather_summaries without stalling the launch stream: the collective runs on the backend's own stream,
+    ordered after the work already queued on the current stream, while the next rollout's kernels go on.
+    The caller must not overwrite `summary8` before result() — keep one buffer per gather in flight."""
+    if summary8.numel() != SUMMARY_LEN:
+        raise ValueError('summary must have %d floats' % SUMMARY_LEN)
+    if not (dist.is_available() and dist.is_initialized()):
+        return PendingGather(None, summary8.reshape(1, SUMMARY_LEN).clone(), None)
+    world = dist.get_world_size(group)
+    out = torch.empty((world, SUMMARY_LEN), dtype=summary8.dtype, device=summary8.device)
+    src = summary8.reshape(-1).contiguous()
+    work = dist.all_gather_into_tensor(out.view(-1), src, group=group, async_op=True)
+    return PendingGather(work, out, src)
 
 
 def combine_summaries(all8):

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from env_build_amd.sharding import combine_summaries, gather_summaries, shard_range  # noqa: E402
+from env_build_amd.sharding import combine_summaries, gather_summaries, gather_summaries_async, shard_range  # noqa: E402
 
 TASK, B, N, H = 'left', 1001, 8, 5
 
@@ -47,6 +47,9 @@ def _worker(rank, world, port, q):
         lo, hi = shard_range(B, rank, world)
         s8, out = _shard_summary(lo, hi)
         all8 = gather_summaries(torch.from_numpy(s8))
+        # the overlapped form bench.py uses: two gathers in flight, collected oldest first
+        pend = [gather_summaries_async(torch.from_numpy(s8)), gather_summaries_async(torch.from_numpy(s8 * 2))]
+        assert torch.equal(pend[0].result(), all8) and torch.equal(pend[1].result(), all8 * 2)
         total = combine_summaries(all8)
         q.put((rank, lo, hi, all8.numpy(), total.numpy(), out[:2].copy()))
     finally:
@@ -66,6 +69,7 @@ def test_shard_ranges_cover_the_batch_once():
 def test_single_process_gather_is_identity():
     s = torch.arange(8, dtype=torch.float32)
     assert torch.equal(gather_summaries(s), s.reshape(1, 8))
+    assert torch.equal(gather_summaries_async(s).result(), s.reshape(1, 8))
     assert torch.equal(combine_summaries(s.reshape(1, 8)), s)
 
 
