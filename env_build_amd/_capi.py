@@ -25,6 +25,14 @@ class EbConfig(C.Structure):
                 ('n_future', C.c_int32), ('mode', C.c_int32), ('device', C.c_int32)]
 
 
+class EbMlpConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('abi_version', 'obs_dim', 'n_hidden', 'n_units', 'out_dim',
+                                         'hidden_act', 'out_act', 'device')]
+
+
+ACT_ID = {'linear': 0, None: 0, 'relu': 1, 'elu': 2, 'tanh': 3}        # EB_ACT_*
+PENALTY_ID = {'veh2veh4real': 0, 'real_punish_term': 1}                # EB_PENALTY_*
+
 _P = C.c_void_p
 _I = C.c_int32
 
@@ -62,6 +70,13 @@ PROTOTYPES = {
     'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_mlp_create': (C.c_int, [C.POINTER(EbMlpConfig), C.POINTER(_P)]),
+    'eb_mlp_destroy': (C.c_int, [_P]),
+    'eb_mlp_set_layer': (C.c_int, [_P, _I, _P, _P]),
+    'eb_mlp_set_obs_scale': (C.c_int, [_P, _P]),
+    'eb_mlp_forward': (C.c_int, [_P, _I, _P, _P, _P]),
+    'eb_policy_run_batch': (C.c_int, [_P, _I, _P, C.c_float, _P, _P]),
+    'eb_shield_is_safe': (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 
@@ -98,6 +113,34 @@ class CApi(object):
         h = _P()
         self.check(self.lib.eb_create(C.byref(cfg), C.byref(h)))
         return h
+
+    def mlp_create_from(self, obs_dim, n_hidden, n_units, out_dim, hidden_act, out_act, layers, obs_scale=None, device=0):
+        """eb_mlp_create + eb_mlp_set_layer for every (kernel [in, out], bias [out]) pair + the obs scale."""
+        import numpy as np
+        cfg = EbMlpConfig(EB_ABI_VERSION, int(obs_dim), int(n_hidden), int(n_units), int(out_dim),
+                          ACT_ID[hidden_act], ACT_ID[out_act], int(device))
+        m = _P()
+        self.check(self.lib.eb_mlp_create(C.byref(cfg), C.byref(m)))
+        try:
+            if len(layers) != n_hidden + 1:
+                raise ValueError('expected %d (kernel, bias) pairs, got %d' % (n_hidden + 1, len(layers)))
+            for L, (k, b) in enumerate(layers):
+                rows = obs_dim if L == 0 else n_units
+                cols = out_dim if L == n_hidden else n_units
+                k = np.ascontiguousarray(k, np.float32)
+                b = np.ascontiguousarray(b, np.float32)
+                if k.shape != (rows, cols) or b.shape != (cols,):
+                    raise ValueError('layer %d: kernel %s / bias %s, expected (%d, %d) / (%d,)' % (L, k.shape, b.shape, rows, cols, cols))
+                self.check(self.lib.eb_mlp_set_layer(m, L, k.ctypes.data, b.ctypes.data))
+            if obs_scale is not None:
+                sc = np.ascontiguousarray(obs_scale, np.float32)
+                if sc.shape != (obs_dim,):
+                    raise ValueError('obs_scale must have %d entries' % obs_dim)
+                self.check(self.lib.eb_mlp_set_obs_scale(m, sc.ctypes.data))
+        except Exception:
+            self.lib.eb_mlp_destroy(m)
+            raise
+        return m
 
     def __getattr__(self, name):
         # eb_xxx(...) with return-code checking: api.rollout_step(h, ...)

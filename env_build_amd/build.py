@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libenvbuild_hip.so')
-SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip']
+SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip', 'eb_policy.hip']
 HEADERS = ['eb_device.h', 'eb_kernels.h', os.path.join('..', '..', 'include', 'envbuild.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
          '-fPIC', '-shared', '-Wno-unused-value', '-Wno-pass-failed',

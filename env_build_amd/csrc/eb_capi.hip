@@ -731,3 +731,166 @@ int eb_event_destroy(eb_event e) {
 }
 
 }  // extern "C"
+
+// ---- policy network + shield ----
+struct eb_mlp_s {
+    eb_mlp_config cfg;
+    int units;                       // padded hidden width
+    int k_pad0;                      // padded obs_dim
+    float* d_w[EB_MLP_MAX_HIDDEN + 1];
+    float* d_b[EB_MLP_MAX_HIDDEN + 1];
+    float* d_scale;
+    bool has_scale;
+    unsigned layers_set;
+};
+
+static int mlp_layer_dims(const eb_mlp_s* m, int layer, int* k_real, int* cols_real, int* k_pad, int* col_tiles) {
+    const bool out = layer == m->cfg.n_hidden;
+    *k_real = layer == 0 ? m->cfg.obs_dim : m->cfg.n_units;
+    *cols_real = out ? m->cfg.out_dim : m->cfg.n_units;
+    *k_pad = layer == 0 ? m->k_pad0 : m->units;
+    *col_tiles = out ? 1 : m->units / 32;
+    return 0;
+}
+
+static int mlp_args(eb_mlp m, int32_t n, const float* obs, float* out, int head, float action_range, eb::MlpArgs* A,
+                    const char* who) {
+    if (!m) return fail(EB_EINVAL, who);
+    if (n < 0 || (n > 0 && (!obs || !out))) return fail(EB_EINVAL, "eb_mlp: bad argument");
+    if (m->layers_set != (1u << (m->cfg.n_hidden + 1)) - 1u) return fail(EB_ESTATE, "eb_mlp: eb_mlp_set_layer has not been called for every layer");
+    if (head == eb::MLP_HEAD_ACTION && (m->cfg.out_dim < 2 || (m->cfg.out_dim & 1)))
+        return fail(EB_EINVAL, "eb_policy_run_batch: out_dim must be 2 * act_dim");
+    A->obs = obs; A->scale = m->has_scale ? m->d_scale : nullptr; A->out = out;
+    A->n = n; A->obs_dim = m->cfg.obs_dim; A->n_hidden = m->cfg.n_hidden; A->units = m->units;
+    A->out_dim = m->cfg.out_dim; A->hidden_act = m->cfg.hidden_act; A->out_act = m->cfg.out_act; A->head = head;
+    A->action_range = action_range;
+    A->row_stride = std::max(m->k_pad0, m->units) + 4;
+    for (int L = 0; L < m->cfg.n_hidden; ++L) {
+        A->hid[L].w = m->d_w[L]; A->hid[L].b = m->d_b[L]; A->hid[L].k_pad = L == 0 ? m->k_pad0 : m->units; A->hid[L].pad_ = 0;
+    }
+    for (int L = m->cfg.n_hidden; L < eb::MLP_MAX_HIDDEN; ++L) A->hid[L] = eb::MlpLayer{nullptr, nullptr, 0, 0};
+    A->outl.w = m->d_w[m->cfg.n_hidden]; A->outl.b = m->d_b[m->cfg.n_hidden]; A->outl.k_pad = m->units; A->outl.pad_ = 0;
+    return EB_OK;
+}
+
+extern "C" {
+
+int eb_mlp_create(const eb_mlp_config* cfg, eb_mlp* out) {
+    if (!cfg || !out) return fail(EB_EINVAL, "eb_mlp_create: null argument");
+    if (cfg->abi_version != EB_ABI_VERSION) return fail(EB_EINVAL, "eb_mlp_create: ABI version mismatch");
+    if (cfg->obs_dim < 1 || cfg->n_hidden < 1 || cfg->n_hidden > EB_MLP_MAX_HIDDEN || cfg->n_units < 1 ||
+        cfg->n_units > EB_MLP_MAX_UNITS || cfg->out_dim < 1 || cfg->out_dim > 32)
+        return fail(EB_EINVAL, "eb_mlp_create: bad dimensions");
+    if (cfg->hidden_act < EB_ACT_LINEAR || cfg->hidden_act > EB_ACT_TANH || cfg->out_act < EB_ACT_LINEAR || cfg->out_act > EB_ACT_TANH)
+        return fail(EB_EINVAL, "eb_mlp_create: unknown activation");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(EB_EDEVICE, "eb_mlp_create: no HIP device (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(EB_EINVAL, "eb_mlp_create: bad device ordinal");
+    EB_HIP(hipSetDevice(cfg->device));
+    eb_mlp_s* m = new (std::nothrow) eb_mlp_s();
+    if (!m) return fail(EB_ENOMEM, "eb_mlp_create: out of memory");
+    m->cfg = *cfg;
+    m->units = eb::mlp_padded_units(cfg->n_units);
+    m->k_pad0 = (cfg->obs_dim + 7) / 8 * 8;
+    if ((size_t)eb::MLP_ROWS * (std::max(m->k_pad0, m->units) + 4) * sizeof(float) > 160 * 1024) {
+        delete m;
+        return fail(EB_EINVAL, "eb_mlp_create: obs_dim too large for the LDS activation buffer");
+    }
+    for (int L = 0; L <= cfg->n_hidden; ++L) {
+        int kr, cr, kp, ct;
+        mlp_layer_dims(m, L, &kr, &cr, &kp, &ct);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_w[L]), sizeof(float) * (size_t)kp * ct * 32);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->d_b[L]), sizeof(float) * ct * 32);
+        if (e != hipSuccess) { eb_mlp_destroy(m); return fail_hip("hipMalloc(mlp layer)", e); }
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_scale), sizeof(float) * cfg->obs_dim);
+    if (e != hipSuccess) { eb_mlp_destroy(m); return fail_hip("hipMalloc(obs scale)", e); }
+    *out = m;
+    return EB_OK;
+}
+
+int eb_mlp_destroy(eb_mlp m) {
+    if (!m) return EB_OK;
+    for (int L = 0; L <= EB_MLP_MAX_HIDDEN; ++L) {
+        if (m->d_w[L]) hipFree(m->d_w[L]);
+        if (m->d_b[L]) hipFree(m->d_b[L]);
+    }
+    if (m->d_scale) hipFree(m->d_scale);
+    delete m;
+    return EB_OK;
+}
+
+int eb_mlp_set_layer(eb_mlp m, int32_t layer, const float* kernel, const float* bias) {
+    if (!m || !kernel || !bias || layer < 0 || layer > m->cfg.n_hidden) return fail(EB_EINVAL, "eb_mlp_set_layer: bad argument");
+    int kr, cr, kp, ct;
+    mlp_layer_dims(m, layer, &kr, &cr, &kp, &ct);
+    std::vector<float> wp((size_t)kp * ct * 32), bp((size_t)ct * 32, 0.0f);
+    eb::pack_weights(kernel, kr, cr, kp, ct, wp.data());
+    std::copy(bias, bias + cr, bp.begin());
+    EB_HIP(hipSetDevice(m->cfg.device));
+    EB_HIP(hipMemcpy(m->d_w[layer], wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+    EB_HIP(hipMemcpy(m->d_b[layer], bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+    m->layers_set |= 1u << layer;
+    return EB_OK;
+}
+
+int eb_mlp_set_obs_scale(eb_mlp m, const float* scale) {
+    if (!m) return fail(EB_EINVAL, "eb_mlp_set_obs_scale: null handle");
+    m->has_scale = scale != nullptr;
+    if (scale) {
+        EB_HIP(hipSetDevice(m->cfg.device));
+        EB_HIP(hipMemcpy(m->d_scale, scale, sizeof(float) * m->cfg.obs_dim, hipMemcpyHostToDevice));
+    }
+    return EB_OK;
+}
+
+int eb_mlp_forward(eb_mlp m, int32_t n, const float* obs, float* out, void* stream) {
+    eb::MlpArgs A;
+    int rc = mlp_args(m, n, obs, out, eb::MLP_HEAD_LOGITS, 0.0f, &A, "eb_mlp_forward: null handle");
+    if (rc || n == 0) return rc;
+    EB_HIP(hipSetDevice(m->cfg.device));
+    EB_HIP(eb::launch_mlp(A, (hipStream_t)stream));
+    return EB_OK;
+}
+
+int eb_policy_run_batch(eb_mlp m, int32_t n, const float* obs, float action_range, float* actions, void* stream) {
+    eb::MlpArgs A;
+    int rc = mlp_args(m, n, obs, actions, eb::MLP_HEAD_ACTION, action_range, &A, "eb_policy_run_batch: null handle");
+    if (rc || n == 0) return rc;
+    EB_HIP(hipSetDevice(m->cfg.device));
+    EB_HIP(eb::launch_mlp(A, (hipStream_t)stream));
+    return EB_OK;
+}
+
+int eb_shield_is_safe(eb_handle h, eb_mlp policy, int32_t n_env, const float* obs_in, const int32_t* ref_idx,
+                      int32_t path_id, int32_t steps, int32_t penalty, float action_range, float* obs_a,
+                      float* obs_b, float* actions, float* out5, float* punish, uint8_t* safe, void* stream) {
+    if (h && policy && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_shield_is_safe: null handle");
+    if (rc) return rc;
+    if (!policy) return fail(EB_EINVAL, "eb_shield_is_safe: null policy");
+    if (n_env < 0 || steps < 1 || !obs_in || !obs_a || !obs_b || !actions || !out5 || !punish || !safe || obs_a == obs_b ||
+        obs_in == obs_a || obs_in == obs_b)
+        return fail(EB_EINVAL, "eb_shield_is_safe: bad argument");
+    if (penalty != EB_PENALTY_VEH2VEH4REAL && penalty != EB_PENALTY_REAL_PUNISH_TERM) return fail(EB_EINVAL, "eb_shield_is_safe: unknown penalty");
+    if (policy->cfg.obs_dim != obs_dim(h->cfg) || policy->cfg.out_dim != 4) return fail(EB_EINVAL, "eb_shield_is_safe: the policy does not fit the model (obs_dim, out_dim = 4)");
+    if (policy->cfg.device != h->cfg.device) return fail(EB_EINVAL, "eb_shield_is_safe: policy and model live on different devices");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t s = pick(h, stream);
+    eb::MlpArgs A;
+    const float* pen = out5 + (size_t)(penalty == EB_PENALTY_VEH2VEH4REAL ? 3 : 2) * n_env;   // rows of rollout_out's outputs (DAM:126)
+    const float* cur = obs_in;
+    for (int t = 0; t < steps; ++t) {
+        float* dst = (t & 1) ? obs_b : obs_a;
+        rc = mlp_args(policy, n_env, cur, actions, eb::MLP_HEAD_ACTION, action_range, &A, "eb_shield_is_safe: null policy");
+        if (rc) return rc;
+        EB_HIP(eb::launch_mlp(A, s));
+        rc = rollout_common(h, n_env, cur, actions, ref_idx, path_id, dst, out5, nullptr, 1, 1, s);
+        if (rc) return rc;
+        EB_HIP(eb::launch_shield_accumulate(n_env, pen, punish, safe, t == 0, t == steps - 1, s));
+        cur = dst;
+    }
+    return EB_OK;
+}
+
+}  // extern "C"

@@ -73,4 +73,35 @@ hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const
                              int m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
                              const uint8_t* v_light, uint8_t* done_code, hipStream_t s);
 
+// ---- policy network in the loop (eb_policy.hip): fused MLP on the f32 matrix cores ----
+constexpr int MLP_ROWS = 64;       // observations per block
+constexpr int MLP_THREADS = 256;   // 4 waves
+constexpr int MLP_MAX_HIDDEN = 8;
+enum { MLP_ACT_LINEAR = 0, MLP_ACT_RELU = 1, MLP_ACT_ELU = 2, MLP_ACT_TANH = 3 };
+enum { MLP_HEAD_LOGITS = 0, MLP_HEAD_ACTION = 1 };
+struct MlpLayer {
+    const float* w;   // packed weights (pack_weights)
+    const float* b;   // bias, zero-padded to the tile width
+    int k_pad;        // inputs, padded to a multiple of 8
+    int pad_;
+};
+struct MlpArgs {
+    const float* obs;
+    const float* scale;   // obs_scale or NULL
+    float* out;           // logits [n, out_dim] or actions [n, out_dim / 2]
+    int n, obs_dim, n_hidden;
+    int units;            // padded hidden width: 64 / 128 / 256 / 512
+    int out_dim, hidden_act, out_act, head;
+    float action_range;
+    int row_stride;       // LDS floats per row: max(k_pad of layer 0, units) + 4
+    MlpLayer hid[MLP_MAX_HIDDEN];
+    MlpLayer outl;
+};
+int mlp_padded_units(int n_units);
+size_t mlp_lds_bytes(const MlpArgs& A);
+void pack_weights(const float* kernel, int k_real, int cols_real, int k_pad, int col_tiles, float* out);
+hipError_t launch_mlp(const MlpArgs& A, hipStream_t s);
+hipError_t launch_shield_accumulate(int n, const float* pen, float* punish, uint8_t* safe, int first, int last,
+                                    hipStream_t s);
+
 }  // namespace eb

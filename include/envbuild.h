@@ -256,6 +256,56 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const uint8_t* cand_mode, const uint8_t* light_flag, const uint8_t* v_light,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream);
 
+/* ---- the policy in the loop: MLPNet + LoadPolicy.run_batch + the safety shield ----
+ *
+ * utils/model.py:18-43 `MLPNet`: Dense(obs_dim -> n_units, act) , (n_hidden - 1) x Dense(n_units -> n_units, act),
+ * Dense(n_units -> out_dim, out_act), all fp32.  Kernels are Keras Dense kernels: HOST float [in, out] row-major,
+ * biases HOST float [out]; layer 0 .. n_hidden - 1 are the hidden layers, layer n_hidden is the output layer.
+ * Arithmetic contract (both libraries, bit for bit): y_j = act(chain_j) where chain_j starts at bias_j and takes
+ * chain = fmaf(x_k, W[k][j], chain) for k = 0, 1, ... in order — the order v_mfma_f32_32x32x2_f32 accumulates in —
+ * exp / tanh are the deterministic fp32 kernels of DESIGN.md.  The preprocessor of utils/preprocessor.py:116-123
+ * ('scale': obs * obs_scale, one fp32 multiply) is applied to the input when a scale vector is set. */
+#define EB_ACT_LINEAR 0
+#define EB_ACT_RELU 1
+#define EB_ACT_ELU 2
+#define EB_ACT_TANH 3
+#define EB_MLP_MAX_HIDDEN 8
+#define EB_MLP_MAX_UNITS 512
+typedef struct eb_mlp_config {
+    int32_t abi_version; /* EB_ABI_VERSION */
+    int32_t obs_dim;     /* input width (args.obs_dim, utils/policy.py:28) */
+    int32_t n_hidden;    /* num_hidden_layers, 1..EB_MLP_MAX_HIDDEN */
+    int32_t n_units;     /* num_hidden_units, 1..EB_MLP_MAX_UNITS */
+    int32_t out_dim;     /* 2*act_dim for the policy net (mean | log_std, utils/policy.py:32), 1 for obj_v; <= 32 */
+    int32_t hidden_act;  /* EB_ACT_* (args.hidden_activation) */
+    int32_t out_act;     /* EB_ACT_* (policy_out_activation / 'relu' for obj_v, utils/policy.py:33-38) */
+    int32_t device;      /* HIP device ordinal (ignored by the oracle) */
+} eb_mlp_config;
+typedef struct eb_mlp_s* eb_mlp;
+int eb_mlp_create(const eb_mlp_config* cfg, eb_mlp* out);
+int eb_mlp_destroy(eb_mlp m);
+/* MLPNet weights of one Dense layer (Model.set_weights order: kernel, bias).  HOST pointers. */
+int eb_mlp_set_layer(eb_mlp m, int32_t layer, const float* kernel, const float* bias);
+/* Preprocessor obs_scale (HOST [obs_dim]); NULL = no preprocessing. */
+int eb_mlp_set_obs_scale(eb_mlp m, const float* scale);
+/* MLPNet.call on the preprocessed obs (utils/model.py:39-43): obs [n, obs_dim] -> out [n, out_dim]. */
+int eb_mlp_forward(eb_mlp m, int32_t n, const float* obs, float* out, void* stream);
+/* LoadPolicy.run_batch with a deterministic policy (utils/load_policy.py:53-57, utils/policy.py:85-92):
+ * actions [n, out_dim/2] = action_range * tanh(mean), mean = the first half of the logits; action_range <= 0
+ * stands for `action_range is None` (the mean itself). */
+int eb_policy_run_batch(eb_mlp m, int32_t n, const float* obs, float action_range, float* actions, void* stream);
+
+/* The model-predictive safety shield `is_safe` for a batch of start states (hier_decision.py:89-97: 5 steps,
+ * veh2veh4real; multi_ego.py:187-197: 20 steps, real_punish_term): `steps` times action = run_batch(obs);
+ * obs, penalties = rollout_out(action); punish += penalty.  obs_in [n_env, D] is not modified.
+ * Workspace owned by the caller: obs_a, obs_b [n_env, D], actions [n_env, 2], out5 [5, n_env].
+ * Outputs: punish [n_env] (0 + p_1 + ... + p_steps in fp32), safe [n_env] uint8 = !(punish > 0). */
+#define EB_PENALTY_VEH2VEH4REAL 0
+#define EB_PENALTY_REAL_PUNISH_TERM 1
+int eb_shield_is_safe(eb_handle h, eb_mlp policy, int32_t n_env, const float* obs_in, const int32_t* ref_idx,
+                      int32_t path_id, int32_t steps, int32_t penalty, float action_range, float* obs_a,
+                      float* obs_b, float* actions, float* out5, float* punish, uint8_t* safe, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1153,3 +1153,226 @@ long long eb_oracle_check_div_exact(float c, uint32_t first, uint32_t last, uint
     if (first_bad) *first_bad = fb;
     return bad;
 }
+
+/* ================================================================================================
+ * Policy network in the loop — TEST INFRASTRUCTURE like the rest of this file.
+ * MLPNet (utils/model.py:18-43), the 'scale' preprocessor (utils/preprocessor.py:116-123), the deterministic
+ * action of Policy4Toyota.compute_action (utils/policy.py:85-92) and the shield loop `is_safe`
+ * (hierarchical_decision/hier_decision.py:89-97, multi_env/multi_ego.py:187-197).
+ * TensorFlow's matmul / exp / tanh kernels are third-party code absent from /root/reference (unpinned,
+ * README.md:37) and leave the summation order unspecified; the contract stated in include/envbuild.h fixes it:
+ * every output is a chain of fused multiply-adds over k = 0, 1, ... starting from the bias.  PARITY UNPINNED
+ * against the reference for this block (it holds no test vectors for the network); tests/ check it against
+ * torch fp32 within 1e-5 and the HIP kernel against this file bit for bit.
+ * ================================================================================================ */
+struct eb_mlp_s {
+    eb_mlp_config cfg;
+    float* w[EB_MLP_MAX_HIDDEN + 1]; /* [in, out] row-major, as given */
+    float* b[EB_MLP_MAX_HIDDEN + 1];
+    float* scale;
+    int has_scale;
+    unsigned layers_set;
+};
+
+static float eb_expf(float x) { /* Cephes expf scheme with explicit fma; device twin: eb_policy.hip:exp_det */
+    if (!(x == x)) return x;
+    x = x > 88.0f ? 88.0f : (x < -87.0f ? -87.0f : x);
+    const float fx = rintf(x * 1.44269504088896341f);
+    float r = fmaf(-fx, 0.693359375f, x);
+    r = fmaf(-fx, -2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float y = fmaf(p, z, r) + 1.0f;
+    const int n = (int)fx;
+    const uint32_t bits = (uint32_t)(n + 127) << 23;
+    float s;
+    memcpy(&s, &bits, 4);
+    return y * s;
+}
+
+static float eb_tanhf(float x) { /* Cephes tanhf scheme; device twin: tanh_det */
+    const float ax = fabsf(x);
+    if (ax > 44.0f) return x > 0.0f ? 1.0f : -1.0f;
+    if (ax >= 0.625f) {
+        const float s = eb_expf(ax + ax);
+        const float t = 1.0f - 2.0f / (s + 1.0f);
+        return x < 0.0f ? -t : t;
+    }
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = fmaf(p, z, 2.06390887954e-2f);
+    p = fmaf(p, z, -5.37397155531e-2f);
+    p = fmaf(p, z, 1.33314422036e-1f);
+    p = fmaf(p, z, -3.33332819422e-1f);
+    return fmaf(p * z, x, x);
+}
+
+static float mlp_activate(int act, float x) {
+    switch (act) {
+        case EB_ACT_RELU: return x > 0.0f ? x : 0.0f;
+        case EB_ACT_ELU: return x > 0.0f ? x : eb_expf(x) - 1.0f;
+        case EB_ACT_TANH: return eb_tanhf(x);
+        default: return x;
+    }
+}
+
+static void mlp_layer_dims(const struct eb_mlp_s* m, int layer, int* k, int* cols) {
+    *k = layer == 0 ? m->cfg.obs_dim : m->cfg.n_units;
+    *cols = layer == m->cfg.n_hidden ? m->cfg.out_dim : m->cfg.n_units;
+}
+
+int eb_mlp_create(const eb_mlp_config* cfg, eb_mlp* out) {
+    if (!cfg || !out) return fail(EB_EINVAL, "eb_mlp_create: null argument");
+    if (cfg->abi_version != EB_ABI_VERSION) return fail(EB_EINVAL, "eb_mlp_create: ABI version mismatch");
+    if (cfg->obs_dim < 1 || cfg->n_hidden < 1 || cfg->n_hidden > EB_MLP_MAX_HIDDEN || cfg->n_units < 1 ||
+        cfg->n_units > EB_MLP_MAX_UNITS || cfg->out_dim < 1 || cfg->out_dim > 32)
+        return fail(EB_EINVAL, "eb_mlp_create: bad dimensions");
+    if (cfg->hidden_act < EB_ACT_LINEAR || cfg->hidden_act > EB_ACT_TANH || cfg->out_act < EB_ACT_LINEAR ||
+        cfg->out_act > EB_ACT_TANH)
+        return fail(EB_EINVAL, "eb_mlp_create: unknown activation");
+    struct eb_mlp_s* m = (struct eb_mlp_s*)calloc(1, sizeof *m);
+    if (!m) return fail(EB_ENOMEM, "eb_mlp_create: out of memory");
+    m->cfg = *cfg;
+    for (int L = 0; L <= cfg->n_hidden; ++L) {
+        int k, cols;
+        mlp_layer_dims(m, L, &k, &cols);
+        m->w[L] = (float*)calloc((size_t)k * cols, sizeof(float));
+        m->b[L] = (float*)calloc((size_t)cols, sizeof(float));
+        if (!m->w[L] || !m->b[L]) { eb_mlp_destroy(m); return fail(EB_ENOMEM, "eb_mlp_create: out of memory"); }
+    }
+    m->scale = (float*)calloc((size_t)cfg->obs_dim, sizeof(float));
+    if (!m->scale) { eb_mlp_destroy(m); return fail(EB_ENOMEM, "eb_mlp_create: out of memory"); }
+    *out = m;
+    return EB_OK;
+}
+
+int eb_mlp_destroy(eb_mlp m) {
+    if (!m) return EB_OK;
+    for (int L = 0; L <= EB_MLP_MAX_HIDDEN; ++L) { free(m->w[L]); free(m->b[L]); }
+    free(m->scale);
+    free(m);
+    return EB_OK;
+}
+
+int eb_mlp_set_layer(eb_mlp m, int32_t layer, const float* kernel, const float* bias) {
+    if (!m || !kernel || !bias || layer < 0 || layer > m->cfg.n_hidden) return fail(EB_EINVAL, "eb_mlp_set_layer: bad argument");
+    int k, cols;
+    mlp_layer_dims(m, layer, &k, &cols);
+    memcpy(m->w[layer], kernel, sizeof(float) * (size_t)k * cols);
+    memcpy(m->b[layer], bias, sizeof(float) * (size_t)cols);
+    m->layers_set |= 1u << layer;
+    return EB_OK;
+}
+
+int eb_mlp_set_obs_scale(eb_mlp m, const float* scale) {
+    if (!m) return fail(EB_EINVAL, "eb_mlp_set_obs_scale: null handle");
+    m->has_scale = scale != NULL;
+    if (scale) memcpy(m->scale, scale, sizeof(float) * (size_t)m->cfg.obs_dim);
+    return EB_OK;
+}
+
+/* one observation through the network; `a` and `b` are scratch rows of max(obs_dim, n_units, out_dim) floats */
+static void mlp_row(const struct eb_mlp_s* m, const float* obs, float* a, float* b, float* logits) {
+    for (int k = 0; k < m->cfg.obs_dim; ++k) a[k] = m->has_scale ? obs[k] * m->scale[k] : obs[k]; /* preprocessor.py:121 */
+    for (int L = 0; L <= m->cfg.n_hidden; ++L) {
+        int K, cols;
+        mlp_layer_dims(m, L, &K, &cols);
+        const float* w = m->w[L];
+        for (int j = 0; j < cols; ++j) b[j] = m->b[L][j];
+        for (int k = 0; k < K; ++k) { /* the chain: k in order, every output j takes one fused multiply-add per k */
+            const float x = a[k];
+            const float* wk = w + (size_t)k * cols;
+#pragma omp simd
+            for (int j = 0; j < cols; ++j) b[j] = fmaf(x, wk[j], b[j]);
+        }
+        const int act = L == m->cfg.n_hidden ? m->cfg.out_act : m->cfg.hidden_act;
+        for (int j = 0; j < cols; ++j) b[j] = mlp_activate(act, b[j]);
+        float* t = a; a = b; b = t;
+    }
+    for (int j = 0; j < m->cfg.out_dim; ++j) logits[j] = a[j];
+}
+
+static int mlp_run(eb_mlp m, int32_t n, const float* obs, float* out, int action_head, float action_range, const char* who) {
+    if (!m) return fail(EB_EINVAL, who);
+    if (n < 0 || (n > 0 && (!obs || !out))) return fail(EB_EINVAL, "eb_mlp: bad argument");
+    if (m->layers_set != (1u << (m->cfg.n_hidden + 1)) - 1u)
+        return fail(EB_ESTATE, "eb_mlp: eb_mlp_set_layer has not been called for every layer");
+    if (action_head && (m->cfg.out_dim < 2 || (m->cfg.out_dim & 1))) return fail(EB_EINVAL, "eb_policy_run_batch: out_dim must be 2 * act_dim");
+    int width = m->cfg.obs_dim > m->cfg.n_units ? m->cfg.obs_dim : m->cfg.n_units;
+    if (width < m->cfg.out_dim) width = m->cfg.out_dim;
+    const int od = m->cfg.out_dim, ad = od / 2;
+    int oom = 0;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        float* a = (float*)malloc(sizeof(float) * (size_t)width * 2 + sizeof(float) * 32);
+        if (!a) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            oom = 1;
+        }
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int i = 0; i < n; ++i) {
+            if (!a) continue;
+            float* logits = a + 2 * (size_t)width;
+            mlp_row(m, obs + (size_t)i * m->cfg.obs_dim, a, a + width, logits);
+            if (!action_head) {
+                for (int j = 0; j < od; ++j) out[(size_t)i * od + j] = logits[j];
+            } else { /* mean, log_std = split(logits); action_range * tanh(mean), policy.py:89-92 */
+                for (int j = 0; j < ad; ++j)
+                    out[(size_t)i * ad + j] = action_range > 0.0f ? action_range * eb_tanhf(logits[j]) : logits[j];
+            }
+        }
+        free(a);
+    }
+    return oom ? fail(EB_ENOMEM, "eb_mlp: out of memory") : EB_OK;
+}
+
+int eb_mlp_forward(eb_mlp m, int32_t n, const float* obs, float* out, void* stream) {
+    (void)stream;
+    return mlp_run(m, n, obs, out, 0, 0.0f, "eb_mlp_forward: null handle");
+}
+
+int eb_policy_run_batch(eb_mlp m, int32_t n, const float* obs, float action_range, float* actions, void* stream) {
+    (void)stream;
+    return mlp_run(m, n, obs, actions, 1, action_range, "eb_policy_run_batch: null handle");
+}
+
+int eb_shield_is_safe(eb_handle h, eb_mlp policy, int32_t n_env, const float* obs_in, const int32_t* ref_idx,
+                      int32_t path_id, int32_t steps, int32_t penalty, float action_range, float* obs_a,
+                      float* obs_b, float* actions, float* out5, float* punish, uint8_t* safe, void* stream) {
+    (void)stream;
+    if (h && policy && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_shield_is_safe: null handle");
+    if (rc) return rc;
+    if (!policy) return fail(EB_EINVAL, "eb_shield_is_safe: null policy");
+    if (n_env < 0 || steps < 1 || !obs_in || !obs_a || !obs_b || !actions || !out5 || !punish || !safe ||
+        obs_a == obs_b || obs_in == obs_a || obs_in == obs_b)
+        return fail(EB_EINVAL, "eb_shield_is_safe: bad argument");
+    if (penalty != EB_PENALTY_VEH2VEH4REAL && penalty != EB_PENALTY_REAL_PUNISH_TERM)
+        return fail(EB_EINVAL, "eb_shield_is_safe: unknown penalty");
+    if (policy->cfg.obs_dim != obs_dim(&h->cfg) || policy->cfg.out_dim != 4)
+        return fail(EB_EINVAL, "eb_shield_is_safe: the policy does not fit the model (obs_dim, out_dim = 4)");
+    const float* pen = out5 + (size_t)(penalty == EB_PENALTY_VEH2VEH4REAL ? 3 : 2) * n_env;
+    const float* cur = obs_in;
+    for (int t = 0; t < steps; ++t) { /* hier_decision.py:92-96 */
+        float* dst = (t & 1) ? obs_b : obs_a;
+        rc = eb_policy_run_batch(policy, n_env, cur, action_range, actions, NULL);   /* action = self.policy.run_batch(obs) */
+        if (rc) return rc;
+        rc = eb_rollout_step(h, n_env, cur, actions, ref_idx, path_id, dst, out5, NULL, NULL); /* obs, ... = rollout_out(action) */
+        if (rc) return rc;
+        for (int i = 0; i < n_env; ++i) punish[i] = (t == 0 ? 0.0f : punish[i]) + pen[i];      /* punish += veh2veh4real */
+        cur = dst;
+    }
+    for (int i = 0; i < n_env; ++i) safe[i] = punish[i] > 0.0f ? 0 : 1;                          /* False if punish > 0 */
+    return EB_OK;
+}

@@ -145,6 +145,33 @@ class HostModel(object):
         self.api.rollout_tape(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work), self._ptr(out), self._ptr(out5), self.stream)
         return self._ret(out), self._ret(out5)
 
+    # ---- policy network + shield (eb_mlp_*, eb_policy_run_batch, eb_shield_is_safe) ----
+    def make_mlp(self, obs_dim, n_hidden, n_units, out_dim, hidden_act, out_act, layers, obs_scale=None):
+        return self.api.mlp_create_from(obs_dim, n_hidden, n_units, out_dim, hidden_act, out_act, layers, obs_scale, 0)
+
+    def mlp_forward(self, mlp, out_dim, obs):
+        ob = self._in(obs)
+        out = self._out((len(ob), out_dim))
+        self.api.mlp_forward(mlp, len(ob), self._ptr(ob), self._ptr(out), self.stream)
+        return self._ret(out)
+
+    def policy_run_batch(self, mlp, act_dim, obs, action_range):
+        ob = self._in(obs)
+        out = self._out((len(ob), act_dim))
+        self.api.policy_run_batch(mlp, len(ob), self._ptr(ob), C.c_float(action_range), self._ptr(out), self.stream)
+        return self._ret(out)
+
+    def shield_is_safe(self, mlp, obs, ref_idx=None, path_id=0, steps=5, penalty=0, action_range=1.0):
+        ob, ri = self._in(obs), self._in(ref_idx, np.int32)
+        n = len(ob)
+        a, b, act, o5 = self._out(ob.shape), self._out(ob.shape), self._out((n, 2)), self._out((5, n))
+        punish, safe = self._out((n,)), self._out((n,), np.uint8)
+        self.api.shield_is_safe(self.h, mlp, n, self._ptr(ob), self._ptr(ri), int(path_id), int(steps), int(penalty),
+                                C.c_float(action_range), self._ptr(a), self._ptr(b), self._ptr(act), self._ptr(o5),
+                                self._ptr(punish), self._ptr(safe), self.stream)
+        last = a if steps % 2 == 1 else b
+        return self._ret(safe), self._ret(punish), self._ret(last), self._ret(act)
+
     def episode_summary(self, out5_steps, obs_final):
         o5, ob = self._in(out5_steps), self._in(obs_final)
         out8 = self._out((8,))

@@ -1,0 +1,131 @@
+"""CPU (-m "not gpu"): the oracle's policy network (oracle/envbuild_oracle.c: eb_mlp_*, eb_policy_run_batch,
+eb_shield_is_safe) against a plain torch fp32 restatement of utils/model.py:18-43 + utils/policy.py:85-92, and
+its deterministic exp / tanh against NumPy.  Tolerance 1e-5 (relative to the layer scale): the reference's
+TensorFlow matmul leaves the summation order open, the contract of include/envbuild.h fixes one."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from env_build_amd.policy import orthogonal  # noqa: E402
+from env_build_amd.synthetic import assemble_obs, make_rollout_inputs  # noqa: E402
+from tests._helpers import HostModel, oracle_lib  # noqa: E402
+
+ACTS = {'linear': lambda x: x, 'relu': torch.relu, 'elu': torch.nn.functional.elu, 'tanh': torch.tanh}
+
+
+def make_layers(rng, obs_dim, n_hidden, n_units, out_dim, bias_scale=0.1):
+    dims = [obs_dim] + [n_units] * n_hidden + [out_dim]
+    layers = []
+    for L in range(n_hidden + 1):
+        gain = np.sqrt(2.) if L < n_hidden else 1.
+        layers.append((orthogonal(rng, dims[L], dims[L + 1], gain),
+                       (bias_scale * rng.standard_normal(dims[L + 1])).astype(np.float32)))
+    return layers
+
+
+def torch_mlp(layers, obs, hidden_act, out_act, scale=None):
+    x = torch.from_numpy(obs)
+    if scale is not None:
+        x = x * torch.from_numpy(scale)
+    for L, (k, b) in enumerate(layers):
+        x = x @ torch.from_numpy(k) + torch.from_numpy(b)
+        x = ACTS[out_act if L == len(layers) - 1 else hidden_act](x)
+    return x.numpy()
+
+
+@pytest.mark.parametrize('obs_dim,n_hidden,n_units,out_dim,hact,oact', [
+    (41, 2, 256, 4, 'elu', 'linear'), (137, 2, 256, 4, 'elu', 'linear'), (29, 1, 64, 4, 'relu', 'linear'),
+    (45, 3, 128, 1, 'tanh', 'relu'), (265, 2, 512, 4, 'elu', 'tanh'), (33, 4, 100, 6, 'elu', 'linear'),
+])
+def test_oracle_mlp_matches_torch_fp32(obs_dim, n_hidden, n_units, out_dim, hact, oact):
+    rng = np.random.default_rng(obs_dim + n_units)
+    api = oracle_lib()
+    layers = make_layers(rng, obs_dim, n_hidden, n_units, out_dim)
+    scale = rng.uniform(0.05, 1.0, obs_dim).astype(np.float32)
+    obs = (rng.standard_normal((257, obs_dim)) * 3).astype(np.float32)
+    host = HostModel(api, 'left')
+    for sc in (None, scale):
+        m = host.make_mlp(obs_dim, n_hidden, n_units, out_dim, hact, oact, layers, sc)
+        got = host.mlp_forward(m, out_dim, obs)
+        want = torch_mlp(layers, obs, hact, oact, sc)
+        assert np.max(np.abs(got - want)) <= 1e-5 * max(1.0, float(np.max(np.abs(want))))
+        if out_dim % 2 == 0:
+            act = host.policy_run_batch(m, out_dim // 2, obs, 1.0)
+            assert np.max(np.abs(act - np.tanh(want[:, :out_dim // 2]))) <= 1e-5
+            raw = host.policy_run_batch(m, out_dim // 2, obs, -1.0)          # action_range is None: the mean itself
+            assert np.array_equal(raw, got[:, :out_dim // 2])
+        api.mlp_destroy(m)
+
+
+def test_oracle_exp_tanh_are_accurate():
+    """The deterministic kernels stay within a few ulp of libm over the ranges the network uses them on."""
+    api = oracle_lib()
+    host = HostModel(api, 'left')
+    x = np.concatenate([np.linspace(-90, 5, 20001), np.linspace(-1e-3, 1e-3, 2001), [0.0, -0.0, -87.5, -1e-30]]).astype(np.float32)
+    eye = (np.eye(1, dtype=np.float32), np.zeros(1, np.float32))
+    # elu(x) = exp(x) - 1 on x <= 0, tanh(x): single-unit identity networks expose the activation itself
+    m_elu = host.make_mlp(1, 1, 1, 1, 'elu', 'linear', [eye, eye])
+    m_tanh = host.make_mlp(1, 1, 1, 1, 'tanh', 'linear', [eye, eye])
+    elu = host.mlp_forward(m_elu, 1, x[:, None])[:, 0]
+    want = np.where(x > 0, x, np.expm1(x.astype(np.float64)))
+    # exp(x) - 1 in fp32 carries the rounding of exp(x) near 1: absolute 1 ulp of 1.0, as the reference's own formula
+    assert np.max(np.abs(elu - want)) <= 1.3e-7
+    th = host.mlp_forward(m_tanh, 1, x[:, None])[:, 0]
+    wt = np.tanh(x.astype(np.float64))
+    assert np.max(np.abs(th - wt) / np.maximum(np.abs(wt), 1e-30)) <= 4e-7
+    big = host.mlp_forward(m_tanh, 1, np.array([[50.0], [-50.0], [np.inf], [-np.inf]], np.float32))[:, 0]
+    assert np.array_equal(big, [1.0, -1.0, 1.0, -1.0])
+    assert np.isnan(host.mlp_forward(m_tanh, 1, np.array([[np.nan]], np.float32))[0, 0])
+    assert np.isnan(host.mlp_forward(m_elu, 1, np.array([[np.nan]], np.float32))[0, 0])
+    api.mlp_destroy(m_elu); api.mlp_destroy(m_tanh)
+
+
+def test_oracle_shield_equals_the_loop_of_calls():
+    """eb_shield_is_safe == the reference's loop spelled out with run_batch / rollout_step (hier_decision.py:89-97)."""
+    api = oracle_lib()
+    task, N, B = 'left', 8, 96
+    host = HostModel(api, task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, 5, seed=4)
+    trk = host.tracking_error(inp['ego'][:, 3], inp['ego'][:, 4], inp['ego'][:, 5], inp['ego'][:, 0], 0, ref_idx=inp['ref_idx'])
+    obs0 = assemble_obs(inp['ego'], trk, inp['veh'])
+    rng = np.random.default_rng(1)
+    layers = make_layers(rng, host.D, 2, 64, 4)
+    scale = rng.uniform(0.02, 0.2, host.D).astype(np.float32)
+    m = host.make_mlp(host.D, 2, 64, 4, 'elu', 'linear', layers, scale)
+    for penalty, row in ((0, 3), (1, 2)):
+        for steps in (1, 5, 6):
+            safe, punish, last, act = host.shield_is_safe(m, obs0, ref_idx=inp['ref_idx'], steps=steps, penalty=penalty)
+            obs, acc = obs0, np.zeros(B, np.float32)
+            for _ in range(steps):
+                a = host.policy_run_batch(m, 2, obs, 1.0)
+                obs, o5, _ = host.rollout_step(obs, a, ref_idx=inp['ref_idx'])
+                acc = acc + o5[row]
+            assert np.array_equal(punish, acc) and np.array_equal(last, obs) and np.array_equal(act, a)
+            assert np.array_equal(safe, (~(acc > 0)).astype(np.uint8))
+    assert 0 < int(safe.sum()) < B          # the scene mixes safe and unsafe starts
+    with pytest.raises(ValueError):
+        bad = host.make_mlp(host.D + 1, 1, 64, 4, 'elu', 'linear', make_layers(rng, host.D + 1, 1, 64, 4))
+        host.shield_is_safe(bad, obs0, ref_idx=inp['ref_idx'])
+    api.mlp_destroy(m)
+
+
+def test_mlp_argument_errors():
+    api = oracle_lib()
+    host = HostModel(api, 'left')
+    rng = np.random.default_rng(0)
+    with pytest.raises(ValueError):
+        host.make_mlp(8, 0, 64, 4, 'elu', 'linear', [])
+    with pytest.raises(ValueError):
+        host.make_mlp(8, 1, 1024, 4, 'elu', 'linear', make_layers(rng, 8, 1, 1024, 4))
+    with pytest.raises(ValueError):
+        host.make_mlp(8, 1, 64, 33, 'elu', 'linear', make_layers(rng, 8, 1, 64, 33))
+    m = host.make_mlp(8, 1, 64, 3, 'elu', 'linear', make_layers(rng, 8, 1, 64, 3))
+    with pytest.raises(ValueError):
+        host.policy_run_batch(m, 1, np.zeros((4, 8), np.float32), 1.0)      # odd out_dim has no (mean | log_std) split
+    assert host.mlp_forward(m, 3, np.zeros((0, 8), np.float32)).shape == (0, 3)
+    api.mlp_destroy(m)
