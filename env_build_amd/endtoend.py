@@ -221,29 +221,42 @@ class CrossroadEnd2end(object):
             self._cand.copy_(torch.where(rows.unsqueeze(2), fresh, self._cand))
 
     def reset(self, **kwargs):  # E2E:99-127
+        """`mask=` (n_env > 1; bool [B]) resets only those envs — the vectorised-env idiom for batched drivers."""
+        mask = kwargs.pop('mask', None)
         if kwargs or self.ref_path is None:
             self.ref_path = ReferencePath(self.training_task, device=self.device, **kwargs)
         elif self.n_env == 1:
             self.ref_path = ReferencePath(self.training_task, device=self.device)
         self.init_state = self._reset_init_state()
-        self._ego.copy_(torch.from_numpy(self._init_ego))
-        self._ref_idx.copy_(torch.from_numpy(self._init_ref))
+        B, dev = self.n_env, self.device
+        m = torch.ones((B,), dtype=torch.bool, device=dev) if mask is None else \
+            torch.as_tensor(np.asarray(mask.t.cpu() if isinstance(mask, DevArray) else (mask.cpu() if isinstance(mask, torch.Tensor) else mask)),
+                            dtype=torch.bool).reshape(B).to(dev)
         miu = self.dynamics.vehicle_params['miu']
-        self._params.copy_(torch.tensor([0., 0., miu, miu], dtype=torch.float32).repeat(self.n_env, 1))   # E2E:110-113
-        self._spawn_traffic()
-        self._v_light.zero_()
+        self._ego.copy_(torch.where(m.unsqueeze(1), torch.from_numpy(self._init_ego).to(dev), self._ego))
+        self._ref_idx.copy_(torch.where(m, torch.from_numpy(self._init_ref).to(dev), self._ref_idx))
+        fresh_par = torch.tensor([0., 0., miu, miu], dtype=torch.float32, device=dev).repeat(B, 1)       # E2E:110-113
+        self._params.copy_(torch.where(m.unsqueeze(1), fresh_par, self._params))
+        self._spawn_traffic(None if mask is None else m.unsqueeze(1).expand(B, self.n_cand))
+        self._v_light.masked_fill_(m, 0)
         if self.mode == 'training':                                                     # E2E:120-126
-            self._virtual.copy_(torch.from_numpy((self.np_random.random(self.n_env) > 0.9).astype(np.uint8)))
+            fresh_v = torch.from_numpy((self.np_random.random(B) > 0.9).astype(np.uint8)).to(dev)
+            self._virtual.copy_(torch.where(m, fresh_v, self._virtual))
         else:
-            self._virtual.zero_()
+            self._virtual.masked_fill_(m, 0)
         self.virtual_red_light_vehicle = bool(self._virtual[0].item()) if self.n_env == 1 else None
         self._injected = False
         self._publish_state()
         self.obs = self._get_obs()
         self.action = None
         self.reward_info = None
-        self.done_type = 'not_done_yet' if self.n_env == 1 else DevArray(torch.zeros((self.n_env,), dtype=torch.uint8,
-                                                                                  device=self.device))
+        if self.n_env == 1:
+            self.done_type = 'not_done_yet'
+        else:
+            code = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            if mask is not None and isinstance(self.done_type, DevArray):
+                code = torch.where(m, code, self.done_type.t)
+            self.done_type = DevArray(code)
         return self.obs
 
     # -- reference-shaped views of the device state (n_env == 1) ---------------------------------

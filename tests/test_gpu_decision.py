@@ -1,0 +1,110 @@
+"""GPU (-m gpu): the batched decision loop (env_build_amd/hier_decision.py, the reference's
+hierarchical_decision/hier_decision.py:109-135) against the same composition spelled out with oracle calls —
+path observations, obj_v values, hysteresis, shield and shielded action for every env and step."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from env_build_amd.endtoend_env_utils import VEH_NUM  # noqa: E402
+from tests._helpers import HostModel, oracle_lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _policy(D, N, units=128):
+    from env_build_amd.policy import LoadPolicy
+    args = SimpleNamespace(obs_dim=D, act_dim=2, num_hidden_layers=2, num_hidden_units=units, hidden_activation='elu',
+                           policy_out_activation='linear', action_range=1.0, deterministic_policy=True,
+                           obs_preprocess_type='scale',
+                           obs_scale=[0.2] * 6 + [1., 1 / 30., 0.2] + [1 / 30., 1 / 30., 0.2, 1 / 180.] * N)
+    return LoadPolicy(args=args), args
+
+
+def _oracle_nets(host, pol, args):
+    out = []
+    for net, od, oact in ((pol.policy.policy, 4, 'linear'), (pol.policy.obj_v, 1, 'relu')):
+        w = net.get_weights()
+        out.append(host.make_mlp(args.obs_dim, 2, args.num_hidden_units, od, 'elu', oact, list(zip(w[0::2], w[1::2])),
+                                 np.asarray(args.obs_scale, np.float32)))
+    return out
+
+
+@pytest.mark.parametrize('task', ['left', 'straight', 'right'])
+def test_batched_decision_steps_match_oracle_composition(task):
+    import torch
+    from env_build_amd.hier_decision import HierarchicalDecision
+    N, B = VEH_NUM[task], 80
+    D = 9 + 4 * N
+    pol, args = _policy(D, N)
+    # make the value net path-sensitive enough for switches to happen: scale its output layer up
+    wv = pol.policy.obj_v.get_weights()
+    wv[-2] = wv[-2] * 3.0
+    wv[-1] = wv[-1] + 40.0            # keeps the relu of the value head open
+    pol.policy.obj_v.set_weights(wv)
+    hd = HierarchicalDecision(task, policy=pol, n_env=B, auto_reset=False)
+    env = hd.env
+    host = HostModel(oracle_lib(), task, n_veh=N, mode='training')
+    mp, mv = _oracle_nets(host, pol, args)
+    rows = np.arange(B)
+    switches = shields = 0
+    for t in range(8):
+        ego, cand = env._ego.cpu().numpy(), env._cand.cpu().numpy()
+        cmode = env._cand_mode.cpu().numpy()
+        light = ((env._v_light != 0) | (env._virtual != 0)).to(torch.uint8).cpu().numpy()
+        if t % 2 == 1:        # start some envs from another path so that the hysteresis has something to decide
+            hd.old_index = torch.from_numpy(np.random.default_rng(t).integers(0, 3, B)).to(hd.device)
+        old = hd.old_index.cpu().numpy()
+        hd.step()
+        obs_k = np.stack([host.get_obs(ego, cand, cmode, light, path_id=k) for k in range(3)])
+        pv = np.stack([host.mlp_forward(mv, 1, obs_k[k])[:, 0] for k in range(3)])
+        new_index, new_value = pv.argmin(0), pv.min(0)
+        path = np.where(pv[old, rows] - new_value < np.float32(0.1), old, new_index)
+        obs_real = obs_k[path, rows]
+        safe, punish, _, _ = host.shield_is_safe(mp, obs_real, ref_idx=path.astype(np.int32), steps=5, penalty=0)
+        act = host.policy_run_batch(mp, 2, obs_real, 1.0)
+        act[safe == 0] = (0., -1.)
+        assert np.array_equal(hd.path_values.cpu().numpy(), pv), 'path values, step %d' % t
+        assert np.array_equal(hd.path_index.cpu().numpy(), path), 'path choice, step %d' % t
+        assert np.array_equal(hd.obs_real.cpu().numpy(), obs_real)
+        assert np.array_equal(hd.is_ss.numpy(), safe == 0), 'shield flags, step %d' % t
+        assert np.array_equal(hd.safe_action.numpy(), act), 'safe action, step %d' % t
+        assert np.array_equal(env._ref_idx.cpu().numpy(), path)
+        switches += int((path != old).sum())
+        shields += int((safe == 0).sum())
+    assert switches > 0 and shields > 0, (switches, shields)        # both branches were exercised
+    host.api.mlp_destroy(mp); host.api.mlp_destroy(mv)
+
+
+def test_single_env_loop_with_log_and_auto_reset(tmp_path):
+    """n_env == 1 keeps the reference's shapes; a logged run writes the reference's .npy layout; a batch with
+    auto_reset restarts finished envs only."""
+    from env_build_amd.hier_decision import HierarchicalDecision
+    N = VEH_NUM['left']
+    D = 9 + 4 * N
+    pol, _ = _policy(D, N, units=64)
+    hd = HierarchicalDecision('left', policy=pol, n_env=1, logdir=str(tmp_path))
+    for _ in range(5):
+        done = hd.step()
+        assert done in (0, 1)
+        if done:
+            hd.reset()
+    hd.reset()
+    a = np.load(os.path.join(str(tmp_path), 'data_across_all_episodes.npy'), allow_pickle=True)
+    assert sum(len(ep) for ep in a) == 5 and all(len(step) == 17 for ep in a for step in ep)
+    B = 64
+    hb = HierarchicalDecision('left', policy=pol, n_env=B)
+    resets = 0
+    for _ in range(40):
+        ego_before = hb.env._ego.clone()
+        done = hb.step().numpy().astype(bool)
+        if done.any():
+            resets += int(done.sum())
+            # finished envs restart from a fresh init state, the others carry on
+            assert np.all(hb.env.done_type.numpy()[done] == 0)
+            assert np.all(hb.old_index.cpu().numpy()[done] == 0)
+    assert resets > 0
