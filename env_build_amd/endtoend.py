@@ -11,11 +11,14 @@ obs`, `step(action) -> (obs, reward, done, info)`, `seed`, `close`, `set_traj`, 
     reward np.float32, done int, info dict); with n_env > 1 they are device arrays of leading size B
     (obs [B, D], reward [B], done uint8 [B]) and `done_type` holds the uint8 done codes (`done_names()` spells them).
   * the traffic source.  The reference co-simulates with SUMO over TraCI (traffic.py; out of scope,
-    SURVEY.md §2 #6).  Here the surrounding vehicles are a fixed pool of `n_cand` candidates per env
-    advanced with the model's own prediction step (EnvironmentModel.veh_predict, DAM:394-427 — the same
-    arithmetic the reference's 5/20-step safety shield trusts) and re-entered at their lane's start when
-    they leave the map.  As in the reference's `multi_display=True` mode (multi_ego.py:46-48, 94-96),
-    `all_vehicles`, `ego_dynamics` and `v_light` can also be injected by hand before `_get_obs(exit_)`.
+    SURVEY.md §2 #6).  Here the surrounding vehicles are vehicle slots per env advanced with the model's own
+    prediction step (EnvironmentModel.veh_predict, DAM:394-427 — the same arithmetic the reference's 5/20-step
+    safety shield trusts).  `traffic='pool'` (default): a fixed pool of `n_cand` candidates re-entered at
+    their lane's start when they leave the map.  `traffic='flows'`: the twelve flows of sumo_files/cross.rou.xml
+    (emission periods, vTypes, random depart position / speed), the traffic-light programme and
+    init_traffic's conflict removal — env_build_amd/traffic.py.  As in the reference's `multi_display=True`
+    mode (multi_ego.py:46-48, 94-96), `all_vehicles`, `ego_dynamics` and `v_light` can also be injected by
+    hand before `_get_obs(exit_)`.
 
 Per step (E2E:132-144): action scaling (E2E:133) -> reward on the CURRENT obs (E2E:134, DAM:186-320) ->
 ego bicycle-model step, v_x floored at 0, phi wrapped (E2E:135, 269-283) -> traffic step -> observation
@@ -93,7 +96,7 @@ def _lane_entry(mode):
 
 class CrossroadEnd2end(object):
     def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
-                 device=None, respawn=True, **kwargs):
+                 device=None, respawn=True, traffic='pool', per_route=5, **kwargs):
         if training_task not in ('left', 'straight', 'right'):
             raise ValueError("training_task must be 'left', 'straight' or 'right'")
         self.device = device if device is not None else _default_device()
@@ -137,7 +140,13 @@ class CrossroadEnd2end(object):
         # handles: the model's (native slot list: rewards, obs construction, done) and one over the candidate pool
         self.api, self._h = self.env_model.api, self.env_model.handle
         native = VEHICLE_MODE_LIST[self.training_task]
+        if traffic not in ('pool', 'flows'):
+            raise ValueError("traffic must be 'pool' or 'flows'")
+        self.traffic_kind = traffic
         self.cand_modes = list(native) * 2 if n_cand is None else [native[i % len(native)] for i in range(int(n_cand))]
+        if traffic == 'flows':      # twelve SUMO flows, per_route slots each (env_build_amd/traffic.py)
+            from .traffic import ROUTES
+            self.cand_modes = [r for r in ROUTES for _ in range(int(per_route))]
         self.n_cand = len(self.cand_modes)
         if not 1 <= self.n_cand <= 64:
             raise ValueError('n_cand must be in 1..64')
@@ -156,6 +165,11 @@ class CrossroadEnd2end(object):
         self._entry = torch.tensor([_lane_entry(m)[:3] for m in self.cand_modes], dtype=torch.float32, device=dev)
         self._entry_dir = torch.tensor([_lane_entry(m)[3] for m in self.cand_modes], dtype=torch.float32, device=dev)
         self._injected = False
+        self._flows = None
+        if traffic == 'flows':
+            from .traffic import FlowTraffic
+            self._flows = FlowTraffic(B, dev, self._gen, self.training_task, mode=self.mode, per_route=per_route,
+                                      step_time=self.step_time)
         self.init_state = self._reset_init_state()
         if not multi_display:                                                           # E2E:84-93
             self.reset()
@@ -168,6 +182,8 @@ class CrossroadEnd2end(object):
         self.np_random = np.random.default_rng(seed)
         self._gen = torch.Generator(device=self.device)      # the traffic pool draws on the GPU: no per-step H2D copy
         self._gen.manual_seed(int(self.np_random.integers(0, 2 ** 31 - 1)))
+        if getattr(self, '_flows', None) is not None:
+            self._flows.gen = self._gen
         return [seed]
 
     def close(self):  # E2E:129-130
@@ -237,8 +253,13 @@ class CrossroadEnd2end(object):
         self._ref_idx.copy_(torch.where(m, torch.from_numpy(self._init_ref).to(dev), self._ref_idx))
         fresh_par = torch.tensor([0., 0., miu, miu], dtype=torch.float32, device=dev).repeat(B, 1)       # E2E:110-113
         self._params.copy_(torch.where(m.unsqueeze(1), fresh_par, self._params))
-        self._spawn_traffic(None if mask is None else m.unsqueeze(1).expand(B, self.n_cand))
-        self._v_light.masked_fill_(m, 0)
+        if self._flows is not None:
+            self._flows.reset(m, self._ego)
+            self._cand, self._cand_mode = self._flows.cand, self._flows.mode()
+            self._v_light.copy_(self._flows.v_light())
+        else:
+            self._spawn_traffic(None if mask is None else m.unsqueeze(1).expand(B, self.n_cand))
+            self._v_light.masked_fill_(m, 0)
         if self.mode == 'training':                                                     # E2E:120-126
             fresh_v = torch.from_numpy((self.np_random.random(B) > 0.9).astype(np.uint8)).to(dev)
             self._virtual.copy_(torch.where(m, fresh_v, self._virtual))
@@ -271,7 +292,7 @@ class CrossroadEnd2end(object):
         names = _NAME_SETTINGS['D']
         self.all_vehicles = [dict(x=float(c[0]), y=float(c[1]), v=float(c[2]), phi=float(c[3]), l=L, w=W,
                                   route=(names[_MODE_EDGES[m][0]], names[_MODE_EDGES[m][1]]))
-                             for c, m in zip(cand, self.cand_modes)]
+                             for c, m, cm in zip(cand, self.cand_modes, self._cand_mode[0].cpu().numpy()) if cm != _capi.VMODE_EMPTY]
         self.v_light = int(self._v_light[0].item())
 
     def _get_ego_dynamics(self, next_ego_state, next_ego_params):  # E2E:150-183 (host floats, as in the reference)
@@ -389,7 +410,12 @@ class CrossroadEnd2end(object):
                           _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(light),
                           _ptr(self._v_light), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out), _ptr(code), self._sp())
         self._obs, self.done_code = obs_out, code
-        if self.respawn:
+        if self._flows is not None:       # exits, emissions and the light for the NEXT step (the obs saw this step's state)
+            self._flows.cand = self._cand
+            self._flows.after_step()
+            self._cand, self._cand_mode = self._flows.cand, self._flows.mode()
+            self._v_light.copy_(self._flows.v_light())
+        elif self.respawn:
             lim = CROSSROAD_SIZE / 2 + 40.
             gone = (self._cand[:, :, 0].abs() > lim) | (self._cand[:, :, 1].abs() > lim)
             if B > 1 or bool(gone.any()):

@@ -1,0 +1,180 @@
+"""SUMO-free traffic source for the batched env: what the reference gets from SUMO over
+TraCI (traffic.py:37-238 with sumo_files/cross.rou.xml and a.net.xml), restated as device-side bookkeeping over a
+fixed pool of vehicle slots per env.
+
+What is reproduced (file:line of the reference's data / behaviour):
+  * the twelve flows of cross.rou.xml:18-44 — one per route, emitting a vehicle every 3600 / vehsPerHour seconds
+    (SUMO's `vehsPerHour` spacing), `departPos="random"` along the 75 m approach lane (a.net.xml:97-101),
+    `departSpeed="random"` in [0, maxSpeed] of the flow's vType (cross.rou.xml:2-13: 8, 8, 7 m/s), vType length /
+    width (4.75 x 1.60, 4.17 x 1.78, 4.17 x 1.78);
+  * the traffic light: phase pinned in 'training' mode (0, or 2 with probability 1/2 for task 'right',
+    traffic.py:158-161, 222-223), otherwise the static 25 / 5 / 25 / 5 s programme of a.net.xml:145-150;
+  * `init_traffic`'s removal of the vehicles in conflict with the ego's start pose (traffic.py:168-192): same two
+    box tests in ego and vehicle coordinates;
+  * vehicles are dropped when they leave the map and only ACTIVE slots are visible to the observation and the
+    collision test (their mode id is EB_VMODE_EMPTY otherwise).
+  * free-flow acceleration of the vTypes (accel = 2.6 m/s^2 up to maxSpeed, cross.rou.xml:2-13): a vehicle that
+    departs slowly speeds up as a Krauss vehicle without a leader does.
+What is not: SUMO's car-following, lane changing and light compliance — between emission and exit a vehicle moves
+with the analytic model's own prediction step (EnvironmentModel.veh_predict, DAM:394-427: straight at its speed,
+arc inside the junction), which is what the safety shield assumes about it anyway.  Vehicles are dropped 40 m past
+the junction, beyond every range filter of the observation (E2E:393-411).
+
+Host logic over torch tensors (plumbing); no arithmetic of the hot path lives here."""
+import math
+
+import torch
+
+from . import _capi
+from .endtoend_env_utils import CROSSROAD_SIZE, LANE_NUMBER, LANE_WIDTH
+
+# route -> (vehsPerHour, vType index): cross.rou.xml:18-44 with the edge pairs of cross.rou.xml:46-60
+FLOWS = dict(dl=(800, 0), du=(800, 1), dr=(800, 2), rd=(600, 0), rl=(600, 1), ru=(800, 2),
+             ur=(800, 0), ud=(800, 1), ul=(800, 2), lu=(600, 0), lr=(800, 1), ld=(800, 2))
+VTYPES = ((4.754264, 1.596668, 8.0), (4.173896, 1.77515, 8.0), (4.173896, 1.77515, 7.0))   # length, width, maxSpeed
+ROUTES = tuple(_capi.VMODES)                    # the twelve modes, in EB_VMODE_* order
+LANE_START = 100.0                              # approach lanes run from |coord| = 100 to the stop line at 25
+EXIT_RANGE = CROSSROAD_SIZE / 2 + 40.0          # a departing vehicle is dropped beyond this
+ACCEL = 2.6                                     # vType accel, cross.rou.xml:2-13
+LIGHT_PROGRAMME = ((25.0, 0), (5.0, 1), (25.0, 2), (5.0, 3))   # a.net.xml:145-150
+
+
+def approach_lane(mode):
+    """(x, y, phi) at the start of the lane a vehicle of `mode` arrives on, and its unit direction: lane index by
+    destination, as SUMO's departLane="best" sorts them (left turn innermost)."""
+    lane = {'l': 0.5, 'u': 1.5, 'r': LANE_NUMBER - 0.5}
+    s, e = mode[0], mode[1]
+    if s == 'd':
+        return (LANE_WIDTH * lane[e], -LANE_START, 90.), (0., 1.)
+    if s == 'u':
+        off = {'r': 0.5, 'd': 1.5, 'l': LANE_NUMBER - 0.5}[e]
+        return (-LANE_WIDTH * off, LANE_START, -90.), (0., -1.)
+    if s == 'r':
+        off = {'d': 0.5, 'l': 1.5, 'u': LANE_NUMBER - 0.5}[e]
+        return (LANE_START, LANE_WIDTH * off, 180.), (-1., 0.)
+    off = {'u': 0.5, 'r': 1.5, 'd': LANE_NUMBER - 0.5}[e]
+    return (-LANE_START, -LANE_WIDTH * off, 0.), (1., 0.)
+
+
+def light_phase(sim_time):
+    """Phase index of the static programme at `sim_time` seconds (tensor or float)."""
+    cycle = sum(d for d, _ in LIGHT_PROGRAMME)
+    t = torch.as_tensor(sim_time, dtype=torch.float64) % cycle
+    out = torch.zeros_like(t, dtype=torch.uint8)
+    edge = 0.0
+    for d, ph in LIGHT_PROGRAMME:
+        out = torch.where((t >= edge) & (t < edge + d), torch.full_like(out, ph), out)
+        edge += d
+    return out
+
+
+class FlowTraffic(object):
+    """Slots: `per_route` per route, route-major — slot j serves route ROUTES[j // per_route] for good, so the
+    prediction handle's per-slot turn table is static while `mode` [B, M] switches between the route's id and
+    EB_VMODE_EMPTY as vehicles come and go."""
+
+    def __init__(self, n_env, device, generator, training_task, mode='training', per_route=5, step_time=0.1):
+        self.B, self.K, self.dev, self.gen = int(n_env), int(per_route), device, generator
+        self.task, self.env_mode, self.dt = training_task, mode, float(step_time)
+        self.M = len(ROUTES) * self.K
+        if self.M > 64:
+            raise ValueError('per_route * 12 must be <= 64')
+        self.slot_modes = [r for r in ROUTES for _ in range(self.K)]
+        dev = device
+        self.route_id = torch.tensor([_capi.VMODE_ID[m] for m in self.slot_modes], dtype=torch.uint8, device=dev)
+        starts = [approach_lane(m) for m in self.slot_modes]
+        self.start = torch.tensor([s[0] for s in starts], dtype=torch.float32, device=dev)          # [M, 3]
+        self.dirn = torch.tensor([s[1] for s in starts], dtype=torch.float32, device=dev)           # [M, 2]
+        self.period = torch.tensor([3600.0 / FLOWS[r][0] for r in ROUTES], dtype=torch.float32, device=dev)   # [12]
+        vt = [VTYPES[FLOWS[m][1]] for m in self.slot_modes]
+        self.lw = torch.tensor([[v[0], v[1]] for v in vt], dtype=torch.float32, device=dev)          # [M, 2]
+        self.vmax = torch.tensor([v[2] for v in vt], dtype=torch.float32, device=dev)               # [M]
+        self.cand = torch.zeros((self.B, self.M, 4), dtype=torch.float32, device=dev)
+        self.active = torch.zeros((self.B, self.M), dtype=torch.bool, device=dev)
+        self.timer = torch.zeros((self.B, len(ROUTES)), dtype=torch.float32, device=dev)
+        self.sim_time = torch.zeros((self.B,), dtype=torch.float64, device=dev)
+        self.phase0 = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
+        self.emitted = torch.zeros((self.B, len(ROUTES)), dtype=torch.int64, device=dev)
+
+    # -- views the env hands to the kernels -----------------------------------------------------------
+    def mode(self):
+        empty = torch.full_like(self.route_id, _capi.VMODE_EMPTY).expand(self.B, self.M)
+        return torch.where(self.active, self.route_id.expand(self.B, self.M), empty).contiguous()
+
+    def cand_lw(self):
+        return self.lw.expand(self.B, self.M, 2).contiguous()
+
+    def v_light(self):
+        if self.env_mode == 'training':                                   # traffic.py:222-223
+            return self.phase0.clone()
+        return light_phase(self.sim_time).to(self.dev)
+
+    # -- dynamics -------------------------------------------------------------------------------------
+    def _rand(self, *shape):
+        return torch.rand(shape, generator=self.gen, device=self.dev)
+
+    def _place(self, where):
+        """New vehicles into the slots of `where` [B, M]: random position on the approach lane, random speed."""
+        pos = self._rand(self.B, self.M) * (LANE_START - CROSSROAD_SIZE / 2)
+        spd = self._rand(self.B, self.M) * self.vmax
+        fresh = torch.stack([self.start[:, 0] + pos * self.dirn[:, 0], self.start[:, 1] + pos * self.dirn[:, 1], spd,
+                             self.start[:, 2].expand(self.B, self.M)], 2)
+        self.cand = torch.where(where.unsqueeze(2), fresh, self.cand)
+        self.active = self.active | where
+
+    def reset(self, rows, ego):
+        """(Re)start the traffic of the envs in `rows` [B] bool around ego start poses `ego` [B, 6]."""
+        B, M, K = self.B, self.M, self.K
+        rows_m = rows.unsqueeze(1).expand(B, M)
+        self.active = self.active & ~rows_m
+        # as many vehicles per route as its flow keeps on the 75 m approach at ~7.5 m/s, at most K
+        expect = ((LANE_START - CROSSROAD_SIZE / 2) / 7.5 / self.period).clamp(max=float(K))          # [12]
+        p = (expect / K).repeat_interleave(K)
+        self._place(rows_m & (self._rand(B, M) < p))
+        self.timer = torch.where(rows.unsqueeze(1), self._rand(B, len(ROUTES)) * self.period, self.timer)
+        self.sim_time = torch.where(rows, torch.zeros_like(self.sim_time), self.sim_time)
+        self.emitted = torch.where(rows.unsqueeze(1), torch.zeros_like(self.emitted), self.emitted)
+        ph = torch.zeros((B,), dtype=torch.uint8, device=self.dev)
+        if self.task == 'right':                                           # traffic.py:159-161
+            ph = torch.where(self._rand(B) > 0.5, torch.full_like(ph, 2), ph)
+        self.phase0 = torch.where(rows, ph, self.phase0)
+        self._remove_conflicts(rows, ego)
+
+    def _remove_conflicts(self, rows, ego):
+        """traffic.py:168-192: drop a vehicle when it sits in the box ahead of / behind the ego in ego coordinates,
+        or the ego sits in the same box in the vehicle's coordinates."""
+        ex, ey, ev, ephi = ego[:, 3:4], ego[:, 4:5], ego[:, 0:1], ego[:, 5:6] * (math.pi / 180.)
+        x, y, v, phi = self.cand[:, :, 0], self.cand[:, :, 1], self.cand[:, :, 2], self.cand[:, :, 3] * (math.pi / 180.)
+        ego_l, veh_l = 4.8, self.lw[:, 0]
+        dx, dy = x - ex, y - ey
+        xe = dx * torch.cos(ephi) + dy * torch.sin(ephi)                    # shift_and_rotate_coordination, UTL:145-149
+        ye = -dx * torch.sin(ephi) + dy * torch.cos(ephi)
+        xv = -dx * torch.cos(phi) - dy * torch.sin(phi)                     # the ego seen from the vehicle
+        yv = dx * torch.sin(phi) - dy * torch.cos(phi)
+        reach = ego_l / 2. + veh_l / 2. + 2.
+        hit = ((xe > -5) & (xe < ev + reach) & (ye.abs() < 3)) | ((xv > -5) & (xv < v + reach) & (yv.abs() < 3))
+        self.active = self.active & ~(hit & rows.unsqueeze(1))
+
+    def after_step(self):
+        """Bookkeeping after the env has advanced every slot by one prediction step: exits, emissions, clock."""
+        B, M, K = self.B, self.M, self.K
+        x, y, phi = self.cand[:, :, 0], self.cand[:, :, 1], self.cand[:, :, 3] * (math.pi / 180.)
+        outward = x * torch.cos(phi) + y * torch.sin(phi) > 0               # heading away from the junction
+        gone = (torch.maximum(x.abs(), y.abs()) > EXIT_RANGE) & outward
+        self.active = self.active & ~gone
+        v = torch.minimum(self.cand[:, :, 2] + ACCEL * self.dt, self.vmax)  # free-flow acceleration to maxSpeed
+        self.cand = torch.cat([self.cand[:, :, :2], v.unsqueeze(2), self.cand[:, :, 3:]], 2)
+        self.timer = self.timer + self.dt
+        due = self.timer >= self.period                                     # [B, 12]
+        free = (~self.active).reshape(B, len(ROUTES), K)
+        first = torch.zeros_like(free)
+        taken = torch.zeros((B, len(ROUTES)), dtype=torch.bool, device=self.dev)
+        for k in range(K):                                                  # first free slot of the route
+            first[:, :, k] = free[:, :, k] & ~taken
+            taken = taken | free[:, :, k]
+        emit = first & due.unsqueeze(2)                                     # a full route keeps its vehicle waiting
+        did = emit.any(2)
+        self.timer = torch.where(did, self.timer - self.period, self.timer)
+        self.emitted = self.emitted + did.to(torch.int64)
+        self._place(emit.reshape(B, M))
+        self.sim_time = self.sim_time + self.dt

@@ -1,0 +1,100 @@
+"""GPU (-m gpu): the SUMO-free flow traffic source (env_build_amd/traffic.py) — emission schedule of
+sumo_files/cross.rou.xml, vTypes, light programme, conflict removal at reset — and that the env built on it still
+equals the oracle composition step for step (inactive slots are invisible to the observation and the done test)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from env_build_amd import _capi  # noqa: E402
+from tests._helpers import HostModel, oracle_lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_flow_schedule_types_and_light():
+    import torch
+    from env_build_amd.endtoend import CrossroadEnd2end
+    from env_build_amd.traffic import FLOWS, ROUTES, VTYPES, light_phase
+    B = 32
+    env = CrossroadEnd2end('left', n_env=B, mode='testing', traffic='flows')
+    fl = env._flows
+    assert env.n_cand == 60 and fl.M == 60
+    # conflict removal at reset (traffic.py:168-192): nothing active in the box ahead of / behind an ego
+    ego, cand, act = env._ego.cpu().numpy(), fl.cand.cpu().numpy(), fl.active.cpu().numpy()
+    for b in range(B):
+        phi = np.deg2rad(ego[b, 5])
+        dx, dy = cand[b, :, 0] - ego[b, 3], cand[b, :, 1] - ego[b, 4]
+        xe, ye = dx * np.cos(phi) + dy * np.sin(phi), -dx * np.sin(phi) + dy * np.cos(phi)
+        reach = ego[b, 0] + 2.4 + fl.lw[:, 0].cpu().numpy() / 2 + 2
+        assert not np.any(act[b] & (xe > -5) & (xe < reach) & (np.abs(ye) < 3))
+    steps = 600                                                      # 60 s of simulated time
+    zero = np.zeros((B, 2), np.float32)
+    lights = []
+    for t in range(steps):
+        env.step(zero)
+        lights.append(int(env._v_light[0].item()))
+    emitted = fl.emitted.cpu().numpy().astype(np.float64)
+    for k, r in enumerate(ROUTES):
+        want = steps * 0.1 * FLOWS[r][0] / 3600.0                    # vehsPerHour spacing
+        assert abs(emitted[:, k].mean() - want) < 1.0, (r, emitted[:, k].mean(), want)
+        assert emitted[:, k].max() <= want + 1
+    # light programme of a.net.xml:145-150 in 'testing' mode: 25 s phase 0, 5 s phase 1, 25 s phase 2, 5 s phase 3
+    want_l = [0] * 249 + [1] * 50 + [2] * 250 + [3] * 50
+    assert sum(a != b for a, b in zip(lights[:599], want_l[:599])) <= 4      # step boundaries at float time
+    assert light_phase(61.0).item() == 0
+    # vTypes: length / width / maxSpeed per flow; nobody exceeds its maxSpeed; everybody speeds up to it
+    lw, v = fl.lw.cpu().numpy(), fl.cand[:, :, 2].cpu().numpy()
+    for j, m in enumerate(fl.slot_modes):
+        assert np.allclose(lw[j], VTYPES[FLOWS[m][1]][:2])
+        assert np.all(v[:, j] <= VTYPES[FLOWS[m][1]][2] + 1e-6)
+    a = fl.active.cpu().numpy()
+    assert 1.5 < a.sum(1).mean() / 12 < 5.0                           # a few vehicles per route on the map
+    mode = fl.mode().cpu().numpy()
+    assert np.all(mode[~a] == _capi.VMODE_EMPTY) and np.all(mode[a] == fl.route_id.cpu().numpy()[None].repeat(B, 0)[a])
+    # training mode pins the phase (traffic.py:158-161, 222-223)
+    env_r = CrossroadEnd2end('right', n_env=256, mode='training', traffic='flows')
+    ph = env_r._v_light.cpu().numpy()
+    assert set(np.unique(ph)) <= {0, 2} and 0.3 < (ph == 2).mean() < 0.7
+    env_r.step(np.zeros((256, 2), np.float32))
+    assert np.array_equal(env_r._v_light.cpu().numpy(), ph)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('task', ['left', 'straight', 'right'])
+def test_env_on_flow_traffic_equals_oracle_composition(task):
+    """obs, reward and done code of every step == the six oracle calls on the same state, with the slot modes the
+    traffic source publishes (EB_VMODE_EMPTY for vacant slots)."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    from env_build_amd.endtoend_env_utils import VEH_NUM
+    B = 48
+    env = CrossroadEnd2end(task, n_env=B, mode='testing', traffic='flows')
+    host = HostModel(oracle_lib(), task, n_veh=VEH_NUM[task])
+    traffic = HostModel(oracle_lib(), task, n_veh=env.n_cand, modes=env.cand_modes)
+    rng = np.random.default_rng(3)
+    hits = 0
+    for t in range(30):
+        ego, par = env._ego.cpu().numpy(), env._params.cpu().numpy()
+        cand, cmode = env._cand.cpu().numpy(), env._cand_mode.cpu().numpy()
+        vl = env._v_light.cpu().numpy()
+        light = ((vl != 0) | (env._virtual.cpu().numpy() != 0)).astype(np.uint8)
+        ri = env._ref_idx.cpu().numpy()
+        obs = env._obs.cpu().numpy()
+        raw = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+        o, r, d, info = env.step(raw)
+        act = host.action_transform(raw)
+        o5, _ = host.compute_rewards(obs, act)
+        ego2, par2 = host.env_ego_step(ego, act)
+        cand2 = traffic.veh_predict(cand.reshape(B, -1)).reshape(cand.shape)
+        obs2 = host.get_obs(ego2, cand2, cmode, light, ref_idx=ri)
+        code = host.judge_done(ego2, par2, obs2, cand2, cmode, None, vl)
+        assert np.array_equal(o.numpy(), obs2), 'obs, step %d' % t
+        assert np.array_equal(r.numpy(), o5[0]), 'reward, step %d' % t
+        assert np.array_equal(env.done_code.cpu().numpy(), code), 'done code, step %d' % t
+        hits += int((code != 0).sum())
+        if (code != 0).any():
+            env.reset(mask=code != 0)
+    assert hits > 0

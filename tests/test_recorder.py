@@ -44,3 +44,21 @@ def test_save_layout_is_what_the_reference_loader_iterates(tmp_path):
     r2.load(str(tmp_path))
     tab = r2.episode_table(0)
     assert set(tab) == set(Recorder.val2record) and tab['path_values'].shape[1] == 3
+
+
+def test_flow_tables_light_programme_and_lanes():
+    """Host tables of env_build_amd/traffic.py against sumo_files/cross.rou.xml / a.net.xml values (restated here)."""
+    from env_build_amd.traffic import FLOWS, LIGHT_PROGRAMME, ROUTES, VTYPES, approach_lane, light_phase
+    assert len(ROUTES) == 12 and set(FLOWS) == set(ROUTES)
+    assert sorted(v[0] for v in FLOWS.values()).count(600) == 3 and sorted(v[0] for v in FLOWS.values()).count(800) == 9   # cross.rou.xml:18-44
+    assert {FLOWS[r][0] for r in ('rd', 'rl', 'lu')} == {600}
+    assert [v[2] for v in VTYPES] == [8.0, 8.0, 7.0] and abs(VTYPES[0][0] - 4.754264) < 1e-9
+    assert LIGHT_PROGRAMME == ((25.0, 0), (5.0, 1), (25.0, 2), (5.0, 3))           # a.net.xml:145-150
+    assert [int(light_phase(t)) for t in (0, 24.9, 25.0, 29.9, 30.0, 54.9, 55.0, 59.9, 60.0, 85.0)] == [0, 0, 1, 1, 2, 2, 3, 3, 0, 1]
+    # lanes of a.net.xml:97-101: 1o_2 (x = 1.88) is the left-turn lane, 1o_0 (x = 9.38) the right-turn lane
+    (x, y, phi), d = approach_lane('dl')
+    assert abs(x - 1.875) < 1e-6 and y == -100.0 and phi == 90.0 and d == (0., 1.)
+    assert abs(approach_lane('dr')[0][0] - 9.375) < 1e-6 and abs(approach_lane('du')[0][0] - 5.625) < 1e-6
+    for m in ROUTES:     # every lane starts 100 m out and points at the junction
+        (x, y, phi), (dx, dy) = approach_lane(m)
+        assert max(abs(x), abs(y)) == 100.0 and x * dx + y * dy < 0
