@@ -775,6 +775,16 @@ static int mlp_args(eb_mlp m, int32_t n, const float* obs, float* out, int head,
 
 extern "C" {
 
+int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
+                       float span, float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, void* stream) {
+    if (!h || n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!cand || !entry)))
+        return fail(EB_EINVAL, "eb_traffic_respawn: bad argument");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, entry, limit, span, v_max, seed, counter, respawned, pick(h, stream)));
+    return EB_OK;
+}
+
 int eb_mlp_create(const eb_mlp_config* cfg, eb_mlp* out) {
     if (!cfg || !out) return fail(EB_EINVAL, "eb_mlp_create: null argument");
     if (cfg->abi_version != EB_ABI_VERSION) return fail(EB_EINVAL, "eb_mlp_create: ABI version mismatch");

@@ -1,10 +1,11 @@
 // eb_env_kernels.hip — batched real-env step pieces of CrossroadEnd2end (endtoend.py), gfx950.
 //
 // One thread per env: these are control-flow-heavy, tiny-data kernels (filter / select / pad of at
-// most a few dozen candidate vehicles, a priority chain of predicates); they run once per env step
-// next to the rollout kernel and are nowhere near a roofline, so they are written for clarity and
-// bit-for-bit agreement with the oracle.  fp32 throughout (see the oracle's note on the reference's
-// NumPy-version-dependent scalar promotion).
+// most a few dozen candidate vehicles, a priority chain of predicates) written for bit-for-bit
+// agreement with the oracle.  The observation kernel, the heaviest of them, stages a wave's 64 envs
+// through LDS — candidates in, observation rows out, both as coalesced 16-byte accesses — because a
+// thread walks its env's candidates a dozen times.  fp32 throughout (see the oracle's note on the
+// reference's NumPy-version-dependent scalar promotion).
 #include "eb_device.h"
 #include "eb_kernels.h"
 #include "../../include/envbuild.h"
@@ -115,17 +116,59 @@ EB_DEV bool fetch_candidate(int m, int i, int m_cand, const float* cand, const u
     return true;
 }
 
-template <int TASK>
-__global__ void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTables pt, VehModes modes,
+// the same for a candidate row staged in LDS as float4s
+EB_DEV bool fetch_candidate_lds(int m, int i, int m_cand, const float4* row, const uint8_t* mrow, bool virt, V4& v) {
+    if (i < m_cand) {
+        if (mrow[i] != m) return false;
+        const float4 q = row[i];
+        v.x = q.x; v.y = q.y; v.v = q.z; v.phi = q.w;
+        return true;
+    }
+    if (!virt || (m != EB_VMODE_DL && m != EB_VMODE_DU)) return false;
+    v.x = m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f;
+    v.y = -HALF_CROSS + 2.5f; v.v = 0.0f; v.phi = 90.0f;
+    return true;
+}
+
+EB_DEV int obs_cand_stride4(int m_cand) { return m_cand + ((m_cand & 1) ? 2 : 1); }   // float4s per LDS row, odd: no bank conflicts
+size_t get_obs_lds_bytes(int D, int m_cand) {
+    const int rs4 = m_cand + ((m_cand & 1) ? 2 : 1);
+    return (size_t)64 * rs4 * 16 + (size_t)64 * (D + 1) * 4 + (size_t)64 * (m_cand + 4);
+}
+
+template <int TASK, bool STAGED>
+__global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTables pt, VehModes modes,
                                const float* __restrict__ ego, const int* __restrict__ ref_idx, int path_id,
                                int m_cand, const float* __restrict__ cand_all, const uint8_t* __restrict__ cmode_all,
                                const uint8_t* __restrict__ light_flag, float* __restrict__ obs_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_env) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // 64 envs per block, one per lane; the block's four waves share the slots of the observation (wave w builds
+    // slots w, w + 4, ...), wave 0 also the ego and tracking columns
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, e0 = blockIdx.x * 64;
+    const int nE = n_env - e0 < 64 ? n_env - e0 : 64;
+    const int i = e0 + lane;
+    const int RS4 = obs_cand_stride4(m_cand), OS = D + 1, MS = m_cand + 4;
+    float4* s_cand = reinterpret_cast<float4*>(smem);                       // [64][RS4]
+    float* s_out = reinterpret_cast<float*>(smem + (size_t)64 * RS4 * 16);  // [64][D + 1]
+    uint8_t* s_mode = smem + (size_t)64 * RS4 * 16 + (size_t)64 * OS * 4;   // [64][m_cand + 4]
+    if (STAGED) {
+        // the tile's candidates are contiguous in memory: coalesced 16-byte loads, one LDS row per env
+        const float4* src = reinterpret_cast<const float4*>(cand_all) + (size_t)e0 * m_cand;
+        const uint8_t* msrc = cmode_all + (size_t)e0 * m_cand;
+        const int total = nE * m_cand;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int e = idx / m_cand, c = idx - e * m_cand;
+            s_cand[e * RS4 + c] = src[idx];
+            s_mode[e * MS + c] = msrc[idx];
+        }
+        __syncthreads();
+    }
+    if (i < n_env) {
     const float* e = ego + 6 * (size_t)i;
-    float* o = obs_out + (size_t)D * i;
+    float* o = STAGED ? s_out + lane * OS : obs_out + (size_t)D * i;
     const int T = 3 * (n_future + 1);
     const float ev = e[0], ex = e[3], ey = e[4], ephi = e[5];
+    if (wave == 0) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) o[c] = e[c];                               // E2E:329-338
     const int p = row_path(pt, ref_idx, path_id, i);
@@ -163,11 +206,14 @@ __global__ void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTable
             o[11 + 3 * k] = deal_with_phi_diff(ephi - pt.phi[p][fi]);
         }
     }
+    }   // wave 0
     const float* cand = cand_all + (size_t)i * m_cand * 4;
     const uint8_t* cmode = cmode_all + (size_t)i * m_cand;
+    const float4* crow = s_cand + lane * RS4;
+    const uint8_t* mrow = s_mode + lane * MS;
     const bool virt = TASK != TASK_RIGHT && light_flag && light_flag[i] != 0 && ey < -HALF_CROSS;   // E2E:386-388
     float* ov = o + 6 + T;
-    for (int s = 0; s < NV; ++s) {
+    for (int s = STAGED ? wave : 0; s < NV; s += STAGED ? 4 : 1) {
         const int m = modes.mode[s];
         int rank = 0;
         for (int t = 0; t < s; ++t) rank += modes.mode[t] == m;
@@ -180,7 +226,8 @@ __global__ void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTable
             int best_i = -1;
             for (int c = 0; c <= m_cand; ++c) {
                 V4 v;
-                if (!fetch_candidate(m, c, m_cand, cand, cmode, virt, v)) continue;
+                if (!(STAGED ? fetch_candidate_lds(m, c, m_cand, crow, mrow, virt, v)
+                             : fetch_candidate(m, c, m_cand, cand, cmode, virt, v))) continue;
                 if (!veh_in_range(TASK, m, v, ex, ey)) continue;
                 if (prev_i >= 0) {
                     const int cp = veh_cmp(TASK, m, prev, v);
@@ -194,18 +241,83 @@ __global__ void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTable
         const V4 r = found ? prev : veh_fill_value(m);                     // slice_or_fill, E2E:431-437
         ov[4 * s] = r.x; ov[4 * s + 1] = r.y; ov[4 * s + 2] = r.v; ov[4 * s + 3] = r.phi;
     }
+    }   // i < n_env
+    if (STAGED) {
+        __syncthreads();
+        float* dst = obs_out + (size_t)e0 * D;                              // the tile's rows are contiguous too
+        const int total = nE * D;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int e = idx / D, c = idx - e * D;
+            dst[idx] = s_out[e * OS + c];
+        }
+    }
 }
 
 hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
                           const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag, float* obs_out,
                           hipStream_t s) {
-    const dim3 g((n_env + 63) / 64), b(64);
+    const size_t lds = get_obs_lds_bytes(D, m_cand);
+    const bool staged = lds <= 150 * 1024 && (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
+    hipError_t e = hipSuccess;
+#define EB_GET_OBS(T)                                                                                                \
+    do {                                                                                                             \
+        const dim3 g((n_env + 63) / 64), b(staged ? 256 : 64);                                                       \
+        if (staged) {                                                                                                \
+            if (lds > 48 * 1024)                                                                                     \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&get_obs_kernel<T, true>),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+            if (e == hipSuccess)                                                                                     \
+                hipLaunchKernelGGL((get_obs_kernel<T, true>), g, b, lds, s, n_env, D, n_future, NV, pt, modes, ego,  \
+                                   ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out);                  \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL((get_obs_kernel<T, false>), g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego,       \
+                               ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out);                      \
+        }                                                                                                            \
+    } while (0)
     switch (task) {
-        case TASK_LEFT: hipLaunchKernelGGL(get_obs_kernel<TASK_LEFT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out); break;
-        case TASK_STRAIGHT: hipLaunchKernelGGL(get_obs_kernel<TASK_STRAIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out); break;
-        default: hipLaunchKernelGGL(get_obs_kernel<TASK_RIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out); break;
+        case TASK_LEFT: EB_GET_OBS(TASK_LEFT); break;
+        case TASK_STRAIGHT: EB_GET_OBS(TASK_STRAIGHT); break;
+        default: EB_GET_OBS(TASK_RIGHT); break;
     }
+#undef EB_GET_OBS
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
+// ---- traffic pool re-entry (eb_traffic_respawn) ----------------------------------------------------
+EB_DEV uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void traffic_respawn_kernel(int n_env, int m_cand, float* __restrict__ cand, const float* __restrict__ entry,
+                                       float limit, float span, float v_max, uint64_t seed, uint64_t counter,
+                                       uint8_t* __restrict__ respawned) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_env * m_cand) return;
+    const int e = idx / m_cand, j = idx - e * m_cand;
+    float4* c = reinterpret_cast<float4*>(cand) + idx;
+    const float4 v = *c;
+    const bool gone = __builtin_fabsf(v.x) > limit || __builtin_fabsf(v.y) > limit;
+    if (gone) {
+        const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)j * 2u;
+        const float u1 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
+        const float u2 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
+        const float* en = entry + 5 * j;
+        const float along = u1 * span;
+        *c = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * v_max, en[2]);
+    }
+    if (respawned) respawned[idx] = gone ? 1 : 0;
+}
+
+hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
+                                  float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, hipStream_t s) {
+    const int n = n_env * m_cand;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(traffic_respawn_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n_env, m_cand, cand, entry, limit,
+                       span, v_max, seed, counter, respawned);
     return hipGetLastError();
 }
 

@@ -73,6 +73,9 @@ hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const
                              int m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
                              const uint8_t* v_light, uint8_t* done_code, hipStream_t s);
 
+hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
+                                  float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, hipStream_t s);
+
 // ---- policy network in the loop (eb_policy.hip): fused MLP on the f32 matrix cores ----
 constexpr int MLP_ROWS = 64;       // observations per block
 constexpr int MLP_THREADS = 256;   // 4 waves

@@ -94,6 +94,16 @@ def _lane_entry(mode):
     return -(h + 35.), -LANE_WIDTH * off, 0., (1., 0.)
 
 
+def _unwrap_action(action, B, dev):
+    """[B, 2] float32 contiguous tensor on `dev` from whatever the caller passed (no copy when it already is one)."""
+    t = action.t if isinstance(action, DevArray) else action
+    if isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.device == dev and t.is_contiguous() and t.shape == (B, 2):
+        return t
+    if isinstance(t, torch.Tensor):
+        return t.to(device=dev, dtype=torch.float32).reshape(B, 2).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(t, np.float32).reshape(B, 2))).to(dev)
+
+
 class CrossroadEnd2end(object):
     def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
                  device=None, respawn=True, traffic='pool', per_route=5, **kwargs):
@@ -164,6 +174,8 @@ class CrossroadEnd2end(object):
         self._obs = torch.zeros((B, self.obs_dim), dtype=torch.float32, device=dev)
         self._entry = torch.tensor([_lane_entry(m)[:3] for m in self.cand_modes], dtype=torch.float32, device=dev)
         self._entry_dir = torch.tensor([_lane_entry(m)[3] for m in self.cand_modes], dtype=torch.float32, device=dev)
+        self._entry5 = torch.cat([self._entry, self._entry_dir], 1).contiguous()       # (x, y, phi, dx, dy) per slot
+        self._light = torch.zeros((B,), dtype=torch.uint8, device=dev)
         self._injected = False
         self._flows = None
         if traffic == 'flows':
@@ -184,6 +196,8 @@ class CrossroadEnd2end(object):
         self._gen.manual_seed(int(self.np_random.integers(0, 2 ** 31 - 1)))
         if getattr(self, '_flows', None) is not None:
             self._flows.gen = self._gen
+        self._respawn_seed = int(self.np_random.integers(0, 2 ** 62))     # eb_traffic_respawn: (seed, counter, env, slot)
+        self._respawn_counter = 0
         return [seed]
 
     def close(self):  # E2E:129-130
@@ -266,6 +280,7 @@ class CrossroadEnd2end(object):
         else:
             self._virtual.masked_fill_(m, 0)
         self.virtual_red_light_vehicle = bool(self._virtual[0].item()) if self.n_env == 1 else None
+        self._light_key = None                                                          # E2E:387-388 flag: recomputed on the next step
         self._injected = False
         self._publish_state()
         self.obs = self._get_obs()
@@ -394,32 +409,37 @@ class CrossroadEnd2end(object):
         traffic step -> observation -> done code; afterwards the traffic pool re-enters the vehicles that left the map
         (the observation saw the pool as this step left it, the way the reference sees SUMO's state of the step)."""
         B, dev = self.n_env, self.device
-        raw = _dev(np.asarray(action, np.float32).reshape(B, 2) if not isinstance(action, (torch.Tensor, DevArray))
-                   else action, dev).reshape(B, 2).contiguous()
+        raw = _unwrap_action(action, B, dev)
         act = torch.empty_like(raw)
         out5 = torch.empty((5, B), dtype=torch.float32, device=dev)
         d16 = torch.empty((16, B), dtype=torch.float32, device=dev)
         obs_out = torch.empty_like(self._obs)
         code = torch.empty((B,), dtype=torch.uint8, device=dev)
-        light = ((self._v_light != 0) | (self._virtual != 0)).to(torch.uint8)          # E2E:387-388
+        key = (self._v_light._version, self._virtual._version)          # in-place writes bump the tensors' versions
+        if key != getattr(self, '_light_key', None):
+            self._light = ((self._v_light != 0) | (self._virtual != 0)).to(torch.uint8)  # E2E:387-388
+            self._light_key = (self._v_light._version, self._virtual._version)
+        light = self._light
         ri = self._ref_idx
         if B == 1:
             ri = torch.tensor([int(self.ref_path.ref_index)], dtype=torch.int32, device=dev)
-        self._cand = self._cand.contiguous()
+        if not self._cand.is_contiguous():
+            self._cand = self._cand.contiguous()
+        sp = self._sp()
         self.api.env_step(self._h, self._traffic.h, B, _ptr(self._obs), _ptr(raw), _ptr(ri), 0, _ptr(self._ego),
                           _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(light),
-                          _ptr(self._v_light), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out), _ptr(code), self._sp())
+                          _ptr(self._v_light), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out), _ptr(code), sp)
         self._obs, self.done_code = obs_out, code
         if self._flows is not None:       # exits, emissions and the light for the NEXT step (the obs saw this step's state)
             self._flows.cand = self._cand
             self._flows.after_step()
             self._cand, self._cand_mode = self._flows.cand, self._flows.mode()
             self._v_light.copy_(self._flows.v_light())
-        elif self.respawn:
-            lim = CROSSROAD_SIZE / 2 + 40.
-            gone = (self._cand[:, :, 0].abs() > lim) | (self._cand[:, :, 1].abs() > lim)
-            if B > 1 or bool(gone.any()):
-                self._spawn_traffic(gone)
+        elif self.respawn:                # vehicles that left the map re-enter on their lane (one kernel, counter-based draws)
+            self._respawn_counter += 1
+            self.api.traffic_respawn(self._traffic.h, B, self.n_cand, _ptr(self._cand), _ptr(self._entry5),
+                                     C.c_float(CROSSROAD_SIZE / 2 + 40.), C.c_float(60.0), C.c_float(EXPECTED_V),
+                                     C.c_uint64(self._respawn_seed), C.c_uint64(self._respawn_counter), None, sp)
         self._publish_state()                                                           # E2E:136, 139
         keys = EnvironmentModel.REWARD_KEYS
         if B == 1:

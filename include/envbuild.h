@@ -256,6 +256,16 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const uint8_t* cand_mode, const uint8_t* light_flag, const uint8_t* v_light,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream);
 
+/* The traffic pool's re-entry rule (the SUMO flows' role for the batched env, TRF:37-238 is out of scope): every
+ * candidate of cand [n_env, m_cand, 4] that has left the square |x|, |y| <= limit is put back on its entry lane,
+ *   (x, y, v, phi) = (entry.x + u1 * span * entry.dx, entry.y + u1 * span * entry.dy, u2 * v_max, entry.phi),
+ * entry [m_cand, 5] = (x, y, phi, dx, dy) per slot.  u1, u2 in [0, 1) come from a counter-based generator —
+ * the top 24 bits of splitmix64(seed + 0x9E3779B97F4A7C15 * (counter * 2^32 + env * 128 + slot * 2 + k)), k = 0, 1 —
+ * so the result depends on (seed, counter, env, slot) only and the two libraries agree bit for bit.
+ * `respawned` (nullable, uint8 [n_env, m_cand]) marks the slots that were re-entered. */
+int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
+                       float span, float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, void* stream);
+
 /* ---- the policy in the loop: MLPNet + LoadPolicy.run_batch + the safety shield ----
  *
  * utils/model.py:18-43 `MLPNet`: Dense(obs_dim -> n_units, act) , (n_hidden - 1) x Dense(n_units -> n_units, act),

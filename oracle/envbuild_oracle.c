@@ -1154,6 +1154,40 @@ long long eb_oracle_check_div_exact(float c, uint32_t first, uint32_t last, uint
     return bad;
 }
 
+/* traffic pool re-entry: the rule stated in include/envbuild.h (not a reference function — the reference's
+ * traffic is SUMO); restated here so that the batched env's traffic is reproducible on the CPU too */
+static uint64_t eb_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
+                       float span, float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!cand || !entry)))
+        return fail(EB_EINVAL, "eb_traffic_respawn: bad argument");
+    for (int e = 0; e < n_env; ++e)
+        for (int j = 0; j < m_cand; ++j) {
+            float* c = cand + ((size_t)e * m_cand + j) * 4;
+            const int gone = fabsf(c[0]) > limit || fabsf(c[1]) > limit;
+            if (gone) {
+                const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)j * 2u;
+                const float u1 = (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
+                const float u2 = (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
+                const float* en = entry + 5 * j;
+                const float along = u1 * span;
+                c[0] = en[0] + along * en[3];
+                c[1] = en[1] + along * en[4];
+                c[2] = u2 * v_max;
+                c[3] = en[2];
+            }
+            if (respawned) respawned[(size_t)e * m_cand + j] = gone ? 1 : 0;
+        }
+    return EB_OK;
+}
+
 /* ================================================================================================
  * Policy network in the loop — TEST INFRASTRUCTURE like the rest of this file.
  * MLPNet (utils/model.py:18-43), the 'scale' preprocessor (utils/preprocessor.py:116-123), the deterministic

@@ -98,3 +98,36 @@ def test_env_on_flow_traffic_equals_oracle_composition(task):
         if (code != 0).any():
             env.reset(mask=code != 0)
     assert hits > 0
+
+
+def test_traffic_respawn_equals_oracle_and_depends_on_its_key_only():
+    """eb_traffic_respawn: bit-exact against the oracle (integer hash + three fp32 ops), and a function of
+    (seed, counter, env, slot) only — the same key gives the same draw in any batch."""
+    from tests._helpers import DeviceModel
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    B, M = 333, 16
+    host, dev = HostModel(oracle_lib(), 'left', n_veh=M), DeviceModel('left', n_veh=M)
+    cand = (rng.uniform(-90, 90, (B, M, 4))).astype(np.float32)
+    entry = rng.uniform(-60, 60, (M, 5)).astype(np.float32)
+    outs = []
+    for mdl in (host, dev):
+        c, en = mdl._in(cand.copy()), mdl._in(entry)
+        flag = mdl._out((B, M), np.uint8)
+        mdl.api.traffic_respawn(mdl.h, B, M, mdl._ptr(c), mdl._ptr(en), C.c_float(65.0), C.c_float(60.0), C.c_float(8.0),
+                                C.c_uint64(12345678901234567), C.c_uint64(77), mdl._ptr(flag), mdl.stream)
+        outs.append((mdl._ret(c), mdl._ret(flag)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    got, flag = outs[1]
+    gone = (np.abs(cand[:, :, 0]) > 65) | (np.abs(cand[:, :, 1]) > 65)
+    assert np.array_equal(flag.astype(bool), gone) and 0.2 < gone.mean() < 0.8
+    assert np.array_equal(got[~gone], cand[~gone])
+    along = (got[gone][:, 0] - np.broadcast_to(entry[:, 0], (B, M))[gone]) / np.broadcast_to(entry[:, 3], (B, M))[gone]
+    assert np.all(got[gone][:, 2] >= 0) and np.all(got[gone][:, 2] < 8) and np.all(along > -1e-3) and np.all(along < 60.001)
+    # the same (env, slot) rows inside a smaller batch draw the same values
+    c2 = dev._in(cand[:100].copy())
+    dev.api.traffic_respawn(dev.h, 100, M, dev._ptr(c2), dev._ptr(dev._in(entry)), C.c_float(65.0), C.c_float(60.0),
+                            C.c_float(8.0), C.c_uint64(12345678901234567), C.c_uint64(77), None, dev.stream)
+    assert np.array_equal(dev._ret(c2), got[:100])
+    u = got[gone][:, 2] / 8.0
+    assert abs(u.mean() - 0.5) < 0.03                                   # roughly uniform draws
