@@ -71,6 +71,8 @@ PROTOTYPES = {
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P]),
+    'eb_traffic_flow_step': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       _I, C.c_uint64, C.c_uint64, _P, _P, _P]),
     'eb_mlp_create': (C.c_int, [C.POINTER(EbMlpConfig), C.POINTER(_P)]),
     'eb_mlp_destroy': (C.c_int, [_P]),
     'eb_mlp_set_layer': (C.c_int, [_P, _I, _P, _P]),

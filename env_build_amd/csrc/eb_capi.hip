@@ -785,6 +785,22 @@ int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, 
     return EB_OK;
 }
 
+int eb_traffic_flow_step(eb_handle h, int32_t n_env, int32_t per_route, float* cand, uint8_t* active, float* timer,
+                         int32_t* emitted, int32_t* sim_step, const float* lane, const float* period,
+                         const float* v_max, float dt, float exit_range, float accel, float lane_len,
+                         int32_t light_cycle, uint64_t seed, uint64_t counter, uint8_t* cand_mode, uint8_t* v_light,
+                         void* stream) {
+    if (!h || n_env < 0 || per_route < 1 || per_route * 12 > 64 || !(dt > 0.0f) ||
+        (n_env > 0 && (!cand || !active || !timer || !emitted || !sim_step || !lane || !period || !v_max || !cand_mode || !v_light)))
+        return fail(EB_EINVAL, "eb_traffic_flow_step: bad argument");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_traffic_flow_step(n_env, per_route, cand, active, timer, emitted, sim_step, lane, period, v_max, dt,
+                                        exit_range, accel, lane_len, light_cycle, seed, counter, cand_mode, v_light,
+                                        pick(h, stream)));
+    return EB_OK;
+}
+
 int eb_mlp_create(const eb_mlp_config* cfg, eb_mlp* out) {
     if (!cfg || !out) return fail(EB_EINVAL, "eb_mlp_create: null argument");
     if (cfg->abi_version != EB_ABI_VERSION) return fail(EB_EINVAL, "eb_mlp_create: ABI version mismatch");

@@ -321,6 +321,75 @@ hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const floa
     return hipGetLastError();
 }
 
+// ---- flow traffic source (eb_traffic_flow_step): one thread per (env, route) ----------------------
+__global__ void traffic_flow_step_kernel(int n_env, int K, float* __restrict__ cand, uint8_t* __restrict__ active,
+                                         float* __restrict__ timer, int* __restrict__ emitted, int* __restrict__ sim_step,
+                                         const float* __restrict__ lane, const float* __restrict__ period,
+                                         const float* __restrict__ v_max, float dt, float exit_range, float accel,
+                                         float lane_len, int light_cycle, uint64_t seed, uint64_t counter,
+                                         uint8_t* __restrict__ cand_mode, uint8_t* __restrict__ v_light) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_env * 12) return;
+    const int e = idx / 12, r = idx - e * 12, M = 12 * K;
+    const size_t s0 = (size_t)e * M + (size_t)r * K;
+    int vacant = -1;
+    for (int k = 0; k < K; ++k) {
+        float4* c = reinterpret_cast<float4*>(cand) + s0 + k;
+        bool on = active[s0 + k] != 0;
+        if (on) {
+            float4 v = *c;
+            float sn, cs;
+            sincos_det(deg2rad(v.w), sn, cs);
+            const bool outward = v.x * cs + v.y * sn > 0.0f;
+            if (__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)) > exit_range && outward) {
+                on = false;
+            } else {
+                const float vn = v.z + accel * dt, vm = v_max[r * K + k];
+                v.z = vn < vm ? vn : vm;
+                *c = v;
+            }
+        }
+        active[s0 + k] = on ? 1 : 0;
+        if (!on && vacant < 0) vacant = k;
+    }
+    float t = timer[idx] + dt;
+    const float per = period[r];
+    if (t >= per && vacant >= 0) {
+        const int j = r * K + vacant;
+        const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)(r * K) * 2u;
+        const float u1 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
+        const float u2 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
+        const float* ln = lane + 5 * j;
+        const float along = u1 * lane_len;
+        reinterpret_cast<float4*>(cand)[s0 + vacant] = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * v_max[j], ln[2]);
+        active[s0 + vacant] = 1;
+        t = t - per;
+        emitted[idx] += 1;
+    }
+    timer[idx] = t;
+    for (int k = 0; k < K; ++k) cand_mode[s0 + k] = active[s0 + k] ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+    if (r == 0) {
+        const int n = sim_step[e] + 1;
+        sim_step[e] = n;
+        if (light_cycle) {   // a.net.xml:145-150: 25 s phase 0, 5 s phase 1, 25 s phase 2, 5 s phase 3, in steps of dt
+            const float tt = (float)(n % (int)(60.0f / dt + 0.5f)) * dt;
+            v_light[e] = tt < 25.0f ? 0 : (tt < 30.0f ? 1 : (tt < 55.0f ? 2 : 3));
+        }
+    }
+}
+
+hipError_t launch_traffic_flow_step(int n_env, int K, float* cand, uint8_t* active, float* timer, int* emitted,
+                                    int* sim_step, const float* lane, const float* period, const float* v_max, float dt,
+                                    float exit_range, float accel, float lane_len, int light_cycle, uint64_t seed,
+                                    uint64_t counter, uint8_t* cand_mode, uint8_t* v_light, hipStream_t s) {
+    const int n = n_env * 12;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(traffic_flow_step_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n_env, K, cand, active, timer,
+                       emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len, light_cycle, seed, counter,
+                       cand_mode, v_light);
+    return hipGetLastError();
+}
+
 // ---- a17: _judge_done, E2E:200-256 ---------------------------------------------------------------
 EB_DEV bool judge_feasible(float x, float y, int task) {   // UTL:73-104
     const float C2 = HALF_CROSS, LW = LANE_W;

@@ -76,6 +76,11 @@ hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
                                   float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, hipStream_t s);
 
+hipError_t launch_traffic_flow_step(int n_env, int K, float* cand, uint8_t* active, float* timer, int* emitted,
+                                    int* sim_step, const float* lane, const float* period, const float* v_max, float dt,
+                                    float exit_range, float accel, float lane_len, int light_cycle, uint64_t seed,
+                                    uint64_t counter, uint8_t* cand_mode, uint8_t* v_light, hipStream_t s);
+
 // ---- policy network in the loop (eb_policy.hip): fused MLP on the f32 matrix cores ----
 constexpr int MLP_ROWS = 64;       // observations per block
 constexpr int MLP_THREADS = 256;   // 4 waves

@@ -182,6 +182,7 @@ class CrossroadEnd2end(object):
             from .traffic import FlowTraffic
             self._flows = FlowTraffic(B, dev, self._gen, self.training_task, mode=self.mode, per_route=per_route,
                                       step_time=self.step_time)
+            self._flows.seed = self._respawn_seed
         self.init_state = self._reset_init_state()
         if not multi_display:                                                           # E2E:84-93
             self.reset()
@@ -197,6 +198,8 @@ class CrossroadEnd2end(object):
         if getattr(self, '_flows', None) is not None:
             self._flows.gen = self._gen
         self._respawn_seed = int(self.np_random.integers(0, 2 ** 62))     # eb_traffic_respawn: (seed, counter, env, slot)
+        if getattr(self, '_flows', None) is not None:
+            self._flows.seed = self._respawn_seed
         self._respawn_counter = 0
         return [seed]
 
@@ -269,8 +272,7 @@ class CrossroadEnd2end(object):
         self._params.copy_(torch.where(m.unsqueeze(1), fresh_par, self._params))
         if self._flows is not None:
             self._flows.reset(m, self._ego)
-            self._cand, self._cand_mode = self._flows.cand, self._flows.mode()
-            self._v_light.copy_(self._flows.v_light())
+            self._cand, self._cand_mode, self._v_light = self._flows.cand, self._flows.mode(), self._flows.v_light()
         else:
             self._spawn_traffic(None if mask is None else m.unsqueeze(1).expand(B, self.n_cand))
             self._v_light.masked_fill_(m, 0)
@@ -415,10 +417,11 @@ class CrossroadEnd2end(object):
         d16 = torch.empty((16, B), dtype=torch.float32, device=dev)
         obs_out = torch.empty_like(self._obs)
         code = torch.empty((B,), dtype=torch.uint8, device=dev)
-        key = (self._v_light._version, self._virtual._version)          # in-place writes bump the tensors' versions
-        if key != getattr(self, '_light_key', None):
+        # in-place torch writes bump a tensor's version; the flow source writes its light through the C-ABI instead
+        key = (id(self._v_light), self._v_light._version, id(self._virtual), self._virtual._version)
+        if self._flows is not None or key != getattr(self, '_light_key', None):
             self._light = ((self._v_light != 0) | (self._virtual != 0)).to(torch.uint8)  # E2E:387-388
-            self._light_key = (self._v_light._version, self._virtual._version)
+            self._light_key = key
         light = self._light
         ri = self._ref_idx
         if B == 1:
@@ -432,9 +435,8 @@ class CrossroadEnd2end(object):
         self._obs, self.done_code = obs_out, code
         if self._flows is not None:       # exits, emissions and the light for the NEXT step (the obs saw this step's state)
             self._flows.cand = self._cand
-            self._flows.after_step()
-            self._cand, self._cand_mode = self._flows.cand, self._flows.mode()
-            self._v_light.copy_(self._flows.v_light())
+            self._flows.after_step(self.api, self._traffic.h, sp)
+            self._cand, self._cand_mode, self._v_light = self._flows.cand, self._flows.mode(), self._flows.v_light()
         elif self.respawn:                # vehicles that left the map re-enter on their lane (one kernel, counter-based draws)
             self._respawn_counter += 1
             self.api.traffic_respawn(self._traffic.h, B, self.n_cand, _ptr(self._cand), _ptr(self._entry5),

@@ -20,7 +20,9 @@ with the analytic model's own prediction step (EnvironmentModel.veh_predict, DAM
 arc inside the junction), which is what the safety shield assumes about it anyway.  Vehicles are dropped 40 m past
 the junction, beyond every range filter of the observation (E2E:393-411).
 
-Host logic over torch tensors (plumbing); no arithmetic of the hot path lives here."""
+The per-step rule is one kernel (eb_traffic_flow_step, include/envbuild.h; identical in the CPU oracle); this module
+holds the tables, the slot state and the (rare) reset logic over torch tensors."""
+import ctypes as C
 import math
 
 import torch
@@ -89,25 +91,34 @@ class FlowTraffic(object):
         vt = [VTYPES[FLOWS[m][1]] for m in self.slot_modes]
         self.lw = torch.tensor([[v[0], v[1]] for v in vt], dtype=torch.float32, device=dev)          # [M, 2]
         self.vmax = torch.tensor([v[2] for v in vt], dtype=torch.float32, device=dev)               # [M]
+        self.lane5 = torch.cat([self.start, self.dirn], 1).contiguous()                              # [M, 5]
         self.cand = torch.zeros((self.B, self.M, 4), dtype=torch.float32, device=dev)
         self.active = torch.zeros((self.B, self.M), dtype=torch.bool, device=dev)
         self.timer = torch.zeros((self.B, len(ROUTES)), dtype=torch.float32, device=dev)
-        self.sim_time = torch.zeros((self.B,), dtype=torch.float64, device=dev)
+        self.sim_step = torch.zeros((self.B,), dtype=torch.int32, device=dev)
         self.phase0 = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
-        self.emitted = torch.zeros((self.B, len(ROUTES)), dtype=torch.int64, device=dev)
+        self.emitted = torch.zeros((self.B, len(ROUTES)), dtype=torch.int32, device=dev)
+        self._mode = torch.full((self.B, self.M), _capi.VMODE_EMPTY, dtype=torch.uint8, device=dev)
+        self._vlight = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
+        self.seed, self.counter = 0x5EED, 0
 
     # -- views the env hands to the kernels -----------------------------------------------------------
     def mode(self):
+        return self._mode
+
+    def _refresh_mode(self):
         empty = torch.full_like(self.route_id, _capi.VMODE_EMPTY).expand(self.B, self.M)
-        return torch.where(self.active, self.route_id.expand(self.B, self.M), empty).contiguous()
+        self._mode = torch.where(self.active, self.route_id.expand(self.B, self.M), empty).contiguous()
 
     def cand_lw(self):
         return self.lw.expand(self.B, self.M, 2).contiguous()
 
     def v_light(self):
-        if self.env_mode == 'training':                                   # traffic.py:222-223
-            return self.phase0.clone()
-        return light_phase(self.sim_time).to(self.dev)
+        return self._vlight
+
+    @property
+    def sim_time(self):
+        return self.sim_step.to(torch.float64) * self.dt
 
     # -- dynamics -------------------------------------------------------------------------------------
     def _rand(self, *shape):
@@ -132,13 +143,17 @@ class FlowTraffic(object):
         p = (expect / K).repeat_interleave(K)
         self._place(rows_m & (self._rand(B, M) < p))
         self.timer = torch.where(rows.unsqueeze(1), self._rand(B, len(ROUTES)) * self.period, self.timer)
-        self.sim_time = torch.where(rows, torch.zeros_like(self.sim_time), self.sim_time)
+        self.sim_step = torch.where(rows, torch.zeros_like(self.sim_step), self.sim_step)
         self.emitted = torch.where(rows.unsqueeze(1), torch.zeros_like(self.emitted), self.emitted)
         ph = torch.zeros((B,), dtype=torch.uint8, device=self.dev)
         if self.task == 'right':                                           # traffic.py:159-161
             ph = torch.where(self._rand(B) > 0.5, torch.full_like(ph, 2), ph)
         self.phase0 = torch.where(rows, ph, self.phase0)
         self._remove_conflicts(rows, ego)
+        self._refresh_mode()
+        # training pins the phase (traffic.py:222-223); otherwise the programme restarts at phase 0 with the clock
+        self._vlight = torch.where(rows, self.phase0 if self.env_mode == 'training' else torch.zeros_like(self.phase0),
+                                   self._vlight)
 
     def _remove_conflicts(self, rows, ego):
         """traffic.py:168-192: drop a vehicle when it sits in the box ahead of / behind the ego in ego coordinates,
@@ -155,26 +170,16 @@ class FlowTraffic(object):
         hit = ((xe > -5) & (xe < ev + reach) & (ye.abs() < 3)) | ((xv > -5) & (xv < v + reach) & (yv.abs() < 3))
         self.active = self.active & ~(hit & rows.unsqueeze(1))
 
-    def after_step(self):
-        """Bookkeeping after the env has advanced every slot by one prediction step: exits, emissions, clock."""
-        B, M, K = self.B, self.M, self.K
-        x, y, phi = self.cand[:, :, 0], self.cand[:, :, 1], self.cand[:, :, 3] * (math.pi / 180.)
-        outward = x * torch.cos(phi) + y * torch.sin(phi) > 0               # heading away from the junction
-        gone = (torch.maximum(x.abs(), y.abs()) > EXIT_RANGE) & outward
-        self.active = self.active & ~gone
-        v = torch.minimum(self.cand[:, :, 2] + ACCEL * self.dt, self.vmax)  # free-flow acceleration to maxSpeed
-        self.cand = torch.cat([self.cand[:, :, :2], v.unsqueeze(2), self.cand[:, :, 3:]], 2)
-        self.timer = self.timer + self.dt
-        due = self.timer >= self.period                                     # [B, 12]
-        free = (~self.active).reshape(B, len(ROUTES), K)
-        first = torch.zeros_like(free)
-        taken = torch.zeros((B, len(ROUTES)), dtype=torch.bool, device=self.dev)
-        for k in range(K):                                                  # first free slot of the route
-            first[:, :, k] = free[:, :, k] & ~taken
-            taken = taken | free[:, :, k]
-        emit = first & due.unsqueeze(2)                                     # a full route keeps its vehicle waiting
-        did = emit.any(2)
-        self.timer = torch.where(did, self.timer - self.period, self.timer)
-        self.emitted = self.emitted + did.to(torch.int64)
-        self._place(emit.reshape(B, M))
-        self.sim_time = self.sim_time + self.dt
+    def after_step(self, api, handle, stream):
+        """Bookkeeping after the env has advanced every slot by one prediction step — exits, free-flow acceleration,
+        emissions, clock and light — as ONE kernel (eb_traffic_flow_step)."""
+        self.counter += 1
+        if not self.cand.is_contiguous():
+            self.cand = self.cand.contiguous()
+        act8 = self.active.view(torch.uint8) if self.active.dtype == torch.bool else self.active
+        p = lambda t: C.c_void_p(t.data_ptr())
+        api.traffic_flow_step(handle, self.B, self.K, p(self.cand), p(act8), p(self.timer), p(self.emitted),
+                              p(self.sim_step), p(self.lane5), p(self.period), p(self.vmax), C.c_float(self.dt),
+                              C.c_float(EXIT_RANGE), C.c_float(ACCEL), C.c_float(LANE_START - CROSSROAD_SIZE / 2),
+                              0 if self.env_mode == 'training' else 1, C.c_uint64(self.seed), C.c_uint64(self.counter),
+                              p(self._mode), p(self._vlight), stream)

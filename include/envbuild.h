@@ -266,6 +266,23 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
 int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
                        float span, float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, void* stream);
 
+/* One step of the SUMO-free FLOW traffic source (env_build_amd/traffic.py states the rules and where each number
+ * comes from in sumo_files/cross.rou.xml and a.net.xml) AFTER the slots have been advanced by eb_veh_predict:
+ * slots are route-major, `per_route` per route, 12 routes in EB_VMODE_* order (m = 12 * per_route <= 64).
+ * Per env and route, in slot order: an active vehicle that is farther than exit_range from the centre and heading
+ * away from it is dropped; the others accelerate, v = min(v + accel * dt, v_max[slot]).  Then timer += dt and, when
+ * timer >= period[route] and the route has a vacant slot, the first vacant slot receives a vehicle at
+ * lane[slot] + u1 * lane_len along the lane with speed u2 * v_max[slot] (u1, u2 as in eb_traffic_respawn, keyed by
+ * the route's first slot), timer -= period, emitted += 1.  sim_step[env] += 1 and, when light_cycle != 0,
+ * v_light[env] = phase of the 25 / 5 / 25 / 5 s programme at sim_step * dt.  cand_mode = route id or EB_VMODE_EMPTY.
+ *   cand [n_env, m, 4], active uint8 [n_env, m], timer [n_env, 12], emitted int32 [n_env, 12], sim_step int32 [n_env],
+ *   lane [m, 5] = (x, y, phi, dx, dy), period [12], v_max [m]; outputs cand_mode uint8 [n_env, m], v_light uint8 [n_env]. */
+int eb_traffic_flow_step(eb_handle h, int32_t n_env, int32_t per_route, float* cand, uint8_t* active, float* timer,
+                         int32_t* emitted, int32_t* sim_step, const float* lane, const float* period,
+                         const float* v_max, float dt, float exit_range, float accel, float lane_len,
+                         int32_t light_cycle, uint64_t seed, uint64_t counter, uint8_t* cand_mode, uint8_t* v_light,
+                         void* stream);
+
 /* ---- the policy in the loop: MLPNet + LoadPolicy.run_batch + the safety shield ----
  *
  * utils/model.py:18-43 `MLPNet`: Dense(obs_dim -> n_units, act) , (n_hidden - 1) x Dense(n_units -> n_units, act),

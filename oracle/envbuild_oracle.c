@@ -1188,6 +1188,69 @@ int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, 
     return EB_OK;
 }
 
+int eb_traffic_flow_step(eb_handle h, int32_t n_env, int32_t per_route, float* cand, uint8_t* active, float* timer,
+                         int32_t* emitted, int32_t* sim_step, const float* lane, const float* period,
+                         const float* v_max, float dt, float exit_range, float accel, float lane_len,
+                         int32_t light_cycle, uint64_t seed, uint64_t counter, uint8_t* cand_mode, uint8_t* v_light,
+                         void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || per_route < 1 || per_route * 12 > 64 || !(dt > 0.0f) ||
+        (n_env > 0 && (!cand || !active || !timer || !emitted || !sim_step || !lane || !period || !v_max || !cand_mode || !v_light)))
+        return fail(EB_EINVAL, "eb_traffic_flow_step: bad argument");
+    const int K = per_route, M = 12 * K;
+    for (int e = 0; e < n_env; ++e) {
+        for (int r = 0; r < 12; ++r) {
+            const size_t s0 = (size_t)e * M + (size_t)r * K;
+            int vacant = -1;
+            for (int k = 0; k < K; ++k) {
+                float* c = cand + (s0 + k) * 4;
+                int on = active[s0 + k] != 0;
+                if (on) {
+                    float sn, cs;
+                    eb_sincosf(deg2rad(c[3]), &sn, &cs);
+                    const int outward = c[0] * cs + c[1] * sn > 0.0f;
+                    if (fmaxf(fabsf(c[0]), fabsf(c[1])) > exit_range && outward) {
+                        on = 0;
+                    } else {
+                        const float vn = c[2] + accel * dt, vm = v_max[r * K + k];
+                        c[2] = vn < vm ? vn : vm;
+                    }
+                }
+                active[s0 + k] = (uint8_t)on;
+                if (!on && vacant < 0) vacant = k;
+            }
+            const size_t idx = (size_t)e * 12 + r;
+            float t = timer[idx] + dt;
+            const float per = period[r];
+            if (t >= per && vacant >= 0) {
+                const int j = r * K + vacant;
+                const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)(r * K) * 2u;
+                const float u1 = (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
+                const float u2 = (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
+                const float* ln = lane + 5 * j;
+                const float along = u1 * lane_len;
+                float* c = cand + (s0 + vacant) * 4;
+                c[0] = ln[0] + along * ln[3];
+                c[1] = ln[1] + along * ln[4];
+                c[2] = u2 * v_max[j];
+                c[3] = ln[2];
+                active[s0 + vacant] = 1;
+                t = t - per;
+                emitted[idx] += 1;
+            }
+            timer[idx] = t;
+            for (int k = 0; k < K; ++k) cand_mode[s0 + k] = active[s0 + k] ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+        }
+        const int n = sim_step[e] + 1;
+        sim_step[e] = n;
+        if (light_cycle) { /* a.net.xml:145-150 */
+            const float tt = (float)(n % (int)(60.0f / dt + 0.5f)) * dt;
+            v_light[e] = tt < 25.0f ? 0 : (tt < 30.0f ? 1 : (tt < 55.0f ? 2 : 3));
+        }
+    }
+    return EB_OK;
+}
+
 /* ================================================================================================
  * Policy network in the loop — TEST INFRASTRUCTURE like the rest of this file.
  * MLPNet (utils/model.py:18-43), the 'scale' preprocessor (utils/preprocessor.py:116-123), the deterministic

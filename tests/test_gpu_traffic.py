@@ -38,13 +38,16 @@ def test_flow_schedule_types_and_light():
         env.step(zero)
         lights.append(int(env._v_light[0].item()))
     emitted = fl.emitted.cpu().numpy().astype(np.float64)
+    assert np.all(fl.sim_step.cpu().numpy() == steps)
     for k, r in enumerate(ROUTES):
         want = steps * 0.1 * FLOWS[r][0] / 3600.0                    # vehsPerHour spacing
         assert abs(emitted[:, k].mean() - want) < 1.0, (r, emitted[:, k].mean(), want)
         assert emitted[:, k].max() <= want + 1
     # light programme of a.net.xml:145-150 in 'testing' mode: 25 s phase 0, 5 s phase 1, 25 s phase 2, 5 s phase 3
-    want_l = [0] * 249 + [1] * 50 + [2] * 250 + [3] * 50
-    assert sum(a != b for a, b in zip(lights[:599], want_l[:599])) <= 4      # step boundaries at float time
+    def phase(n):                                                     # n steps of 0.1 s since the reset
+        n %= 600
+        return 0 if n < 250 else (1 if n < 300 else (2 if n < 550 else 3))
+    assert lights == [phase(t + 1) for t in range(steps)]             # lights[t] is the phase after step t + 1
     assert light_phase(61.0).item() == 0
     # vTypes: length / width / maxSpeed per flow; nobody exceeds its maxSpeed; everybody speeds up to it
     lw, v = fl.lw.cpu().numpy(), fl.cand[:, :, 2].cpu().numpy()
@@ -131,3 +134,56 @@ def test_traffic_respawn_equals_oracle_and_depends_on_its_key_only():
     assert np.array_equal(dev._ret(c2), got[:100])
     u = got[gone][:, 2] / 8.0
     assert abs(u.mean() - 0.5) < 0.03                                   # roughly uniform draws
+
+
+def test_flow_step_kernel_equals_oracle():
+    """eb_traffic_flow_step: device == oracle bit for bit over 300 steps of a free-running traffic state (exits,
+    acceleration, emissions, slot modes, clock, light), each side advancing its slots with its own eb_veh_predict."""
+    import ctypes as C
+    from tests._helpers import DeviceModel
+    from env_build_amd.traffic import ACCEL, EXIT_RANGE, FLOWS, LANE_START, ROUTES, VTYPES, approach_lane
+    K, B = 5, 40
+    M = 12 * K
+    slot_modes = [r for r in ROUTES for _ in range(K)]
+    host, dev = HostModel(oracle_lib(), 'left', n_veh=M, modes=slot_modes), DeviceModel('left', n_veh=M, modes=slot_modes)
+    lane = np.array([list(approach_lane(m)[0]) + list(approach_lane(m)[1]) for m in slot_modes], np.float32)
+    period = np.array([3600.0 / FLOWS[r][0] for r in ROUTES], np.float32)
+    vmax = np.array([VTYPES[FLOWS[m][1]][2] for m in slot_modes], np.float32)
+    rng = np.random.default_rng(5)
+    state0 = dict(cand=np.zeros((B, M, 4), np.float32), active=np.zeros((B, M), np.uint8),
+                  timer=(rng.random((B, 12)) * period).astype(np.float32), emitted=np.zeros((B, 12), np.int32),
+                  sim_step=np.zeros((B,), np.int32))
+    res = []
+    for mdl in (host, dev):
+        st = {k: mdl._in(v.copy(), v.dtype) if k in ('cand', 'timer') else None for k, v in state0.items()}
+        if mdl is host:
+            st = {k: v.copy() for k, v in state0.items()}
+            ln, pe, vm = lane, period, vmax
+            mode, light = np.zeros((B, M), np.uint8), np.zeros((B,), np.uint8)
+            ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        else:
+            t = mdl.torch
+            st = {k: t.from_numpy(v.copy()).to(mdl.dev) for k, v in state0.items()}
+            ln, pe, vm = (t.from_numpy(x).to(mdl.dev) for x in (lane, period, vmax))
+            mode, light = t.zeros((B, M), dtype=t.uint8, device=mdl.dev), t.zeros((B,), dtype=t.uint8, device=mdl.dev)
+            ptr = lambda a: C.c_void_p(a.data_ptr())
+        trace = []
+        for step in range(300):
+            flat = st['cand'].reshape(B, 4 * M)
+            mdl.api.veh_predict(mdl.h, B, ptr(flat), ptr(flat), mdl.stream)          # in place, as eb_env_step does
+            mdl.api.traffic_flow_step(mdl.h, B, K, ptr(st['cand']), ptr(st['active']), ptr(st['timer']), ptr(st['emitted']),
+                                      ptr(st['sim_step']), ptr(ln), ptr(pe), ptr(vm), C.c_float(0.1), C.c_float(EXIT_RANGE),
+                                      C.c_float(ACCEL), C.c_float(LANE_START - 25.0), 1, C.c_uint64(99), C.c_uint64(step + 1),
+                                      ptr(mode), ptr(light), mdl.stream)
+            if step % 50 == 49:
+                get = (lambda a: a.copy()) if mdl is host else (lambda a: (mdl.torch.cuda.synchronize(), a.cpu().numpy())[1])
+                trace.append({k: get(v) for k, v in dict(st, mode=mode, light=light).items()})
+        res.append(trace)
+    for a, b in zip(*res):
+        on = a['active'] != 0
+        assert np.array_equal(a['active'], b['active']) and np.array_equal(a['mode'], b['mode'])
+        assert np.array_equal(a['cand'][on], b['cand'][on])
+        for k in ('timer', 'emitted', 'sim_step', 'light'):
+            assert np.array_equal(a[k], b[k]), k
+    last = res[1][-1]
+    assert last['emitted'].min() >= 4 and (last['active'] != 0).sum() > 12 * B and set(np.unique(last['light'])) <= {0, 1, 2, 3}
