@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--n-env', type=int, default=N_ENV, help='envs per GPU (default: configs[2])')
     ap.add_argument('--n-veh', type=int, default=N_VEH)
     ap.add_argument('--eager', action='store_true', help='one host launch per step instead of hipGraph replays')
+    ap.add_argument('--graph', action='store_true', help='hipGraph replays (default: whichever of the two the warm-up finds faster)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--open-loop', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
@@ -202,6 +203,21 @@ def main():
 
     run(args.warmup, False)
     torch.cuda.synchronize()
+    # launch form of the timed region: the same 25 launches per rollout either as one hipGraph replay or as 25 host
+    # calls; which one keeps the queue fuller depends on the host, so two warm rollouts of each are timed first
+    if not (args.eager or args.graph or args.open_loop) and args.warmup >= HORIZON:
+        trial = {False: [], True: []}
+        for form in (False, True, False, True, False, True):
+            args.eager = form
+            run(HORIZON, False)
+            lib.eb_event_record(ev[0], sp)
+            run(4 * HORIZON, False)
+            lib.eb_event_record(ev[1], sp)
+            ms_t = C.c_float()
+            api.event_elapsed_ms(ev[0], ev[1], C.byref(ms_t))
+            trial[form].append(ms_t.value)
+        args.eager = min(trial[True]) < min(trial[False])
+        torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()

@@ -264,9 +264,12 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
     do {                                                                                                             \
         const dim3 g((n_env + 63) / 64), b(staged ? 256 : 64);                                                       \
         if (staged) {                                                                                                \
-            if (lds > 48 * 1024)                                                                                     \
+            static size_t granted = 48 * 1024;   /* the > 48 KB opt-in is per kernel and sticky */                   \
+            if (lds > granted) {                                                                                     \
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&get_obs_kernel<T, true>),                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+                if (e == hipSuccess) granted = lds;                                                                  \
+            }                                                                                                        \
             if (e == hipSuccess)                                                                                     \
                 hipLaunchKernelGGL((get_obs_kernel<T, true>), g, b, lds, s, n_env, D, n_future, NV, pt, modes, ego,  \
                                    ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out);                  \

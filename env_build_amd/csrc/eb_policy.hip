@@ -255,11 +255,15 @@ hipError_t launch_mlp(const MlpArgs& A, hipStream_t s) {
     const dim3 g((A.n + MLP_ROWS - 1) / MLP_ROWS), b(MLP_THREADS);
     const size_t lds = mlp_lds_bytes(A);
     hipError_t e = hipSuccess;
+    // the opt-in for > 48 KB of dynamic LDS is per kernel and sticky: raise it only when a launch needs more
 #define EB_MLP_LAUNCH(RT, CT)                                                                                     \
     do {                                                                                                          \
-        if (lds > 48 * 1024)                                                                                      \
+        static size_t granted = 48 * 1024;                                                                        \
+        if (lds > granted) {                                                                                      \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<RT, CT>),                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+            if (e == hipSuccess) granted = lds;                                                                   \
+        }                                                                                                         \
         if (e == hipSuccess) hipLaunchKernelGGL((mlp_kernel<RT, CT>), g, b, lds, s, A);                           \
     } while (0)
     switch (A.units) {
