@@ -10,9 +10,10 @@ end of every 25-step horizon, inside the timed region.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-The K timed steps run as K // 25 replays of a 25-launch hipGraph (eb_plan_*, one kernel launch per
-rollout step — the policy-in-the-loop form, not a fused open-loop kernel) plus K % 25 eager
-eb_rollout_step launches.  Rank 0 prints ONE JSON line with two extra objects:
+The K timed steps run as K // 25 rollouts of 25 launches (one kernel launch per rollout step — the
+policy-in-the-loop form, not a fused open-loop kernel), either as replays of a 25-launch hipGraph (eb_plan_*,
+--graph) or as 25 eager eb_rollout_step calls (--eager); by default the warm-up times both and the timed
+region uses the faster.  Rank 0 prints ONE JSON line with two extra objects:
   roofline     — algorithmic bytes per launch (104 + 32*N_veh per env-step) divided
                  by the rollout kernel's average launch duration, measured with HIP event pairs
                  (eb_event_*) on the launch stream around every graph replay — so the figure includes
@@ -33,6 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import env_build_amd  # noqa: E402,F401  (sets HIP_FORCE_DEV_KERNARG before the HIP runtime starts)
 
 TASK, N_ENV, N_VEH, HORIZON = 'left', 65536, 32, 25
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec

@@ -3,4 +3,12 @@
 Host code is Python calling hand-written HIP kernels (gfx950) through the C-ABI of
 include/envbuild.h.  There is no CPU fallback: using any compute entry point without
 env_build_amd/lib/libenvbuild_hip.so and a visible MI355X raises."""
+import os as _os
+
+# Kernel arguments in device memory instead of host-coherent memory: the first waves of every launch read them,
+# and the rollout is one short launch per step (measured: 16.2 -> 15.6 us per launch).  The HIP runtime reads the
+# variable when it initialises, so it is set on import — before torch or this package touches the GPU; an explicit
+# setting of the caller wins.
+_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
 __version__ = '0.1.0'
