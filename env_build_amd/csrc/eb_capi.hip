@@ -586,11 +586,27 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         return fail(EB_EINVAL, "eb_env_step: bad argument");
     if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_step: the traffic handle must have n_veh == m_cand");
     if (n_env == 0) return EB_OK;
-    int rc = eb_action_transform(h, n_env, actions, scaled_actions, stream);                     /* E2E:133 */
-    if (!rc) rc = eb_compute_rewards(h, n_env, obs, scaled_actions, out5, out_dict16, stream);      /* E2E:134 */
-    if (!rc) rc = eb_env_ego_step(h, n_env, ego, scaled_actions, ego, params, stream);           /* E2E:135 */
-    if (!rc) rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                            /* TRF:220-238's role */
-    if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, stream);   /* E2E:140 */
+    // E2E:133-135 in one launch: action scaling, reward on the current obs, ego step in place (the same device
+    // functions eb_action_transform / eb_compute_rewards / eb_env_ego_step run)
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_env_pre(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, obs, actions,
+                              scaled_actions, out5, out_dict16, ego, params, pick(h, stream)));
+    int rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                                 /* TRF:220-238's role */
+    if (rc) return rc;
+    if (m_cand > 0 && eb::get_obs_is_staged(obs_dim(h->cfg), m_cand, cand)) {
+        // E2E:140-141 in one launch: the observation kernel keeps the tile's candidates and the new delta_y in LDS and
+        // appends _judge_done (the same device functions eb_judge_done runs)
+        rc = check_paths(h, "eb_env_step: null handle");
+        if (!rc) rc = check_modes(h);
+        if (rc) return rc;
+        if (!cand_mode) return fail(EB_EINVAL, "eb_env_step: bad argument");
+        if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
+        EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
+                                  ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, pick(h, stream), params,
+                                  nullptr, v_light, done_code));
+        return EB_OK;
+    }
+    rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, stream);   /* E2E:140 */
     if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, nullptr, v_light, done_code, stream);   /* E2E:141 */
     return rc;
 }

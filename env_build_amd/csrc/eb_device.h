@@ -330,4 +330,46 @@ EB_DEV float wrap_deal_with_phi(float phi) {  // UTL:232-237
     return phi;
 }
 
+// compute_rewards (DAM:186-320) for env i with the scaled action (steer, a_x); same per-vehicle association as the
+// fused rollout kernel
+template <int TASK>
+EB_DEV void rewards_env(int i, int n_env, int D, int n_future, int NV, const float* __restrict__ obs, float steer,
+                        float a_x, float* __restrict__ out5, float* __restrict__ d16) {
+    const float* o = obs + (size_t)D * i;
+    const float* veh = o + 6 + 3 * (n_future + 1);
+    const float punish_steer = -sq(steer), punish_a_x = -sq(a_x), punish_yaw_rate = -sq(o[2]);
+    const float devi_y = -sq(o[6]), devi_phi = -sq(deg2rad(o[7])), devi_v = -sq(o[8]);
+    float es, ec;
+    sincos_det(deg2rad(o[5]), es, ec);
+    const float4 pts = make_float4(o[3] + LWS * ec, o[4] + LWS * es, o[3] - LWS * ec, o[4] - LWS * es);
+    float v2v_train = 0.0f, v2v_real = 0.0f;
+    for (int j = 0; j < NV; ++j) {
+        const float* v = veh + 4 * j;
+        float vs, vc, t35[4], t25[4];
+        sincos_det(deg2rad(v[3]), vs, vc);
+        veh2veh_terms(pts, v[0], v[1], vs, vc, t35, t25);
+        v2v_train += ((t35[0] + t35[1]) + t35[2]) + t35[3];
+        v2v_real += ((t25[0] + t25[1]) + t25[2]) + t25[3];
+    }
+    float road_t = 0.0f, road_r = 0.0f;
+    road_terms<TASK>(pts.x, pts.y, road_t, road_r);
+    road_terms<TASK>(pts.z, pts.w, road_t, road_r);
+    const float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                          5.0f * punish_steer + 0.05f * punish_a_x;
+    const size_t n = (size_t)n_env;
+    out5[i] = rewards;
+    out5[n + i] = v2v_train + road_t;
+    out5[2 * n + i] = v2v_real + road_r;
+    out5[3 * n + i] = v2v_real;
+    out5[4 * n + i] = road_r;
+    if (d16) {  // DAM:302-318
+        d16[i] = punish_steer; d16[n + i] = punish_a_x; d16[2 * n + i] = punish_yaw_rate;
+        d16[3 * n + i] = devi_v; d16[4 * n + i] = devi_y; d16[5 * n + i] = devi_phi;
+        d16[6 * n + i] = 5.0f * punish_steer; d16[7 * n + i] = 0.05f * punish_a_x;
+        d16[8 * n + i] = 0.02f * punish_yaw_rate; d16[9 * n + i] = 0.05f * devi_v;
+        d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
+        d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
+    }
+}
+
 }  // namespace eb

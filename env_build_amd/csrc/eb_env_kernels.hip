@@ -17,6 +17,16 @@ namespace eb {
 struct V4 { float x, y, v, phi; };
 
 // a14: _get_next_ego_state, E2E:269-283
+EB_DEV void env_ego_step_row(const float (&st)[6], float steer, float a_x, float (&nx)[6], float (&pr)[4]) {
+    const float phi_rad = deg2rad(st[5]);
+    float sn, cs;
+    sincos_det(phi_rad, sn, cs);
+    f_xu_core(st, steer, a_x, TAU10, phi_rad, sn, cs, nx);   // E2E:279
+    f_xu_params(st, steer, a_x, pr);
+    nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;                     // E2E:281
+    nx[5] = wrap_deal_with_phi(nx[5]);                        // E2E:282
+}
+
 // (ego and next_ego may be the same buffer: eb_env_step updates the state in place)
 __global__ void env_ego_step_kernel(int n, const float* ego, const float* __restrict__ actions,
                                     float* next_ego, float* __restrict__ params) {
@@ -25,18 +35,45 @@ __global__ void env_ego_step_kernel(int n, const float* ego, const float* __rest
     float st[6], nx[6], pr[4];
 #pragma unroll
     for (int c = 0; c < 6; ++c) st[c] = ego[6 * (size_t)i + c];
-    const float steer = actions[2 * (size_t)i], a_x = actions[2 * (size_t)i + 1];
-    const float phi_rad = deg2rad(st[5]);
-    float sn, cs;
-    sincos_det(phi_rad, sn, cs);
-    f_xu_core(st, steer, a_x, TAU10, phi_rad, sn, cs, nx);   // E2E:279
-    f_xu_params(st, steer, a_x, pr);
-    nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;                     // E2E:281
-    nx[5] = wrap_deal_with_phi(nx[5]);                        // E2E:282
+    env_ego_step_row(st, actions[2 * (size_t)i], actions[2 * (size_t)i + 1], nx, pr);
 #pragma unroll
     for (int c = 0; c < 6; ++c) next_ego[6 * (size_t)i + c] = nx[c];
 #pragma unroll
     for (int c = 0; c < 4; ++c) params[4 * (size_t)i + c] = pr[c];
+}
+
+// The first three calls of CrossroadEnd2end.step for one env in one launch (eb_env_step): action scaling (E2E:133),
+// reward on the current obs (E2E:134) and the ego step (E2E:135), each the same device function its own kernel runs.
+template <int TASK>
+__global__ void env_pre_kernel(int n_env, int D, int n_future, int NV, const float* __restrict__ obs,
+                               const float* __restrict__ raw, float* __restrict__ scaled, float* __restrict__ out5,
+                               float* __restrict__ d16, float* __restrict__ ego, float* __restrict__ params) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_env) return;
+    float steer, a_x;
+    action_transform(raw[2 * (size_t)i], raw[2 * (size_t)i + 1], steer, a_x);
+    scaled[2 * (size_t)i] = steer;
+    scaled[2 * (size_t)i + 1] = a_x;
+    rewards_env<TASK>(i, n_env, D, n_future, NV, obs, steer, a_x, out5, d16);
+    float st[6], nx[6], pr[4];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st[c] = ego[6 * (size_t)i + c];
+    env_ego_step_row(st, steer, a_x, nx, pr);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ego[6 * (size_t)i + c] = nx[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) params[4 * (size_t)i + c] = pr[c];
+}
+
+hipError_t launch_env_pre(int task, int n_env, int D, int n_future, int NV, const float* obs, const float* raw,
+                          float* scaled, float* out5, float* d16, float* ego, float* params, hipStream_t s) {
+    const dim3 g((n_env + 127) / 128), b(128);
+    switch (task) {
+        case TASK_LEFT: hipLaunchKernelGGL(env_pre_kernel<TASK_LEFT>, g, b, 0, s, n_env, D, n_future, NV, obs, raw, scaled, out5, d16, ego, params); break;
+        case TASK_STRAIGHT: hipLaunchKernelGGL(env_pre_kernel<TASK_STRAIGHT>, g, b, 0, s, n_env, D, n_future, NV, obs, raw, scaled, out5, d16, ego, params); break;
+        default: hipLaunchKernelGGL(env_pre_kernel<TASK_RIGHT>, g, b, 0, s, n_env, D, n_future, NV, obs, raw, scaled, out5, d16, ego, params); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, float* next_ego, float* params,
@@ -116,6 +153,89 @@ EB_DEV bool fetch_candidate(int m, int i, int m_cand, const float* cand, const u
     return true;
 }
 
+// ---- a17: _judge_done, E2E:200-256 ---------------------------------------------------------------
+EB_DEV bool judge_feasible(float x, float y, int task) {   // UTL:73-104
+    const float C2 = HALF_CROSS, LW = LANE_W;
+    const bool middle = (-C2 < y && y < C2) && (-C2 < x && x < C2);
+    if (task == TASK_LEFT)
+        return (0.0f < x && x < LW && y <= -C2) || (0.0f < y && y < LW * 3.0f && x < -C2) || middle;
+    if (task == TASK_STRAIGHT)
+        return (LW < x && x < LW * 2.0f && y <= -C2) || (0.0f < x && x < LW * 3.0f && y >= C2) || middle;
+    return (LW * 2.0f < x && x < LW * 3.0f && y <= -C2) || (-LW * 3.0f < y && y < 0.0f && x > C2) || middle;
+}
+
+// Traffic.collision_check (TRF:263-295) of one ego against the candidates c = first, first + stride, ...; `row` holds
+// the candidates as (x, y, v, phi) float4s, `mrow` their mode ids, `lw` their (l, w) pairs or NULL for (4.8, 2.0)
+struct EgoCircles { float x0, y0, x1, y1; };
+EB_DEV EgoCircles ego_circles(float x, float y, float phi) {
+    float es, ec;
+    sincos_det(phi / 180.0f * PI_F, es, ec);
+    const float ego_lw = (4.8f - 2.0f) / 2;
+    return EgoCircles{x + ec * ego_lw, y + es * ego_lw, x - ec * ego_lw, y - es * ego_lw};
+}
+EB_DEV bool collision_with(const EgoCircles& E, float x, float y, const float4 v, float vl, float vw) {
+    const float EGO_W = 2.0f;
+    if (!(__builtin_fabsf(v.x - x) < 10.0f && __builtin_fabsf(v.y - y) < 10.0f)) return false;
+    const float s_lw = (vl - vw) / 2;
+    float ss, sc;
+    sincos_det(v.w / 180.0f * PI_F, ss, sc);
+    const float sx0 = v.x + sc * s_lw, sy0 = v.y + ss * s_lw, sx1 = v.x - sc * s_lw, sy1 = v.y - ss * s_lw;
+    const float thr = sq((vw + EGO_W) / 2 + 0.5f);
+    return sq(E.x0 - sx0) + sq(E.y0 - sy0) < thr || sq(E.x0 - sx1) + sq(E.y0 - sy1) < thr ||
+           sq(E.x1 - sx1) + sq(E.y1 - sy1) < thr || sq(E.x1 - sx0) + sq(E.y1 - sy0) < thr;
+}
+
+// the rest of _judge_done (E2E:200-256) once the collision flag is known
+EB_DEV uint8_t judge_code(int task, bool collision, float v_x, float r, float x, float y, float phi, float miu_r,
+                          float delta_y, bool red_light) {
+    const float EGO_L = 4.8f, EGO_W = 2.0f;
+    // corner points (E2E:171-176, UTL:120-157) through judge_feasible
+    float rs, rc;
+    sincos_det(-phi * PI_F / 180.0f, rs, rc);
+    bool feasible = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float cx = (q < 2 ? EGO_L : -EGO_L) / 2, cy = ((q & 1) ? -EGO_W : EGO_W) / 2;
+        const float tx = cx * rc + cy * rs;
+        const float ty = -cx * rs + cy * rc;
+        const float X = tx - (-x), Y = ty - (-y);
+        feasible = feasible && judge_feasible(X, Y, task);
+    }
+    const float r_bound = miu_r * 9.81f / (__builtin_fabsf(v_x) + 1e-8f);   // E2E:167
+    bool goal;
+    if (task == TASK_LEFT) goal = x < -HALF_CROSS - 10.0f && 0.0f < y && y < 3.0f * LANE_W;
+    else if (task == TASK_RIGHT) goal = x > HALF_CROSS + 10.0f && -3.0f * LANE_W < y && y < 0.0f;
+    else goal = y > HALF_CROSS + 10.0f && 0.0f < x && x < 3.0f * LANE_W;
+    if (collision) return EB_DONE_COLLISION;
+    if (!feasible) return EB_DONE_BREAK_ROAD;
+    if (__builtin_fabsf(delta_y) > 15.0f) return EB_DONE_DEVIATE;                 // E2E:224
+    if (!(-r_bound < r && r < r_bound)) return EB_DONE_STABILITY;
+    if (red_light && y > -HALF_CROSS && task != TASK_RIGHT) return EB_DONE_RED_LIGHT;
+    if (goal) return EB_DONE_GOOD;
+    return EB_DONE_NOT_YET;
+}
+
+__global__ void judge_done_kernel(int task, int n_env, int D, const float* __restrict__ ego,
+                                  const float* __restrict__ params, const float* __restrict__ obs, int m_cand,
+                                  const float* __restrict__ cand, const uint8_t* __restrict__ cand_mode,
+                                  const float* __restrict__ cand_lw, const uint8_t* __restrict__ v_light,
+                                  uint8_t* __restrict__ done_code) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_env) return;
+    const float* e = ego + 6 * (size_t)i;
+    const float v_x = e[0], r = e[2], x = e[3], y = e[4], phi = e[5];
+    const EgoCircles E = ego_circles(x, y, phi);
+    bool collision = false;
+    for (int k = 0; k < m_cand; ++k) {
+        const size_t ck = (size_t)i * m_cand + k;
+        if (cand_mode[ck] == EB_VMODE_EMPTY) continue;
+        const float4 v = make_float4(cand[ck * 4], cand[ck * 4 + 1], cand[ck * 4 + 2], cand[ck * 4 + 3]);
+        collision = collision || collision_with(E, x, y, v, cand_lw ? cand_lw[ck * 2] : 4.8f, cand_lw ? cand_lw[ck * 2 + 1] : 2.0f);
+    }
+    done_code[i] = judge_code(task, collision, v_x, r, x, y, phi, params[4 * (size_t)i + 3], obs[(size_t)D * i + 6],
+                              v_light && v_light[i] != 0);
+}
+
 // the same for a candidate row staged in LDS as float4s
 EB_DEV bool fetch_candidate_lds(int m, int i, int m_cand, const float4* row, const uint8_t* mrow, bool virt, V4& v) {
     if (i < m_cand) {
@@ -133,14 +253,22 @@ EB_DEV bool fetch_candidate_lds(int m, int i, int m_cand, const float4* row, con
 EB_DEV int obs_cand_stride4(int m_cand) { return m_cand + ((m_cand & 1) ? 2 : 1); }   // float4s per LDS row, odd: no bank conflicts
 size_t get_obs_lds_bytes(int D, int m_cand) {
     const int rs4 = m_cand + ((m_cand & 1) ? 2 : 1);
-    return (size_t)64 * rs4 * 16 + (size_t)64 * (D + 1) * 4 + (size_t)64 * (m_cand + 4);
+    return (size_t)64 * rs4 * 16 + (size_t)64 * (D + 1) * 4 + (size_t)64 * (m_cand + 4) + (size_t)256 * (m_cand + 1);
 }
+
+// _judge_done appended to the observation kernel (eb_env_step): the tile's candidates and the new delta_y are in LDS
+struct JudgeArgs {
+    const float* params;      // [n_env, 4]
+    const float* cand_lw;     // [n_env, m_cand, 2] or NULL
+    const uint8_t* v_light;   // [n_env] or NULL
+    uint8_t* done_code;       // NULL: observation only (eb_get_obs)
+};
 
 template <int TASK, bool STAGED>
 __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTables pt, VehModes modes,
                                const float* __restrict__ ego, const int* __restrict__ ref_idx, int path_id,
                                int m_cand, const float* __restrict__ cand_all, const uint8_t* __restrict__ cmode_all,
-                               const uint8_t* __restrict__ light_flag, float* __restrict__ obs_out) {
+                               const uint8_t* __restrict__ light_flag, float* __restrict__ obs_out, const JudgeArgs J) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // 64 envs per block, one per lane; the block's four waves share the slots of the observation (wave w builds
     // slots w, w + 4, ...), wave 0 also the ego and tracking columns
@@ -151,6 +279,7 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
     float4* s_cand = reinterpret_cast<float4*>(smem);                       // [64][RS4]
     float* s_out = reinterpret_cast<float*>(smem + (size_t)64 * RS4 * 16);  // [64][D + 1]
     uint8_t* s_mode = smem + (size_t)64 * RS4 * 16 + (size_t)64 * OS * 4;   // [64][m_cand + 4]
+    uint8_t* s_list = s_mode + (size_t)64 * MS;                             // [4 waves][64][m_cand + 1] in-range index lists
     if (STAGED) {
         // the tile's candidates are contiguous in memory: coalesced 16-byte loads, one LDS row per env
         const float4* src = reinterpret_cast<const float4*>(cand_all) + (size_t)e0 * m_cand;
@@ -213,7 +342,53 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
     const uint8_t* mrow = s_mode + lane * MS;
     const bool virt = TASK != TASK_RIGHT && light_flag && light_flag[i] != 0 && ey < -HALF_CROSS;   // E2E:386-388
     float* ov = o + 6 + T;
-    for (int s = STAGED ? wave : 0; s < NV; s += STAGED ? 4 : 1) {
+    if (STAGED) {
+        // The distinct modes of the slot list are dealt round-robin to the four waves.  For its mode a lane first
+        // compacts the in-range candidates of that mode into a short index list (one walk over the candidates),
+        // then fills the mode's slots in order, each the next candidate after the previous pick under (sort key,
+        // insertion order) — the same sequence of picks as one selection pass per rank from scratch (E2E:414-437).
+        uint8_t* list = s_list + (wave * 64 + lane) * (m_cand + 1);
+        int distinct = 0;
+        for (int s = 0; s < NV; ++s) {
+            const int m = modes.mode[s];
+            bool first = true;
+            for (int t = 0; t < s; ++t) first = first && modes.mode[t] != m;
+            if (!first) continue;
+            if ((distinct++ & 3) != wave) continue;
+            int L = 0;
+            for (int c = 0; c <= m_cand; ++c) {
+                V4 v;
+                if (!fetch_candidate_lds(m, c, m_cand, crow, mrow, virt, v)) continue;
+                if (!veh_in_range(TASK, m, v, ex, ey)) continue;
+                list[L++] = (uint8_t)c;
+            }
+            V4 prev = {0, 0, 0, 0};
+            int prev_i = -1;
+            bool found = true;
+            for (int s2 = s; s2 < NV; ++s2) {
+                if (modes.mode[s2] != m) continue;
+                if (found) {
+                    V4 best = {0, 0, 0, 0};
+                    int best_i = -1;
+                    for (int q = 0; q < L; ++q) {
+                        const int c = list[q];
+                        V4 v;
+                        fetch_candidate_lds(m, c, m_cand, crow, mrow, virt, v);
+                        if (prev_i >= 0) {
+                            const int cp = veh_cmp(TASK, m, prev, v);
+                            if (!(cp < 0 || (cp == 0 && prev_i < c))) continue;   // not after the previous pick
+                        }
+                        if (best_i < 0 || veh_cmp(TASK, m, v, best) < 0) { best = v; best_i = c; }
+                    }
+                    if (best_i < 0) found = false;
+                    else { prev = best; prev_i = best_i; }
+                }
+                const V4 r = found ? prev : veh_fill_value(m);                 // slice_or_fill, E2E:431-437
+                ov[4 * s2] = r.x; ov[4 * s2 + 1] = r.y; ov[4 * s2 + 2] = r.v; ov[4 * s2 + 3] = r.phi;
+            }
+        }
+    } else {
+    for (int s = 0; s < NV; ++s) {
         const int m = modes.mode[s];
         int rank = 0;
         for (int t = 0; t < s; ++t) rank += modes.mode[t] == m;
@@ -226,8 +401,7 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
             int best_i = -1;
             for (int c = 0; c <= m_cand; ++c) {
                 V4 v;
-                if (!(STAGED ? fetch_candidate_lds(m, c, m_cand, crow, mrow, virt, v)
-                             : fetch_candidate(m, c, m_cand, cand, cmode, virt, v))) continue;
+                if (!fetch_candidate(m, c, m_cand, cand, cmode, virt, v)) continue;
                 if (!veh_in_range(TASK, m, v, ex, ey)) continue;
                 if (prev_i >= 0) {
                     const int cp = veh_cmp(TASK, m, prev, v);
@@ -241,9 +415,35 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
         const V4 r = found ? prev : veh_fill_value(m);                     // slice_or_fill, E2E:431-437
         ov[4 * s] = r.x; ov[4 * s + 1] = r.y; ov[4 * s + 2] = r.v; ov[4 * s + 3] = r.phi;
     }
+    }   // !STAGED
     }   // i < n_env
     if (STAGED) {
         __syncthreads();
+        if (J.done_code) {
+            // E2E:141 on the state just built: the four waves share the collision test (candidates w, w + 4, ...),
+            // wave 0 folds the flags and walks the priority chain
+            bool col = false;
+            if (i < n_env) {
+                const float* e = ego + 6 * (size_t)i;
+                const EgoCircles E = ego_circles(e[3], e[4], e[5]);
+                const float4* crow = s_cand + lane * RS4;
+                const uint8_t* mrow = s_mode + lane * MS;
+                for (int c = wave; c < m_cand; c += 4) {
+                    if (mrow[c] == EB_VMODE_EMPTY) continue;
+                    const size_t ck = (size_t)i * m_cand + c;
+                    col = col || collision_with(E, e[3], e[4], crow[c], J.cand_lw ? J.cand_lw[ck * 2] : 4.8f,
+                                                J.cand_lw ? J.cand_lw[ck * 2 + 1] : 2.0f);
+                }
+            }
+            s_list[wave * 64 + lane] = col ? 1 : 0;                         // the index lists are dead by now
+            __syncthreads();
+            if (wave == 0 && i < n_env) {
+                const float* e = ego + 6 * (size_t)i;
+                const bool collision = (s_list[lane] | s_list[64 + lane] | s_list[128 + lane] | s_list[192 + lane]) != 0;
+                J.done_code[i] = judge_code(TASK, collision, e[0], e[2], e[3], e[4], e[5], J.params[4 * (size_t)i + 3],
+                                            s_out[lane * OS + 6], J.v_light && J.v_light[i] != 0);
+            }
+        }
         float* dst = obs_out + (size_t)e0 * D;                              // the tile's rows are contiguous too
         const int total = nE * D;
         for (int idx = threadIdx.x; idx < total; idx += 256) {
@@ -253,12 +453,20 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
     }
 }
 
+bool get_obs_is_staged(int D, int m_cand, const float* cand) {
+    return get_obs_lds_bytes(D, m_cand) <= 150 * 1024 && (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
+}
+
+// done_code != NULL appends _judge_done (needs the staged form: check get_obs_is_staged first)
 hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
                           const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag, float* obs_out,
-                          hipStream_t s) {
+                          hipStream_t s, const float* params, const float* cand_lw, const uint8_t* v_light,
+                          uint8_t* done_code) {
     const size_t lds = get_obs_lds_bytes(D, m_cand);
-    const bool staged = lds <= 150 * 1024 && (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
+    const bool staged = get_obs_is_staged(D, m_cand, cand);
+    if (done_code && !staged) return hipErrorInvalidValue;
+    const JudgeArgs J{params, cand_lw, v_light, done_code};
     hipError_t e = hipSuccess;
 #define EB_GET_OBS(T)                                                                                                \
     do {                                                                                                             \
@@ -272,10 +480,10 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
             }                                                                                                        \
             if (e == hipSuccess)                                                                                     \
                 hipLaunchKernelGGL((get_obs_kernel<T, true>), g, b, lds, s, n_env, D, n_future, NV, pt, modes, ego,  \
-                                   ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out);                  \
+                                   ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, J);               \
         } else {                                                                                                     \
             hipLaunchKernelGGL((get_obs_kernel<T, false>), g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego,       \
-                               ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out);                      \
+                               ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, J);                   \
         }                                                                                                            \
     } while (0)
     switch (task) {
@@ -391,81 +599,6 @@ hipError_t launch_traffic_flow_step(int n_env, int K, float* cand, uint8_t* acti
                        emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len, light_cycle, seed, counter,
                        cand_mode, v_light);
     return hipGetLastError();
-}
-
-// ---- a17: _judge_done, E2E:200-256 ---------------------------------------------------------------
-EB_DEV bool judge_feasible(float x, float y, int task) {   // UTL:73-104
-    const float C2 = HALF_CROSS, LW = LANE_W;
-    const bool middle = (-C2 < y && y < C2) && (-C2 < x && x < C2);
-    if (task == TASK_LEFT)
-        return (0.0f < x && x < LW && y <= -C2) || (0.0f < y && y < LW * 3.0f && x < -C2) || middle;
-    if (task == TASK_STRAIGHT)
-        return (LW < x && x < LW * 2.0f && y <= -C2) || (0.0f < x && x < LW * 3.0f && y >= C2) || middle;
-    return (LW * 2.0f < x && x < LW * 3.0f && y <= -C2) || (-LW * 3.0f < y && y < 0.0f && x > C2) || middle;
-}
-
-__global__ void judge_done_kernel(int task, int n_env, int D, const float* __restrict__ ego,
-                                  const float* __restrict__ params, const float* __restrict__ obs, int m_cand,
-                                  const float* __restrict__ cand, const uint8_t* __restrict__ cand_mode,
-                                  const float* __restrict__ cand_lw, const uint8_t* __restrict__ v_light,
-                                  uint8_t* __restrict__ done_code) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_env) return;
-    const float EGO_L = 4.8f, EGO_W = 2.0f;
-    const float* e = ego + 6 * (size_t)i;
-    const float v_x = e[0], r = e[2], x = e[3], y = e[4], phi = e[5];
-    // Traffic.collision_check, TRF:263-295
-    float es, ec;
-    sincos_det(phi / 180.0f * PI_F, es, ec);
-    const float ego_lw = (EGO_L - EGO_W) / 2;
-    const float ex0 = x + ec * ego_lw, ey0 = y + es * ego_lw, ex1 = x - ec * ego_lw, ey1 = y - es * ego_lw;
-    bool collision = false;
-    for (int k = 0; k < m_cand; ++k) {
-        const size_t ck = (size_t)i * m_cand + k;
-        if (cand_mode[ck] == EB_VMODE_EMPTY) continue;
-        const float* v = cand + ck * 4;
-        const float vl = cand_lw ? cand_lw[ck * 2] : EGO_L;
-        const float vw = cand_lw ? cand_lw[ck * 2 + 1] : EGO_W;
-        if (__builtin_fabsf(v[0] - x) < 10.0f && __builtin_fabsf(v[1] - y) < 10.0f) {
-            const float s_lw = (vl - vw) / 2;
-            float ss, sc;
-            sincos_det(v[3] / 180.0f * PI_F, ss, sc);
-            const float sx0 = v[0] + sc * s_lw, sy0 = v[1] + ss * s_lw, sx1 = v[0] - sc * s_lw, sy1 = v[1] - ss * s_lw;
-            const float thr = sq((vw + EGO_W) / 2 + 0.5f);
-            if (sq(ex0 - sx0) + sq(ey0 - sy0) < thr) collision = true;
-            else if (sq(ex0 - sx1) + sq(ey0 - sy1) < thr) collision = true;
-            else if (sq(ex1 - sx1) + sq(ey1 - sy1) < thr) collision = true;
-            else if (sq(ex1 - sx0) + sq(ey1 - sy0) < thr) collision = true;
-        }
-    }
-    // corner points (E2E:171-176, UTL:120-157) through judge_feasible
-    float rs, rc;
-    sincos_det(-phi * PI_F / 180.0f, rs, rc);
-    bool feasible = true;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float cx = (q < 2 ? EGO_L : -EGO_L) / 2, cy = ((q & 1) ? -EGO_W : EGO_W) / 2;
-        const float tx = cx * rc + cy * rs;
-        const float ty = -cx * rs + cy * rc;
-        const float X = tx - (-x), Y = ty - (-y);
-        feasible = feasible && judge_feasible(X, Y, task);
-    }
-    const float miu_r = params[4 * (size_t)i + 3];
-    const float r_bound = miu_r * 9.81f / (__builtin_fabsf(v_x) + 1e-8f);   // E2E:167
-    const float delta_y = obs[(size_t)D * i + 6];                            // E2E:224
-    bool goal;
-    if (task == TASK_LEFT) goal = x < -HALF_CROSS - 10.0f && 0.0f < y && y < 3.0f * LANE_W;
-    else if (task == TASK_RIGHT) goal = x > HALF_CROSS + 10.0f && -3.0f * LANE_W < y && y < 0.0f;
-    else goal = y > HALF_CROSS + 10.0f && 0.0f < x && x < 3.0f * LANE_W;
-    uint8_t code;
-    if (collision) code = EB_DONE_COLLISION;
-    else if (!feasible) code = EB_DONE_BREAK_ROAD;
-    else if (__builtin_fabsf(delta_y) > 15.0f) code = EB_DONE_DEVIATE;
-    else if (!(-r_bound < r && r < r_bound)) code = EB_DONE_STABILITY;
-    else if (v_light && v_light[i] != 0 && y > -HALF_CROSS && task != TASK_RIGHT) code = EB_DONE_RED_LIGHT;
-    else if (goal) code = EB_DONE_GOOD;
-    else code = EB_DONE_NOT_YET;
-    done_code[i] = code;
 }
 
 hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const float* params, const float* obs,

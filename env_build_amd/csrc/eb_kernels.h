@@ -65,10 +65,15 @@ hipError_t launch_summary(int n_env, int horizon, int D, const float* out5_steps
 // real-env step pieces (eb_env_kernels.hip)
 hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, float* next_ego, float* params,
                                hipStream_t s);
+hipError_t launch_env_pre(int task, int n_env, int D, int n_future, int NV, const float* obs, const float* raw,
+                          float* scaled, float* out5, float* d16, float* ego, float* params, hipStream_t s);
+bool get_obs_is_staged(int D, int m_cand, const float* cand);
+// done_code != NULL appends _judge_done to the observation kernel (only in its LDS-staged form: get_obs_is_staged)
 hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
                           const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag, float* obs_out,
-                          hipStream_t s);
+                          hipStream_t s, const float* params = nullptr, const float* cand_lw = nullptr,
+                          const uint8_t* v_light = nullptr, uint8_t* done_code = nullptr);
 hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const float* params, const float* obs,
                              int m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
                              const uint8_t* v_light, uint8_t* done_code, hipStream_t s);
