@@ -223,20 +223,38 @@ class CrossroadEnd2end(object):
     # -- reset ----------------------------------------------------------------------------------
     def _reset_init_state(self):  # E2E:472-499, per env
         span = {'left': 900 + 500, 'straight': 1200 + 500, 'right': 420 + 500}[self.training_task]
-        B = self.n_env
-        ref = np.full((B,), int(self.ref_path.ref_index), np.int32) if B == 1 else \
-            self.np_random.integers(0, len(self.ref_path.path_list), B).astype(np.int32)
-        index = (self.np_random.random(B) * span).astype(np.int64) + 700                # E2E:474-478
-        v = (EXPECTED_V * self.np_random.random(B)).astype(np.float32)                  # E2E:482
-        ego = np.zeros((B, 6), np.float32)
-        for k, path in enumerate(self.ref_path.path_list):
-            rows = ref == k
-            i = np.clip(index[rows], 0, len(path[0]) - 1)                               # indexs2points, DAM:727-728
-            ego[rows, 3], ego[rows, 4], ego[rows, 5] = path[0][i], path[1][i], path[2][i]
-        ego[:, 0] = v
+        B, dev = self.n_env, self.device
         route = {'left': 'dl', 'straight': 'du', 'right': 'dr'}[self.training_task]
-        self._init_ego, self._init_ref = ego, ref
-        return dict(ego=dict(v_x=ego[0, 0], v_y=0, r=0, x=ego[0, 3], y=ego[0, 4], phi=ego[0, 5], l=self.ego_l,
+        if B == 1:       # the reference's own draws, on the host
+            ref = np.full((1,), int(self.ref_path.ref_index), np.int32)
+            index = (self.np_random.random(1) * span).astype(np.int64) + 700            # E2E:474-478
+            v = (EXPECTED_V * self.np_random.random(1)).astype(np.float32)              # E2E:482
+            ego = np.zeros((1, 6), np.float32)
+            path = self.ref_path.path_list[int(ref[0])]
+            i = int(np.clip(index[0], 0, len(path[0]) - 1))                             # indexs2points, DAM:727-728
+            ego[0, 3], ego[0, 4], ego[0, 5] = path[0][i], path[1][i], path[2][i]
+            ego[0, 0] = v[0]
+            self._init_ego, self._init_ref = torch.from_numpy(ego).to(dev), torch.from_numpy(ref).to(dev)
+        else:            # a batch draws on the device: path per env, start index, start speed
+            if getattr(self, '_path_dev', None) is None:
+                pl = self.ref_path.path_list
+                lmax = max(len(p[0]) for p in pl)
+                tab = np.zeros((len(pl), lmax, 3), np.float32)
+                for k, p in enumerate(pl):
+                    for c in range(3):
+                        tab[k, :len(p[0]), c] = p[c]
+                self._path_dev = torch.from_numpy(tab).to(dev)
+                self._path_len = torch.tensor([len(p[0]) for p in pl], dtype=torch.int64, device=dev)
+            ref = torch.randint(0, self._path_dev.shape[0], (B,), generator=self._gen, device=dev)
+            index = (torch.rand((B,), generator=self._gen, device=dev) * span).to(torch.int64) + 700
+            index = torch.minimum(index, self._path_len[ref] - 1)
+            pose = self._path_dev[ref, index]                                           # [B, 3]
+            v = EXPECTED_V * torch.rand((B,), generator=self._gen, device=dev)
+            z = torch.zeros_like(v)
+            self._init_ego = torch.stack([v, z, z, pose[:, 0], pose[:, 1], pose[:, 2]], 1)
+            self._init_ref = ref.to(torch.int32)
+        e0 = self._init_ego[0].cpu().numpy()
+        return dict(ego=dict(v_x=e0[0], v_y=0, r=0, x=e0[3], y=e0[4], phi=e0[5], l=self.ego_l,
                              w=self.ego_w, routeID=route))
 
     def _spawn_traffic(self, rows=None):
@@ -262,12 +280,14 @@ class CrossroadEnd2end(object):
             self.ref_path = ReferencePath(self.training_task, device=self.device)
         self.init_state = self._reset_init_state()
         B, dev = self.n_env, self.device
-        m = torch.ones((B,), dtype=torch.bool, device=dev) if mask is None else \
-            torch.as_tensor(np.asarray(mask.t.cpu() if isinstance(mask, DevArray) else (mask.cpu() if isinstance(mask, torch.Tensor) else mask)),
-                            dtype=torch.bool).reshape(B).to(dev)
+        if mask is None:
+            m = torch.ones((B,), dtype=torch.bool, device=dev)
+        else:
+            mt = mask.t if isinstance(mask, DevArray) else mask
+            m = (mt if isinstance(mt, torch.Tensor) else torch.from_numpy(np.asarray(mt))).to(dev).bool().reshape(B)
         miu = self.dynamics.vehicle_params['miu']
-        self._ego.copy_(torch.where(m.unsqueeze(1), torch.from_numpy(self._init_ego).to(dev), self._ego))
-        self._ref_idx.copy_(torch.where(m, torch.from_numpy(self._init_ref).to(dev), self._ref_idx))
+        self._ego.copy_(torch.where(m.unsqueeze(1), self._init_ego, self._ego))
+        self._ref_idx.copy_(torch.where(m, self._init_ref, self._ref_idx))
         fresh_par = torch.tensor([0., 0., miu, miu], dtype=torch.float32, device=dev).repeat(B, 1)       # E2E:110-113
         self._params.copy_(torch.where(m.unsqueeze(1), fresh_par, self._params))
         if self._flows is not None:

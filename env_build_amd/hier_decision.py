@@ -48,7 +48,8 @@ class HierarchicalDecision(object):
 
     def reset(self, mask=None):                                                         # :66-81
         self.obs = self.env.reset() if mask is None else self.env.reset(mask=mask)
-        self.recorder.reset(None if mask is None else _unwrap(mask).cpu().numpy())
+        if self.logdir is not None:             # episodes are only kept when a log is being written
+            self.recorder.reset(None if mask is None else _unwrap(mask).cpu().numpy())
         if mask is None:
             self.old_index.zero_()
         else:

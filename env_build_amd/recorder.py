@@ -28,8 +28,9 @@ class Recorder(object):
         return self._current[0]
 
     def reset(self, mask=None):                 # recorder.py:50-56
-        for i in range(self.n_env):
-            if (mask is None or bool(mask[i])) and self._current[i]:
+        rows = range(self.n_env) if mask is None else np.flatnonzero(np.asarray(mask).reshape(self.n_env))
+        for i in rows:
+            if self._current[i]:
                 self.data_across_all_episodes.append(self._current[i])
                 self._current[i] = []
 
