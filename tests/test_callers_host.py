@@ -1,4 +1,4 @@
-"""CPU: env_build_amd/recorder.py against fixture G10 (the reference's own Recorder.record on the same inputs,
+"""CPU: host-side pieces of the callers around the hot path — env_build_amd/recorder.py against fixture G10
 oracle/gen_golden_recorder.py) and the on-disk layout the reference's tools read (utils/recorder.py:93-108)."""
 import os
 import sys
@@ -62,3 +62,25 @@ def test_flow_tables_light_programme_and_lanes():
     for m in ROUTES:     # every lane starts 100 m out and points at the junction
         (x, y, phi), (dx, dy) = approach_lane(m)
         assert max(abs(x), abs(y)) == 100.0 and x * dx + y * dy < 0
+
+
+def test_path_hysteresis_rule_on_cpu_tensors():
+    """HierarchicalDecision.select_path (hier_decision.py:118-121 per env): keep the old path unless the best one is
+    better by at least 0.1 — the method is plain tensor arithmetic, checked here against the reference's scalar rule."""
+    import torch
+    from types import SimpleNamespace
+    from env_build_amd.hier_decision import HierarchicalDecision
+    rng = np.random.default_rng(2)
+    B = 500
+    pv = rng.uniform(0, 1, (3, B)).astype(np.float32)
+    pv[:, :50] = pv[0, :50]                                   # ties: argmin takes the first, nothing beats the old path
+    pv[1, 50:100] = pv[0, 50:100] - np.float32(0.1)           # exactly on the threshold
+    old = rng.integers(0, 3, B)
+    fake = SimpleNamespace(old_index=torch.from_numpy(old))
+    got = HierarchicalDecision.select_path(fake, torch.from_numpy(pv)).numpy()
+    for b in range(B):
+        path_values = pv[:, b]
+        old_value = path_values[old[b]]
+        new_index, new_value = int(np.argmin(path_values)), min(path_values)          # hier_decision.py:119
+        want = old[b] if old_value - new_value < 0.1 else new_index                   # hier_decision.py:120
+        assert got[b] == want, b
