@@ -1,5 +1,7 @@
-"""CPU: host-side pieces of the callers around the hot path — env_build_amd/recorder.py against fixture G10
-oracle/gen_golden_recorder.py) and the on-disk layout the reference's tools read (utils/recorder.py:93-108)."""
+"""CPU: host-side pieces of the callers around the hot path — env_build_amd/recorder.py against fixture G10 (the
+reference's own Recorder.record on the same inputs, oracle/gen_golden_recorder.py) and the on-disk layout the
+reference's tools read (utils/recorder.py:93-108); the flow / light tables of env_build_amd/traffic.py; the path
+hysteresis rule of env_build_amd/hier_decision.py."""
 import os
 import sys
 
