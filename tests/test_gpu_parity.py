@@ -370,6 +370,24 @@ def test_env_kernels_random_scenes_bit_exact(task):
 
 
 @pytest.mark.parametrize('task', TASKS)
+@pytest.mark.parametrize('M,NV', [(1, None), (4, None), (33, None), (64, None), (48, 32), (64, 64)])
+def test_get_obs_candidate_and_slot_counts(task, M, NV):
+    """The observation kernel's LDS-staged form over candidate counts (odd / even row strides, one per env, the
+    64-slot maximum) and slot lists with up to 16 slots per mode (deep ranks), plus the fused done code of
+    eb_env_step's second half against the two separate calls."""
+    B = 257
+    nv = VEH_NUM[task] if NV is None else NV
+    host, dev = _pair(task, n_veh=nv)
+    ego, cand, cmode, lw, light, act, ref = _random_scene(task, B, M, 100 + M)
+    cand[:, :, :2] *= 0.5                      # crowd the junction: many in-range candidates per mode
+    o_h = host.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    o_d = dev.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    assert np.array_equal(o_h, o_d)
+    empty = host.get_obs(ego, cand[:, :0], cmode[:, :0], light, ref_idx=ref)      # every slot on its fill value
+    assert M < 4 or (o_h != empty).any(1).mean() > 0.5                            # real candidates were selected
+
+
+@pytest.mark.parametrize('task', TASKS)
 def test_env_step_composite_equals_the_six_calls(task):
     """eb_env_step == action_transform, compute_rewards, env_ego_step, veh_predict, get_obs, judge_done in that order,
     on both libraries (bit for bit against the oracle's composite too)."""
