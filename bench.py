@@ -84,6 +84,94 @@ def cpu_baseline(inp, obs0, n_veh, budget_s=18.0):
                       % (b_cpu, '/'.join(str(v[1]) for v in res.values()), '/'.join(str(k) for k in res), n_veh)}
 
 
+def shield_bench(args):
+    """The model-predictive safety shield with the policy network on the GPU (hier_decision.py:89-97): one JSON line in
+    the same format; the roofline object is the policy kernel's (f32 matrix cores), the bound of this loop."""
+    import torch
+    from types import SimpleNamespace
+    from env_build_amd.dynamics_and_models import EnvironmentModel
+    from env_build_amd.policy import LoadPolicy
+    from env_build_amd.synthetic import make_rollout_inputs
+    if args.gpus != 1:
+        raise SystemExit('--shield runs on one GPU')
+    B, N, steps_ahead, units, hidden = args.n_env, args.n_veh, 5, 256, 2
+    dev = torch.device('cuda', 0)
+    model = EnvironmentModel(TASK, 0, mode='training', n_veh=N, device=dev)
+    D = model.obs_dim
+    pargs = SimpleNamespace(obs_dim=D, act_dim=2, num_hidden_layers=hidden, num_hidden_units=units, hidden_activation='elu',
+                            policy_out_activation='linear', action_range=1.0, deterministic_policy=True,
+                            obs_preprocess_type='scale',
+                            obs_scale=[0.2] * 6 + [1., 1 / 30., 0.2] + [1 / 30., 1 / 30., 0.2, 1 / 180.] * N)
+    pol = LoadPolicy(args=pargs, device=dev)                      # random orthogonal weights (no checkpoints travel)
+    inp = make_rollout_inputs(TASK, B, N, HORIZON, seed=0)
+    ego = torch.from_numpy(inp['ego']).to(dev)
+    ref = torch.from_numpy(inp['ref_idx']).to(dev)
+    trk = model.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(),
+                                                       ego[:, 0].contiguous(), 0, ref_indexes=ref).t
+    obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
+    net = pol.policy.policy
+    api, lib = model.api, model.api.lib
+    p = lambda t: C.c_void_p(t.data_ptr())
+    a, b = torch.empty_like(obs0), torch.empty_like(obs0)
+    act = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    out5 = torch.empty((5, B), dtype=torch.float32, device=dev)
+    punish = torch.empty((B,), dtype=torch.float32, device=dev)
+    safe = torch.empty((B,), dtype=torch.uint8, device=dev)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def shield():
+        rc = lib.eb_shield_is_safe(model.handle, net._handle, B, p(obs0), p(ref), 0, steps_ahead, 0, C.c_float(1.0), p(a), p(b),
+                                   p(act), p(out5), p(punish), p(safe), sp)
+        if rc != 0:
+            api.check(rc)
+
+    def policy_only():
+        rc = lib.eb_policy_run_batch(net._handle, B, p(obs0), C.c_float(1.0), p(act), sp)
+        if rc != 0:
+            api.check(rc)
+
+    for _ in range(max(1, args.warmup // 10)):
+        shield()
+    ev = []
+    for _ in range(2):
+        e = C.c_void_p()
+        api.event_create(model.handle, C.byref(e))
+        ev.append(e)
+    lib.eb_event_record(ev[0], sp)
+    for _ in range(20):
+        policy_only()
+    lib.eb_event_record(ev[1], sp)
+    ms = C.c_float()
+    api.event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+    policy_s = ms.value * 1e-3 / 20
+    n_pass = max(1, args.steps // 10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_pass):
+        shield()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flops = 2.0 * B * (D * units + (hidden - 1) * units * units + units * 4)
+    line = {
+        'metric': 'shield checks/s (start states through a %d-step policy-in-the-loop look-ahead)' % steps_ahead,
+        'value': B * n_pass / dt, 'unit': 'states/s', 'n_gpus': 1, 'steps': n_pass, 'warmup': max(1, args.warmup // 10),
+        'ms_per_step': dt * 1e3 / n_pass, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'SEPARATE figure: eb_shield_is_safe on configs[2] states (N_env=%d, N_veh=%d, task=%s): %d x [MLPNet '
+                               '%d -> %s -> 4 (ELU, random orthogonal weights) -> rollout_out], penalty veh2veh4real'
+                               % (B, N, TASK, steps_ahead, D, ' -> '.join([str(units)] * hidden)),
+                   'n_env_per_gpu': B, 'n_veh': N, 'look_ahead': steps_ahead, 'parallelism': 'single GPU'},
+        'roofline': {'bound': 'mfma', 'achieved': flops / policy_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
+                     'frac': flops / policy_s / 1e12 / 157.3, 'traffic': None, 'kernel': 'eb::mlp_kernel<2, 2>',
+                     'alg_flop_per_launch': flops, 'avg_launch_us': policy_s * 1e6, 'launches_timed': 20},
+        'cpu_baseline': None,
+        'unsafe_fraction': float(1.0 - safe.float().mean().item()),
+    }
+    print(json.dumps(line))
+    for e in ev:
+        api.event_destroy(e)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,8 +185,13 @@ def main():
     ap.add_argument('--open-loop', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
                          'state in registers — VALU-bound, not the HBM-bound closed-loop headline')
+    ap.add_argument('--shield', action='store_true',
+                    help='SEPARATE figure (SURVEY.md §8(f)2): eb_shield_is_safe — 5 x [policy MLP (137 -> 256 -> 256 -> 4, ELU) -> '
+                         'rollout step] per start state; a "step" is one shield pass over the batch; N = 1 only')
     args = ap.parse_args()
     n_env, n_veh = args.n_env, args.n_veh
+    if args.shield:
+        return shield_bench(args)
 
     import torch
     import torch.distributed as dist
