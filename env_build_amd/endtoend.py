@@ -422,6 +422,29 @@ class CrossroadEnd2end(object):
         # a batch keeps the uint8 codes on the device (EB_DONE_*; done_names() spells them out on request)
         return DevArray(code), DevArray((code != 0).to(torch.uint8))
 
+    # the single predicates of E2E:223-256 on the published host state (n_env == 1; multi_ego.py:128 calls the last one)
+    def _deviate_too_much(self):
+        return bool(abs(float(np.asarray(self.obs)[self.ego_info_dim])) > 15)
+
+    def _break_road_constrain(self):
+        from .endtoend_env_utils import judge_feasible
+        return not all(judge_feasible(x, y, self.training_task) for x, y in self.ego_dynamics['Corner_point'])
+
+    def _break_stability(self):
+        r_bound = self.ego_dynamics['r_bound']
+        return not (-r_bound < self.ego_dynamics['r'] < r_bound)
+
+    def _break_red_light(self):
+        return bool(self.v_light != 0 and self.ego_dynamics['y'] > -CROSSROAD_SIZE / 2 and self.training_task != 'right')
+
+    def _is_achieve_goal(self):
+        x, y = self.ego_dynamics['x'], self.ego_dynamics['y']
+        if self.training_task == 'left':
+            return bool(x < -CROSSROAD_SIZE / 2 - 10 and 0 < y < LANE_NUMBER * LANE_WIDTH)
+        if self.training_task == 'right':
+            return bool(x > CROSSROAD_SIZE / 2 + 10 and -LANE_NUMBER * LANE_WIDTH < y < 0)
+        return bool(y > CROSSROAD_SIZE / 2 + 10 and 0 < x < LANE_NUMBER * LANE_WIDTH)
+
     def done_names(self):
         """done_type strings of the last step for every env of a batch (E2E:208-221)."""
         return [_capi.DONE_NAMES[int(c)] for c in self.done_code.cpu().numpy()]

@@ -187,3 +187,28 @@ def test_flow_step_kernel_equals_oracle():
             assert np.array_equal(a[k], b[k]), k
     last = res[1][-1]
     assert last['emitted'].min() >= 4 and (last['active'] != 0).sum() > 12 * B and set(np.unique(last['light'])) <= {0, 1, 2, 3}
+
+
+def test_single_env_predicates_agree_with_the_done_code():
+    """n_env == 1: the reference's predicate methods (E2E:223-256) on the published host state reproduce the
+    priority chain of the done code the kernel returned (collision aside, which only the kernel sees)."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    rng = np.random.default_rng(12)
+    seen = set()
+    for task in ('left', 'straight', 'right'):
+        env = CrossroadEnd2end(task, n_env=1, mode='testing', traffic='flows')
+        env.reset()
+        for t in range(250):
+            a = rng.uniform(-1, 1, 2).astype(np.float32) if t % 40 < 30 else np.array([rng.choice([-1., 1.]), 1.], np.float32)
+            obs, r, done, info = env.step(a)
+            if env.done_type != 'collision':
+                chain = ('break_road_constrain' if env._break_road_constrain() else
+                         'deviate_too_much' if env._deviate_too_much() else
+                         'break_stability' if env._break_stability() else
+                         'break_red_light' if env._break_red_light() else
+                         'good_done' if env._is_achieve_goal() else 'not_done_yet')
+                assert chain == env.done_type, (task, t, chain, env.done_type)
+            seen.add(env.done_type)
+            if done:
+                env.reset()
+    assert len(seen) >= 3
