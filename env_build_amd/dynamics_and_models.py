@@ -15,8 +15,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .endtoend_env_utils import (CROSSROAD_SIZE, EXPECTED_V, L, LANE_NUMBER, LANE_WIDTH, VEHICLE_MODE_LIST, W,
-                                 tiled_mode_list)
+from .endtoend_env_utils import EXPECTED_V, VEHICLE_MODE_LIST, tiled_mode_list
 from .ref_path_tables import build_ref_paths
 
 __all__ = ['VehicleDynamics', 'EnvironmentModel', 'ReferencePath', 'DevArray', 'deal_with_phi_diff']

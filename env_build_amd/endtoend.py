@@ -28,8 +28,6 @@ TRF:263-295, UTL:73-104).  Every one of these is a C-ABI call into libenvbuild_h
 the device buffers.  There is no CPU path.
 """
 import ctypes as C
-import math
-from collections import OrderedDict
 
 import numpy as np
 import torch

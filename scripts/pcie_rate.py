@@ -4,7 +4,7 @@ rollout_out copies obs + actions to the GPU and the six results back.  Never use
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from env_build_amd.dynamics_and_models import EnvironmentModel
 from env_build_amd.synthetic import assemble_obs, make_rollout_inputs
 

@@ -2,7 +2,7 @@
 """Timing aid: where a HierarchicalDecision.step goes (synchronising after every stage)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from types import SimpleNamespace
 from env_build_amd.endtoend_env_utils import VEH_NUM
 from env_build_amd.hier_decision import HierarchicalDecision

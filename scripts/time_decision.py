@@ -4,7 +4,7 @@ for a batch of envs, policy 2 x 256 ELU."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from types import SimpleNamespace
 from env_build_amd.endtoend_env_utils import VEH_NUM
 from env_build_amd.hier_decision import HierarchicalDecision

@@ -3,7 +3,7 @@
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from env_build_amd.endtoend import CrossroadEnd2end
 ap = argparse.ArgumentParser()
 ap.add_argument('--sizes', default='1,4096,65536'); ap.add_argument('--traffic', default='pool'); ap.add_argument('--steps', type=int, default=50)

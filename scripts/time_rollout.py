@@ -3,7 +3,7 @@
 import argparse, ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from env_build_amd.dynamics_and_models import EnvironmentModel
 from env_build_amd.synthetic import make_rollout_inputs
 
