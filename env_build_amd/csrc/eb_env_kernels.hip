@@ -467,16 +467,19 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
     const bool staged = get_obs_is_staged(D, m_cand, cand);
     if (done_code && !staged) return hipErrorInvalidValue;
     const JudgeArgs J{params, cand_lw, v_light, done_code};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= 64 ? 0 : dev;
     hipError_t e = hipSuccess;
 #define EB_GET_OBS(T)                                                                                                \
     do {                                                                                                             \
         const dim3 g((n_env + 63) / 64), b(staged ? 256 : 64);                                                       \
         if (staged) {                                                                                                \
-            static size_t granted = 48 * 1024;   /* the > 48 KB opt-in is per kernel and sticky */                   \
-            if (lds > granted) {                                                                                     \
+            static size_t granted[64];   /* the > 48 KB opt-in is per kernel and device, and sticky */               \
+            if (lds > 48 * 1024 && lds > granted[dev]) {                                                             \
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&get_obs_kernel<T, true>),                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-                if (e == hipSuccess) granted = lds;                                                                  \
+                if (e == hipSuccess) granted[dev] = lds;                                                             \
             }                                                                                                        \
             if (e == hipSuccess)                                                                                     \
                 hipLaunchKernelGGL((get_obs_kernel<T, true>), g, b, lds, s, n_env, D, n_future, NV, pt, modes, ego,  \

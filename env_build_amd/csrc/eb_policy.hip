@@ -255,14 +255,17 @@ hipError_t launch_mlp(const MlpArgs& A, hipStream_t s) {
     const dim3 g((A.n + MLP_ROWS - 1) / MLP_ROWS), b(MLP_THREADS);
     const size_t lds = mlp_lds_bytes(A);
     hipError_t e = hipSuccess;
-    // the opt-in for > 48 KB of dynamic LDS is per kernel and sticky: raise it only when a launch needs more
+    // the opt-in for > 48 KB of dynamic LDS is per kernel and device and sticky: raise it only when a launch needs more
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= 64 ? 0 : dev;
 #define EB_MLP_LAUNCH(RT, CT)                                                                                     \
     do {                                                                                                          \
-        static size_t granted = 48 * 1024;                                                                        \
-        if (lds > granted) {                                                                                      \
+        static size_t granted[64];                                                                                \
+        if (lds > 48 * 1024 && lds > granted[dev]) {                                                              \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<RT, CT>),                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-            if (e == hipSuccess) granted = lds;                                                                   \
+            if (e == hipSuccess) granted[dev] = lds;                                                              \
         }                                                                                                         \
         if (e == hipSuccess) hipLaunchKernelGGL((mlp_kernel<RT, CT>), g, b, lds, s, A);                           \
     } while (0)
