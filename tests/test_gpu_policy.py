@@ -152,3 +152,64 @@ def test_facade_policy_and_native_shield():
     with pytest.raises(ValueError):
         net(np.zeros((3, D + 1), np.float32))
     torch.cuda.synchronize()
+
+
+def test_policy_and_traffic_entry_points_reject_bad_arguments():
+    """Error behaviour of the newer entry points on the HIP library: bad handles, sizes and pointers come back as
+    ValueError / EbError with a message, nothing is launched and nothing crashes; the same calls fail the same way
+    in the oracle."""
+    import ctypes as C
+    from env_build_amd import _capi
+    rng = np.random.default_rng(0)
+    for mdl in (HostModel(oracle_lib(), 'left'), DeviceModel('left')):
+        api = mdl.api
+        with pytest.raises(ValueError):
+            mdl.make_mlp(8, 9, 64, 4, 'elu', 'linear', [])                      # too many hidden layers
+        with pytest.raises(ValueError):
+            mdl.make_mlp(8, 1, 64, 4, 'elu', 'linear', make_layers(rng, 8, 1, 64, 4)[:1])   # a layer missing
+        cfg = _capi.EbMlpConfig(_capi.EB_ABI_VERSION + 1, 8, 1, 64, 4, 2, 0, 0)
+        h = C.c_void_p()
+        with pytest.raises(ValueError):
+            api.mlp_create(C.byref(cfg), C.byref(h))                             # ABI version mismatch
+        cfg = _capi.EbMlpConfig(_capi.EB_ABI_VERSION, 8, 1, 64, 4, 7, 0, 0)
+        with pytest.raises(ValueError):
+            api.mlp_create(C.byref(cfg), C.byref(h))                             # unknown activation
+        cfg = _capi.EbMlpConfig(_capi.EB_ABI_VERSION, 8, 1, 64, 4, 2, 0, 0)
+        api.mlp_create(C.byref(cfg), C.byref(h))
+        obs = mdl._in(np.zeros((4, 8), np.float32))
+        out = mdl._out((4, 4))
+        with pytest.raises(_capi.EbError):
+            api.mlp_forward(h, 4, mdl._ptr(obs), mdl._ptr(out), mdl.stream)      # weights never set: EB_ESTATE
+        with pytest.raises(ValueError):
+            api.mlp_set_layer(h, 5, mdl._ptr(obs), None)                         # layer out of range, null bias
+        with pytest.raises(ValueError):
+            api.mlp_forward(None, 4, mdl._ptr(obs), mdl._ptr(out), mdl.stream)
+        api.mlp_destroy(h)
+        assert api.lib.eb_mlp_destroy(None) == 0
+        # shield: policy that does not fit the model, bad step count, aliased work buffers
+        good = mdl.make_mlp(mdl.D, 1, 64, 4, 'elu', 'linear', make_layers(rng, mdl.D, 1, 64, 4))
+        ob = np.zeros((4, mdl.D), np.float32)
+        ri = np.zeros(4, np.int32)
+        with pytest.raises(ValueError):
+            mdl.shield_is_safe(good, ob, ref_idx=ri, steps=0)
+        with pytest.raises(ValueError):
+            mdl.shield_is_safe(good, ob, ref_idx=ri, penalty=5)
+        with pytest.raises(ValueError):
+            mdl.shield_is_safe(None, ob, ref_idx=ri)
+        a = mdl._in(ob); o5 = mdl._out((5, 4)); act = mdl._out((4, 2)); pu = mdl._out((4,)); sf = mdl._out((4,), np.uint8)
+        with pytest.raises(ValueError):                                           # obs_a == obs_b
+            api.shield_is_safe(mdl.h, good, 4, mdl._ptr(mdl._in(ob)), mdl._ptr(mdl._in(ri, np.int32)), 0, 5, 0, C.c_float(1.0),
+                               mdl._ptr(a), mdl._ptr(a), mdl._ptr(act), mdl._ptr(o5), mdl._ptr(pu), mdl._ptr(sf), mdl.stream)
+        api.mlp_destroy(good)
+        # traffic kernels
+        c = mdl._in(np.zeros((2, 4, 4), np.float32)); en = mdl._in(np.zeros((4, 5), np.float32))
+        with pytest.raises(ValueError):
+            api.traffic_respawn(mdl.h, 2, 0, mdl._ptr(c), mdl._ptr(en), C.c_float(65.), C.c_float(60.), C.c_float(8.),
+                                C.c_uint64(1), C.c_uint64(1), None, mdl.stream)  # m_cand < 1
+        with pytest.raises(ValueError):
+            api.traffic_respawn(mdl.h, 2, 4, None, mdl._ptr(en), C.c_float(65.), C.c_float(60.), C.c_float(8.),
+                                C.c_uint64(1), C.c_uint64(1), None, mdl.stream)
+        with pytest.raises(ValueError):
+            api.traffic_flow_step(mdl.h, 2, 6, None, None, None, None, None, None, None, None, C.c_float(0.1), C.c_float(65.),
+                                  C.c_float(2.6), C.c_float(75.), 1, C.c_uint64(1), C.c_uint64(1), None, None, mdl.stream)   # 72 slots
+        assert api.lib.eb_traffic_respawn(mdl.h, 0, 4, None, None, C.c_float(1), C.c_float(1), C.c_float(1), 1, 1, None, None) == 0
