@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched model rollout (EnvironmentModel.rollout_out) on MI355X.
 
-A "step" is one rollout_out pass over the whole batch = B env-steps.  Workload at N GPUs:
-BASELINE.json configs[2] per GPU (N_env = 65 536, N_veh = 32, horizon 25, task `left`, training
-mode, fp32) — weak scaling: every rank owns an independent shard of envs, there is no data-path
-collective; the only exchange is one all-gather (RCCL) of the 8-float episodic-return summary at the
-end of every 25-step horizon, inside the timed region.
+A "step" is one rollout_out pass over the whole batch = B env-steps: ONE kernel launch per step (the closed-loop
+form — a policy may sit between two steps — not the fused open-loop kernel).  Headline workload at N GPUs:
+BASELINE.json configs[2] per GPU (N_env = 65 536, N_veh = 32, horizon 25, task `left`, training mode, fp32), weak
+scaling: every rank owns an independent shard of envs and there is no data-path collective; the only exchange is one
+all-gather (RCCL) of the 8-float episodic-return summary at the end of every horizon, inside the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-The K timed steps run as K // 25 rollouts of 25 launches (one kernel launch per rollout step — the
-policy-in-the-loop form, not a fused open-loop kernel), either as replays of a 25-launch hipGraph (eb_plan_*,
---graph) or as 25 eager eb_rollout_step calls (--eager); by default the warm-up times both and the timed
-region uses the faster.  Rank 0 prints ONE JSON line with two extra objects:
-  roofline     — algorithmic bytes per launch (104 + 32*N_veh per env-step) divided
-                 by the rollout kernel's average launch duration, measured with HIP event pairs
-                 (eb_event_*) on the launch stream around every graph replay — so the figure includes
-                 the inter-kernel gaps — against the 8 TB/s HBM peak;
-  cpu_baseline — the CPU oracle (oracle/, plain-C port of the reference path, OpenMP over envs) timed
-                 on this box's host cores on a bounded sample of the same workload.  The oracle is
-                 only the thing timed there, never part of the GPU path.
+The K timed steps run as rollouts of min(K, 25) launches (+ a shorter last one when 25 does not divide K), each followed
+by the episodic summary (two small kernels) and its all-gather; the K-step region is bracketed by barrier +
+synchronize, measured `--repeats` times (default 11) and the MEDIAN is `value` (min / max are reported too).  The
+launches go out either as one hipGraph replay per rollout (eb_plan_*, --graph) or as host calls (--eager); by default
+a short untimed trial picks the faster form and `config.workload` names the one that ran.  Rank 0 prints ONE JSON line:
+
+  roofline      algorithmic bytes per launch (104 + 32 N_veh per env-step) / the rollout kernel's
+                average launch duration from HIP event pairs (eb_event_*) on the launch stream around every rollout of
+                the timed region (inter-kernel gaps included), against the 8 TB/s HBM peak.  The headline working set
+                (two 36 MB obs buffers + outputs) fits the 256 MiB Infinity Cache, so
+  roofline.hbm_resident   repeats the measurement where it cannot: (a) the same kernel and batch size cycling over 8
+                independent env sets (lane l steps, then lane l+1, ...: 518 MB of other traffic between a line's write
+                and its re-read, 0.9 GB footprint), (b) one batch of 524 288 envs (290 MB per obs buffer);
+  strong        BASELINE configs[3]: 262 144 envs in total, split 262 144 / N per rank (strong scaling; at N = 1 the
+                one-GPU reference point of that curve);
+  extra         configs[1] (4 096 x 16, fp32) and configs[4] (65 536 x 64, fp16 state) on rank 0 at N = 1;
+  cpu_baseline  the CPU oracle (oracle/, plain-C port of the reference path, OpenMP over envs) timed on this box's host
+                cores on a bounded sample of the same workload; never part of the GPU path.
 """
 import argparse
 import ctypes as C
@@ -35,12 +42,14 @@ if ROOT not in sys.path:
 import env_build_amd  # noqa: E402,F401  (sets HIP_FORCE_DEV_KERNARG before the HIP runtime starts)
 
 TASK, N_ENV, N_VEH, HORIZON = 'left', 65536, 32, 25
-HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec
-MAX_EVENT_PAIRS = 256
+STRONG_TOTAL = 262144                            # BASELINE.json configs[3]
+HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a float4 copy reaches)
+MALL_BYTES = 256 << 20                           # Infinity Cache
+MAX_PAIRS = 64                                   # HIP event pairs per repeat
 
 
-def alg_bytes_per_env_step(n_veh):
-    return 104 + 32 * n_veh                      # fp32, SURVEY.md §8(d): 1128 B at N_veh = 32
+def alg_bytes_per_env_step(n_veh, f16=False):
+    return (68 + 16 * n_veh) if f16 else (104 + 32 * n_veh)   # 1128 B at N_veh = 32 fp32
 
 
 def host_cores():
@@ -50,10 +59,16 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def median(xs):
+    s = sorted(xs)
+    n = len(s)
+    return s[n // 2] if n & 1 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+
+
 def cpu_baseline(inp, obs0, n_veh, budget_s=18.0):
     """Oracle timed on host cores on a bounded sample (8192 envs x HORIZON steps, repeated until the budget is
-    used): 1 thread (the reference pins TF to 1 thread) and OpenMP over envs on 8 / 32 / all usable cores
-    (a cgroup CPU quota can make "all" slower than 8, so every count is reported and the best one is `value`)."""
+    used): 1 thread (the reference pins TF to 1 thread) and OpenMP over envs on 8 / 32 / 64 threads where the box
+    has them (a cgroup CPU quota can make more threads slower, so every count is reported and the best is `value`)."""
     from tests._helpers import HostModel, oracle_lib
     api = oracle_lib()
     api.lib.eb_oracle_set_threads.restype = C.c_int
@@ -61,7 +76,7 @@ def cpu_baseline(inp, obs0, n_veh, budget_s=18.0):
     b_cpu = 8192
     host = HostModel(api, TASK, n_veh=n_veh)
     obs, act, ref = obs0[:b_cpu].copy(), inp['actions'][:, :b_cpu].copy(), inp['ref_idx'][:b_cpu].copy()
-    counts = sorted(set([1] + [c for c in (8, 32) if c < host_cores()] + [host_cores()]))
+    counts = sorted(set([1] + [c for c in (8, 32, 64) if c <= host_cores()]))
     res = {}
     for threads in counts:
         used = api.lib.eb_oracle_set_threads(int(threads))
@@ -77,9 +92,244 @@ def cpu_baseline(inp, obs0, n_veh, budget_s=18.0):
     best = max(res, key=lambda k: res[k][0])
     return {'value': res[best][0], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
             'value_1core': res[1][0], 'by_threads': {str(k): v[0] for k, v in res.items()},
+            'host_logical_cpus': host_cores(),
             'sample': '%d envs x %s steps on %s threads (N_veh=%d, same seeded inputs), oracle/envbuild_oracle.c, OpenMP '
                       'over envs; the 1-thread figure is the reference-faithful setting (the reference pins TF to 1 thread)'
                       % (b_cpu, '/'.join(str(v[1]) for v in res.values()), '/'.join(str(k) for k in res), n_veh)}
+
+
+class Shard(object):
+    """One rank's resident buffers for a (n_env, n_veh, storage) workload and the launch forms over them.
+
+    `lanes` > 1: that many independent env sets of n_env rows each (same inputs, distinct buffers), stepped round-robin —
+    lane 0 step t, lane 1 step t, ... — so that every launch streams from and to memory no other recent launch touched."""
+
+    def __init__(self, torch, model, n_env, n_veh, seed, f16=False, lanes=1, keep_host=False):
+        from env_build_amd.synthetic import make_rollout_inputs
+        self.torch, self.model, self.n_env, self.n_veh, self.f16, self.lanes = torch, model, n_env, n_veh, f16, lanes
+        dev = model.device
+        inp = make_rollout_inputs(TASK, n_env, n_veh, HORIZON, seed=seed)
+        ego = torch.from_numpy(inp['ego']).to(dev)
+        self.ref_idx = torch.from_numpy(inp['ref_idx']).to(dev)
+        trk = model.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(),
+                                                           ego[:, 5].contiguous(), ego[:, 0].contiguous(), 0,
+                                                           ref_indexes=self.ref_idx).t
+        obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
+        self.obs0_f32 = obs0 if keep_host else None
+        self.inp = inp if keep_host else None
+        if f16:
+            obs0 = obs0.to(torch.float16).contiguous()
+        self.tape = torch.from_numpy(inp['actions']).to(dev)                      # [H, B, 2]
+        self.obs0 = [obs0] + [obs0.clone() for _ in range(lanes - 1)]
+        self.work = [torch.empty_like(obs0) for _ in range(lanes)]
+        self.final = [torch.empty_like(obs0) for _ in range(lanes)]
+        self.out5 = [torch.empty((HORIZON, 5, n_env), dtype=torch.float32, device=dev) for _ in range(lanes)]
+        self.api, self.h, self.lib = model.api, model.handle, model.api.lib
+        self.sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.step_fn = self.lib.eb_rollout_step_f16 if f16 else self.lib.eb_rollout_step
+        self._eager, self._plans = {}, {}
+
+    def footprint_bytes(self):
+        per = self.obs0[0].numel() * self.obs0[0].element_size()
+        return self.lanes * (3 * per + self.out5[0].numel() * 4) + self.tape.numel() * 4
+
+    def eager_args(self, h):
+        """argument tuples of an h-step rollout, ping-ponging as eb_rollout_tape does (the last step lands in `final`)"""
+        if h not in self._eager:
+            p = lambda t: C.c_void_p(t.data_ptr())
+            per_lane = []
+            for l in range(self.lanes):
+                dst = [self.final[l] if (h - 1 - t) % 2 == 0 else self.work[l] for t in range(h)]
+                src = [self.obs0[l]] + dst[:-1]
+                per_lane.append([(self.h, self.n_env, p(src[t]), p(self.tape[t]), p(self.ref_idx), 0, p(dst[t]),
+                                  p(self.out5[l][t]), None, self.sp) for t in range(h)])
+            self._eager[h] = [per_lane[l][t] for t in range(h) for l in range(self.lanes)]   # round-robin over the lanes
+        return self._eager[h]
+
+    def plan(self, h):
+        if self.f16 or self.lanes != 1:
+            return None
+        if h not in self._plans:
+            p = lambda t: C.c_void_p(t.data_ptr())
+            plan = C.c_void_p()
+            self.api.plan_create(self.h, self.n_env, h, p(self.obs0[0]), p(self.tape), p(self.ref_idx), 0, p(self.work[0]),
+                                 p(self.final[0]), p(self.out5[0]), None, C.byref(plan))
+            self._plans[h] = plan
+        return self._plans[h]
+
+    def launch_rollout(self, h, eager):
+        """h closed-loop steps (per lane): one kernel launch each"""
+        plan = None if eager else self.plan(h)
+        if plan is not None:
+            rc = self.lib.eb_plan_launch(plan, self.sp)
+            if rc != 0:
+                self.api.check(rc)
+            return
+        fn = self.step_fn
+        for a in self.eager_args(h):
+            rc = fn(*a)
+            if rc != 0:
+                self.api.check(rc)
+
+    def launch_tape(self, h):
+        p = lambda t: C.c_void_p(t.data_ptr())
+        fn = self.lib.eb_rollout_tape_f16 if self.f16 else self.lib.eb_rollout_tape
+        rc = fn(self.h, self.n_env, h, p(self.obs0[0]), p(self.tape), p(self.ref_idx), 0, p(self.work[0]), p(self.final[0]),
+                p(self.out5[0]), self.sp)
+        if rc != 0:
+            self.api.check(rc)
+
+    def close(self):
+        for plan in self._plans.values():
+            self.api.plan_destroy(plan)
+        self._plans = {}
+
+
+class Timer(object):
+    """K steps of a Shard as rollouts of <= HORIZON launches, event pairs around every rollout, `repeats` timed regions
+    each bracketed by barrier + synchronize, max over ranks per region."""
+
+    def __init__(self, torch, dist, use_dist, shard, with_summary):
+        self.torch, self.dist, self.use_dist, self.s, self.with_summary = torch, dist, use_dist, shard, with_summary
+        self.api, self.lib = shard.api, shard.lib
+        self.ev = []
+        for _ in range(2 * MAX_PAIRS):
+            e = C.c_void_p()
+            self.api.event_create(shard.h, C.byref(e))
+            self.ev.append(e)
+        dev = shard.model.device
+        world = dist.get_world_size() if use_dist else 1
+        # two summary buffers: the all-gather of rollout k overlaps the kernels of rollout k+1 (RCCL's own stream)
+        self.summaries = [torch.zeros((8,), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.in_flight = [None, None]
+        self.gathered = torch.zeros((world, 8), dtype=torch.float32, device=dev)
+        self.n_rollouts = 0
+        self.eager = True
+        self.open_loop = False
+
+    @staticmethod
+    def segments(n_steps):
+        full, rem = divmod(n_steps, HORIZON)
+        return [HORIZON] * full + ([rem] if rem else [])
+
+    def end_of_rollout(self, h):
+        # episodic-return summary of this shard (two small kernels), then the only inter-GPU exchange
+        from env_build_amd.sharding import gather_summaries_async
+        s = self.s
+        slot = self.n_rollouts & 1
+        self.n_rollouts += 1
+        if self.in_flight[slot] is not None:
+            self.gathered = self.in_flight[slot].result()      # the gather of two rollouts ago: long finished
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self.api.episode_summary(s.h, s.n_env, h, p(s.out5[0]), p(s.final[0]), p(self.summaries[slot]), s.sp)
+        self.in_flight[slot] = gather_summaries_async(self.summaries[slot])   # env_build_amd/sharding.py: 8 floats per rank
+
+    def drain(self):
+        for slot in (self.n_rollouts & 1, (self.n_rollouts + 1) & 1):      # oldest first
+            if self.in_flight[slot] is not None:
+                self.gathered = self.in_flight[slot].result()
+                self.in_flight[slot] = None
+
+    def run(self, n_steps, marks):
+        segs = self.segments(n_steps)
+        for k, h in enumerate(segs):
+            m = marks and k < MAX_PAIRS
+            if m:
+                self.lib.eb_event_record(self.ev[2 * k], self.s.sp)
+            if self.open_loop:
+                self.s.launch_tape(h)
+            else:
+                self.s.launch_rollout(h, self.eager)
+            if m:
+                self.lib.eb_event_record(self.ev[2 * k + 1], self.s.sp)
+            if self.with_summary:
+                self.end_of_rollout(h)
+        if self.with_summary:
+            self.drain()
+        return segs
+
+    def pick_form(self):
+        """graph replay or host calls: whichever keeps the queue fuller on this host (untimed trial, three rounds each)"""
+        if self.s.plan(HORIZON) is None:
+            self.eager = True
+            return
+        trial = {False: [], True: []}
+        ms = C.c_float()
+        for form in (False, True, False, True, False, True):
+            self.eager = form
+            self.run(HORIZON, False)
+            self.lib.eb_event_record(self.ev[0], self.s.sp)
+            self.run(4 * HORIZON, False)
+            self.lib.eb_event_record(self.ev[1], self.s.sp)
+            self.api.event_elapsed_ms(self.ev[0], self.ev[1], C.byref(ms))
+            trial[form].append(ms.value)
+        self.eager = min(trial[True]) < min(trial[False])
+        self.torch.cuda.synchronize()
+
+    def measure(self, n_steps, warmup, repeats):
+        """-> dict(dt = [per-repeat seconds, max over ranks], launch_us = event-timed average per launch, launches_timed)"""
+        torch, dist = self.torch, self.dist
+        self.run(warmup, False)
+        torch.cuda.synchronize()
+        dts, ev_ms, ev_launches = [], 0.0, 0
+        ms = C.c_float()
+        for _ in range(repeats):
+            if self.use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            segs = self.run(n_steps, True)
+            torch.cuda.synchronize()
+            if self.use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+            for k, h in enumerate(segs[:MAX_PAIRS]):
+                self.api.event_elapsed_ms(self.ev[2 * k], self.ev[2 * k + 1], C.byref(ms))
+                ev_ms += ms.value
+                ev_launches += (1 if self.open_loop else h * self.s.lanes)
+        t = torch.tensor(dts, dtype=torch.float64, device=self.s.model.device)
+        if self.use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return dict(dt=[float(x) for x in t.tolist()], launch_us=ev_ms * 1e3 / max(1, ev_launches), launches_timed=ev_launches)
+
+    def close(self):
+        for e in self.ev:
+            self.api.event_destroy(e)
+        self.s.close()
+
+
+def roofline_of(alg_bytes, launch_us):
+    achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+    return achieved, achieved / HBM_PEAK_GBS
+
+
+def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, f16=False, lanes=1, use_dist=False,
+                forms=('graph', 'eager')):
+    """One more workload through the same protocol (no summary kernels): -> compact result dict."""
+    shard = Shard(torch, model, n_env, n_veh, seed, f16=f16, lanes=lanes)
+    tm = Timer(torch, dist, use_dist, shard, with_summary=False)
+    tm.run(min(warmup, HORIZON), False)
+    torch.cuda.synchronize()
+    if 'graph' in forms and 'eager' in forms:
+        tm.pick_form()
+    else:
+        tm.eager = 'graph' not in forms or shard.plan(HORIZON) is None
+    r = tm.measure(steps, warmup, repeats)
+    world = dist.get_world_size() if use_dist else 1
+    dt = median(r['dt'])
+    alg = alg_bytes_per_env_step(n_veh, f16) * n_env
+    achieved, frac = roofline_of(alg, r['launch_us'])
+    out = {'n_env_per_gpu': n_env, 'n_veh': n_veh, 'dtype': 'f16 state / f32 arithmetic' if f16 else 'f32', 'lanes': lanes,
+           'value': n_env * lanes * world * steps / dt, 'unit': 'env-steps/s',
+           'ms_per_step': dt * 1e3 / (steps * lanes), 'steps': steps, 'repeats': len(r['dt']),
+           'launch_form': 'eager' if (tm.eager or shard.plan(HORIZON) is None) else 'hipGraph',
+           'alg_bytes_per_launch': alg, 'avg_launch_us': r['launch_us'], 'launches_timed': r['launches_timed'],
+           'achieved_GBs': achieved, 'frac': frac, 'footprint_MB': shard.footprint_bytes() / 1e6}
+    tm.close()
+    del shard, tm
+    torch.cuda.empty_cache()
+    return out
 
 
 def shield_bench(args):
@@ -175,11 +425,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--repeats', type=int, default=11, help='timed regions of --steps steps each; the median is reported')
     ap.add_argument('--n-env', type=int, default=N_ENV, help='envs per GPU (default: configs[2])')
     ap.add_argument('--n-veh', type=int, default=N_VEH)
     ap.add_argument('--eager', action='store_true', help='one host launch per step instead of hipGraph replays')
-    ap.add_argument('--graph', action='store_true', help='hipGraph replays (default: whichever of the two the warm-up finds faster)')
+    ap.add_argument('--graph', action='store_true', help='hipGraph replays (default: whichever of the two an untimed trial finds faster)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side', action='store_true', help='skip hbm_resident / strong / extra (headline line only)')
     ap.add_argument('--open-loop', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
                          'state in registers — VALU-bound, not the HBM-bound closed-loop headline')
@@ -188,14 +440,15 @@ def main():
                          'rollout step] per start state; a "step" is one shield pass over the batch; N = 1 only')
     args = ap.parse_args()
     n_env, n_veh = args.n_env, args.n_veh
+    if args.steps < 1 or args.repeats < 1:
+        raise SystemExit('--steps and --repeats must be >= 1')
     if args.shield:
         return shield_bench(args)
 
     import torch
     import torch.distributed as dist
     from env_build_amd.dynamics_and_models import EnvironmentModel
-    from env_build_amd.synthetic import make_rollout_inputs
-    from env_build_amd.sharding import combine_summaries, gather_summaries_async
+    from env_build_amd.sharding import combine_summaries
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -209,180 +462,121 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
 
-    # ---- synthetic shard of this rank (seed = rank: independent envs per GPU), resident in HBM ----
-    inp = make_rollout_inputs(TASK, n_env, n_veh, HORIZON, seed=rank)
+    # ---- headline: this rank's synthetic shard (seed = rank: independent envs per GPU), resident in HBM ----
     model = EnvironmentModel(TASK, num_future_data=0, mode='training', n_veh=n_veh, device=dev)
-    ego = torch.from_numpy(inp['ego']).to(dev)
-    ref_idx = torch.from_numpy(inp['ref_idx']).to(dev)
-    trk = model.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(),
-                                                       ego[:, 5].contiguous(), ego[:, 0].contiguous(), 0,
-                                                       ref_indexes=ref_idx).t
-    obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
-    tape = torch.from_numpy(inp['actions']).to(dev)                      # [H, B, 2]
-    work, final = torch.empty_like(obs0), torch.empty_like(obs0)
-    out5 = torch.empty((HORIZON, 5, n_env), dtype=torch.float32, device=dev)
-    # two summary buffers: the all-gather of rollout k overlaps the kernels of rollout k+1 (own RCCL stream)
-    summaries = [torch.zeros((8,), dtype=torch.float32, device=dev) for _ in range(2)]
-    in_flight = [None, None]
-    gathered = [torch.zeros((world, 8), dtype=torch.float32, device=dev)]
-    n_rollouts = [0]
-
-    api, h = model.api, model.handle
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
-    p = lambda t: C.c_void_p(t.data_ptr())
-    plan = C.c_void_p()
-    api.plan_create(h, n_env, HORIZON, p(obs0), p(tape), p(ref_idx), 0, p(work), p(final), p(out5), None, C.byref(plan))
-    lib = api.lib
-    # the eager form ping-pongs exactly as eb_rollout_tape does, so that step 24 lands in `final`
-    dst = [final if (HORIZON - 1 - t) % 2 == 0 else work for t in range(HORIZON)]
-    src = [obs0] + dst[:-1]
-    eager_args = [(h, n_env, p(src[t]), p(tape[t]), p(ref_idx), 0, p(dst[t]), p(out5[t]), None, sp) for t in range(HORIZON)]
-
-    def tape_launch():
-        rc = lib.eb_rollout_tape(h, n_env, HORIZON, p(obs0), p(tape), p(ref_idx), 0, p(work), p(final), p(out5), sp)
-        if rc != 0:
-            api.check(rc)
-
-    def eager_steps(t0, t1):
-        for t in range(t0, t1):
-            rc = lib.eb_rollout_step(*eager_args[t])
-            if rc != 0:
-                api.check(rc)
-
-    def end_of_horizon():
-        # episodic-return summary of this shard (two small kernels), then the only inter-GPU exchange
-        slot = n_rollouts[0] & 1
-        n_rollouts[0] += 1
-        if in_flight[slot] is not None:
-            gathered[0] = in_flight[slot].result()   # the gather of two rollouts ago: long finished
-        api.episode_summary(h, n_env, HORIZON, p(out5), p(final), p(summaries[slot]), sp)
-        in_flight[slot] = gather_summaries_async(summaries[slot])   # env_build_amd/sharding.py: 8 floats per rank
-
-    def drain_gathers():
-        order = [n_rollouts[0] & 1, (n_rollouts[0] + 1) & 1]       # oldest first
-        for slot in order:
-            if in_flight[slot] is not None:
-                gathered[0] = in_flight[slot].result()
-                in_flight[slot] = None
-
-    n_pairs = min(MAX_EVENT_PAIRS, max(1, args.steps // HORIZON))
-    ev = []
-    for _ in range(2 * n_pairs):
-        e = C.c_void_p()
-        api.event_create(h, C.byref(e))
-        ev.append(e)
-
-    def run(n_steps, timed):
-        full, rem = divmod(n_steps, HORIZON)
-        for k in range(full):
-            marks = timed and k < n_pairs
-            if marks:
-                lib.eb_event_record(ev[2 * k], sp)
-            if args.open_loop:
-                tape_launch()
-            elif args.eager:
-                eager_steps(0, HORIZON)
-            else:
-                rc = lib.eb_plan_launch(plan, sp)
-                if rc != 0:
-                    api.check(rc)
-            if marks:
-                lib.eb_event_record(ev[2 * k + 1], sp)
-            end_of_horizon()
-        eager_steps(0, rem)
-        drain_gathers()
-        return full
-
-    run(args.warmup, False)
+    shard = Shard(torch, model, n_env, n_veh, seed=rank, keep_host=(rank == 0))
+    tm = Timer(torch, dist, use_dist, shard, with_summary=True)
+    tm.open_loop = args.open_loop
+    tm.run(min(args.warmup, HORIZON), False)
     torch.cuda.synchronize()
-    # launch form of the timed region: the same 25 launches per rollout either as one hipGraph replay or as 25 host
-    # calls; which one keeps the queue fuller depends on the host, so two warm rollouts of each are timed first
-    if not (args.eager or args.graph or args.open_loop) and args.warmup >= HORIZON:
-        trial = {False: [], True: []}
-        for form in (False, True, False, True, False, True):
-            args.eager = form
-            run(HORIZON, False)
-            lib.eb_event_record(ev[0], sp)
-            run(4 * HORIZON, False)
-            lib.eb_event_record(ev[1], sp)
-            ms_t = C.c_float()
-            api.event_elapsed_ms(ev[0], ev[1], C.byref(ms_t))
-            trial[form].append(ms_t.value)
-        args.eager = min(trial[True]) < min(trial[False])
-        torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    full = run(args.steps, True)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    if args.open_loop:
+        tm.eager = True
+    elif args.eager or args.graph:
+        tm.eager = args.eager
+    else:
+        tm.pick_form()
+        if use_dist:                       # every rank runs the same form: rank 0's pick
+            flag = torch.tensor([1 if tm.eager else 0], dtype=torch.int32, device=dev)
+            dist.broadcast(flag, 0)
+            tm.eager = bool(flag.item())
+    r = tm.measure(args.steps, args.warmup, args.repeats)
+    dt = median(r['dt'])
+    summary = [float(x) for x in combine_summaries(tm.gathered).tolist()]
+    headline_form = 'eager host launches' if tm.eager else 'hipGraph replays of <= %d launches' % HORIZON
 
-    ms = C.c_float()
-    ev_ms, n_marked = 0.0, min(full, n_pairs)
-    for k in range(n_marked):
-        api.event_elapsed_ms(ev[2 * k], ev[2 * k + 1], C.byref(ms))
-        ev_ms += ms.value
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    # ---- side measurements (untimed for `value`) ----
+    strong = hbm = None
+    extra = []
+    if not args.no_side and not args.open_loop:
+        side_steps, side_warm, side_rep = max(HORIZON, min(args.steps, 500)), HORIZON, min(args.repeats, 7)
+        _MODELS[n_veh] = model
+        m32 = model_for(torch, EnvironmentModel, dev, N_VEH)
+        per = STRONG_TOTAL // world
+        s = side_config(torch, dist, m32, per, N_VEH, 1000 + rank, side_steps, side_warm, side_rep, use_dist=use_dist)
+        if rank == 0:
+            strong = dict(s, workload='configs[3]: N_env=%d in total, %d per GPU, N_veh=%d, horizon=%d (strong scaling: the total '
+                                      'is fixed as N grows)' % (STRONG_TOTAL, per, N_VEH, HORIZON), n_gpus=world, scaling='strong')
+        if world == 1:
+            lanes = 8
+            a = side_config(torch, dist, m32, N_ENV, N_VEH, 0, 100, HORIZON, min(args.repeats, 5), lanes=lanes, forms=('eager',))
+            b = side_config(torch, dist, m32, 8 * N_ENV, N_VEH, 7, 100, HORIZON, min(args.repeats, 5))
+            hbm = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                   'achieved': a['achieved_GBs'], 'frac': a['frac'],
+                   'exceeds_infinity_cache': 'both: (a) 8 env sets x 65 536 envs stepped round-robin — 7 x 74 MB of other traffic '
+                                             'between a line\'s write and its re-read, footprint %.0f MB; (b) one batch of 524 288 envs '
+                                             '— 290 MB per obs buffer, footprint %.0f MB; Infinity Cache = 268 MB'
+                                             % (a['footprint_MB'], b['footprint_MB']),
+                   'lanes8_x_65536': a, 'single_524288': b}
+            extra.append(dict(side_config(torch, dist, model_for(torch, EnvironmentModel, dev, 16), 4096, 16, 11, side_steps, side_warm,
+                                          side_rep), workload='configs[1]: N_env=4096, N_veh=16, horizon=25, fp32'))
+            extra.append(dict(side_config(torch, dist, model_for(torch, EnvironmentModel, dev, 64), N_ENV, 64, 12, side_steps, side_warm,
+                                          side_rep, f16=True), workload='configs[4]: N_env=65536, N_veh=64, fp16 state / fp32 reward accumulate'))
 
     if rank == 0:
-        value = n_env * world * args.steps / dt_max
+        value = n_env * world * args.steps / dt
         alg = alg_bytes_per_env_step(n_veh) * n_env
-        if n_marked:
-            launch_s = ev_ms * 1e-3 / (n_marked * HORIZON)   # HIP events on the launch stream, per rollout launch
-        else:
-            launch_s = dt_max / args.steps                   # fewer than 25 steps: whole-region wall time
-        achieved = alg / launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')   # from a separate --pmc run (scripts/pmc_traffic.sh)
-        if os.path.isfile(tpath) and n_env == N_ENV and n_veh == N_VEH:
-            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        launch_us = r['launch_us']
+        traffic, traffic_src = None, None
+        for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):      # separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
+            tpath = os.path.join(ROOT, 'profiles', name)
+            if os.path.isfile(tpath) and n_env == N_ENV and n_veh == N_VEH and not args.open_loop:
+                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+                traffic_src = 'profiles/%s: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes of this kernel, not measured in this run' % name
+                break
         cfg = 'configs[2]' if (n_env, n_veh) == (N_ENV, N_VEH) else 'custom'
         kernel = 'eb::rollout_fused_4x8<0, true, float>'
-        form = 'closed-loop rollout_out (one kernel launch per step, %s)' % ('eager' if args.eager else '25-launch hipGraph replays')
+        form = 'closed-loop rollout_out (one kernel launch per step, %s)' % headline_form
         if args.open_loop:
-            # one launch per 25-step tape; HBM sees the initial and final obs once, actions and outputs every step
-            alg = (28 * HORIZON + 72 + 32 * n_veh) * n_env
-            launch_s *= HORIZON
-            achieved = alg / launch_s / 1e9
-            traffic = None
+            # one launch per tape; HBM sees the initial and final obs once, actions and outputs every step
+            h_eff = min(args.steps, HORIZON)
+            alg = (28 * h_eff + 72 + 32 * n_veh) * n_env
             kernel = 'eb::rollout_tape_4x8<0, true, float>'
             form = ('OPEN-LOOP eb_rollout_tape (the whole %d-step action tape in one launch, records and ego state in registers; '
-                    'VALU-bound — reported apart from the closed-loop headline)' % HORIZON)
+                    'VALU-bound — reported apart from the closed-loop headline)' % h_eff)
+        achieved, frac = roofline_of(alg, launch_us)
+        ws = shard.footprint_bytes()
         line = {
             'metric': 'env-steps/s (batched rollout) at N_env x N_veh; achieved HBM GB/s vs peak',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt_max * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': dt * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: N_env=%d per GPU, N_veh=%d, horizon=%d, task=%s, mode=training, %s'
-                                   % (cfg, n_env, n_veh, HORIZON, TASK, form),
-                       'n_env_per_gpu': n_env, 'n_veh': n_veh, 'horizon': HORIZON,
+                                   % (cfg, n_env, n_veh, min(args.steps, HORIZON), TASK, form),
+                       'n_env_per_gpu': n_env, 'n_veh': n_veh, 'horizon': min(args.steps, HORIZON),
                        'parallelism': 'env-shard x%d, all-gather of the 8-float episodic summary per horizon' % world},
+            'repeats': {'n': len(r['dt']), 'statistic': 'median', 'ms_per_step_min': min(r['dt']) * 1e3 / args.steps,
+                        'ms_per_step_median': dt * 1e3 / args.steps, 'ms_per_step_max': max(r['dt']) * 1e3 / args.steps},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': frac, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': kernel, 'alg_bytes_per_launch': alg,
-                         'avg_launch_us': launch_s * 1e6,
-                         'launches_timed': n_marked * (1 if args.open_loop else HORIZON)},
-            'summary': [float(x) for x in combine_summaries(gathered[0]).tolist()],
+                         'avg_launch_us': launch_us, 'launches_timed': r['launches_timed'],
+                         'working_set_MB': ws / 1e6,
+                         'residency': ('working set %.0f MB < 268 MB Infinity Cache: this fraction is cache-assisted; see hbm_resident'
+                                       % (ws / 1e6)) if ws < MALL_BYTES else 'working set exceeds the Infinity Cache',
+                         'hbm_resident': hbm},
+            'summary': summary,
+            'strong': strong,
+            'extra': extra,
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
-            line['cpu_baseline'] = cpu_baseline(inp, obs0.cpu().numpy(), n_veh)
+            line['cpu_baseline'] = cpu_baseline(shard.inp, shard.obs0_f32.cpu().numpy(), n_veh)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
-    for e in ev:
-        api.event_destroy(e)
-    api.plan_destroy(plan)
+    tm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_MODELS = {}
+
+
+def model_for(torch, EnvironmentModel, dev, n_veh):
+    """EnvironmentModel per slot count (the handle fixes n_veh); state dtype is chosen per call by the entry point used"""
+    if n_veh not in _MODELS:
+        _MODELS[n_veh] = EnvironmentModel(TASK, num_future_data=0, mode='training', n_veh=n_veh, device=dev)
+    return _MODELS[n_veh]
 
 
 if __name__ == '__main__':

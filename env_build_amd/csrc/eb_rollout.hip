@@ -43,6 +43,13 @@ template <> struct Stored<float> {
     static EB_DEV void store4(float* p, f4u v) { *reinterpret_cast<f4u*>(p) = v; }
     static EB_DEV void store1(float* p, float v) { *p = v; }
     static EB_DEV float round(float v) { return v; }                    // what a store + load does to a value
+    // record store with a cache policy (wave-uniform `pol`): 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
+    static EB_DEV void store4_pol(float* p, f4u v, int pol) {
+        if (pol == 0) store4(p, v);
+        else if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+        else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+    }
 };
 typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
 template <> struct Stored<_Float16> {
@@ -56,6 +63,15 @@ template <> struct Stored<_Float16> {
     }
     static EB_DEV void store1(_Float16* p, float v) { *p = (_Float16)v; }
     static EB_DEV float round(float v) { return (float)(_Float16)v; }
+    static EB_DEV void store4_pol(_Float16* p, f4u v, int pol) {
+        const h4u h = h4u{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        const u2v bits = __builtin_bit_cast(u2v, h);
+        if (pol == 0) store4(p, v);
+        else if (pol == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(bits) : "memory");
+        else if (pol == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(bits) : "memory");
+        else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(bits) : "memory");
+    }
 };
 
 // LDS-only workgroup barrier: orders this wave's LDS traffic, leaves global loads/stores in flight
@@ -406,6 +422,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         EB_MARK(A, trow, 3);                                                // ego seen
     }
     const bool test_near = H.do_rewards && !(A.ablate & 8);
+    const int store_pol = (A.ablate >> 5) & 3;          // profiling aid: cache policy of the record stores
     int k_late = test_near ? RPT : 0;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -423,7 +440,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         }
         if (valid) {
             const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
-            Stored<ST>::store4(tout + off, predict_record_pk<ST>(rec[k], tc));
+            Stored<ST>::store4_pol(tout + off, predict_record_pk<ST>(rec[k], tc), store_pol);
         }
         if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
         if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored

@@ -10,7 +10,7 @@ from env_build_amd.synthetic import make_rollout_inputs
 ap = argparse.ArgumentParser()
 ap.add_argument('--task', default='left'); ap.add_argument('--n-env', type=int, default=65536)
 ap.add_argument('--n-veh', type=int, default=32); ap.add_argument('--mode', default='training')
-ap.add_argument('--iters', type=int, default=200); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])')
+ap.add_argument('--iters', type=int, default=200); ap.add_argument('--lanes', type=int, default=1, help='independent env sets stepped round-robin (8: the working set leaves the Infinity Cache)'); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 inp = make_rollout_inputs(a.task, a.n_env, a.n_veh, 25, seed=0)
@@ -22,14 +22,16 @@ trk = m.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4]
 obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
 if a.f16: obs0 = obs0.to(torch.float16)
 tape = torch.from_numpy(inp['actions']).to(dev)
-bufs = [torch.empty_like(obs0), torch.empty_like(obs0)]; out5 = torch.empty((25, 5, a.n_env), device=dev)
+L = a.lanes
+obs0s = [obs0] + [obs0.clone() for _ in range(L - 1)]
+bufs = [[torch.empty_like(obs0), torch.empty_like(obs0)] for _ in range(L)]; out5 = [torch.empty((25, 5, a.n_env), device=dev) for _ in range(L)]
 p = lambda t: C.c_void_p(t.data_ptr())
 st = torch.cuda.current_stream(); sp = C.c_void_p(st.cuda_stream)
 fn = m.api.lib.eb_rollout_step_f16 if a.f16 else m.api.lib.eb_rollout_step
 def step(i):
-    t = i % 25
-    src = obs0 if t == 0 else bufs[(t - 1) & 1]
-    rc = fn(m.handle, a.n_env, p(src), p(tape[t]), p(ref) if a.mode == 'training' else None, 1, p(bufs[t & 1]), p(out5[t]), None, sp)
+    l, t = i % L, (i // L) % 25
+    src = obs0s[l] if t == 0 else bufs[l][(t - 1) & 1]
+    rc = fn(m.handle, a.n_env, p(src), p(tape[t]), p(ref) if a.mode == 'training' else None, 1, p(bufs[l][t & 1]), p(out5[l][t]), None, sp)
     assert rc == 0, m.api.lib.eb_last_error()
 for i in range(50): step(i)
 torch.cuda.synchronize()
@@ -43,5 +45,5 @@ t2 = time.perf_counter()
 print('wall: enqueue %.2f us/step, enqueue+drain %.2f us/step; torch events %.2f us/step' % ((t1 - t0) * 1e6 / a.iters, (t2 - t0) * 1e6 / a.iters, e0.elapsed_time(e1) * 1e3 / a.iters))
 us = (t2 - t0) * 1e6 / a.iters
 alg = ((68 + 16 * a.n_veh) if a.f16 else (104 + 32 * a.n_veh)) * a.n_env
-print(('f16 ' if a.f16 else '') + 'ablate=%s task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
+print(('f16 ' if a.f16 else '') + 'lanes=%d ' % L + 'ablate=%s task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
       % (os.environ.get('EB_ABLATE', '0'), a.task, a.n_env, a.n_veh, a.mode, us, a.n_env / us / 1e3, alg / us / 1e3, alg / us / 1e3 / 80))

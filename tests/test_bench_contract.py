@@ -1,0 +1,38 @@
+"""bench.py's protocol: segmenting of the timed steps (CPU) and one small run under the driver's own flags (GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_segments_cover_exactly_the_requested_steps():
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in (1, 5, 20, 25, 26, 49, 50, 2000, 2013):
+        segs = bench.Timer.segments(k)
+        assert sum(segs) == k and all(1 <= s <= bench.HORIZON for s in segs)
+        assert segs[:-1] == [bench.HORIZON] * (len(segs) - 1)          # only the last rollout may be shorter
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5
+    assert bench.alg_bytes_per_env_step(32) == 1128 and bench.alg_bytes_per_env_step(64, f16=True) == 1092
+
+
+@pytest.mark.gpu
+def test_driver_invocation_times_events_summary_and_repeats():
+    """`--steps 20 --warmup 5` (fewer steps than one horizon): the rollout is planned with horizon 20, so the event
+    pairs, the summary kernels and the all-gather all run, and the label names the launch form that ran."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5',
+                          '--n-env', '8192', '--no-cpu-baseline', '--no-side', '--repeats', '5'],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['steps'] == 20 and line['warmup'] == 5 and line['n_gpus'] == 1
+    assert line['roofline']['launches_timed'] == 5 * 20
+    assert line['repeats']['n'] == 5 and line['repeats']['ms_per_step_min'] <= line['ms_per_step'] <= line['repeats']['ms_per_step_max']
+    s = line['summary']
+    assert s[6] == 8192 and s[7] == 20 and s[0] != 0.0                  # n_env, horizon, sum of rewards
+    assert ('eager' in line['config']['workload']) != ('hipGraph' in line['config']['workload'])
+    assert abs(line['value'] - 8192 * 20 / (line['ms_per_step'] * 1e-3 * 20)) / line['value'] < 1e-9
