@@ -8,13 +8,15 @@ with the same class to compare the two libraries call-for-call.)
 import ctypes as C
 import os
 
-EB_ABI_VERSION = 1
+EB_ABI_VERSION = 2
 TASK_ID = {'left': 0, 'straight': 1, 'right': 2}
 MODE_TRAINING, MODE_SELECTING = 0, 1
 # vehicle mode ids (EB_VMODE_*), in the order of the twelve lists of E2E:354
 VMODES = ('dl', 'du', 'dr', 'rd', 'rl', 'ru', 'ur', 'ud', 'ul', 'lu', 'lr', 'ld')
 VMODE_ID = {m: i for i, m in enumerate(VMODES)}
 VMODE_EMPTY = 255
+EXITS = ('D', 'R', 'U', 'L')                    # EB_EXIT_*: multi_ego.py:33 ROTATE_ANGLE = 0 / 90 / 180 / -90 degrees
+EXIT_ID = {e: i for i, e in enumerate(EXITS)}
 
 DONE_NAMES = ('not_done_yet', 'collision', 'break_road_constrain', 'deviate_too_much',
               'break_stability', 'break_red_light', 'good_done')  # E2E:208-221
@@ -62,15 +64,25 @@ PROTOTYPES = {
     'eb_event_record': (C.c_int, [_P, _P]),
     'eb_event_elapsed_ms': (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     'eb_event_destroy': (C.c_int, [_P]),
-    'eb_find_closest_point': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
+    'eb_find_closest_point': (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    'eb_path_points': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P]),
+    'eb_phi_diff': (C.c_int, [_P, _I, _P, _P, _P]),
+    'eb_ego_predict': (C.c_int, [_P, _I, _P, _P, _P, _P]),
     'eb_tracking_error': (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     'eb_veh_predict': (C.c_int, [_P, _I, _P, _P, _P]),
     'eb_ss': (C.c_int, [_P, _I, _P, _P, _P, _I, C.c_double, _P, _P]),
     'eb_env_ego_step': (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
-    'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_exit_frame': (C.c_int, [_P, _I, _P, _I, _P, _P, _P]),
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
-    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P]),
+    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P]),
+    'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, _P]),
+    'eb_traffic_flow_reset': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I,
+                                        C.c_uint64, C.c_uint64, _P, _P, _P]),
+    'eb_debug_set_tile': (C.c_int, [_P, _I]),
+    'eb_debug_set_tape_stepwise': (C.c_int, [_P, _I]),
+    'eb_debug_set_trace': (C.c_int, [_P, _P]),
     'eb_traffic_flow_step': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                        _I, C.c_uint64, C.c_uint64, _P, _P, _P]),
     'eb_mlp_create': (C.c_int, [C.POINTER(EbMlpConfig), C.POINTER(_P)]),
@@ -169,10 +181,20 @@ def hip_api():
         # same HIP runtime (one runtime per process: shared device pointers and streams).  Loading
         # ours first makes torch see no GPU.
         import torch  # noqa: F401
-        if not os.path.isfile(HIP_LIB_PATH):
-            raise EbError('HIP extension missing: %s — run `python -c "import __graft_entry__ as g; '
-                          'g.build()"` (hipcc --offload-arch=gfx950).  env_build_amd has no CPU '
-                          'fallback.' % HIP_LIB_PATH)
+        from . import build as _build
+        ok, why = _build.check_fresh()
+        if not ok:
+            # never load a binary that does not come from the sources next to it: rebuild when the compiler is
+            # here (seconds), refuse otherwise
+            hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+            if os.path.isfile(hipcc):
+                try:
+                    _build.build()
+                except Exception as e:   # noqa: BLE001
+                    raise EbError('%s; rebuilding it failed: %s.  env_build_amd has no CPU fallback.' % (why, e))
+            else:
+                raise EbError('%s — run `python -c "import __graft_entry__ as g; g.build()"` (hipcc '
+                              '--offload-arch=gfx950).  env_build_amd has no CPU fallback.' % why)
         _hip_api = CApi(HIP_LIB_PATH)
         if _hip_api.backend != 'hip':
             raise EbError('%s is not the HIP backend' % HIP_LIB_PATH)

@@ -1,13 +1,21 @@
 """Builds env_build_amd/lib/libenvbuild_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
 -ffp-contract=off is part of the numerical contract: every fp32 op of the reference is one IEEE
-rounding, so no FMA contraction."""
+rounding, so no FMA contraction.
+
+Staleness is decided by CONTENT, not by mtime: the SHA-256 of every source, header and compiler flag is
+written next to the library (libenvbuild_hip.so.srchash) when it is built, and `needs_build()` /
+`check_fresh()` compare it with the hash of the sources present.  A library that was copied somewhere
+together with different sources (e.g. a snapshot pushed to a GPU box) is therefore never silently reused:
+it is rebuilt when hipcc is there, and `_capi.hip_api()` refuses to load it otherwise."""
+import hashlib
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libenvbuild_hip.so')
+HASH_FILE = LIB + '.srchash'
 SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip', 'eb_policy.hip']
 HEADERS = ['eb_device.h', 'eb_kernels.h', os.path.join('..', '..', 'include', 'envbuild.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
@@ -15,11 +23,37 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fn
          '-mllvm', '-amdgpu-kernarg-preload-count=12']   # the rollout kernel's leading arguments arrive in SGPRs
 
 
+def source_hash():
+    """SHA-256 over the compiler flags and the bytes of every source and header, in a fixed order."""
+    h = hashlib.sha256()
+    h.update('\0'.join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        h.update(b'\0' + f.encode() + b'\0')
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def built_hash():
+    try:
+        with open(HASH_FILE) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
 def needs_build():
+    return not os.path.isfile(LIB) or built_hash() != source_hash()
+
+
+def check_fresh():
+    """(ok, message): does the library on disk come from the sources on disk?"""
     if not os.path.isfile(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+        return False, 'HIP extension missing: %s' % LIB
+    if built_hash() != source_hash():
+        return False, ('%s was built from different sources or flags than the ones in %s (hash %s, sources %s)'
+                       % (LIB, CSRC, built_hash(), source_hash()))
+    return True, ''
 
 
 def build(force=False, verbose=False):
@@ -27,10 +61,15 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ['-o', LIB]
+    tmp = LIB + '.tmp%d' % os.getpid()
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ['-o', tmp]
     if verbose:
         print(' '.join(cmd))
+    digest = source_hash()           # of what the compiler is about to read
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
+    with open(HASH_FILE, 'w') as fh:
+        fh.write(digest + '\n')
     return LIB
 
 

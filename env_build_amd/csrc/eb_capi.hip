@@ -53,6 +53,7 @@ struct eb_handle_s {
     eb::VehModes modes;
     int modes_set;
     long long* trace;         // profiling aid, see eb_debug_set_trace
+    eb::ExitConsts xc;        // cos / sin of the exit angles (eb_get_obs with exit ids, eb_exit_frame)
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
     int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
 };
@@ -72,12 +73,17 @@ static hipStream_t pick(eb_handle, void* stream) { return (hipStream_t)stream; }
 // kernel's cell assignment and of its dist^2 values at these coordinates (<= 1e-5 m).  The kernel
 // scans [lo, hi] in index order with the reference's fp32 expression and a strict '<', which is the
 // reference's full-scan argmin (first minimum) restricted to a range that provably contains it.
-static int build_cell_grid(eb_handle_s* h, const float* hred, int n_paths) {
+struct CellGrid {
+    std::vector<uint32_t> cells;
+    double x0, y0;
+    int nx, ny;
+};
+static int build_cell_grid(const int* red_off, const int* red_len, const float* hred, int n_paths, CellGrid* out) {
     const double cell = 1.0 / (double)eb::CELL_INV, margin = 20.0;   // beyond that: the pruned full search
     double x0 = 1e30, x1 = -1e30, y0 = 1e30, y1 = -1e30;
     for (int k = 0; k < n_paths; ++k) {
-        const float* r = hred + 2 * (size_t)h->red_off[k];
-        for (int i = 0; i < h->pt.red_len[k]; ++i) {
+        const float* r = hred + 2 * (size_t)red_off[k];
+        for (int i = 0; i < red_len[k]; ++i) {
             if (!std::isfinite(r[2 * i]) || !std::isfinite(r[2 * i + 1])) return fail(EB_EINVAL, "eb_set_paths: non-finite path point");
             x0 = std::min(x0, (double)r[2 * i]); x1 = std::max(x1, (double)r[2 * i]);
             y0 = std::min(y0, (double)r[2 * i + 1]); y1 = std::max(y1, (double)r[2 * i + 1]);
@@ -87,11 +93,11 @@ static int build_cell_grid(eb_handle_s* h, const float* hred, int n_paths) {
     int nx = (int)std::ceil((x1 + margin - x0) / cell), ny = (int)std::ceil((y1 + margin - y0) / cell);
     nx = std::min(nx, 1024); ny = std::min(ny, 1024);   // positions outside the grid take the pruned full search
     const double hd = cell * std::sqrt(2.0) / 2.0, win = 2.0 * hd + 0.01;
-    std::vector<uint32_t> cells((size_t)n_paths * nx * ny);
+    out->cells.assign((size_t)n_paths * nx * ny, 0u);
     std::vector<double> d;
     for (int k = 0; k < n_paths; ++k) {
-        const float* r = hred + 2 * (size_t)h->red_off[k];
-        const int n = h->pt.red_len[k];
+        const float* r = hred + 2 * (size_t)red_off[k];
+        const int n = red_len[k];
         d.resize(n);
         for (int iy = 0; iy < ny; ++iy)
             for (int ix = 0; ix < nx; ++ix) {
@@ -106,15 +112,10 @@ static int build_cell_grid(eb_handle_s* h, const float* hred, int n_paths) {
                 int lo = 0, hi = n - 1;
                 while (d[lo] > lim) ++lo;
                 while (d[hi] > lim) --hi;
-                cells[((size_t)k * ny + iy) * nx + ix] = (uint32_t)lo | ((uint32_t)hi << 16);
+                out->cells[((size_t)k * ny + iy) * nx + ix] = (uint32_t)lo | ((uint32_t)hi << 16);
             }
     }
-    if (h->d_cells) { hipFree(h->d_cells); h->d_cells = nullptr; }
-    EB_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_cells), cells.size() * sizeof(uint32_t)));
-    EB_HIP(hipMemcpy(h->d_cells, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    h->pt.cells = h->d_cells;
-    h->pt.gx0 = (float)x0; h->pt.gy0 = (float)y0;   // integers: exact in fp32
-    h->pt.gnx = nx; h->pt.gny = ny;
+    out->x0 = x0; out->y0 = y0; out->nx = nx; out->ny = ny;
     return EB_OK;
 }
 
@@ -148,6 +149,15 @@ int eb_create(const eb_config* cfg, eb_handle* out) {
     std::memset(h, 0, sizeof *h);
     h->cfg = *cfg;
     h->tile_variant = -1;
+    {   // rotate_coordination's coordi_rotate_d * math.pi / 180 and math.cos / math.sin (UTL:130-132), by the host's libm
+        const int ang[4] = {0, 90, 180, -90};   // multi_ego.py:33
+        for (int k = 0; k < 4; ++k) {
+            const double r = ang[k] * 3.141592653589793 / 180, ri = -ang[k] * 3.141592653589793 / 180;
+            h->xc.c[k] = std::cos(r); h->xc.s[k] = std::sin(r);
+            h->xc.cf[k] = (float)std::cos(r); h->xc.sf[k] = (float)std::sin(r);
+            h->xc.cf[4 + k] = (float)std::cos(ri); h->xc.sf[4 + k] = (float)std::sin(ri);
+        }
+    }
     {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, cfg->device);
@@ -188,11 +198,14 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     size_t total = 0, red_total = 0;
     for (int k = 0; k < n_paths; ++k) {
         if (lens[k] < 3) return fail(EB_EINVAL, "eb_set_paths: path too short");
+        if ((lens[k] + 9) / 10 > 512) return fail(EB_EINVAL, "eb_set_paths: path longer than 5120 points (32 search blocks)");
         total += (size_t)lens[k];
         red_total += (size_t)(lens[k] + 9) / 10;   // len(np.arange(0, path_len, 10)), DAM:704
     }
-    for (int k = 0; k < n_paths; ++k)
-        if ((lens[k] + 9) / 10 > 512) return fail(EB_EINVAL, "eb_set_paths: path longer than 5120 points (32 search blocks)");
+    for (size_t i = 0; i < total; ++i)
+        if (!std::isfinite(xs[i]) || !std::isfinite(ys[i]) || !std::isfinite(phis[i]))
+            return fail(EB_EINVAL, "eb_set_paths: non-finite path point");
+    // ---- everything below is built into temporaries; the handle changes only once all of it has succeeded ----
     // host staging: [x | y | phi] full resolution, then float2 stride-10 tables
     std::vector<float> host(3 * total + 2 * red_total + 4 + 96 + 8 + red_total + 8 + 8, 0.0f);
     float* hx = host.data();
@@ -203,9 +216,11 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     std::memcpy(hx, xs, total * sizeof(float));
     std::memcpy(hy, ys, total * sizeof(float));
     std::memcpy(hp, phis, total * sizeof(float));
+    int red_off[3] = {0, 0, 0}, red_len[3] = {0, 0, 0};
     size_t off = 0, roff = 0;
     for (int k = 0; k < n_paths; ++k) {
-        h->red_off[k] = (int)roff;
+        red_off[k] = (int)roff;
+        red_len[k] = (lens[k] + 9) / 10;
         for (int i = 0; i < lens[k]; i += 10) {
             hred[2 * roff] = xs[off + i];
             hred[2 * roff + 1] = ys[off + i];
@@ -213,17 +228,14 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
         }
         off += (size_t)lens[k];
     }
-    EB_HIP(hipSetDevice(h->cfg.device));
-    EB_HIP(hipDeviceSynchronize());
-    if (h->d_tables) { hipFree(h->d_tables); h->d_tables = nullptr; }
     // block radii of the pruned search: R_b >= max_r |P_r - c_b| over block b = [16b, 16b+16), with
     // c_b = P_min(16b+8, n-1); evaluated in double on the fp32 table values and inflated by 1e-4 m
     const size_t rad_byte_off = (red_byte_off + 2 * red_total * sizeof(float) + 15) / 16 * 16;
     float* hrad = reinterpret_cast<float*>(reinterpret_cast<char*>(host.data()) + rad_byte_off);
     for (int i = 0; i < 96; ++i) hrad[i] = 0.0f;
     for (int k = 0; k < n_paths; ++k) {
-        const float* rx = hred + 2 * (size_t)h->red_off[k];
-        const int n = (lens[k] + 9) / 10;
+        const float* rx = hred + 2 * (size_t)red_off[k];
+        const int n = red_len[k];
         for (int b = 0; 16 * b < n; ++b) {
             const int c = std::min(16 * b + 8, n - 1);
             double r2 = 0.0;
@@ -244,27 +256,62 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
         off += (size_t)lens[k];
     }
     const size_t bytes = phi10_byte_off + (red_total + 8) * sizeof(float);
-    EB_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_tables), bytes));
-    EB_HIP(hipMemcpy(h->d_tables, host.data(), bytes, hipMemcpyHostToDevice));
-    h->d_red_all = reinterpret_cast<float2*>(reinterpret_cast<char*>(h->d_tables) + red_byte_off);
-    h->d_rad_all = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_tables) + rad_byte_off);
-    h->d_phi10_all = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_tables) + phi10_byte_off);
-    std::memset(&h->pt, 0, sizeof h->pt);
+    CellGrid grid;
+    int rc = build_cell_grid(red_off, red_len, hred, n_paths, &grid);
+    if (rc) return rc;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    float* d_tables = nullptr;
+    uint32_t* d_cells = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_tables), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cells), grid.cells.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_tables, host.data(), bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cells, grid.cells.data(), grid.cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // nothing in flight reads the old tables any more
+    if (e != hipSuccess) {
+        if (d_tables) hipFree(d_tables);
+        if (d_cells) hipFree(d_cells);
+        return fail_hip("eb_set_paths: device tables", e);
+    }
+    // ---- swap ----
+    eb::PathTables pt;
+    std::memset(&pt, 0, sizeof pt);
+    float2* d_red_all = reinterpret_cast<float2*>(reinterpret_cast<char*>(d_tables) + red_byte_off);
     off = 0;
     for (int k = 0; k < n_paths; ++k) {
-        h->pt.x[k] = h->d_tables + off;
-        h->pt.y[k] = h->d_tables + total + off;
-        h->pt.phi[k] = h->d_tables + 2 * total + off;
-        h->pt.red[k] = h->d_red_all + h->red_off[k];
-        h->pt.len[k] = lens[k];
-        h->pt.red_len[k] = (lens[k] + 9) / 10;
+        pt.x[k] = d_tables + off;
+        pt.y[k] = d_tables + total + off;
+        pt.phi[k] = d_tables + 2 * total + off;
+        pt.red[k] = d_red_all + red_off[k];
+        pt.len[k] = lens[k];
+        pt.red_len[k] = red_len[k];
         off += (size_t)lens[k];
     }
-    h->pt.n_paths = n_paths;
+    pt.n_paths = n_paths;
+    pt.cells = d_cells;
+    pt.gx0 = (float)grid.x0; pt.gy0 = (float)grid.y0;   // integers: exact in fp32
+    pt.gnx = grid.nx; pt.gny = grid.ny;
+    const eb::PathTables old_pt = h->pt;
+    float* old_tables = h->d_tables;
+    uint32_t* old_cells = h->d_cells;
+    int old_off[3] = {h->red_off[0], h->red_off[1], h->red_off[2]};
+    h->pt = pt;
+    for (int k = 0; k < 3; ++k) h->red_off[k] = red_off[k];
+    e = upload_tables(h);
+    if (e != hipSuccess) {   // the device copy of the table descriptor still names the old tables: keep them
+        h->pt = old_pt;
+        for (int k = 0; k < 3; ++k) h->red_off[k] = old_off[k];
+        hipFree(d_tables);
+        hipFree(d_cells);
+        return fail_hip("eb_set_paths: upload", e);
+    }
+    h->d_tables = d_tables;
+    h->d_cells = d_cells;
+    h->d_red_all = d_red_all;
+    h->d_rad_all = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + rad_byte_off);
+    h->d_phi10_all = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + phi10_byte_off);
     h->red_total = (int)red_total;
-    int rc = build_cell_grid(h, hred, n_paths);
-    if (rc) return rc;
-    EB_HIP(upload_tables(h));
+    if (old_tables) hipFree(old_tables);
+    if (old_cells) hipFree(old_cells);
     return EB_OK;
 }
 
@@ -490,15 +537,43 @@ int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint1
 }
 
 int eb_find_closest_point(eb_handle h, int32_t n, const float* xs, const float* ys, const int32_t* ref_idx,
-                          int32_t path_id, int32_t* out_index, float* out_points, void* stream) {
+                          int32_t path_id, int32_t ratio, int32_t* out_index, float* out_points, void* stream) {
     int rc = check_paths(h, "eb_find_closest_point: null handle");
     if (rc) return rc;
-    if (n < 0 || !xs || !ys || !out_index) return fail(EB_EINVAL, "eb_find_closest_point: bad argument");
+    if (n < 0 || !xs || !ys || !out_index || ratio < 1) return fail(EB_EINVAL, "eb_find_closest_point: bad argument");
     if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_find_closest_point: bad path_id");
     if (n == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
-    EB_HIP(eb::launch_tracking(h->cfg.task, n, h->pt, xs, ys, nullptr, nullptr, ref_idx, path_id, 0, nullptr,
+    EB_HIP(eb::launch_tracking(h->cfg.task, n, h->pt, xs, ys, nullptr, nullptr, ref_idx, path_id, 0, ratio, nullptr,
                                out_index, out_points, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_path_points(eb_handle h, int32_t n, const int32_t* index, const int32_t* ref_idx, int32_t path_id,
+                   int32_t n_future, float* out_points, void* stream) {
+    int rc = check_paths(h, "eb_path_points: null handle");
+    if (rc) return rc;
+    if (n < 0 || n_future < 0 || (n > 0 && (!index || !out_points))) return fail(EB_EINVAL, "eb_path_points: bad argument");
+    if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_path_points: bad path_id");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_path_points(n, h->pt, index, ref_idx, path_id, n_future, out_points, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_phi_diff(eb_handle h, int32_t n, const float* phi_diff, float* out, void* stream) {
+    if (!h || n < 0 || (n > 0 && (!phi_diff || !out))) return fail(EB_EINVAL, "eb_phi_diff: bad argument");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_phi_diff(n, phi_diff, out, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_ego_predict(eb_handle h, int32_t n, const float* ego, const float* actions, float* next_ego, void* stream) {
+    if (!h || n < 0 || (n > 0 && (!ego || !actions || !next_ego))) return fail(EB_EINVAL, "eb_ego_predict: bad argument");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_ego_predict(n, ego, actions, next_ego, pick(h, stream)));
     return EB_OK;
 }
 
@@ -510,7 +585,7 @@ int eb_tracking_error(eb_handle h, int32_t n, const float* xs, const float* ys, 
     if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_tracking_error: bad path_id");
     if (n == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
-    EB_HIP(eb::launch_tracking(h->cfg.task, n, h->pt, xs, ys, phis, vs, ref_idx, path_id, n_future, out, nullptr,
+    EB_HIP(eb::launch_tracking(h->cfg.task, n, h->pt, xs, ys, phis, vs, ref_idx, path_id, n_future, 10, out, nullptr,
                                nullptr, pick(h, stream)));
     return EB_OK;
 }
@@ -549,8 +624,8 @@ int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actio
 }
 
 int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx, int32_t path_id,
-               int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag,
-               float* obs_out, void* stream) {
+               int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* v_light,
+               const uint8_t* virtual_flag, const uint8_t* exit_id, float* obs_out, void* stream) {
     int rc = check_paths(h, "eb_get_obs: null handle");
     if (rc) return rc;
     rc = check_modes(h);
@@ -560,8 +635,19 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
     if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_get_obs: bad path_id");
     if (n_env == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
+    // (exit ids live in device memory: the kernel masks them to 0..3 instead of a host-side range check)
     EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
-                              ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, pick(h, stream)));
+                              ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, pick(h, stream),
+                              nullptr, nullptr, nullptr, exit_id, &h->xc));
+    return EB_OK;
+}
+
+int eb_exit_frame(eb_handle h, int32_t n, const uint8_t* exit_id, int32_t inverse, const float* ego, float* ego_out,
+                  void* stream) {
+    if (!h || n < 0 || (n > 0 && (!exit_id || !ego || !ego_out))) return fail(EB_EINVAL, "eb_exit_frame: bad argument");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_exit_frame(n, exit_id, inverse ? 1 : 0, h->xc, ego, ego_out, pick(h, stream)));
     return EB_OK;
 }
 
@@ -579,39 +665,56 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
 
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
-                const uint8_t* cand_mode, const uint8_t* light_flag, const uint8_t* v_light,
+                const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream) {
+    // every check first: an error return leaves ego / params / cand untouched
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
-    if (n_env < 0 || !obs || !actions || !ego || !params || !scaled_actions || !out5 || !obs_out || !done_code || obs == obs_out)
+    if (n_env < 0 || !obs || !actions || !ego || !params || !scaled_actions || !out5 || !obs_out || !done_code || obs == obs_out ||
+        m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)))
         return fail(EB_EINVAL, "eb_env_step: bad argument");
     if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_step: the traffic handle must have n_veh == m_cand");
+    if (traffic->cfg.device != h->cfg.device) return fail(EB_EINVAL, "eb_env_step: the two handles live on different devices");
+    int rc = check_paths(h, "eb_env_step: null handle");
+    if (!rc) rc = check_modes(h);
+    if (!rc) rc = check_modes(traffic);
+    if (rc) return rc;
+    if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (n_env == 0) return EB_OK;
+    hipStream_t s = pick(h, stream);
     // E2E:133-135 in one launch: action scaling, reward on the current obs, ego step in place (the same device
     // functions eb_action_transform / eb_compute_rewards / eb_env_ego_step run)
     EB_HIP(hipSetDevice(h->cfg.device));
     EB_HIP(eb::launch_env_pre(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, obs, actions,
-                              scaled_actions, out5, out_dict16, ego, params, pick(h, stream)));
-    int rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                                 /* TRF:220-238's role */
-    if (rc) return rc;
+                              scaled_actions, out5, out_dict16, ego, params, s));
+    if (m_cand > 0) EB_HIP(eb::launch_veh_predict(n_env, m_cand, traffic->modes, cand, cand, s));   /* TRF:220-238's role */
     if (m_cand > 0 && eb::get_obs_is_staged(obs_dim(h->cfg), m_cand, cand)) {
         // E2E:140-141 in one launch: the observation kernel keeps the tile's candidates and the new delta_y in LDS and
         // appends _judge_done (the same device functions eb_judge_done runs)
-        rc = check_paths(h, "eb_env_step: null handle");
-        if (!rc) rc = check_modes(h);
-        if (rc) return rc;
-        if (!cand_mode) return fail(EB_EINVAL, "eb_env_step: bad argument");
-        if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
         EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
-                                  ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, pick(h, stream), params,
-                                  nullptr, v_light, done_code));
+                                  ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, s, params,
+                                  cand_lw, done_code));
         return EB_OK;
     }
-    rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, stream);   /* E2E:140 */
-    if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, nullptr, v_light, done_code, stream);   /* E2E:141 */
-    return rc;
+    EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
+                              ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, s));   /* E2E:140 */
+    EB_HIP(eb::launch_judge_done(h->cfg.task, n_env, obs_dim(h->cfg), ego, params, obs_out, m_cand, cand, cand_mode,
+                                 cand_lw, v_light, done_code, s));                                          /* E2E:141 */
+    return EB_OK;
 }
 
-// Profiling aid (not part of include/envbuild.h): device buffer of [n_waves][8] int64 that the rollout kernel
+int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter, int32_t training,
+                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code, void* stream) {
+    int rc = check_paths(h, "eb_env_reset: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || (n_env > 0 && (!ego || !params || !ref_idx))) return fail(EB_EINVAL, "eb_env_reset: bad argument");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx,
+                                virtual_next, done_code, pick(h, stream)));
+    return EB_OK;
+}
+
+// Diagnostics (include/envbuild.h, last section): device buffer of [n_waves][8] int64 that the rollout kernel
 // fills with per-wave wall-clock marks (100 MHz) — scripts/trace_rollout.py.  NULL switches it off.
 int eb_debug_set_trace(eb_handle h, long long* device_buf) {
     if (!h) return fail(EB_EINVAL, "eb_debug_set_trace: null handle");
@@ -619,17 +722,17 @@ int eb_debug_set_trace(eb_handle h, long long* device_buf) {
     return EB_OK;
 }
 
-// Test / tuning aid (not part of include/envbuild.h): force the rollout kernel's tile shape — 0: 2048-record
+// Test / tuning aid: force the rollout kernel's tile shape — 0: 2048-record
 // tiles (4 record waves x 8 records per lane), 1: 1024 (4 x 4), 2: 256 (1 x 4); -1: pick by batch size.
 // Every shape computes the same bits; the tests run all of them at small sizes.
-int eb_debug_set_tile(eb_handle h, int variant) {
+int eb_debug_set_tile(eb_handle h, int32_t variant) {
     if (!h || variant < -1 || variant > 2) return fail(EB_EINVAL, "eb_debug_set_tile: bad argument");
     h->tile_variant = variant;
     return EB_OK;
 }
 
-// Test aid (not part of include/envbuild.h): 1 = eb_rollout_tape[_f16] as H per-step launches, 0 = one tape-kernel launch.
-int eb_debug_set_tape_stepwise(eb_handle h, int on) {
+// Test aid: 1 = eb_rollout_tape[_f16] as H per-step launches, 0 = one tape-kernel launch.
+int eb_debug_set_tape_stepwise(eb_handle h, int32_t on) {
     if (!h) return fail(EB_EINVAL, "eb_debug_set_tape_stepwise: null handle");
     h->tape_stepwise = on ? 1 : 0;
     return EB_OK;
@@ -792,12 +895,31 @@ static int mlp_args(eb_mlp m, int32_t n, const float* obs, float* out, int head,
 extern "C" {
 
 int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
-                       float span, float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, void* stream) {
+                       float span, float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask,
+                       uint8_t* respawned, void* stream) {
     if (!h || n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!cand || !entry)))
         return fail(EB_EINVAL, "eb_traffic_respawn: bad argument");
     if (n_env == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
-    EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, entry, limit, span, v_max, seed, counter, respawned, pick(h, stream)));
+    EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, entry, limit, span, v_max, seed, counter, env_mask, respawned,
+                                      pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const uint8_t* mask, const float* ego,
+                          float* cand, uint8_t* active, float* timer, int32_t* emitted, int32_t* sim_step,
+                          uint8_t* phase0, const float* lane, const float* period, const float* v_max,
+                          const float* cand_len, float lane_len, int32_t random_phase, int32_t training,
+                          uint64_t seed, uint64_t counter, uint8_t* cand_mode, uint8_t* v_light, void* stream) {
+    if (!h || n_env < 0 || per_route < 1 || per_route * 12 > 64 ||
+        (n_env > 0 && (!ego || !cand || !active || !timer || !emitted || !sim_step || !phase0 || !lane || !period || !v_max ||
+                       !cand_len || !cand_mode || !v_light)))
+        return fail(EB_EINVAL, "eb_traffic_flow_reset: bad argument");
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_traffic_flow_reset(n_env, per_route, mask, ego, cand, active, timer, emitted, sim_step, phase0, lane,
+                                         period, v_max, cand_len, lane_len, random_phase ? 1 : 0, training ? 1 : 0, seed,
+                                         counter, cand_mode, v_light, pick(h, stream)));
     return EB_OK;
 }
 

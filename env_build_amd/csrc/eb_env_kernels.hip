@@ -260,7 +260,6 @@ size_t get_obs_lds_bytes(int D, int m_cand) {
 struct JudgeArgs {
     const float* params;      // [n_env, 4]
     const float* cand_lw;     // [n_env, m_cand, 2] or NULL
-    const uint8_t* v_light;   // [n_env] or NULL
     uint8_t* done_code;       // NULL: observation only (eb_get_obs)
 };
 
@@ -268,7 +267,8 @@ template <int TASK, bool STAGED>
 __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_future, int NV, PathTables pt, VehModes modes,
                                const float* __restrict__ ego, const int* __restrict__ ref_idx, int path_id,
                                int m_cand, const float* __restrict__ cand_all, const uint8_t* __restrict__ cmode_all,
-                               const uint8_t* __restrict__ light_flag, float* __restrict__ obs_out, const JudgeArgs J) {
+                               const uint8_t* __restrict__ v_light, const uint8_t* __restrict__ virtual_flag,
+                               float* __restrict__ obs_out, const JudgeArgs J) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // 64 envs per block, one per lane; the block's four waves share the slots of the observation (wave w builds
     // slots w, w + 4, ...), wave 0 also the ego and tracking columns
@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
     const uint8_t* cmode = cmode_all + (size_t)i * m_cand;
     const float4* crow = s_cand + lane * RS4;
     const uint8_t* mrow = s_mode + lane * MS;
-    const bool virt = TASK != TASK_RIGHT && light_flag && light_flag[i] != 0 && ey < -HALF_CROSS;   // E2E:386-388
+    const bool light = (v_light && v_light[i] != 0) || (virtual_flag && virtual_flag[i] != 0);        // E2E:387-388
+    const bool virt = TASK != TASK_RIGHT && light && ey < -HALF_CROSS;                                // E2E:386-388
     float* ov = o + 6 + T;
     if (STAGED) {
         // The distinct modes of the slot list are dealt round-robin to the four waves.  For its mode a lane first
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
                 const float* e = ego + 6 * (size_t)i;
                 const bool collision = (s_list[lane] | s_list[64 + lane] | s_list[128 + lane] | s_list[192 + lane]) != 0;
                 J.done_code[i] = judge_code(TASK, collision, e[0], e[2], e[3], e[4], e[5], J.params[4 * (size_t)i + 3],
-                                            s_out[lane * OS + 6], J.v_light && J.v_light[i] != 0);
+                                            s_out[lane * OS + 6], v_light && v_light[i] != 0);
             }
         }
         float* dst = obs_out + (size_t)e0 * D;                              // the tile's rows are contiguous too
@@ -457,16 +458,228 @@ bool get_obs_is_staged(int D, int m_cand, const float* cand) {
     return get_obs_lds_bytes(D, m_cand) <= 150 * 1024 && (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
 }
 
+// ---- the 12-ego scene's exit-relative frames (multi_ego.py:33, 84-120; UTL:120-196; E2E:345-385) ----
+// One thread per env, the oracle's algorithm line for line: a vehicle's (x, y, phi) are float64 after
+// cal_info_in_transform_coordination, compared with ego-derived fp32 values after rounding to fp32 (NumPy >= 2 scalar
+// rules) and with python constants / each other in float64; the observation holds them rounded to fp32.
+struct V4d { double x, y, phi; float v; };
+EB_DEV bool lt_ego(double a, float b) { return (float)a < b; }
+EB_DEV bool gt_ego(double a, float b) { return (float)a > b; }
+
+EB_DEV bool veh_in_range_d(int task, int m, const V4d& v, float ego_x, float ego_y) {   // E2E:393-411
+    const double C2 = 25.0;
+    switch (m) {
+        case EB_VMODE_DL: return v.x > -C2 - 10 && gt_ego(v.y, ego_y - 2.0f);
+        case EB_VMODE_DU: return gt_ego(v.y, ego_y - 2.0f) && v.y < C2 + 10 && lt_ego(v.x, ego_x + 5.0f);
+        case EB_VMODE_DR: return v.x < C2 + 10 && gt_ego(v.y, ego_y);
+        case EB_VMODE_RU: return v.x < C2 + 10 && v.y < C2 + 10;
+        case EB_VMODE_UR:
+            if (task == TASK_STRAIGHT) return lt_ego(v.x, ego_x + 7.0f) && gt_ego(v.y, ego_y) && v.y < C2 + 10;
+            if (task == TASK_RIGHT) return v.x < C2 + 10 && v.y < C2;
+            return true;
+        case EB_VMODE_UD: {
+            const float ey2 = ego_y - 2.0f;
+            const bool lower = (-25.0f > ey2) ? (-C2 < v.y) : gt_ego(v.y, ey2);
+            return lower && v.y < C2 && lt_ego(v.x, ego_x);
+        }
+        case EB_VMODE_UL: return -C2 - 10 < v.x && lt_ego(v.x, ego_x) && v.y < C2;
+        case EB_VMODE_LR: return -C2 - 10 < v.x && v.x < C2 + 10;
+        default: return true;
+    }
+}
+
+EB_DEV int veh_cmp_d(int task, int m, const V4d& a, const V4d& b) {
+#define EB_ASC(f) do { if (a.f < b.f) return -1; if (a.f > b.f) return 1; } while (0)
+#define EB_DESC(f) do { if (a.f > b.f) return -1; if (a.f < b.f) return 1; } while (0)
+    switch (m) {
+        case EB_VMODE_DL: EB_ASC(y); EB_DESC(x); return 0;
+        case EB_VMODE_DU: EB_ASC(y); return 0;
+        case EB_VMODE_DR: EB_ASC(y); EB_ASC(x); return 0;
+        case EB_VMODE_RU: EB_ASC(x); EB_DESC(y); return 0;
+        case EB_VMODE_UR:
+            if (task == TASK_STRAIGHT) { EB_ASC(y); return 0; }
+            if (task == TASK_RIGHT) { EB_ASC(y); EB_DESC(x); return 0; }
+            return 0;
+        case EB_VMODE_UD: EB_ASC(y); return 0;
+        case EB_VMODE_UL: EB_ASC(y); EB_ASC(x); return 0;
+        case EB_VMODE_LR: EB_DESC(x); return 0;
+        default: return 0;
+    }
+#undef EB_ASC
+#undef EB_DESC
+}
+
+EB_DEV V4d veh_fill_value_d(int m) {   // mode2fillvalue, E2E:439-447 (python floats)
+    const double C2 = 25.0, LW = 3.75;
+    V4d f = {0.0, 0.0, 0.0, 0.0f};
+    switch (m) {
+        case EB_VMODE_DL: f.x = LW / 2; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_DU: f.x = LW * 1.5; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_DR: f.x = LW * 2.5; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_RU: f.x = C2 + 15; f.y = LW * 2.5; f.phi = 180; break;
+        case EB_VMODE_UR: f.x = -LW / 2; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_UD: f.x = -LW * 1.5; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_UL: f.x = -LW * 2.5; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_LR: f.x = -(C2 + 20); f.y = -LW * 1.5; f.phi = 0; break;
+        default: break;
+    }
+    return f;
+}
+
+// route of a WORLD mode seen from exit k: world direction d -> (d - k) mod 4 (E2E:345-385)
+EB_DEV int exit_relative_mode(int world_mode, int k) {
+    if (world_mode < 0 || world_mode >= EB_VMODE_COUNT) return EB_VMODE_EMPTY;
+    const int st = world_mode / 3, en = (3 - world_mode % 3 + st) & 3;   // end directions of dl du dr | rd rl ru | ur ud ul | lu lr ld
+    const int rs = (st - k + 4) & 3, re = (en - k + 4) & 3;
+    return rs * 3 + ((rs - re + 4) & 3) - 1;                            // [start][end] -> EB_VMODE_*
+}
+
+// candidate c of the env under exit k and mode m, or the virtual red-light car at c == m_cand (E2E:386-390)
+EB_DEV bool fetch_candidate_exit(int m, int c, int m_cand, const float* cand, const uint8_t* cmode, bool virt, int k,
+                                 const ExitConsts& xc, V4d& v) {
+    if (c < m_cand) {
+        if (exit_relative_mode(cmode[c], k) != m) return false;
+        const double x = (double)cand[4 * c] - 0, y = (double)cand[4 * c + 1] - 0;   // shift by (0, 0), UTL:116-117
+        v.x = x * xc.c[k] + y * xc.s[k];                                             // UTL:131
+        v.y = -x * xc.s[k] + y * xc.c[k];                                            // UTL:132
+        const int ang = k == 0 ? 0 : k == 1 ? 90 : k == 2 ? 180 : -90;
+        double t = (double)cand[4 * c + 3] - ang;                                    // UTL:133-139
+        if (t > 180) { while (t > 180) t = t - 360; }
+        else if (t <= -180) { while (t <= -180) t = t + 360; }
+        v.phi = t;
+        v.v = cand[4 * c + 2];
+        return true;
+    }
+    if (!virt || (m != EB_VMODE_DL && m != EB_VMODE_DU)) return false;
+    v.x = m == EB_VMODE_DL ? 3.75 / 2 : 3.75 * 1.5;
+    v.y = -25.0 + 2.5; v.v = 0.0f; v.phi = 90.0;
+    return true;
+}
+
+template <int TASK>
+__global__ __launch_bounds__(64) void get_obs_exit_kernel(int n_env, int D, int n_future, int NV, PathTables pt, VehModes modes,
+                                    const float* __restrict__ ego, const int* __restrict__ ref_idx, int path_id,
+                                    int m_cand, const float* __restrict__ cand_all, const uint8_t* __restrict__ cmode_all,
+                                    const uint8_t* __restrict__ v_light, const uint8_t* __restrict__ virtual_flag,
+                                    const uint8_t* __restrict__ exit_id, const ExitConsts xc, float* __restrict__ obs_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_env) return;
+    const float* e = ego + 6 * (size_t)i;
+    float* o = obs_out + (size_t)D * i;
+    const int T = 3 * (n_future + 1);
+    const float ev = e[0], ex = e[3], ey = e[4], ephi = e[5];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o[c] = e[c];                               // E2E:329-338
+    const int p = row_path(pt, ref_idx, path_id, i);
+    if (p < 0) { for (int c = 0; c < T; ++c) o[6 + c] = 0.0f; }
+    else {
+        const float2* red = pt.red[p];
+        const int nr = pt.red_len[p];
+        float best = __builtin_inff();
+        int bi = 0;
+        for (int r = 0; r < nr; ++r) {                                      // DAM:702-715 (full scan: this is not the hot path)
+            const float2 q = red[r];
+            const float d = sq(ex - q.x) + sq(ey - q.y);
+            if (d < best) { best = d; bi = r; }
+        }
+        const int idx = bi * 10, len = pt.len[p];
+        const int ci = clamp_index(idx, len);
+        o[6] = two2one<TASK>(ex, ey, pt.x[p][ci], pt.y[p][ci]);
+        o[7] = deal_with_phi_diff(ephi - pt.phi[p][ci]);
+        o[8] = ev - EXP_V;
+        int cur = idx;
+        for (int k = 0; k < n_future; ++k) {
+            cur += 80;
+            if (cur >= len - 2) cur = len - 2;
+            const int fi = clamp_index(cur, len);
+            o[9 + 3 * k] = pt.x[p][fi] - ex;
+            o[10 + 3 * k] = pt.y[p][fi] - ey;
+            o[11 + 3 * k] = deal_with_phi_diff(ephi - pt.phi[p][fi]);
+        }
+    }
+    const int k = exit_id[i] & 3;
+    int vl = v_light ? v_light[i] : 0;
+    if (k == EB_EXIT_R || k == EB_EXIT_L) vl = vl != 2 ? 2 : 0;            // multi_ego.py:89-92
+    const bool light = vl != 0 || (virtual_flag && virtual_flag[i] != 0);  // E2E:387-388
+    const bool virt = TASK != TASK_RIGHT && light && ey < -HALF_CROSS;
+    const float* cand = cand_all + (size_t)i * m_cand * 4;
+    const uint8_t* cmode = cmode_all + (size_t)i * m_cand;
+    float* ov = o + 6 + T;
+    for (int s = 0; s < NV; ++s) {
+        const int m = modes.mode[s];
+        int rank = 0;
+        for (int t = 0; t < s; ++t) rank += modes.mode[t] == m;
+        // select the rank-th candidate of mode m under (sort key, insertion order): E2E:414-437
+        V4d prev = {0, 0, 0, 0};
+        int prev_i = -1;
+        bool found = true;
+        for (int it = 0; it <= rank && found; ++it) {
+            V4d bestv = {0, 0, 0, 0};
+            int best_i = -1;
+            for (int c = 0; c <= m_cand; ++c) {
+                V4d v;
+                if (!fetch_candidate_exit(m, c, m_cand, cand, cmode, virt, k, xc, v)) continue;
+                if (!veh_in_range_d(TASK, m, v, ex, ey)) continue;
+                if (prev_i >= 0) {
+                    const int cp = veh_cmp_d(TASK, m, prev, v);
+                    if (!(cp < 0 || (cp == 0 && prev_i < c))) continue;   // not after the previous pick
+                }
+                if (best_i < 0 || veh_cmp_d(TASK, m, v, bestv) < 0) { bestv = v; best_i = c; }
+            }
+            if (best_i < 0) found = false;
+            else { prev = bestv; prev_i = best_i; }
+        }
+        const V4d r = found ? prev : veh_fill_value_d(m);                  // slice_or_fill, E2E:431-437
+        ov[4 * s] = (float)r.x; ov[4 * s + 1] = (float)r.y; ov[4 * s + 2] = r.v; ov[4 * s + 3] = (float)r.phi;
+    }
+}
+
+// cal_ego_info_in_transform_coordination (UTL:184-196) on fp32 fields
+__global__ void exit_frame_kernel(int n, const uint8_t* __restrict__ exit_id, int inverse, const ExitConsts xc,
+                                  const float* __restrict__ ego, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* e = ego + 6 * (size_t)i;
+    float* o = out + 6 * (size_t)i;
+    const int k = exit_id[i] & 3, q = inverse ? 4 + k : k;
+    const int a0 = k == 0 ? 0 : k == 1 ? 90 : k == 2 ? 180 : -90;
+    const float a = (float)(inverse ? -a0 : a0);
+    const float c = xc.cf[q], sn = xc.sf[q];
+    const float x = e[3] - 0.0f, y = e[4] - 0.0f;                          // UTL:116-117
+    const float tx = x * c + y * sn;                                        // UTL:131
+    const float ty = -x * sn + y * c;                                       // UTL:132
+    float d = e[5] - a;                                                     // UTL:133-139
+    if (d > 180.0f) { while (d > 180.0f) d = d - 360.0f; }
+    else if (d <= -180.0f) { while (d <= -180.0f) d = d + 360.0f; }
+    o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = tx; o[4] = ty; o[5] = d;
+}
+
+hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const ExitConsts& xc, const float* ego, float* out,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(exit_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, exit_id, inverse, xc, ego, out);
+    return hipGetLastError();
+}
+
 // done_code != NULL appends _judge_done (needs the staged form: check get_obs_is_staged first)
 hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
-                          const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag, float* obs_out,
-                          hipStream_t s, const float* params, const float* cand_lw, const uint8_t* v_light,
-                          uint8_t* done_code) {
+                          const float* cand, const uint8_t* cand_mode, const uint8_t* v_light, const uint8_t* virtual_flag,
+                          float* obs_out, hipStream_t s, const float* params, const float* cand_lw,
+                          uint8_t* done_code, const uint8_t* exit_id, const ExitConsts* xc) {
+    if (exit_id) {
+        if (done_code || !xc) return hipErrorInvalidValue;
+        const dim3 g((n_env + 63) / 64), b(64);
+        switch (task) {
+            case TASK_LEFT: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_LEFT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, obs_out); break;
+            case TASK_STRAIGHT: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_STRAIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, obs_out); break;
+            default: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_RIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, obs_out); break;
+        }
+        return hipGetLastError();
+    }
     const size_t lds = get_obs_lds_bytes(D, m_cand);
     const bool staged = get_obs_is_staged(D, m_cand, cand);
     if (done_code && !staged) return hipErrorInvalidValue;
-    const JudgeArgs J{params, cand_lw, v_light, done_code};
+    const JudgeArgs J{params, cand_lw, done_code};
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;
@@ -483,10 +696,10 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
             }                                                                                                        \
             if (e == hipSuccess)                                                                                     \
                 hipLaunchKernelGGL((get_obs_kernel<T, true>), g, b, lds, s, n_env, D, n_future, NV, pt, modes, ego,  \
-                                   ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, J);               \
+                                   ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, J);    \
         } else {                                                                                                     \
             hipLaunchKernelGGL((get_obs_kernel<T, false>), g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego,       \
-                               ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, J);                   \
+                               ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, J);        \
         }                                                                                                            \
     } while (0)
     switch (task) {
@@ -506,19 +719,23 @@ EB_DEV uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+EB_DEV float u01(uint64_t seed, uint64_t idx) {   // top 24 bits of splitmix64(seed + GOLDEN * idx) -> [0, 1)
+    return (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * idx) >> 40) * 5.9604644775390625e-8f;
+}
+
 __global__ void traffic_respawn_kernel(int n_env, int m_cand, float* __restrict__ cand, const float* __restrict__ entry,
                                        float limit, float span, float v_max, uint64_t seed, uint64_t counter,
-                                       uint8_t* __restrict__ respawned) {
+                                       const uint8_t* __restrict__ env_mask, uint8_t* __restrict__ respawned) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_env * m_cand) return;
     const int e = idx / m_cand, j = idx - e * m_cand;
     float4* c = reinterpret_cast<float4*>(cand) + idx;
     const float4 v = *c;
-    const bool gone = __builtin_fabsf(v.x) > limit || __builtin_fabsf(v.y) > limit;
+    const bool chosen = !env_mask || env_mask[e] != 0;
+    const bool gone = chosen && (limit < 0.0f || __builtin_fabsf(v.x) > limit || __builtin_fabsf(v.y) > limit);
     if (gone) {
         const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)j * 2u;
-        const float u1 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
-        const float u2 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
+        const float u1 = u01(seed, base), u2 = u01(seed, base + 1);
         const float* en = entry + 5 * j;
         const float along = u1 * span;
         *c = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * v_max, en[2]);
@@ -527,11 +744,118 @@ __global__ void traffic_respawn_kernel(int n_env, int m_cand, float* __restrict_
 }
 
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
-                                  float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, hipStream_t s) {
+                                  float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask, uint8_t* respawned,
+                                  hipStream_t s) {
     const int n = n_env * m_cand;
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(traffic_respawn_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n_env, m_cand, cand, entry, limit,
-                       span, v_max, seed, counter, respawned);
+                       span, v_max, seed, counter, env_mask, respawned);
+    return hipGetLastError();
+}
+
+// ---- a18: CrossroadEnd2end.reset + _reset_init_state for the masked envs (E2E:99-127, 472-499), one thread per env ----
+__global__ void env_reset_kernel(int task, int n_env, PathTables pt, const uint8_t* __restrict__ mask, uint64_t seed,
+                                 uint64_t counter, int training, float* __restrict__ ego, float* __restrict__ params,
+                                 int* __restrict__ ref_idx, uint8_t* __restrict__ virtual_next, uint8_t* __restrict__ done_code) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_env) return;
+    if (mask && !mask[e]) return;
+    const float span = task == TASK_LEFT ? 900 + 500 : task == TASK_STRAIGHT ? 1200 + 500 : 420 + 500;   // E2E:473-478
+    const uint64_t base = (counter << 32) + (uint64_t)e * 128u;
+    const float u0 = u01(seed, base), u1 = u01(seed, base + 1), u2 = u01(seed, base + 2), u3 = u01(seed, base + 3);
+    int p = (int)(u0 * (float)pt.n_paths);                                 // DAM:591
+    if (p > pt.n_paths - 1) p = pt.n_paths - 1;
+    const int index = (int)(u1 * span) + 700;                              // E2E:474-478
+    const int ci = clamp_index(index, pt.len[p]);                          // indexs2points, DAM:727-728
+    float* g = ego + 6 * (size_t)e;
+    g[0] = 8.0f * u2; g[1] = 0.0f; g[2] = 0.0f;                            // E2E:482-486
+    g[3] = pt.x[p][ci]; g[4] = pt.y[p][ci]; g[5] = pt.phi[p][ci];
+    float* pr = params + 4 * (size_t)e;
+    pr[0] = 0.0f; pr[1] = 0.0f; pr[2] = VehParams::miu; pr[3] = VehParams::miu;   // E2E:110-113
+    ref_idx[e] = p;
+    if (virtual_next) virtual_next[e] = (training && u3 > 0.9f) ? 1 : 0;  // E2E:120-126
+    if (done_code) done_code[e] = EB_DONE_NOT_YET;                         // E2E:119
+}
+
+hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
+                            int training, float* ego, float* params, int* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
+                            hipStream_t s) {
+    if (n_env <= 0) return hipSuccess;
+    hipLaunchKernelGGL(env_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, s, task, n_env, pt, mask, seed, counter,
+                       training, ego, params, ref_idx, virtual_next, done_code);
+    return hipGetLastError();
+}
+
+// ---- Traffic.init_traffic's role for the flow source (TRF:151-195), one thread per (env, route) ----
+EB_DEV void shift_rotate(float x, float y, float d, float sx, float sy, float rd, float& ox, float& oy, float& od) {   // UTL:145-149
+    const float hx = x - sx, hy = y - sy;
+    float sn, cs;
+    sincos_det(rd * PI_F / 180.0f, sn, cs);
+    ox = hx * cs + hy * sn;
+    oy = -hx * sn + hy * cs;
+    float t = d - rd;
+    if (t > 180.0f) { while (t > 180.0f) t = t - 360.0f; }
+    else if (t <= -180.0f) { while (t <= -180.0f) t = t + 360.0f; }
+    od = t;
+}
+EB_DEV bool init_conflict(const float* ego6, float ego_l, float x, float y, float a, float veh_v, float veh_l) {   // TRF:168-192
+    float xe, ye, ae, xv, yv, av;
+    shift_rotate(x, y, a, ego6[3], ego6[4], ego6[5], xe, ye, ae);
+    shift_rotate(0.0f, 0.0f, 0.0f, xe, ye, ae, xv, yv, av);
+    return (-5.0f < xe && xe < 1.0f * ego6[0] + ego_l / 2.0f + veh_l / 2.0f + 2.0f && __builtin_fabsf(ye) < 3.0f) ||
+           (-5.0f < xv && xv < 1.0f * veh_v + ego_l / 2.0f + veh_l / 2.0f + 2.0f && __builtin_fabsf(yv) < 3.0f);   // TRF:183-184
+}
+
+__global__ void traffic_flow_reset_kernel(int n_env, int K, const uint8_t* __restrict__ mask, const float* __restrict__ ego,
+                                          float* __restrict__ cand, uint8_t* __restrict__ active, float* __restrict__ timer,
+                                          int* __restrict__ emitted, int* __restrict__ sim_step, uint8_t* __restrict__ phase0,
+                                          const float* __restrict__ lane, const float* __restrict__ period,
+                                          const float* __restrict__ v_max, const float* __restrict__ cand_len, float lane_len,
+                                          int random_phase, int training, uint64_t seed, uint64_t counter,
+                                          uint8_t* __restrict__ cand_mode, uint8_t* __restrict__ v_light) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_env * 12) return;
+    const int e = idx / 12, r = idx - e * 12, M = 12 * K;
+    if (mask && !mask[e]) return;
+    const uint64_t env_base = (counter << 32) + (uint64_t)e * 256u;
+    float expect = lane_len / 7.5f / period[r];
+    if (expect > (float)K) expect = (float)K;
+    const float p = expect / (float)K;
+    for (int k = 0; k < K; ++k) {
+        const int j = r * K + k;
+        const size_t s = (size_t)e * M + j;
+        const float u0 = u01(seed, env_base + 4u * j), u1 = u01(seed, env_base + 4u * j + 1), u2 = u01(seed, env_base + 4u * j + 2);
+        bool on = u0 < p;
+        if (on) {
+            const float* ln = lane + 5 * j;
+            const float along = u1 * lane_len;
+            const float4 c = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * v_max[j], ln[2]);
+            reinterpret_cast<float4*>(cand)[s] = c;
+            if (init_conflict(ego + 6 * (size_t)e, 4.8f, c.x, c.y, c.w, c.z, cand_len[j])) on = false;
+        }
+        active[s] = on ? 1 : 0;
+        cand_mode[s] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+    }
+    timer[idx] = u01(seed, env_base + 4u * (r * K) + 3) * period[r];
+    emitted[idx] = 0;
+    if (r == 0) {
+        sim_step[e] = 0;
+        const uint8_t ph = (random_phase && u01(seed, env_base + 255u) > 0.5f) ? 2 : 0;   // TRF:158-161
+        phase0[e] = ph;
+        v_light[e] = training ? ph : 0;                                                    // TRF:222-223
+    }
+}
+
+hipError_t launch_traffic_flow_reset(int n_env, int K, const uint8_t* mask, const float* ego, float* cand, uint8_t* active,
+                                     float* timer, int* emitted, int* sim_step, uint8_t* phase0, const float* lane,
+                                     const float* period, const float* v_max, const float* cand_len, float lane_len,
+                                     int random_phase, int training, uint64_t seed, uint64_t counter, uint8_t* cand_mode,
+                                     uint8_t* v_light, hipStream_t s) {
+    const int n = n_env * 12;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(traffic_flow_reset_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n_env, K, mask, ego, cand, active,
+                       timer, emitted, sim_step, phase0, lane, period, v_max, cand_len, lane_len, random_phase, training, seed,
+                       counter, cand_mode, v_light);
     return hipGetLastError();
 }
 

@@ -51,8 +51,12 @@ hipError_t launch_action_transform(int n, const float* in, float* out, hipStream
 hipError_t launch_rewards(int task, int n_env, int D, int n_future, int NV, const float* obs, const float* act,
                           float* out5, float* d16, hipStream_t s);
 hipError_t launch_tracking(int task, int n, const PathTables& pt, const float* xs, const float* ys, const float* phis,
-                           const float* vs, const int* ref_idx, int path_id, int n_future, float* out,
+                           const float* vs, const int* ref_idx, int path_id, int n_future, int ratio, float* out,
                            int* out_index, float* out_points, hipStream_t s);
+hipError_t launch_path_points(int n, const PathTables& pt, const int* index, const int* ref_idx, int path_id, int n_future,
+                              float* out, hipStream_t s);
+hipError_t launch_phi_diff(int n, const float* in, float* out, hipStream_t s);
+hipError_t launch_ego_predict(int n, const float* ego, const float* actions, float* next, hipStream_t s);
 hipError_t launch_veh_predict(int n_env, int NV, const VehModes& modes, const float* veh, float* out, hipStream_t s);
 hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const PathTables& pt, const VehModes& modes,
                      const float* obs, const float* actions, const int* ref_idx, int path_id, int training,
@@ -68,18 +72,36 @@ hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, fl
 hipError_t launch_env_pre(int task, int n_env, int D, int n_future, int NV, const float* obs, const float* raw,
                           float* scaled, float* out5, float* d16, float* ego, float* params, hipStream_t s);
 bool get_obs_is_staged(int D, int m_cand, const float* cand);
-// done_code != NULL appends _judge_done to the observation kernel (only in its LDS-staged form: get_obs_is_staged)
+// cos / sin of the four exit angles (multi_ego.py:33), evaluated by the host's libm in float64 exactly as the reference's
+// math.cos / math.sin do; *_f: the same rounded to fp32 for the forward (index k) and inverse (index 4 + k) ego transform
+struct ExitConsts {
+    double c[4], s[4];
+    float cf[8], sf[8];
+};
+// done_code != NULL appends _judge_done to the observation kernel (only in its LDS-staged form: get_obs_is_staged).
+// exit_id != NULL: the 12-ego scene's frames (one thread per env, float64 vehicle coordinates); needs `xc`.
 hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
-                          const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag, float* obs_out,
-                          hipStream_t s, const float* params = nullptr, const float* cand_lw = nullptr,
-                          const uint8_t* v_light = nullptr, uint8_t* done_code = nullptr);
+                          const float* cand, const uint8_t* cand_mode, const uint8_t* v_light, const uint8_t* virtual_flag,
+                          float* obs_out, hipStream_t s, const float* params = nullptr, const float* cand_lw = nullptr,
+                          uint8_t* done_code = nullptr, const uint8_t* exit_id = nullptr, const ExitConsts* xc = nullptr);
+hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const ExitConsts& xc, const float* ego, float* out,
+                             hipStream_t s);
+hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
+                            int training, float* ego, float* params, int* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
+                            hipStream_t s);
+hipError_t launch_traffic_flow_reset(int n_env, int K, const uint8_t* mask, const float* ego, float* cand, uint8_t* active,
+                                     float* timer, int* emitted, int* sim_step, uint8_t* phase0, const float* lane,
+                                     const float* period, const float* v_max, const float* cand_len, float lane_len,
+                                     int random_phase, int training, uint64_t seed, uint64_t counter, uint8_t* cand_mode,
+                                     uint8_t* v_light, hipStream_t s);
 hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const float* params, const float* obs,
                              int m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
                              const uint8_t* v_light, uint8_t* done_code, hipStream_t s);
 
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
-                                  float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, hipStream_t s);
+                                  float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask, uint8_t* respawned,
+                                  hipStream_t s);
 
 hipError_t launch_traffic_flow_step(int n_env, int K, float* cand, uint8_t* active, float* timer, int* emitted,
                                     int* sim_step, const float* lane, const float* period, const float* v_max, float dt,

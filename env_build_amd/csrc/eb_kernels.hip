@@ -30,6 +30,20 @@ EB_DEV int closest_index_scan(const PathTables& pt, int p, float x, float y) {
     }
     return bi * 10;
 }
+// the same over every `ratio`-th point of the full-resolution path (find_closest_point(ratio != 10), DAM:702-715)
+EB_DEV int closest_index_scan_ratio(const PathTables& pt, int p, float x, float y, int ratio) {
+    if (ratio == 10) return closest_index_scan(pt, p, x, y);
+    const float* px = pt.x[p];
+    const float* py = pt.y[p];
+    const int len = pt.len[p];
+    float best = __builtin_inff();
+    int bi = 0;
+    for (int i = 0; i < len; i += ratio) {
+        const float d = sq(x - px[i]) + sq(y - py[i]);
+        if (d < best) { best = d; bi = i; }
+    }
+    return bi;
+}
 
 template <int TASK>
 EB_DEV void tracking_from_index(const PathTables& pt, int p, int idx, float ex, float ey, float ephi,
@@ -120,7 +134,7 @@ hipError_t launch_rewards(int task, int n_env, int D, int n_future, int NV, cons
 template <int TASK>
 __global__ void tracking_kernel(int n, PathTables pt, const float* __restrict__ xs, const float* __restrict__ ys,
                                 const float* __restrict__ phis, const float* __restrict__ vs,
-                                const int* __restrict__ ref_idx, int path_id, int n_future,
+                                const int* __restrict__ ref_idx, int path_id, int n_future, int ratio,
                                 float* __restrict__ out, int* __restrict__ out_index, float* __restrict__ out_points) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -132,7 +146,7 @@ __global__ void tracking_kernel(int n, PathTables pt, const float* __restrict__ 
         if (out_points) { out_points[i] = 0.0f; out_points[(size_t)n + i] = 0.0f; out_points[2 * (size_t)n + i] = 0.0f; }
         return;
     }
-    const int idx = closest_index_scan(pt, p, xs[i], ys[i]);
+    const int idx = closest_index_scan_ratio(pt, p, xs[i], ys[i], ratio);
     if (out_index) out_index[i] = idx;
     if (out_points) {
         const int ci = clamp_index(idx, pt.len[p]);
@@ -144,14 +158,69 @@ __global__ void tracking_kernel(int n, PathTables pt, const float* __restrict__ 
 }
 
 hipError_t launch_tracking(int task, int n, const PathTables& pt, const float* xs, const float* ys, const float* phis,
-                           const float* vs, const int* ref_idx, int path_id, int n_future, float* out,
+                           const float* vs, const int* ref_idx, int path_id, int n_future, int ratio, float* out,
                            int* out_index, float* out_points, hipStream_t s) {
     const dim3 g((n + 127) / 128), b(128);
     switch (task) {
-        case TASK_LEFT: hipLaunchKernelGGL(tracking_kernel<TASK_LEFT>, g, b, 0, s, n, pt, xs, ys, phis, vs, ref_idx, path_id, n_future, out, out_index, out_points); break;
-        case TASK_STRAIGHT: hipLaunchKernelGGL(tracking_kernel<TASK_STRAIGHT>, g, b, 0, s, n, pt, xs, ys, phis, vs, ref_idx, path_id, n_future, out, out_index, out_points); break;
-        default: hipLaunchKernelGGL(tracking_kernel<TASK_RIGHT>, g, b, 0, s, n, pt, xs, ys, phis, vs, ref_idx, path_id, n_future, out, out_index, out_points); break;
+        case TASK_LEFT: hipLaunchKernelGGL(tracking_kernel<TASK_LEFT>, g, b, 0, s, n, pt, xs, ys, phis, vs, ref_idx, path_id, n_future, ratio, out, out_index, out_points); break;
+        case TASK_STRAIGHT: hipLaunchKernelGGL(tracking_kernel<TASK_STRAIGHT>, g, b, 0, s, n, pt, xs, ys, phis, vs, ref_idx, path_id, n_future, ratio, out, out_index, out_points); break;
+        default: hipLaunchKernelGGL(tracking_kernel<TASK_RIGHT>, g, b, 0, s, n, pt, xs, ys, phis, vs, ref_idx, path_id, n_future, ratio, out, out_index, out_points); break;
     }
+    return hipGetLastError();
+}
+
+// indexs2points + future_n_data (DAM:717-733), one thread per row
+__global__ void path_points_kernel(int n, PathTables pt, const int* __restrict__ index, const int* __restrict__ ref_idx,
+                                   int path_id, int n_future, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = row_path(pt, ref_idx, path_id, i);
+    int cur = index[i];
+    for (int k = 0; k <= n_future; ++k) {
+        float* o = out + (size_t)k * 3 * n;
+        if (p < 0) { o[i] = 0.0f; o[(size_t)n + i] = 0.0f; o[2 * (size_t)n + i] = 0.0f; continue; }
+        const int len = pt.len[p];
+        if (k > 0) {                                   // DAM:719-722
+            cur += 80;
+            if (cur >= len - 2) cur = len - 2;
+        }
+        const int ci = clamp_index(cur, len);          // DAM:727-728
+        o[i] = pt.x[p][ci]; o[(size_t)n + i] = pt.y[p][ci]; o[2 * (size_t)n + i] = pt.phi[p][ci];
+    }
+}
+hipError_t launch_path_points(int n, const PathTables& pt, const int* index, const int* ref_idx, int path_id, int n_future,
+                              float* out, hipStream_t s) {
+    hipLaunchKernelGGL(path_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, pt, index, ref_idx, path_id, n_future, out);
+    return hipGetLastError();
+}
+
+__global__ void phi_diff_kernel(int n, const float* __restrict__ in, float* __restrict__ out) {   // DAM:577-580
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = deal_with_phi_diff(in[i]);
+}
+hipError_t launch_phi_diff(int n, const float* in, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(phi_diff_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, in, out);
+    return hipGetLastError();
+}
+
+// ego_predict (DAM:386-392): f_xu at 10 Hz, v_x clipped to [0, 35]
+__global__ void ego_predict_kernel(int n, const float* __restrict__ ego, const float* __restrict__ actions,
+                                   float* __restrict__ next) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float st[6], nx[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st[c] = ego[6 * (size_t)i + c];
+    const float phi_rad = deg2rad(st[5]);
+    float sn, cs;
+    sincos_det(phi_rad, sn, cs);
+    f_xu_core(st, actions[2 * (size_t)i], actions[2 * (size_t)i + 1], TAU10, phi_rad, sn, cs, nx);   // DAM:387
+    nx[0] = __builtin_fminf(__builtin_fmaxf(nx[0], 0.0f), 35.0f);                                    // DAM:390
+#pragma unroll
+    for (int c = 0; c < 6; ++c) next[6 * (size_t)i + c] = nx[c];
+}
+hipError_t launch_ego_predict(int n, const float* ego, const float* actions, float* next, hipStream_t s) {
+    hipLaunchKernelGGL(ego_predict_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, ego, actions, next);
     return hipGetLastError();
 }
 

@@ -180,9 +180,12 @@ def _util_handle(device, task='left', mode_name=None):
 
 def deal_with_phi_diff(phi_diff):  # DAM:577-580
     t = _unwrap(phi_diff)
-    t = torch.where(t > 180., t - 360., t)
-    t = torch.where(t < -180., t + 360., t)
-    return DevArray(t)
+    dev = t.device if isinstance(t, torch.Tensor) and t.is_cuda else _default_device()
+    x = _dev(t, dev)
+    out = torch.empty_like(x)
+    hd = _util_handle(dev)
+    hd.api.phi_diff(hd.h, x.numel(), _ptr(x), _ptr(out), _stream(dev))
+    return DevArray(out)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -244,46 +247,56 @@ class ReferencePath(object):
         for k, p in enumerate(self.path_list):
             if p is self.path:
                 return k
-        raise ValueError('ReferencePath.path must be one of path_list (custom trajectories are not supported)')
+        return None
 
-    def _tables_on_device(self):
-        if self._dev_tables is None:
-            dev = self._dev()
-            self._dev_tables = [tuple(torch.from_numpy(c).to(dev) for c in p) for p in self.path_list]
-        return self._dev_tables
+    def _query(self):
+        """(handle, path id) the current `path` is answered from: the task's shared tables, or — when `path` was
+        assigned a custom (xs, ys, phis) triple — a private one-path handle built on first use (the reference accepts
+        any path there, DAM:594-596, E2E:793-795)."""
+        k = self._current_path_id()
+        if k is not None:
+            return self._hd(), k
+        cached = getattr(self, '_custom', None)
+        if cached is None or cached[0] is not self.path:
+            xs, ys, ph = (np.ascontiguousarray(np.asarray(_unwrap(c) if not isinstance(_unwrap(c), torch.Tensor)
+                                                          else _unwrap(c).cpu().numpy()), np.float32) for c in self.path)
+            if not (xs.ndim == ys.ndim == ph.ndim == 1 and len(xs) == len(ys) == len(ph)):
+                raise ValueError('ReferencePath.path must be three 1-D arrays of equal length')
+            hd = _Handle(self.task, 1, 0, _capi.MODE_SELECTING, self._dev(), modes=['du'], with_paths=False)
+            lens = np.array([len(xs)], np.int32)
+            hd.api.set_paths(hd.h, xs.ctypes.data_as(C.c_void_p), ys.ctypes.data_as(C.c_void_p),
+                             ph.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), 1)
+            self._custom = (self.path, hd)
+        return self._custom[1], 0
 
     def find_closest_point(self, xs, ys, ratio=10):  # DAM:702-715
-        if ratio != 10:
-            raise ValueError('find_closest_point: only ratio=10 (the reference default, DAM:702) is implemented')
-        dev, hd = self._dev(), self._hd()
+        dev = self._dev()
+        hd, pid = self._query()
         x, y = _dev(xs, dev), _dev(ys, dev)
         n = x.shape[0]
         idx = torch.empty((n,), dtype=torch.int32, device=dev)
         pts = torch.empty((3, n), dtype=torch.float32, device=dev)
-        hd.api.find_closest_point(hd.h, n, _ptr(x), _ptr(y), None, self._current_path_id(), _ptr(idx), _ptr(pts),
-                                  _stream(dev))
+        hd.api.find_closest_point(hd.h, n, _ptr(x), _ptr(y), None, pid, int(ratio), _ptr(idx), _ptr(pts), _stream(dev))
         return DevArray(idx.to(torch.int64)), (DevArray(pts[0]), DevArray(pts[1]), DevArray(pts[2]))
 
-    def indexs2points(self, indexs):  # DAM:726-733 — a clamped gather, no arithmetic
-        px, py, pphi = self._tables_on_device()[self._current_path_id()]
+    def _points(self, indexs, n_future):
+        dev = self._dev()
+        hd, pid = self._query()
         i = _unwrap(indexs)
         if not isinstance(i, torch.Tensor):
-            i = torch.as_tensor(np.asarray(i), device=px.device)
-        i = i.to(px.device).long().clamp(0, px.shape[0] - 1)
-        return DevArray(px[i]), DevArray(py[i]), DevArray(pphi[i])
-
-    def future_n_data(self, current_indexs, n):  # DAM:717-724
-        i = _unwrap(current_indexs)
-        if not isinstance(i, torch.Tensor):
-            i = torch.as_tensor(np.asarray(i), device=self._dev())
-        i = i.to(torch.int32)
-        out = []
-        plen = len(self.path[0])
-        for _ in range(n):
-            i = i + 80
-            i = torch.where(i >= plen - 2, torch.full_like(i, plen - 2), i)
-            out.append(self.indexs2points(i))
+            i = torch.from_numpy(np.ascontiguousarray(np.asarray(i).reshape(-1)))
+        i = i.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+        out = torch.empty((n_future + 1, 3, i.shape[0]), dtype=torch.float32, device=dev)
+        hd.api.path_points(hd.h, i.shape[0], _ptr(i), None, pid, int(n_future), _ptr(out), _stream(dev))
         return out
+
+    def indexs2points(self, indexs):  # DAM:726-733 (eb_path_points: a clamped gather)
+        o = self._points(indexs, 0)[0]
+        return DevArray(o[0]), DevArray(o[1]), DevArray(o[2])
+
+    def future_n_data(self, current_indexs, n):  # DAM:717-724 (eb_path_points: + 80 per point, clamped to len - 2)
+        o = self._points(current_indexs, n)
+        return [(DevArray(o[k][0]), DevArray(o[k][1]), DevArray(o[k][2])) for k in range(1, n + 1)]
 
     def tracking_error_vector(self, ego_xs, ego_ys, ego_phis, ego_vs, n):  # DAM:735-770
         return self.tracking_error_vector_batched(ego_xs, ego_ys, ego_phis, ego_vs, n, ref_indexes=None)
@@ -291,13 +304,14 @@ class ReferencePath(object):
     def tracking_error_vector_batched(self, ego_xs, ego_ys, ego_phis, ego_vs, n, ref_indexes=None):
         """tracking_error_vector with an optional per-row path id (what compute_next_obses'
         training-mode loop over path_list + tf.where computes, DAM:342-353)."""
-        dev, hd = self._dev(), self._hd()
+        dev = self._dev()
+        hd, pid = (self._hd(), 0) if ref_indexes is not None else self._query()
         x, y, ph, v = _dev(ego_xs, dev), _dev(ego_ys, dev), _dev(ego_phis, dev), _dev(ego_vs, dev)
         ri = None if ref_indexes is None else _dev(ref_indexes, dev, torch.int32)
         rows = x.shape[0]
         out = torch.empty((rows, 3 * (n + 1)), dtype=torch.float32, device=dev)
-        hd.api.tracking_error(hd.h, rows, _ptr(x), _ptr(y), _ptr(ph), _ptr(v), _ptr(ri),
-                              0 if ri is not None else self._current_path_id(), int(n), _ptr(out), _stream(dev))
+        hd.api.tracking_error(hd.h, rows, _ptr(x), _ptr(y), _ptr(ph), _ptr(v), _ptr(ri), pid, int(n), _ptr(out),
+                              _stream(dev))
         return DevArray(out)
 
 
@@ -374,7 +388,11 @@ class EnvironmentModel(object):  # DAM:90-427
             if self._ref_idx_dev is None:
                 raise ValueError("mode='training' needs ref_indexes: call reset(obses, ref_indexes) (DAM:344)")
             return self._ref_idx_dev, 0
-        return None, self.ref_path._current_path_id()
+        k = self.ref_path._current_path_id()
+        if k is None:
+            raise ValueError('EnvironmentModel tracks the paths of its task (ref_path.path_list); set one with '
+                             'ref_path.set_path(i) / add_traj(obses, i)')
+        return None, k
 
     def _after_tracking(self):
         if self.mode == 'training':   # the reference's loop leaves ref_path.path on the last path, DAM:345-346
@@ -464,10 +482,10 @@ class EnvironmentModel(object):  # DAM:90-427
 
     def ego_predict(self, ego_infos, actions):  # DAM:386-392
         ego = _dev(ego_infos, self.device)[:, :6].contiguous()
-        nxt, _ = self.vehicle_dynamics.prediction(ego, actions, self.base_frequency)
-        t = nxt.t
-        t[:, 0].clamp_(0., 35.)                                                       # DAM:390
-        return DevArray(t)
+        act = _dev(actions, self.device)
+        out = torch.empty_like(ego)
+        self.api.ego_predict(self.handle, ego.shape[0], _ptr(ego), _ptr(act), _ptr(out), _stream(self.device))   # f_xu + clip, DAM:387-390
+        return DevArray(out)
 
     def veh_predict(self, veh_infos):  # DAM:394-403
         veh = _dev(veh_infos, self.device)

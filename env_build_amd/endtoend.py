@@ -173,12 +173,16 @@ class CrossroadEnd2end(object):
         self._entry = torch.tensor([_lane_entry(m)[:3] for m in self.cand_modes], dtype=torch.float32, device=dev)
         self._entry_dir = torch.tensor([_lane_entry(m)[3] for m in self.cand_modes], dtype=torch.float32, device=dev)
         self._entry5 = torch.cat([self._entry, self._entry_dir], 1).contiguous()       # (x, y, phi, dx, dy) per slot
-        self._light = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._virtual_next = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._exit_id = None
+        self._ego_exit = None
+        self._reset_counter = 0
+        self.done_code = torch.zeros((B,), dtype=torch.uint8, device=dev)
         self._injected = False
         self._flows = None
         if traffic == 'flows':
             from .traffic import FlowTraffic
-            self._flows = FlowTraffic(B, dev, self._gen, self.training_task, mode=self.mode, per_route=per_route,
+            self._flows = FlowTraffic(B, dev, None, self.training_task, mode=self.mode, per_route=per_route,
                                       step_time=self.step_time)
             self._flows.seed = self._respawn_seed
         self.init_state = self._reset_init_state()
@@ -191,14 +195,12 @@ class CrossroadEnd2end(object):
     # -- gym plumbing ---------------------------------------------------------------------------
     def seed(self, seed=None):  # E2E:95-97
         self.np_random = np.random.default_rng(seed)
-        self._gen = torch.Generator(device=self.device)      # the traffic pool draws on the GPU: no per-step H2D copy
-        self._gen.manual_seed(int(self.np_random.integers(0, 2 ** 31 - 1)))
-        if getattr(self, '_flows', None) is not None:
-            self._flows.gen = self._gen
-        self._respawn_seed = int(self.np_random.integers(0, 2 ** 62))     # eb_traffic_respawn: (seed, counter, env, slot)
+        # every device-side draw is counter-based (eb_env_reset, eb_traffic_respawn, eb_traffic_flow_*): one 62-bit seed
+        self._respawn_seed = int(self.np_random.integers(0, 2 ** 62))     # keys: (seed, counter, env, slot)
         if getattr(self, '_flows', None) is not None:
             self._flows.seed = self._respawn_seed
         self._respawn_counter = 0
+        self._reset_counter = 0
         return [seed]
 
     def close(self):  # E2E:129-130
@@ -219,100 +221,78 @@ class CrossroadEnd2end(object):
         return t[0].detach().cpu().numpy() if self.n_env == 1 else DevArray(t)
 
     # -- reset ----------------------------------------------------------------------------------
-    def _reset_init_state(self):  # E2E:472-499, per env
+    _RESET_SALT, _POOL_SALT = 0x2545F4914F6CDD1D, 0x5DEECE66D
+
+    def _reset_init_state(self, mask8=None):  # E2E:472-499, per env
+        """n_env == 1: the reference's own host-side draws (np.random, E2E:474-482).  A batch: ONE kernel, eb_env_reset —
+        path, start index, start speed, parameters, the next virtual-red-light flag and the done code of the masked envs."""
         span = {'left': 900 + 500, 'straight': 1200 + 500, 'right': 420 + 500}[self.training_task]
         B, dev = self.n_env, self.device
         route = {'left': 'dl', 'straight': 'du', 'right': 'dr'}[self.training_task]
-        if B == 1:       # the reference's own draws, on the host
-            ref = np.full((1,), int(self.ref_path.ref_index), np.int32)
-            index = (self.np_random.random(1) * span).astype(np.int64) + 700            # E2E:474-478
-            v = (EXPECTED_V * self.np_random.random(1)).astype(np.float32)              # E2E:482
-            ego = np.zeros((1, 6), np.float32)
-            path = self.ref_path.path_list[int(ref[0])]
-            i = int(np.clip(index[0], 0, len(path[0]) - 1))                             # indexs2points, DAM:727-728
-            ego[0, 3], ego[0, 4], ego[0, 5] = path[0][i], path[1][i], path[2][i]
-            ego[0, 0] = v[0]
-            self._init_ego, self._init_ref = torch.from_numpy(ego).to(dev), torch.from_numpy(ref).to(dev)
-        else:            # a batch draws on the device: path per env, start index, start speed
-            if getattr(self, '_path_dev', None) is None:
-                pl = self.ref_path.path_list
-                lmax = max(len(p[0]) for p in pl)
-                tab = np.zeros((len(pl), lmax, 3), np.float32)
-                for k, p in enumerate(pl):
-                    for c in range(3):
-                        tab[k, :len(p[0]), c] = p[c]
-                self._path_dev = torch.from_numpy(tab).to(dev)
-                self._path_len = torch.tensor([len(p[0]) for p in pl], dtype=torch.int64, device=dev)
-            ref = torch.randint(0, self._path_dev.shape[0], (B,), generator=self._gen, device=dev)
-            index = (torch.rand((B,), generator=self._gen, device=dev) * span).to(torch.int64) + 700
-            index = torch.minimum(index, self._path_len[ref] - 1)
-            pose = self._path_dev[ref, index]                                           # [B, 3]
-            v = EXPECTED_V * torch.rand((B,), generator=self._gen, device=dev)
-            z = torch.zeros_like(v)
-            self._init_ego = torch.stack([v, z, z, pose[:, 0], pose[:, 1], pose[:, 2]], 1)
-            self._init_ref = ref.to(torch.int32)
-        e0 = self._init_ego[0].cpu().numpy()
+        miu = self.dynamics.vehicle_params['miu']
+        if B == 1:
+            ref = int(self.ref_path.ref_index)
+            index = int(self.np_random.random() * span) + 700                            # E2E:474-478
+            v = np.float32(EXPECTED_V * self.np_random.random())                         # E2E:482
+            path = self.ref_path.path_list[ref]
+            i = int(np.clip(index, 0, len(path[0]) - 1))                                 # indexs2points, DAM:727-728
+            ego = np.array([[v, 0., 0., path[0][i], path[1][i], path[2][i]]], np.float32)
+            self._ego.copy_(torch.from_numpy(ego))
+            self._params.copy_(torch.tensor([[0., 0., miu, miu]], dtype=torch.float32))  # E2E:110-113
+            self._ref_idx.fill_(ref)
+            e0 = ego[0]
+        else:
+            self._reset_counter += 1
+            self._virtual_next.copy_(self._virtual)                                      # unmasked envs keep their flag
+            self.api.env_reset(self._h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
+                               C.c_uint64(self._reset_counter), 1 if self.mode == 'training' else 0, _ptr(self._ego),
+                               _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual_next), _ptr(self.done_code),
+                               self._sp())
+            e0 = self._ego[0].cpu().numpy()
         return dict(ego=dict(v_x=e0[0], v_y=0, r=0, x=e0[3], y=e0[4], phi=e0[5], l=self.ego_l,
                              w=self.ego_w, routeID=route))
 
-    def _spawn_traffic(self, rows=None):
-        """(Re)place candidates at a random distance along their entry lane (the SUMO flows' role)."""
-        B, M = self.n_env, self.n_cand
-        u = torch.rand((B, M), generator=self._gen, device=self.device)
-        spd = torch.rand((B, M), generator=self._gen, device=self.device) * EXPECTED_V
-        along = u * 60.0                                                                # up to the stop line + junction
-        fresh = torch.stack([self._entry[:, 0] + along * self._entry_dir[:, 0],
-                             self._entry[:, 1] + along * self._entry_dir[:, 1], spd,
-                             self._entry[:, 2].expand(B, M)], 2)
-        if rows is None:
-            self._cand.copy_(fresh)
-        else:
-            self._cand.copy_(torch.where(rows.unsqueeze(2), fresh, self._cand))
-
     def reset(self, **kwargs):  # E2E:99-127
-        """`mask=` (n_env > 1; bool [B]) resets only those envs — the vectorised-env idiom for batched drivers."""
+        """`mask=` (n_env > 1; bool / uint8 [B]) resets only those envs — the vectorised-env idiom for batched drivers."""
         mask = kwargs.pop('mask', None)
         if kwargs or self.ref_path is None:
             self.ref_path = ReferencePath(self.training_task, device=self.device, **kwargs)
         elif self.n_env == 1:
-            self.ref_path = ReferencePath(self.training_task, device=self.device)
-        self.init_state = self._reset_init_state()
+            self.ref_path = ReferencePath(self.training_task, device=self.device)       # E2E:100: a fresh random path
         B, dev = self.n_env, self.device
-        if mask is None:
-            m = torch.ones((B,), dtype=torch.bool, device=dev)
-        else:
+        mask8 = None
+        if mask is not None and B > 1:
             mt = mask.t if isinstance(mask, DevArray) else mask
-            m = (mt if isinstance(mt, torch.Tensor) else torch.from_numpy(np.asarray(mt))).to(dev).bool().reshape(B)
-        miu = self.dynamics.vehicle_params['miu']
-        self._ego.copy_(torch.where(m.unsqueeze(1), self._init_ego, self._ego))
-        self._ref_idx.copy_(torch.where(m, self._init_ref, self._ref_idx))
-        fresh_par = torch.tensor([0., 0., miu, miu], dtype=torch.float32, device=dev).repeat(B, 1)       # E2E:110-113
-        self._params.copy_(torch.where(m.unsqueeze(1), fresh_par, self._params))
-        if self._flows is not None:
-            self._flows.reset(m, self._ego)
+            mt = mt if isinstance(mt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(mt)))
+            mask8 = mt.to(device=dev).reshape(B).to(torch.uint8).contiguous()
+        if B > 1:
+            self.done_code = self.done_code.clone()      # the array handed out by the last step stays as it was
+        self.init_state = self._reset_init_state(mask8)                                 # E2E:101
+        sp = self._sp()
+        if self._flows is not None:                                                      # E2E:102-103 (init_traffic)
+            self._flows.reset(self.api, self._traffic.h, mask8, self._ego, sp)
             self._cand, self._cand_mode, self._v_light = self._flows.cand, self._flows.mode(), self._flows.v_light()
-        else:
-            self._spawn_traffic(None if mask is None else m.unsqueeze(1).expand(B, self.n_cand))
-            self._v_light.masked_fill_(m, 0)
-        if self.mode == 'training':                                                     # E2E:120-126
-            fresh_v = torch.from_numpy((self.np_random.random(B) > 0.9).astype(np.uint8)).to(dev)
-            self._virtual.copy_(torch.where(m, fresh_v, self._virtual))
-        else:
-            self._virtual.masked_fill_(m, 0)
-        self.virtual_red_light_vehicle = bool(self._virtual[0].item()) if self.n_env == 1 else None
-        self._light_key = None                                                          # E2E:387-388 flag: recomputed on the next step
+        else:   # the pool: every candidate of the chosen envs re-enters on its lane (limit < 0 = unconditional)
+            self._reset_counter += 1
+            if not self._cand.is_contiguous():
+                self._cand = self._cand.contiguous()
+            self.api.traffic_respawn(self._traffic.h, B, self.n_cand, _ptr(self._cand), _ptr(self._entry5), C.c_float(-1.0),
+                                     C.c_float(60.0), C.c_float(EXPECTED_V), C.c_uint64(self._respawn_seed ^ self._POOL_SALT),
+                                     C.c_uint64(self._reset_counter), _ptr(mask8), None, sp)
         self._injected = False
-        self._publish_state()
-        self.obs = self._get_obs()
+        self._publish_state()                                                            # E2E:104-115
+        self.obs = self._get_obs()                                                       # E2E:116 (with the OLD flag)
         self.action = None
         self.reward_info = None
-        if self.n_env == 1:
+        if B == 1:
             self.done_type = 'not_done_yet'
+            flag = bool(self.mode == 'training' and self.np_random.random() > 0.9)       # E2E:120-126
+            self._virtual.fill_(1 if flag else 0)
+            self.virtual_red_light_vehicle = flag
         else:
-            code = torch.zeros((B,), dtype=torch.uint8, device=dev)
-            if mask is not None and isinstance(self.done_type, DevArray):
-                code = torch.where(m, code, self.done_type.t)
-            self.done_type = DevArray(code)
+            self._virtual.copy_(self._virtual_next)                                      # E2E:120-126, drawn by eb_env_reset
+            self.virtual_red_light_vehicle = None
+            self.done_type = DevArray(self.done_code)
         return self.obs
 
     # -- reference-shaped views of the device state (n_env == 1) ---------------------------------
@@ -359,19 +339,50 @@ class CrossroadEnd2end(object):
         return cand.to(self.device), cmode.to(self.device)
 
     # -- observation (E2E:285-303, 329-464) -------------------------------------------------------
+    def _exit_ids(self, exit_):
+        """'D' / 'R' / 'U' / 'L' for every env, or one id (or letter) per env -> uint8 [B] on the device"""
+        if isinstance(exit_, str):
+            return torch.full((self.n_env,), _capi.EXIT_ID[exit_], dtype=torch.uint8, device=self.device)
+        t = exit_.t if isinstance(exit_, DevArray) else exit_
+        if not isinstance(t, torch.Tensor):
+            a = np.asarray(t)
+            if a.dtype.kind in 'US':
+                a = np.array([_capi.EXIT_ID[str(e)] for e in a.ravel()], np.uint8)
+            t = torch.from_numpy(np.ascontiguousarray(a.astype(np.uint8)))
+        return t.to(device=self.device, dtype=torch.uint8).reshape(self.n_env).contiguous()
+
+    def exit_frame(self, ego, exit_, inverse=False):
+        """cal_ego_info_in_transform_coordination for a batch (UTL:184-196, multi_ego.py:88, 118): ego [B, 6] into
+        (or, inverse=True, back out of) the frame of each env's exit.  One kernel (eb_exit_frame)."""
+        e = _dev(ego, self.device).reshape(self.n_env, 6).contiguous()
+        out = torch.empty_like(e)
+        self.api.exit_frame(self._h, self.n_env, _ptr(self._exit_ids(exit_)), 1 if inverse else 0, _ptr(e), _ptr(out), self._sp())
+        return DevArray(out)
+
     def _get_obs(self, exit_='D'):
+        """n_env == 1: the reference's call — with multi_display the caller has put ego_dynamics / all_vehicles /
+        v_light (already in the ego's frame, multi_ego.py:94-96) on the object and exit_ only renames the routes.
+        A batch with exit_ other than 'D' is the 12-ego scene in one call: `_ego`, the candidates and the light are
+        WORLD values; every env's ego goes into its exit's frame (kept as `_ego_exit`), the candidates follow
+        (rotation in float64, route renaming, light rule of multi_ego.py:89-92) inside eb_get_obs."""
         cand, cmode = self._cand, self._cand_mode
+        ego, exit_ids = self._ego, None
         if self.n_env == 1 and (self.multi_display or exit_ != 'D'):
             inj = self._absorb_injected(exit_)
             if inj[0] is not None:
                 cand, cmode = inj
-        light = ((self._v_light != 0) | (self._virtual != 0)).to(torch.uint8)          # E2E:387-388
+        elif self.n_env > 1 and not (isinstance(exit_, str) and exit_ == 'D'):
+            exit_ids = self._exit_ids(exit_)
+            self._ego_exit = torch.empty_like(self._ego)
+            self.api.exit_frame(self._h, self.n_env, _ptr(exit_ids), 0, _ptr(self._ego), _ptr(self._ego_exit), self._sp())
+            ego = self._ego_exit
         m = cand.shape[1]
         ri = self._ref_idx
         if self.n_env == 1:
             ri = torch.tensor([int(self.ref_path.ref_index)], dtype=torch.int32, device=self.device)
-        self.api.get_obs(self._h, self.n_env, _ptr(self._ego), _ptr(ri), 0, m, _ptr(cand.contiguous()),
-                         _ptr(cmode.contiguous()), _ptr(light), _ptr(self._obs), self._sp())
+        self.api.get_obs(self._h, self.n_env, _ptr(ego), _ptr(ri), 0, m, _ptr(cand.contiguous()),
+                         _ptr(cmode.contiguous()), _ptr(self._v_light), _ptr(self._virtual), _ptr(exit_ids),
+                         _ptr(self._obs), self._sp())
         return self._ret(self._obs.clone())
 
     # -- step (E2E:132-144) -----------------------------------------------------------------------
@@ -397,21 +408,23 @@ class CrossroadEnd2end(object):
         return nxt, par
 
     def _traffic_step(self):
-        """SUMO's role (TRF:220-238): advance every candidate by the model's prediction step."""
+        """SUMO's role (TRF:220-238): advance every candidate by the model's prediction step (in place), then the pool's
+        re-entry rule — two kernels."""
+        if not self._cand.is_contiguous():
+            self._cand = self._cand.contiguous()
         flat = self._cand.reshape(self.n_env, 4 * self.n_cand)
-        out = torch.empty_like(flat)
-        self.api.veh_predict(self._traffic.h, self.n_env, _ptr(flat), _ptr(out), self._sp())
-        self._cand = out.reshape(self.n_env, self.n_cand, 4)
-        if self.respawn:
-            lim = CROSSROAD_SIZE / 2 + 40.
-            gone = (self._cand[:, :, 0].abs() > lim) | (self._cand[:, :, 1].abs() > lim)
-            if self.n_env > 1 or bool(gone.any()):
-                self._spawn_traffic(gone)
+        self.api.veh_predict(self._traffic.h, self.n_env, _ptr(flat), _ptr(flat), self._sp())
+        if self.respawn and self._flows is None:
+            self._respawn_counter += 1
+            self.api.traffic_respawn(self._traffic.h, self.n_env, self.n_cand, _ptr(self._cand), _ptr(self._entry5),
+                                     C.c_float(CROSSROAD_SIZE / 2 + 40.), C.c_float(60.0), C.c_float(EXPECTED_V),
+                                     C.c_uint64(self._respawn_seed), C.c_uint64(self._respawn_counter), None, None, self._sp())
 
     def _judge_done(self):  # E2E:200-256 -> (done_type, done)
         code = torch.empty((self.n_env,), dtype=torch.uint8, device=self.device)
+        lw = self._flows.cand_lw() if self._flows is not None else None
         self.api.judge_done(self._h, self.n_env, _ptr(self._ego), _ptr(self._params), _ptr(self._obs), self.n_cand,
-                            _ptr(self._cand.contiguous()), _ptr(self._cand_mode), None, _ptr(self._v_light), _ptr(code),
+                            _ptr(self._cand.contiguous()), _ptr(self._cand_mode), _ptr(lw), _ptr(self._v_light), _ptr(code),
                             self._sp())
         self.done_code = code
         if self.n_env == 1:
@@ -458,21 +471,17 @@ class CrossroadEnd2end(object):
         d16 = torch.empty((16, B), dtype=torch.float32, device=dev)
         obs_out = torch.empty_like(self._obs)
         code = torch.empty((B,), dtype=torch.uint8, device=dev)
-        # in-place torch writes bump a tensor's version; the flow source writes its light through the C-ABI instead
-        key = (id(self._v_light), self._v_light._version, id(self._virtual), self._virtual._version)
-        if self._flows is not None or key != getattr(self, '_light_key', None):
-            self._light = ((self._v_light != 0) | (self._virtual != 0)).to(torch.uint8)  # E2E:387-388
-            self._light_key = key
-        light = self._light
         ri = self._ref_idx
         if B == 1:
             ri = torch.tensor([int(self.ref_path.ref_index)], dtype=torch.int32, device=dev)
         if not self._cand.is_contiguous():
             self._cand = self._cand.contiguous()
+        lw = self._flows.cand_lw() if self._flows is not None else None      # the vTypes' (l, w): TRF:263-295
         sp = self._sp()
         self.api.env_step(self._h, self._traffic.h, B, _ptr(self._obs), _ptr(raw), _ptr(ri), 0, _ptr(self._ego),
-                          _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(light),
-                          _ptr(self._v_light), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out), _ptr(code), sp)
+                          _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(lw),
+                          _ptr(self._v_light), _ptr(self._virtual), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out),
+                          _ptr(code), sp)
         self._obs, self.done_code = obs_out, code
         if self._flows is not None:       # exits, emissions and the light for the NEXT step (the obs saw this step's state)
             self._flows.cand = self._cand
@@ -482,7 +491,7 @@ class CrossroadEnd2end(object):
             self._respawn_counter += 1
             self.api.traffic_respawn(self._traffic.h, B, self.n_cand, _ptr(self._cand), _ptr(self._entry5),
                                      C.c_float(CROSSROAD_SIZE / 2 + 40.), C.c_float(60.0), C.c_float(EXPECTED_V),
-                                     C.c_uint64(self._respawn_seed), C.c_uint64(self._respawn_counter), None, sp)
+                                     C.c_uint64(self._respawn_seed), C.c_uint64(self._respawn_counter), None, None, sp)
         self._publish_state()                                                           # E2E:136, 139
         keys = EnvironmentModel.REWARD_KEYS
         if B == 1:

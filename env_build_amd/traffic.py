@@ -20,11 +20,9 @@ with the analytic model's own prediction step (EnvironmentModel.veh_predict, DAM
 arc inside the junction), which is what the safety shield assumes about it anyway.  Vehicles are dropped 40 m past
 the junction, beyond every range filter of the observation (E2E:393-411).
 
-The per-step rule is one kernel (eb_traffic_flow_step, include/envbuild.h; identical in the CPU oracle); this module
-holds the tables, the slot state and the (rare) reset logic over torch tensors."""
+The per-step rule and the reset are one kernel each (eb_traffic_flow_step, eb_traffic_flow_reset; include/envbuild.h;
+identical in the CPU oracle); this module holds the tables and the slot state — no arithmetic."""
 import ctypes as C
-import math
-
 import torch
 
 from . import _capi
@@ -39,6 +37,7 @@ LANE_START = 100.0                              # approach lanes run from |coord
 EXIT_RANGE = CROSSROAD_SIZE / 2 + 40.0          # a departing vehicle is dropped beyond this
 ACCEL = 2.6                                     # vType accel, cross.rou.xml:2-13
 LIGHT_PROGRAMME = ((25.0, 0), (5.0, 1), (25.0, 2), (5.0, 3))   # a.net.xml:145-150
+RESET_SALT = 0x5DEECE66D                        # resets draw from a different stream than the per-step emissions
 
 
 def approach_lane(mode):
@@ -93,25 +92,26 @@ class FlowTraffic(object):
         self.vmax = torch.tensor([v[2] for v in vt], dtype=torch.float32, device=dev)               # [M]
         self.lane5 = torch.cat([self.start, self.dirn], 1).contiguous()                              # [M, 5]
         self.cand = torch.zeros((self.B, self.M, 4), dtype=torch.float32, device=dev)
-        self.active = torch.zeros((self.B, self.M), dtype=torch.bool, device=dev)
+        self.active = torch.zeros((self.B, self.M), dtype=torch.uint8, device=dev)
         self.timer = torch.zeros((self.B, len(ROUTES)), dtype=torch.float32, device=dev)
         self.sim_step = torch.zeros((self.B,), dtype=torch.int32, device=dev)
         self.phase0 = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
         self.emitted = torch.zeros((self.B, len(ROUTES)), dtype=torch.int32, device=dev)
         self._mode = torch.full((self.B, self.M), _capi.VMODE_EMPTY, dtype=torch.uint8, device=dev)
         self._vlight = torch.zeros((self.B,), dtype=torch.uint8, device=dev)
-        self.seed, self.counter = 0x5EED, 0
+        self.veh_len = self.lw[:, 0].contiguous()                                                   # [M]
+        self._lw_b = None
+        self.seed, self.counter, self.reset_counter = 0x5EED, 0, 0
 
     # -- views the env hands to the kernels -----------------------------------------------------------
     def mode(self):
         return self._mode
 
-    def _refresh_mode(self):
-        empty = torch.full_like(self.route_id, _capi.VMODE_EMPTY).expand(self.B, self.M)
-        self._mode = torch.where(self.active, self.route_id.expand(self.B, self.M), empty).contiguous()
-
     def cand_lw(self):
-        return self.lw.expand(self.B, self.M, 2).contiguous()
+        """(l, w) of every slot's vType for the collision test (TRF:263-295 reads veh['l'], veh['w']): [B, M, 2]"""
+        if self._lw_b is None:
+            self._lw_b = self.lw.expand(self.B, self.M, 2).contiguous()
+        return self._lw_b
 
     def v_light(self):
         return self._vlight
@@ -120,65 +120,25 @@ class FlowTraffic(object):
     def sim_time(self):
         return self.sim_step.to(torch.float64) * self.dt
 
-    # -- dynamics -------------------------------------------------------------------------------------
-    def _rand(self, *shape):
-        return torch.rand(shape, generator=self.gen, device=self.dev)
-
-    def _place(self, where):
-        """New vehicles into the slots of `where` [B, M]: random position on the approach lane, random speed."""
-        pos = self._rand(self.B, self.M) * (LANE_START - CROSSROAD_SIZE / 2)
-        spd = self._rand(self.B, self.M) * self.vmax
-        fresh = torch.stack([self.start[:, 0] + pos * self.dirn[:, 0], self.start[:, 1] + pos * self.dirn[:, 1], spd,
-                             self.start[:, 2].expand(self.B, self.M)], 2)
-        self.cand = torch.where(where.unsqueeze(2), fresh, self.cand)
-        self.active = self.active | where
-
-    def reset(self, rows, ego):
-        """(Re)start the traffic of the envs in `rows` [B] bool around ego start poses `ego` [B, 6]."""
-        B, M, K = self.B, self.M, self.K
-        rows_m = rows.unsqueeze(1).expand(B, M)
-        self.active = self.active & ~rows_m
-        # as many vehicles per route as its flow keeps on the 75 m approach at ~7.5 m/s, at most K
-        expect = ((LANE_START - CROSSROAD_SIZE / 2) / 7.5 / self.period).clamp(max=float(K))          # [12]
-        p = (expect / K).repeat_interleave(K)
-        self._place(rows_m & (self._rand(B, M) < p))
-        self.timer = torch.where(rows.unsqueeze(1), self._rand(B, len(ROUTES)) * self.period, self.timer)
-        self.sim_step = torch.where(rows, torch.zeros_like(self.sim_step), self.sim_step)
-        self.emitted = torch.where(rows.unsqueeze(1), torch.zeros_like(self.emitted), self.emitted)
-        ph = torch.zeros((B,), dtype=torch.uint8, device=self.dev)
-        if self.task == 'right':                                           # traffic.py:159-161
-            ph = torch.where(self._rand(B) > 0.5, torch.full_like(ph, 2), ph)
-        self.phase0 = torch.where(rows, ph, self.phase0)
-        self._remove_conflicts(rows, ego)
-        self._refresh_mode()
-        # training pins the phase (traffic.py:222-223); otherwise the programme restarts at phase 0 with the clock
-        self._vlight = torch.where(rows, self.phase0 if self.env_mode == 'training' else torch.zeros_like(self.phase0),
-                                   self._vlight)
-
-    def _remove_conflicts(self, rows, ego):
-        """traffic.py:168-192: drop a vehicle when it sits in the box ahead of / behind the ego in ego coordinates,
-        or the ego sits in the same box in the vehicle's coordinates."""
-        ex, ey, ev, ephi = ego[:, 3:4], ego[:, 4:5], ego[:, 0:1], ego[:, 5:6] * (math.pi / 180.)
-        x, y, v, phi = self.cand[:, :, 0], self.cand[:, :, 1], self.cand[:, :, 2], self.cand[:, :, 3] * (math.pi / 180.)
-        ego_l, veh_l = 4.8, self.lw[:, 0]
-        dx, dy = x - ex, y - ey
-        xe = dx * torch.cos(ephi) + dy * torch.sin(ephi)                    # shift_and_rotate_coordination, UTL:145-149
-        ye = -dx * torch.sin(ephi) + dy * torch.cos(ephi)
-        xv = -dx * torch.cos(phi) - dy * torch.sin(phi)                     # the ego seen from the vehicle
-        yv = dx * torch.sin(phi) - dy * torch.cos(phi)
-        reach = ego_l / 2. + veh_l / 2. + 2.
-        hit = ((xe > -5) & (xe < ev + reach) & (ye.abs() < 3)) | ((xv > -5) & (xv < v + reach) & (yv.abs() < 3))
-        self.active = self.active & ~(hit & rows.unsqueeze(1))
+    # -- dynamics: both rules are ONE kernel each (include/envbuild.h); nothing is computed here ---------
+    def reset(self, api, handle, rows, ego, stream):
+        """(Re)start the traffic of the envs whose byte in `rows` (uint8 [B], None = all) is set, around the ego start
+        poses `ego` [B, 6]: eb_traffic_flow_reset — presence draws, random depart position / speed, init_traffic's
+        conflict removal (TRF:168-192), timers, clock and light."""
+        self.reset_counter += 1
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        api.traffic_flow_reset(handle, self.B, self.K, p(rows), p(ego), p(self.cand), p(self.active), p(self.timer),
+                               p(self.emitted), p(self.sim_step), p(self.phase0), p(self.lane5), p(self.period), p(self.vmax),
+                               p(self.veh_len), C.c_float(LANE_START - CROSSROAD_SIZE / 2), 1 if self.task == 'right' else 0,
+                               1 if self.env_mode == 'training' else 0, C.c_uint64(self.seed ^ RESET_SALT),
+                               C.c_uint64(self.reset_counter), p(self._mode), p(self._vlight), stream)
 
     def after_step(self, api, handle, stream):
         """Bookkeeping after the env has advanced every slot by one prediction step — exits, free-flow acceleration,
         emissions, clock and light — as ONE kernel (eb_traffic_flow_step)."""
         self.counter += 1
-        if not self.cand.is_contiguous():
-            self.cand = self.cand.contiguous()
-        act8 = self.active.view(torch.uint8) if self.active.dtype == torch.bool else self.active
         p = lambda t: C.c_void_p(t.data_ptr())
-        api.traffic_flow_step(handle, self.B, self.K, p(self.cand), p(act8), p(self.timer), p(self.emitted),
+        api.traffic_flow_step(handle, self.B, self.K, p(self.cand), p(self.active), p(self.timer), p(self.emitted),
                               p(self.sim_step), p(self.lane5), p(self.period), p(self.vmax), C.c_float(self.dt),
                               C.c_float(EXIT_RANGE), C.c_float(ACCEL), C.c_float(LANE_START - CROSSROAD_SIZE / 2),
                               0 if self.env_mode == 'training' else 1, C.c_uint64(self.seed), C.c_uint64(self.counter),

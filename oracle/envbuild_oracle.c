@@ -365,19 +365,21 @@ int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float
 /* ------------------------------------------------------------------------------------------ */
 /* a8: ReferencePath closest point + tracking error, DAM:577-580, 702-770                      */
 /* ------------------------------------------------------------------------------------------ */
-static int closest_index(const eb_handle h, int p, float x, float y) { /* DAM:702-715 */
+static int closest_index_ratio(const eb_handle h, int p, float x, float y, int ratio) { /* DAM:702-715 */
     const int len = h->lens[p];
     const float* px = h->px[p];
     const float* py = h->py[p];
     float best = INFINITY;
     int best_i = 0;
-    for (int i = 0; i < len; i += 10) { /* np.arange(0, path_len, ratio), DAM:704 */
+    for (int i = 0; i < len; i += ratio) { /* np.arange(0, path_len, ratio), DAM:704 */
         float d = sq(x - px[i]) + sq(y - py[i]); /* DAM:712 */
         if (d < best) { best = d; best_i = i; }  /* tf.argmin: first minimum, DAM:714 */
     }
     /* NaN inputs: np/tf argmin returns the first NaN position; with every d NaN that is 0 */
     return best_i;
 }
+
+static int closest_index(const eb_handle h, int p, float x, float y) { return closest_index_ratio(h, p, x, y, 10); }
 
 static inline int clamp_index(int i, int len) { /* indexs2points, DAM:727-728 */
     if (i < 0) i = 0;
@@ -445,12 +447,12 @@ static inline int row_path(const eb_handle h, const int32_t* ref_idx, int path_i
 }
 
 int eb_find_closest_point(eb_handle h, int32_t n, const float* xs, const float* ys,
-                          const int32_t* ref_idx, int32_t path_id, int32_t* out_index,
+                          const int32_t* ref_idx, int32_t path_id, int32_t ratio, int32_t* out_index,
                           float* out_points, void* stream) {
     (void)stream;
     int rc = check_paths(h, "eb_find_closest_point: null handle");
     if (rc) return rc;
-    if (n < 0 || !xs || !ys || !out_index) return fail(EB_EINVAL, "eb_find_closest_point: bad argument");
+    if (n < 0 || !xs || !ys || !out_index || ratio < 1) return fail(EB_EINVAL, "eb_find_closest_point: bad argument");
     if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_find_closest_point: bad path_id");
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
@@ -460,7 +462,7 @@ int eb_find_closest_point(eb_handle h, int32_t n, const float* xs, const float* 
             if (out_points) { out_points[i] = 0; out_points[(size_t)n + i] = 0; out_points[2 * (size_t)n + i] = 0; }
             continue;
         }
-        int idx = closest_index(h, p, xs[i], ys[i]);
+        int idx = closest_index_ratio(h, p, xs[i], ys[i], ratio);
         out_index[i] = idx;
         if (out_points) {
             int ci = clamp_index(idx, h->lens[p]);
@@ -488,6 +490,40 @@ int eb_tracking_error(eb_handle h, int32_t n, const float* xs, const float* ys, 
         if (p < 0) { for (int k = 0; k < T; ++k) o[k] = 0.0f; continue; } /* DAM:342, 352 */
         tracking_row(h, p, xs[i], ys[i], phis[i], vs[i], n_future, o);
     }
+    return EB_OK;
+}
+
+/* ReferencePath.indexs2points (DAM:726-733) + future_n_data (DAM:717-724) */
+int eb_path_points(eb_handle h, int32_t n, const int32_t* index, const int32_t* ref_idx, int32_t path_id,
+                   int32_t n_future, float* out_points, void* stream) {
+    (void)stream;
+    int rc = check_paths(h, "eb_path_points: null handle");
+    if (rc) return rc;
+    if (n < 0 || n_future < 0 || (n > 0 && (!index || !out_points))) return fail(EB_EINVAL, "eb_path_points: bad argument");
+    if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_path_points: bad path_id");
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const int p = row_path(h, ref_idx, path_id, i);
+        int cur = index[i];
+        for (int k = 0; k <= n_future; ++k) {
+            float* o = out_points + (size_t)k * 3 * n;
+            if (p < 0) { o[i] = 0; o[(size_t)n + i] = 0; o[2 * (size_t)n + i] = 0; continue; }
+            const int len = h->lens[p];
+            if (k > 0) {                               /* DAM:719-722 */
+                cur += 80;
+                if (cur >= len - 2) cur = len - 2;
+            }
+            const int ci = clamp_index(cur, len);      /* DAM:727-728 */
+            o[i] = h->px[p][ci]; o[(size_t)n + i] = h->py[p][ci]; o[2 * (size_t)n + i] = h->pphi[p][ci];
+        }
+    }
+    return EB_OK;
+}
+
+int eb_phi_diff(eb_handle h, int32_t n, const float* phi_diff, float* out, void* stream) { /* DAM:577-580 */
+    (void)stream;
+    if (!h || n < 0 || (n > 0 && (!phi_diff || !out))) return fail(EB_EINVAL, "eb_phi_diff: bad argument");
+    for (int i = 0; i < n; ++i) out[i] = deal_with_phi_diff(phi_diff[i]);
     return EB_OK;
 }
 
@@ -544,6 +580,20 @@ static void next_obs_row(const eb_handle h, const float* obs, const float* act, 
     else tracking_row(h, p, nx[3], nx[4], nx[5], nx[0], c->n_future, out + 6); /* DAM:335-339 / 347-351 */
     const float* veh = obs + 6 + T;
     for (int j = 0; j < c->n_veh; ++j) veh_predict_one(veh + 4 * j, h->turn[j], out + 6 + T + 4 * j); /* DAM:355 */
+}
+
+/* a7: EnvironmentModel.ego_predict, DAM:386-392 */
+int eb_ego_predict(eb_handle h, int32_t n, const float* ego, const float* actions, float* next_ego, void* stream) {
+    (void)stream;
+    if (!h || n < 0 || (n > 0 && (!ego || !actions || !next_ego))) return fail(EB_EINVAL, "eb_ego_predict: bad argument");
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        float nx[6];
+        f_xu_row(ego + 6 * (size_t)i, actions + 2 * (size_t)i, (float)(1 / 10.), nx, NULL);   /* DAM:387 */
+        nx[0] = fminf(fmaxf(nx[0], 0.0f), 35.0f);                                             /* DAM:390 */
+        memcpy(next_ego + 6 * (size_t)i, nx, sizeof nx);
+    }
+    return EB_OK;
 }
 
 static int check_rollout(eb_handle h, int n_env, const int32_t* ref_idx, int path_id, const char* who) {
@@ -777,23 +827,34 @@ int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actio
     return EB_OK;
 }
 
-/* a16: _construct_veh_vector_short, E2E:340-464 */
-typedef struct { float x, y, v, phi; } veh4;
+/* a16: _construct_veh_vector_short, E2E:340-464.
+ * Values flow as in the reference's Python: a vehicle's x, y, phi are python floats (float64) — fp32-valued in the
+ * plain env, genuinely float64 after cal_info_in_transform_coordination in the 12-ego scene — while everything
+ * derived from ego_dynamics is np.float32.  Comparing a python float with an np.float32 rounds the python float to
+ * fp32 first (NumPy >= 2 scalar rules); comparing with a python constant, or two vehicles with each other in a sort
+ * key, happens in float64.  For fp32-valued vehicles both kinds are plain fp32 comparisons. */
+typedef struct { double x, y, phi; float v; } veh4;
+static inline int lt_ego(double a, float b) { return (float)a < b; }
+static inline int gt_ego(double a, float b) { return (float)a > b; }
 
 static int veh_in_range(int task, int m, const veh4* v, float ego_x, float ego_y) { /* E2E:393-411 */
-    const float C2 = HALF_CROSS;
+    const double C2 = 25.0;
     switch (m) {
-        case EB_VMODE_DL: return v->x > -C2 - 10.0f && v->y > ego_y - 2.0f;
-        case EB_VMODE_DU: return ego_y - 2.0f < v->y && v->y < C2 + 10.0f && v->x < ego_x + 5.0f;
-        case EB_VMODE_DR: return v->x < C2 + 10.0f && v->y > ego_y;
-        case EB_VMODE_RU: return v->x < C2 + 10.0f && v->y < C2 + 10.0f;
+        case EB_VMODE_DL: return v->x > -C2 - 10 && gt_ego(v->y, ego_y - 2.0f);
+        case EB_VMODE_DU: return gt_ego(v->y, ego_y - 2.0f) && v->y < C2 + 10 && lt_ego(v->x, ego_x + 5.0f);
+        case EB_VMODE_DR: return v->x < C2 + 10 && gt_ego(v->y, ego_y);
+        case EB_VMODE_RU: return v->x < C2 + 10 && v->y < C2 + 10;
         case EB_VMODE_UR:
-            if (task == EB_TASK_STRAIGHT) return v->x < ego_x + 7.0f && ego_y < v->y && v->y < C2 + 10.0f;
-            if (task == EB_TASK_RIGHT) return v->x < C2 + 10.0f && v->y < C2;
+            if (task == EB_TASK_STRAIGHT) return lt_ego(v->x, ego_x + 7.0f) && gt_ego(v->y, ego_y) && v->y < C2 + 10;
+            if (task == EB_TASK_RIGHT) return v->x < C2 + 10 && v->y < C2;
             return 1;
-        case EB_VMODE_UD: return fmaxf(ego_y - 2.0f, -C2) < v->y && v->y < C2 && ego_x > v->x;
-        case EB_VMODE_UL: return -C2 - 10.0f < v->x && v->x < ego_x && v->y < C2;
-        case EB_VMODE_LR: return -C2 - 10.0f < v->x && v->x < C2 + 10.0f;
+        case EB_VMODE_UD: {
+            const float ey2 = ego_y - 2.0f;   /* max(ego_y - 2, -CROSSROAD_SIZE / 2): python's max keeps the first unless the second is larger */
+            const int lower = (-25.0f > ey2) ? (-C2 < v->y) : gt_ego(v->y, ey2);
+            return lower && v->y < C2 && lt_ego(v->x, ego_x);
+        }
+        case EB_VMODE_UL: return -C2 - 10 < v->x && lt_ego(v->x, ego_x) && v->y < C2;
+        case EB_VMODE_LR: return -C2 - 10 < v->x && v->x < C2 + 10;
         default: return 1; /* rd rl lu ld: "not interest in case of traffic light", E2E:398-411 */
     }
 }
@@ -821,24 +882,45 @@ static int veh_cmp(int task, int m, const veh4* a, const veh4* b) {
 }
 
 static veh4 veh_fill_value(int m) { /* mode2fillvalue, E2E:439-447 */
-    const float C2 = HALF_CROSS, LW = LANE_W;
+    const double C2 = 25.0, LW = 3.75;
     veh4 f = {0, 0, 0, 0};
     switch (m) {
         case EB_VMODE_DL: f.x = LW / 2; f.y = -(C2 + 30); f.phi = 90; break;
-        case EB_VMODE_DU: f.x = LW * 1.5f; f.y = -(C2 + 30); f.phi = 90; break;
-        case EB_VMODE_DR: f.x = LW * 2.5f; f.y = -(C2 + 30); f.phi = 90; break;
-        case EB_VMODE_RU: f.x = C2 + 15; f.y = LW * 2.5f; f.phi = 180; break;
+        case EB_VMODE_DU: f.x = LW * 1.5; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_DR: f.x = LW * 2.5; f.y = -(C2 + 30); f.phi = 90; break;
+        case EB_VMODE_RU: f.x = C2 + 15; f.y = LW * 2.5; f.phi = 180; break;
         case EB_VMODE_UR: f.x = -LW / 2; f.y = C2 + 20; f.phi = -90; break;
-        case EB_VMODE_UD: f.x = -LW * 1.5f; f.y = C2 + 20; f.phi = -90; break;
-        case EB_VMODE_UL: f.x = -LW * 2.5f; f.y = C2 + 20; f.phi = -90; break;
-        case EB_VMODE_LR: f.x = -(C2 + 20); f.y = -LW * 1.5f; f.phi = 0; break;
+        case EB_VMODE_UD: f.x = -LW * 1.5; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_UL: f.x = -LW * 2.5; f.y = C2 + 20; f.phi = -90; break;
+        case EB_VMODE_LR: f.x = -(C2 + 20); f.y = -LW * 1.5; f.phi = 0; break;
         default: break; /* the reference defines no fill value for rd rl lu ld (never requested) */
     }
     return f;
 }
 
+/* ---- exit-relative frames of the 12-ego scene: multi_ego.py:33, 84-120; UTL:120-196; E2E:345-385 ---- */
+static const int EXIT_ANGLE[4] = {0, 90, 180, -90};                  /* ROTATE_ANGLE, multi_ego.py:33 */
+static const int MODE_END[12] = {3, 2, 1, 0, 3, 2, 1, 0, 3, 2, 1, 0}; /* end direction (d r u l = 0 1 2 3) of dl du dr rd rl ru ur ud ul lu lr ld */
+static const int MODE_OF[4][4] = {{-1, 2, 1, 0}, {3, -1, 5, 4}, {7, 6, -1, 8}, {11, 10, 9, -1}};   /* [start][end] -> EB_VMODE_* */
+/* route of a WORLD mode seen from exit k (E2E:345-385: exit R names world edge '2o' as 'do', ...) */
+static int exit_relative_mode(int world_mode, int k) {
+    if (world_mode < 0 || world_mode >= EB_VMODE_COUNT) return EB_VMODE_EMPTY;
+    const int st = world_mode / 3, en = MODE_END[world_mode];
+    return MODE_OF[(st - k + 4) & 3][(en - k + 4) & 3];
+}
+/* rotate_coordination (UTL:120-141) on python floats: float64 throughout */
+static void rotate_f64(double x, double y, double d, int rotate_d, double* ox, double* oy, double* od) {
+    const double r = rotate_d * PI_D / 180;
+    *ox = x * cos(r) + y * sin(r);
+    *oy = -x * sin(r) + y * cos(r);
+    double t = d - rotate_d;
+    if (t > 180) { while (t > 180) t = t - 360; }
+    else if (t <= -180) { while (t <= -180) t = t + 360; }
+    *od = t;
+}
+
 static void build_veh_row(const eb_handle h, int m_cand, const float* cand, const uint8_t* cmode,
-                          float ego_x, float ego_y, int light, float* out) {
+                          float ego_x, float ego_y, int light, int exit_k, float* out) {
     const int task = h->cfg.task, N = h->cfg.n_veh;
     int taken_rank[EB_MAX_VEH]; /* per slot: how many earlier slots share its mode */
     for (int s = 0; s < N; ++s) {
@@ -853,13 +935,17 @@ static void build_veh_row(const eb_handle h, int m_cand, const float* cand, cons
         /* gather this mode's candidates in insertion order */
         veh4 lst[256 + 1];
         int cnt = 0;
-        for (int i = 0; i < m_cand && cnt < 256; ++i)
-            if (cmode[i] == m) {
-                veh4 v = {cand[4 * i], cand[4 * i + 1], cand[4 * i + 2], cand[4 * i + 3]};
-                if (veh_in_range(task, m, &v, ego_x, ego_y)) lst[cnt++] = v;
-            }
+        for (int i = 0; i < m_cand && cnt < 256; ++i) {
+            const int mi = exit_k < 0 ? cmode[i] : exit_relative_mode(cmode[i], exit_k);
+            if (mi != m) continue;
+            veh4 v = {cand[4 * i], cand[4 * i + 1], cand[4 * i + 3], cand[4 * i + 2]};
+            if (exit_k >= 0)   /* cal_info_in_transform_coordination(vehicles, 0, 0, rotate_angle), multi_ego.py:87 */
+                rotate_f64((double)cand[4 * i] - 0, (double)cand[4 * i + 1] - 0, (double)cand[4 * i + 3], EXIT_ANGLE[exit_k],
+                           &v.x, &v.y, &v.phi);
+            if (veh_in_range(task, m, &v, ego_x, ego_y)) lst[cnt++] = v;
+        }
         if (virt && (m == EB_VMODE_DL || m == EB_VMODE_DU)) {
-            veh4 v = {m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f};
+            veh4 v = {m == EB_VMODE_DL ? 3.75 / 2 : 3.75 * 1.5, -25.0 + 2.5, 90.0, 0.0f};
             if (veh_in_range(task, m, &v, ego_x, ego_y)) lst[cnt++] = v;
         }
         /* stable insertion sort under the mode's key */
@@ -870,14 +956,14 @@ static void build_veh_row(const eb_handle h, int m_cand, const float* cand, cons
             lst[j + 1] = key;
         }
         veh4 r = taken_rank[s] < cnt ? lst[taken_rank[s]] : veh_fill_value(m); /* slice_or_fill, E2E:431-437 */
-        out[4 * s] = r.x; out[4 * s + 1] = r.y; out[4 * s + 2] = r.v; out[4 * s + 3] = r.phi; /* E2E:460-462 */
+        out[4 * s] = (float)r.x; out[4 * s + 1] = (float)r.y; out[4 * s + 2] = r.v; out[4 * s + 3] = (float)r.phi; /* E2E:460-463 */
     }
 }
 
 /* a16: _get_obs, E2E:285-303 */
 int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx, int32_t path_id,
-               int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* light_flag,
-               float* obs_out, void* stream) {
+               int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* v_light,
+               const uint8_t* virtual_flag, const uint8_t* exit_id, float* obs_out, void* stream) {
     (void)stream;
     int rc = check_paths(h, "eb_get_obs: null handle");
     if (rc) return rc;
@@ -886,6 +972,9 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
     if (n_env < 0 || !ego || m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)) || !obs_out)
         return fail(EB_EINVAL, "eb_get_obs: bad argument (m_cand <= 256)");
     if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_get_obs: bad path_id");
+    if (exit_id)
+        for (int i = 0; i < n_env; ++i)
+            if (exit_id[i] > EB_EXIT_L) return fail(EB_EINVAL, "eb_get_obs: bad exit id");
     const eb_config* c = &h->cfg;
     const int D = obs_dim(c), T = 3 * (c->n_future + 1);
 #pragma omp parallel for schedule(static)
@@ -896,8 +985,37 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
         int p = row_path(h, ref_idx, path_id, i);
         if (p < 0) for (int k = 0; k < T; ++k) o[6 + k] = 0.0f;
         else tracking_row(h, p, e[3], e[4], e[5], e[0], c->n_future, o + 6); /* E2E:293-297 */
-        build_veh_row(h, m_cand, cand + (size_t)i * m_cand * 4, cand_mode + (size_t)i * m_cand, e[3], e[4],
-                      light_flag ? light_flag[i] : 0, o + 6 + T);
+        const int ek = exit_id ? exit_id[i] : -1;
+        int vl = v_light ? v_light[i] : 0;
+        if (ek == EB_EXIT_R || ek == EB_EXIT_L) vl = vl != 2 ? 2 : 0;   /* multi_ego.py:89-92 */
+        const int light = vl != 0 || (virtual_flag && virtual_flag[i] != 0);   /* E2E:387-388 */
+        build_veh_row(h, m_cand, cand + (size_t)i * m_cand * 4, cand_mode + (size_t)i * m_cand, e[3], e[4], light, ek,
+                      o + 6 + T);
+    }
+    return EB_OK;
+}
+
+/* cal_ego_info_in_transform_coordination (UTL:184-196) on np.float32 fields: np.float32 * python float is an fp32
+ * product with the python float rounded to fp32 (NumPy >= 2) */
+int eb_exit_frame(eb_handle h, int32_t n, const uint8_t* exit_id, int32_t inverse, const float* ego, float* ego_out,
+                  void* stream) {
+    (void)stream;
+    if (!h || n < 0 || (n > 0 && (!exit_id || !ego || !ego_out))) return fail(EB_EINVAL, "eb_exit_frame: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (exit_id[i] > EB_EXIT_L) return fail(EB_EINVAL, "eb_exit_frame: bad exit id");
+    for (int i = 0; i < n; ++i) {
+        const float* e = ego + 6 * (size_t)i;
+        float* o = ego_out + 6 * (size_t)i;
+        const int a = inverse ? -EXIT_ANGLE[exit_id[i]] : EXIT_ANGLE[exit_id[i]];
+        const double r = a * PI_D / 180;                               /* UTL:130 */
+        const float c = (float)cos(r), sn = (float)sin(r);
+        const float x = e[3] - 0.0f, y = e[4] - 0.0f;                  /* shift_coordination by (0, 0), UTL:116-117 */
+        const float tx = x * c + y * sn;                               /* UTL:131 */
+        const float ty = -x * sn + y * c;                              /* UTL:132 */
+        float d = e[5] - (float)a;                                     /* UTL:133 */
+        if (d > 180.0f) { while (d > 180.0f) d = d - 360.0f; }         /* UTL:134-139 */
+        else if (d <= -180.0f) { while (d <= -180.0f) d = d + 360.0f; }
+        o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = tx; o[4] = ty; o[5] = d;
     }
     return EB_OK;
 }
@@ -1077,19 +1195,25 @@ int eb_event_destroy(eb_event e) {
 /* a13: CrossroadEnd2end.step as one call, E2E:132-144 */
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
-                const uint8_t* cand_mode, const uint8_t* light_flag, const uint8_t* v_light,
+                const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream) {
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
-    if (n_env < 0 || !obs || !actions || !ego || !params || !scaled_actions || !out5 || !obs_out || !done_code || obs == obs_out)
+    if (n_env < 0 || !obs || !actions || !ego || !params || !scaled_actions || !out5 || !obs_out || !done_code || obs == obs_out ||
+        m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)))
         return fail(EB_EINVAL, "eb_env_step: bad argument");
     if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_step: the traffic handle must have n_veh == m_cand");
+    int rc = check_paths(h, "eb_env_step: null handle");
+    if (!rc) rc = check_modes(h);
+    if (!rc) rc = check_modes(traffic);
+    if (rc) return rc;
+    if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (n_env == 0) return EB_OK;
-    int rc = eb_action_transform(h, n_env, actions, scaled_actions, stream);                     /* E2E:133 */
+    rc = eb_action_transform(h, n_env, actions, scaled_actions, stream);                         /* E2E:133 */
     if (!rc) rc = eb_compute_rewards(h, n_env, obs, scaled_actions, out5, out_dict16, stream);      /* E2E:134 */
     if (!rc) rc = eb_env_ego_step(h, n_env, ego, scaled_actions, ego, params, stream);           /* E2E:135 */
     if (!rc) rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                            /* TRF:220-238's role */
-    if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, light_flag, obs_out, stream);   /* E2E:140 */
-    if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, NULL, v_light, done_code, stream);   /* E2E:141 */
+    if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, NULL, obs_out, stream);   /* E2E:140 */
+    if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, cand_lw, v_light, done_code, stream);   /* E2E:141 */
     return rc;
 }
 
@@ -1163,19 +1287,24 @@ static uint64_t eb_splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+static inline float eb_u01(uint64_t seed, uint64_t idx) {   /* top 24 bits of splitmix64(seed + GOLDEN * idx) -> [0, 1) */
+    return (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * idx) >> 40) * 5.9604644775390625e-8f;
+}
+
 int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
-                       float span, float v_max, uint64_t seed, uint64_t counter, uint8_t* respawned, void* stream) {
+                       float span, float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask,
+                       uint8_t* respawned, void* stream) {
     (void)stream;
     if (!h || n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!cand || !entry)))
         return fail(EB_EINVAL, "eb_traffic_respawn: bad argument");
     for (int e = 0; e < n_env; ++e)
         for (int j = 0; j < m_cand; ++j) {
             float* c = cand + ((size_t)e * m_cand + j) * 4;
-            const int gone = fabsf(c[0]) > limit || fabsf(c[1]) > limit;
+            const int chosen = !env_mask || env_mask[e] != 0;
+            const int gone = chosen && (limit < 0.0f || fabsf(c[0]) > limit || fabsf(c[1]) > limit);
             if (gone) {
                 const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)j * 2u;
-                const float u1 = (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
-                const float u2 = (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
+                const float u1 = eb_u01(seed, base), u2 = eb_u01(seed, base + 1);
                 const float* en = entry + 5 * j;
                 const float along = u1 * span;
                 c[0] = en[0] + along * en[3];
@@ -1187,6 +1316,118 @@ int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, 
         }
     return EB_OK;
 }
+
+/* a18: CrossroadEnd2end.reset + _reset_init_state for the masked envs of a batch (E2E:99-127, 472-499) */
+int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter, int32_t training,
+                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code, void* stream) {
+    (void)stream;
+    int rc = check_paths(h, "eb_env_reset: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || (n_env > 0 && (!ego || !params || !ref_idx))) return fail(EB_EINVAL, "eb_env_reset: bad argument");
+    const float span = h->cfg.task == EB_TASK_LEFT ? 900 + 500 : h->cfg.task == EB_TASK_STRAIGHT ? 1200 + 500 : 420 + 500; /* E2E:473-478 */
+    for (int e = 0; e < n_env; ++e) {
+        if (mask && !mask[e]) continue;
+        const uint64_t base = (counter << 32) + (uint64_t)e * 128u;
+        const float u0 = eb_u01(seed, base), u1 = eb_u01(seed, base + 1), u2 = eb_u01(seed, base + 2), u3 = eb_u01(seed, base + 3);
+        int p = (int)(u0 * (float)h->n_paths);                          /* DAM:591 */
+        if (p > h->n_paths - 1) p = h->n_paths - 1;
+        const int index = (int)(u1 * span) + 700;                       /* E2E:474-478 */
+        const int ci = clamp_index(index, h->lens[p]);                  /* indexs2points, DAM:727-728 */
+        float* g = ego + 6 * (size_t)e;
+        g[0] = 8.0f * u2; g[1] = 0.0f; g[2] = 0.0f;                     /* E2E:482-486: EXPECTED_V * random */
+        g[3] = h->px[p][ci]; g[4] = h->py[p][ci]; g[5] = h->pphi[p][ci];
+        float* pr = params + 4 * (size_t)e;
+        pr[0] = 0.0f; pr[1] = 0.0f; pr[2] = VP.miu; pr[3] = VP.miu;    /* E2E:110-113 */
+        ref_idx[e] = p;
+        if (virtual_next) virtual_next[e] = (training && u3 > 0.9f) ? 1 : 0;   /* E2E:120-126 */
+        if (done_code) done_code[e] = EB_DONE_NOT_YET;                  /* E2E:119 */
+    }
+    return EB_OK;
+}
+
+/* Traffic.init_traffic's conflict test, TRF:168-192: the vehicle (x, y, a, speed v, length l) against the ego pose,
+ * through shift_and_rotate_coordination (UTL:145-149), fp32 with the deterministic sin / cos */
+static void shift_rotate_f32(float x, float y, float d, float sx, float sy, float rd, float* ox, float* oy, float* od) {
+    const float hx = x - sx, hy = y - sy;                               /* UTL:116-117 */
+    float sn, cs;
+    eb_sincosf(rd * PI_F / 180.0f, &sn, &cs);                           /* UTL:130 */
+    *ox = hx * cs + hy * sn;                                            /* UTL:131 */
+    *oy = -hx * sn + hy * cs;                                           /* UTL:132 */
+    float t = d - rd;                                                   /* UTL:133-139 */
+    if (t > 180.0f) { while (t > 180.0f) t = t - 360.0f; }
+    else if (t <= -180.0f) { while (t <= -180.0f) t = t + 360.0f; }
+    *od = t;
+}
+static int init_conflict(const float* ego6, float ego_l, float x, float y, float a, float veh_v, float veh_l) {
+    const float ego_v_x = ego6[0], ego_x = ego6[3], ego_y = ego6[4], ego_phi = ego6[5];
+    float xe, ye, ae, xv, yv, av;
+    shift_rotate_f32(x, y, a, ego_x, ego_y, ego_phi, &xe, &ye, &ae);    /* TRF:177-178 */
+    shift_rotate_f32(0.0f, 0.0f, 0.0f, xe, ye, ae, &xv, &yv, &av);      /* TRF:179-182 */
+    return (-5.0f < xe && xe < 1.0f * ego_v_x + ego_l / 2.0f + veh_l / 2.0f + 2.0f && fabsf(ye) < 3.0f) ||
+           (-5.0f < xv && xv < 1.0f * veh_v + ego_l / 2.0f + veh_l / 2.0f + 2.0f && fabsf(yv) < 3.0f);   /* TRF:183-184 */
+}
+/* test hook: the predicate alone on n (ego [5] = x, y, phi, v_x, l; veh [5] = x, y, a, v, l) pairs */
+void eb_oracle_init_conflict(int n, const float* ego5, const float* veh5, uint8_t* hit) {
+    for (int i = 0; i < n; ++i) {
+        const float* e = ego5 + 5 * (size_t)i;
+        const float* v = veh5 + 5 * (size_t)i;
+        const float ego6[6] = {e[3], 0, 0, e[0], e[1], e[2]};
+        hit[i] = (uint8_t)init_conflict(ego6, e[4], v[0], v[1], v[2], v[3], v[4]);
+    }
+}
+
+int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const uint8_t* mask, const float* ego,
+                          float* cand, uint8_t* active, float* timer, int32_t* emitted, int32_t* sim_step,
+                          uint8_t* phase0, const float* lane, const float* period, const float* v_max,
+                          const float* cand_len, float lane_len, int32_t random_phase, int32_t training,
+                          uint64_t seed, uint64_t counter, uint8_t* cand_mode, uint8_t* v_light, void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || per_route < 1 || per_route * 12 > 64 ||
+        (n_env > 0 && (!ego || !cand || !active || !timer || !emitted || !sim_step || !phase0 || !lane || !period || !v_max ||
+                       !cand_len || !cand_mode || !v_light)))
+        return fail(EB_EINVAL, "eb_traffic_flow_reset: bad argument");
+    const int K = per_route, M = 12 * K;
+    for (int e = 0; e < n_env; ++e) {
+        if (mask && !mask[e]) continue;
+        const uint64_t env_base = (counter << 32) + (uint64_t)e * 256u;
+        for (int r = 0; r < 12; ++r) {
+            float expect = lane_len / 7.5f / period[r];
+            if (expect > (float)K) expect = (float)K;
+            const float p = expect / (float)K;
+            for (int k = 0; k < K; ++k) {
+                const int j = r * K + k;
+                const size_t s = (size_t)e * M + j;
+                const float u0 = eb_u01(seed, env_base + 4u * j), u1 = eb_u01(seed, env_base + 4u * j + 1),
+                            u2 = eb_u01(seed, env_base + 4u * j + 2);
+                int on = u0 < p;
+                if (on) {
+                    const float* ln = lane + 5 * j;
+                    const float along = u1 * lane_len;
+                    float* c = cand + s * 4;
+                    c[0] = ln[0] + along * ln[3];
+                    c[1] = ln[1] + along * ln[4];
+                    c[2] = u2 * v_max[j];
+                    c[3] = ln[2];
+                    if (init_conflict(ego + 6 * (size_t)e, 4.8f, c[0], c[1], c[3], c[2], cand_len[j])) on = 0;
+                }
+                active[s] = (uint8_t)on;
+                cand_mode[s] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+            }
+            timer[(size_t)e * 12 + r] = eb_u01(seed, env_base + 4u * (r * K) + 3) * period[r];
+            emitted[(size_t)e * 12 + r] = 0;
+        }
+        sim_step[e] = 0;
+        const uint8_t ph = (random_phase && eb_u01(seed, env_base + 255u) > 0.5f) ? 2 : 0;   /* TRF:158-161 */
+        phase0[e] = ph;
+        v_light[e] = training ? ph : 0;                                                       /* TRF:222-223 */
+    }
+    return EB_OK;
+}
+
+/* diagnostics of the HIP library: accepted and ignored here */
+int eb_debug_set_tile(eb_handle h, int32_t variant) { (void)variant; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_tile: null handle"); }
+int eb_debug_set_tape_stepwise(eb_handle h, int32_t on) { (void)on; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_tape_stepwise: null handle"); }
+int eb_debug_set_trace(eb_handle h, long long* device_buf) { (void)device_buf; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_trace: null handle"); }
 
 int eb_traffic_flow_step(eb_handle h, int32_t n_env, int32_t per_route, float* cand, uint8_t* active, float* timer,
                          int32_t* emitted, int32_t* sim_step, const float* lane, const float* period,

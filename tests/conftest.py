@@ -16,3 +16,15 @@ def pytest_configure(config):
 def oracle():
     from tests._helpers import oracle_lib
     return oracle_lib()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """observed parity margins: for every tolerance-based fixture check, the largest excess over the rtol term that
+    was actually seen next to the atol it is held to"""
+    from tests._helpers import PARITY_LOG
+    if not PARITY_LOG:
+        return
+    terminalreporter.write_sep('-', 'parity margins (max |got - want| - rtol |want|   vs   atol)')
+    for k in sorted(PARITY_LOG):
+        ex, atol = PARITY_LOG[k]
+        terminalreporter.write_line('%-58s %10.3e   %8.1e' % (k, max(ex, 0.0), atol))

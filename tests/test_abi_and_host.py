@@ -11,7 +11,7 @@ import pytest
 from env_build_amd import _capi, build as eb_build
 from env_build_amd import endtoend_env_utils as U
 from env_build_amd.synthetic import assemble_obs, make_rollout_inputs
-from tests._helpers import ROOT, HostModel, oracle_lib
+from tests._helpers import golden, ROOT, HostModel, oracle_lib
 
 HEADER = os.path.join(ROOT, 'include', 'envbuild.h')
 
@@ -188,20 +188,21 @@ def test_oracle_plan_summary_and_events():
 
 
 def test_exit_frame_transforms_match_reference_values():
-    """endtoend_env_utils.cal_info_in_transform_coordination / cal_ego_info_in_transform_coordination (UTL:160-196);
-    expected values produced by the reference's own functions (container run, rounded to 1e-9)."""
+    """endtoend_env_utils' coordinate helpers (UTL:107-196) against fixture G12: the outputs of the reference's own
+    functions on the same python floats (oracle/gen_golden.py g12) — equal to the last bit (same libm, same op order)."""
     from env_build_amd import endtoend_env_utils as U
-    vehs = [dict(x=12.5, y=-3.25, v=4.0, phi=170.0, w=2., l=4.8, route=('2o', '4i')),
-            dict(x=-30.0, y=1.875, v=0.0, phi=-90.0, w=2.5, l=5., route=('3o', '1i'))]
-    expect = [(90, [(3.75, -9.5, 80.0), (8.875, 33.0, 180.0)], (-23.0, 2.0, 2.0), [(-21.0, 1.0), (-21.0, 3.0)]),
-              (-90, [(-3.75, 9.5, -100.0), (-8.875, -33.0, 0.0)], (23.0, -2.0, -178.0), [(21.0, -1.0), (21.0, -3.0)]),
-              (180, [(-9.5, -3.75, -10.0), (33.0, -8.875, 90.0)], (2.0, 23.0, -88.0), [(1.0, 21.0), (3.0, 21.0)]),
-              (37.5, [(9.819712092, -2.808158549, 132.5), (-20.777902547, 27.130138052, -127.5)],
-               (-15.588219548, -17.029603969, 54.5), [(-13.577343349, -16.051658717), (-15.16405003, -14.834135859)])]
-    for rot, ev, ee, ec in expect:
-        got = U.cal_info_in_transform_coordination(vehs, 3.0, -7.0, rot)
-        for g, e, v in zip(got, ev, vehs):
-            assert np.allclose((g['x'], g['y'], g['phi']), e, atol=2e-9) and g['v'] == v['v'] and g['route'] == v['route']
-        ego = U.cal_ego_info_in_transform_coordination(dict(x=1.0, y=-30.0, phi=92.0, Corner_point=[(2., -28.), (0., -28.)]),
-                                                       3., -7., rot)
-        assert np.allclose((ego['x'], ego['y'], ego['phi']), ee, atol=2e-9) and np.allclose(ego['Corner_point'], ec, atol=2e-9)
+    g = golden('g12_utl_frames')
+    n = len(g['x'])
+    for i in range(n):
+        x, y, d = float(g['x'][i]), float(g['y'][i]), float(g['d'][i])
+        sx, sy = float(g['shift_x'][i]), float(g['shift_y'][i])
+        r = int(g['rotate'][i]) if i < n // 2 else float(g['rotate'][i])
+        assert tuple(g['out_rotate'][i]) == U.rotate_coordination(x, y, d, r)
+        assert tuple(g['out_shift_rotate'][i]) == U.shift_and_rotate_coordination(x, y, d, sx, sy, r)
+        assert tuple(g['out_rotate_shift'][i]) == U.rotate_and_shift_coordination(x, y, d, sx, sy, r)
+        t = U.cal_info_in_transform_coordination([dict(x=x, y=y, v=3.0, phi=d, w=2.0, l=4.8, route=('1o', '4i'))], sx, sy, r)[0]
+        assert (t['x'], t['y'], t['phi']) == tuple(g['out_veh'][i]) and t['v'] == 3.0 and t['route'] == ('1o', '4i')
+        ego = U.cal_ego_info_in_transform_coordination(
+            dict(x=x, y=y, phi=d, Corner_point=[(x + 2.4, y + 1.0), (x - 2.4, y - 1.0)]), sx, sy, r)
+        assert (ego['x'], ego['y'], ego['phi']) == tuple(g['out_ego'][i])
+        assert np.array_equal(np.array(ego['Corner_point'], np.float64).ravel(), g['out_corners'][i])

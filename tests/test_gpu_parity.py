@@ -397,7 +397,18 @@ def test_env_step_composite_equals_the_six_calls(task):
     modes = [native[i % len(native)] for i in range(M)]
     ego, cand, _, _, light, _, ref = _random_scene(task, B, M, 44)
     cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
-    raw = np.random.default_rng(2).uniform(-1.2, 1.2, (B, 2)).astype(np.float32)
+    rng = np.random.default_rng(2)
+    raw = rng.uniform(-1.2, 1.2, (B, 2)).astype(np.float32)
+    # per-candidate (l, w) as the flow source's vTypes give them (TRF:263-295 reads veh['l'], veh['w']); a third of the
+    # candidates sit next to the ego so that the collision outcome depends on them
+    lw = np.stack([rng.choice([4.754264, 4.173896, 4.8], (B, M)), rng.choice([1.596668, 1.77515, 2.0, 2.4], (B, M))], 2).astype(np.float32)
+    close = rng.random((B, M)) < 0.33
+    ang, dist = rng.uniform(-np.pi, np.pi, (B, M)), rng.uniform(1.5, 3.6, (B, M))
+    cand = cand.copy()
+    cand[:, :, 0] = np.where(close, ego[:, 3:4] + dist * np.cos(ang), cand[:, :, 0])
+    cand[:, :, 1] = np.where(close, ego[:, 4:5] + dist * np.sin(ang), cand[:, :, 1])
+    virtual = (rng.random(B) < 0.3).astype(np.uint8)
+    v_light = rng.integers(0, 4, B).astype(np.uint8)
     outs = []
     for Model in (HostModel, DeviceModel):
         args = (oracle_lib(),) if Model is HostModel else ()
@@ -408,17 +419,12 @@ def test_env_step_composite_equals_the_six_calls(task):
         o5, d16 = m.compute_rewards(obs0, act)
         ego1, par1 = m.env_ego_step(ego, act)
         cand1 = tr.veh_predict(cand.reshape(B, -1)).reshape(B, M, 4)
-        obs1 = m.get_obs(ego1, cand1, cmode, light, ref_idx=ref)
-        done1 = m.judge_done(ego1, par1, obs1, cand1, cmode, None, light)
+        obs1 = m.get_obs(ego1, cand1, cmode, v_light, ref_idx=ref, virtual=virtual)
+        done1 = m.judge_done(ego1, par1, obs1, cand1, cmode, lw, v_light)
+        done_default = m.judge_done(ego1, par1, obs1, cand1, cmode, None, v_light)
+        assert (done1 != done_default).any()       # the (l, w) pairs matter in this scene (4.8 x 2.0 is not assumed)
         # the composite (state updated in place)
-        e_io, c_io = m._in(ego.copy()), m._in(cand.copy())       # updated in place: never the test's own arrays
-        ob, rw, ri = m._in(obs0), m._in(raw), m._in(ref, np.int32)
-        cm, lf = m._in(cmode, np.uint8), m._in(light, np.uint8)
-        par, sc, out5, dd = m._out((B, 4)), m._out((B, 2)), m._out((5, B)), m._out((16, B))
-        obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
-        m.api.env_step(m.h, tr.h, B, m._ptr(ob), m._ptr(rw), m._ptr(ri), 0, m._ptr(e_io), m._ptr(par), M, m._ptr(c_io),
-                       m._ptr(cm), m._ptr(lf), m._ptr(lf), m._ptr(sc), m._ptr(out5), m._ptr(dd), m._ptr(obs_o), m._ptr(code), m.stream)
-        got = [m._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code)]
+        got = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, cand_lw=lw, v_light=v_light, virtual=virtual)
         want = [act, o5, d16, ego1, par1, cand1, obs1, done1]
         for g, w in zip(got, want):
             assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w)
@@ -451,7 +457,7 @@ def test_crossroad_env_facade_matches_oracle_composition(task, n_env):
         obs0, ref = env._obs.cpu().numpy(), env._ref_idx.cpu().numpy()
         if n_env == 1:
             ref = np.array([env.ref_path.ref_index], np.int32)
-        light = ((env._v_light != 0) | (env._virtual != 0)).cpu().numpy().astype(np.uint8)
+        v_light, virtual = env._v_light.cpu().numpy(), env._virtual.cpu().numpy()
         action = rng.uniform(-1, 1, (n_env, 2)).astype(np.float32)
         obs, reward, done, info = env.step(action[0] if n_env == 1 else action)
         act = host.action_transform(action)
@@ -461,8 +467,8 @@ def test_crossroad_env_facade_matches_oracle_composition(task, n_env):
         gone = (np.abs(cand1[:, :, 0]) > 65) | (np.abs(cand1[:, :, 1]) > 65)
         cand_env = env._cand.cpu().numpy()
         assert np.array_equal(cand_env[~gone], cand1[~gone])              # re-entered vehicles are the env's own business
-        obs1 = host.get_obs(ego1, cand1, cmode, light, ref_idx=ref)        # the step observes the pool before re-entry
-        done1 = host.judge_done(ego1, par1, obs1, cand1, cmode, None, env._v_light.cpu().numpy())
+        obs1 = host.get_obs(ego1, cand1, cmode, v_light, ref_idx=ref, virtual=virtual)   # the step observes the pool before re-entry
+        done1 = host.judge_done(ego1, par1, obs1, cand1, cmode, None, v_light)
         if n_env == 1:
             assert isinstance(done, int) and np.asarray(reward).shape == () and 'reward_info' in info
             assert np.array_equal(obs, obs1[0]) and reward == o5[0, 0] and done == int(done1[0] != 0)

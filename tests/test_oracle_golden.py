@@ -19,10 +19,14 @@ import pytest
 from env_build_amd import _capi
 from env_build_amd.endtoend_env_utils import VEH_NUM, VEHICLE_MODE_LIST
 from env_build_amd.ref_path_tables import build_ref_paths
-from tests._helpers import GOLDEN, HostModel, golden
+from tests._helpers import GOLDEN, HostModel, close, golden
 
 TASKS = ('left', 'straight', 'right')
 RTOL = 1e-5
+# absolute slack next to north_star's rtol 1e-5, per check — set from the OBSERVED excess (printed at the end of a run
+# under "parity margins"), not the other way round.  1 step = the transcendental kernels' <= 2 ulp; closed loops compound it.
+ATOL = dict(g2=1e-6, g2_cancel=5e-6, g3=5e-6, g4=5e-6, g5_teacher=5e-6, g5_closed_loop=5e-6, g7_reward=5e-6, g7_state=5e-6,
+            g8=5e-6, g9=5e-6)
 
 
 # ---- G1: path tables ---------------------------------------------------------------------------
@@ -45,9 +49,9 @@ def test_g2_f_xu(oracle):
     for name, tau in zip(('tau0p1', 'tau0p05'), g['taus']):
         nxt, par = host.f_xu(g['states'], g['actions'], float(tau))
         # v_x, x, y: no cancellation -> tight; v_y, r: sums of 1e4..1e5-magnitude terms that cancel
-        np.testing.assert_allclose(nxt[:, [0, 3, 4, 5]], g['next_' + name][:, [0, 3, 4, 5]], rtol=RTOL, atol=1e-6)
-        np.testing.assert_allclose(nxt[:, 1:3], g['next_' + name][:, 1:3], rtol=RTOL, atol=1e-5)
-        np.testing.assert_allclose(par, g['params_' + name], rtol=RTOL, atol=1e-6)
+        close(nxt[:, [0, 3, 4, 5]], g['next_' + name][:, [0, 3, 4, 5]], RTOL, ATOL['g2'], 'G2 f_xu next (v_x, x, y, phi)')
+        close(nxt[:, 1:3], g['next_' + name][:, 1:3], RTOL, ATOL['g2_cancel'], 'G2 f_xu next (v_y, r)')
+        close(par, g['params_' + name], RTOL, ATOL['g2'], 'G2 f_xu params')
 
 
 # ---- G3: compute_rewards -----------------------------------------------------------------------
@@ -57,8 +61,8 @@ def test_g3_compute_rewards(oracle, task):
     host = HostModel(oracle, task)
     out5, d16 = host.compute_rewards(g['obs'], g['actions'])
     assert [str(k) for k in g['dict_keys']] == list(REWARD_KEYS)
-    np.testing.assert_allclose(out5, g['out5'], rtol=RTOL, atol=1e-5)
-    np.testing.assert_allclose(d16, g['dict16'], rtol=RTOL, atol=1e-5)
+    close(out5, g['out5'], RTOL, ATOL['g3'], 'G3 compute_rewards out5 (%s)' % task)
+    close(d16, g['dict16'], RTOL, ATOL['g3'], 'G3 compute_rewards dict16 (%s)' % task)
     # the penalty MASKS (which envs are penalised at all) are bit-exact
     assert np.array_equal(out5[1:] > 0, g['out5'][1:] > 0)
 
@@ -76,7 +80,7 @@ def test_g4_reference_own_vector(oracle):
     host = HostModel(oracle, 'straight')
     for k in range(3):
         out = host.tracking_error(g['ref_xs'], g['ref_ys'], g['ref_phis'], g['ref_vs'], 10, path_id=k)
-        np.testing.assert_allclose(out, g['ref_out_path%d_n10' % k], rtol=RTOL, atol=1e-5)
+        close(out, g['ref_out_path%d_n10' % k], RTOL, ATOL['g4'], 'G4 reference own vector (DAM:805-808)')
 
 
 @pytest.mark.parametrize('task', TASKS)
@@ -92,7 +96,7 @@ def test_g4_tracking(oracle, task):
         for nf in (0, 3):
             out = host.tracking_error(x, y, phi, v, nf, path_id=k)
             ref = g['out_%s_n%d' % (tag, nf)]
-            np.testing.assert_allclose(out, ref, rtol=RTOL, atol=1e-5)
+            close(out, ref, RTOL, ATOL['g4'], 'G4 tracking_error_vector (%s)' % task)
             assert np.array_equal(out[:, 2], ref[:, 2])                        # v - 8: exact
 
 
@@ -102,6 +106,8 @@ G5 = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, 'g5
 
 @pytest.mark.parametrize('name', G5)
 def test_g5_rollout(oracle, name):
+    """25 closed-loop steps from obs0 (the per-step error compounds: see the teacher-forced tests below for the per-step
+    figure)."""
     _, _, task, N, mode, nf = name.split('_')
     g = golden(name)
     host = HostModel(oracle, task, n_veh=int(N[1:]), n_future=int(nf[2:]), mode=mode,
@@ -109,14 +115,37 @@ def test_g5_rollout(oracle, name):
     obs, keep = g['obs0'], list(g['obs_step_index'])
     for t in range(g['actions'].shape[0]):
         obs, o5, _ = host.rollout_step(obs, g['actions'][t], g['ref_idx'], 1)
-        np.testing.assert_allclose(o5, g['out5'][t], rtol=RTOL, atol=1e-4, err_msg='step %d' % t)
+        close(o5, g['out5'][t], RTOL, ATOL['g5_closed_loop'], 'G5 closed loop x25: out5')
         if t in keep:
-            np.testing.assert_allclose(obs, g['obs_steps'][keep.index(t)], rtol=RTOL, atol=1e-4,
-                                       err_msg='step %d' % t)
+            close(obs, g['obs_steps'][keep.index(t)], RTOL, ATOL['g5_closed_loop'], 'G5 closed loop x25: obs')
     # the tape entry point is the same arithmetic
     out, o5s = host.rollout_tape(g['obs0'], g['actions'], g['ref_idx'], 1)
     assert np.array_equal(out, obs)
-    np.testing.assert_allclose(o5s, g['out5'], rtol=RTOL, atol=1e-4)
+    close(o5s, g['out5'], RTOL, ATOL['g5_closed_loop'], 'G5 closed loop x25: out5')
+
+
+@pytest.mark.parametrize('name', [n for n in G5 if len(golden(n)['obs_step_index']) == golden(n)['actions'].shape[0]])
+def test_g5_teacher_forced_native(oracle, name):
+    """The native-size fixtures hold the reference's obs after EVERY step: feed step t from the reference's state and
+    compare one step — the per-step error, free of closed-loop drift."""
+    _, _, task, N, mode, nf = name.split('_')
+    g = golden(name)
+    host = HostModel(oracle, task, n_veh=int(N[1:]), n_future=int(nf[2:]), mode=mode, modes=[str(m) for m in g['modes']])
+    states = [g['obs0']] + [g['obs_steps'][t] for t in range(g['actions'].shape[0])]
+    for t in range(g['actions'].shape[0]):
+        obs, o5, _ = host.rollout_step(states[t], g['actions'][t], g['ref_idx'], 1)
+        close(obs, states[t + 1], RTOL, ATOL['g5_teacher'], 'G5 teacher-forced: obs (native N)')
+        close(o5, g['out5'][t], RTOL, ATOL['g5_teacher'], 'G5 teacher-forced: out5 (native N)')
+
+
+@pytest.mark.parametrize('task', TASKS)
+def test_g5t_teacher_forced_n32(oracle, task):
+    g = golden('g5t_teacher_%s_N32' % task)
+    host = HostModel(oracle, task, n_veh=32, mode='training', modes=[str(m) for m in g['modes']])
+    for t in range(g['actions'].shape[0]):
+        obs, o5, _ = host.rollout_step(g['obs_all'][t], g['actions'][t], g['ref_idx'])
+        close(obs, g['obs_all'][t + 1], RTOL, ATOL['g5_teacher'], 'G5T teacher-forced: obs (N = 32)')
+        close(o5, g['out5'][t], RTOL, ATOL['g5_teacher'], 'G5T teacher-forced: out5 (N = 32)')
 
 
 def test_g5_covers_every_task_mode_and_size():
@@ -133,7 +162,7 @@ def test_g9_ss(oracle, task):
     g = golden('g9_ss_%s' % task)
     host = HostModel(oracle, task)
     out = host.ss(g['obs'], g['actions'], g['ref_idx'], 0, float(g['lam']))
-    np.testing.assert_allclose(out, g['out'], rtol=1e-4, atol=1e-4)
+    close(out, g['out'], RTOL, ATOL['g9'], 'G9 ss (%s)' % task)
     assert np.array_equal(out > 0, g['out'] > 0)
 
 
@@ -147,7 +176,7 @@ def test_g6_get_obs_and_judge_done(oracle, task):
     obs = host.get_obs(g['ego'], g['cand'], g['cand_mode'], light_flag, ref_idx=g['ref_index'])
     assert obs.shape == (n, 9 + 4 * VEH_NUM[task])
     assert np.array_equal(obs[:, :6], g['obs'][:, :6])                          # ego vector: copy
-    np.testing.assert_allclose(obs[:, 6:9], g['obs'][:, 6:9], rtol=RTOL, atol=1e-5)
+    close(obs[:, 6:9], g['obs'][:, 6:9], RTOL, ATOL['g4'], 'G6 _get_obs tracking columns (%s)' % task)
     assert np.array_equal(obs[:, 9:], g['obs'][:, 9:])                          # filter / sort / pad: copies
     done = host.judge_done(g['ego'], g['params'], g['obs'], g['cand'], g['cand_mode'], g['cand_lw'], g['v_light'])
     assert np.array_equal(done, g['done_code'])                                 # integer mask: bit-exact
@@ -174,10 +203,10 @@ def test_g7_config1_single_env_200_steps(oracle):
         veh = host.veh_predict(veh.reshape(1, -1)).reshape(-1, 4)              # SUMO-free traffic
         obs = host.get_obs(ego, veh[None], cmode, np.zeros(1, np.uint8), ref_idx=ref)   # E2E:140
         done = host.judge_done(ego, params, obs, veh[None], cmode, None, np.zeros(1, np.uint8))
-        np.testing.assert_allclose(out5[0, 0], g['reward'][t], rtol=RTOL, atol=1e-5, err_msg='t=%d' % t)
-        np.testing.assert_allclose(ego[0], g['ego'][t + 1], rtol=RTOL, atol=2e-4, err_msg='t=%d' % t)
-        np.testing.assert_allclose(veh, g['veh'][t + 1], rtol=RTOL, atol=2e-4, err_msg='t=%d' % t)
-        np.testing.assert_allclose(obs[0], g['obs'][t + 1], rtol=RTOL, atol=2e-4, err_msg='t=%d' % t)
+        close(out5[0, 0], g['reward'][t], RTOL, ATOL['g7_reward'], 'G7 200-step closed loop: reward')
+        close(ego[0], g['ego'][t + 1], RTOL, ATOL['g7_state'], 'G7 200-step closed loop: ego')
+        close(veh, g['veh'][t + 1], RTOL, ATOL['g7_state'], 'G7 200-step closed loop: vehicles')
+        close(obs[0], g['obs'][t + 1], RTOL, ATOL['g7_state'], 'G7 200-step closed loop: obs')
         n_done_mismatch += int(done[0] != g['done_code'][t])
     assert n_done_mismatch == 0
 
@@ -201,7 +230,7 @@ def test_g8_fp16_state_storage(oracle, task):
     n_off = 0
     for t in range(g['actions'].shape[0]):
         out, o5, _ = host.rollout_step_f16(g['obs_in'][t], g['actions'][t], g['ref_idx'])
-        np.testing.assert_allclose(o5, g['out5'][t], rtol=RTOL, atol=1e-4)
+        close(o5, g['out5'][t], RTOL, ATOL['g8'], 'G8 fp16 state: out5 (%s)' % task)
         d = _half_ulps(out, g['obs_out'][t])
         assert d.max() <= 1, 't=%d' % t
         n_off += int((d > 0).sum())
@@ -223,3 +252,76 @@ def test_fp16_storage_equals_fp32_path_on_fp16_inputs(oracle):
         o, o5, _ = host.rollout_step_f16(o, g['actions'][t], g['ref_idx'])
         o5s.append(o5)
     assert np.array_equal(tape_out, o) and np.array_equal(tape_o5, np.stack(o5s))
+
+
+# ---- G6X: the 12-ego scene's exit-relative frames (multi_ego.py:84-120) -----------------------------
+@pytest.mark.parametrize('task', TASKS)
+def test_g6x_exit_frames(oracle, task):
+    """World-frame ego, vehicles and light -> eb_exit_frame + eb_get_obs(exit ids) == the reference's
+    cal_*_in_transform_coordination + v_light rule + _get_obs(exit_) for exits D / R / U / L; and back to the world."""
+    g = golden('g6x_exit_frames_%s' % task)
+    host = HostModel(oracle, task, mode='training')
+    n = len(g['exit_id'])
+    assert sorted(set(g['exit_id'].tolist())) == [0, 1, 2, 3]
+    ego_t = host.exit_frame(g['exit_id'], g['ego_world'])
+    assert np.array_equal(ego_t[:, :3], g['ego_world'][:, :3])                          # velocities: untouched
+    assert np.array_equal(ego_t[:, 3:].astype(np.float64), g['ego_trans'])              # fp32 rotation: bit-exact
+    obs = host.get_obs(ego_t, g['cand_world'], g['cand_mode_world'], g['v_light_world'], ref_idx=g['ref_index'],
+                       virtual=g['virtual'], exit_id=g['exit_id'])
+    assert obs.shape == (n, 9 + 4 * VEH_NUM[task])
+    assert np.array_equal(obs[:, :6], g['obs'][:, :6])
+    close(obs[:, 6:9], g['obs'][:, 6:9], RTOL, ATOL['g4'], 'G6X exit frames: tracking columns (%s)' % task)
+    assert np.array_equal(obs[:, 9:], g['obs'][:, 9:])        # rotation in float64 + renaming + filter / sort / pad: bit-exact
+    back = host.exit_frame(g['exit_id'], ego_t, inverse=True)
+    assert np.array_equal(back[:, 3:].astype(np.float64), g['ego_back'])
+    # the scenes are not degenerate: most slots hold a real (transformed) vehicle, and R / L scenes differ from D
+    fills = (obs[:, 9:].reshape(n, -1, 4)[:, :, 2] == 0).mean()
+    assert fills < 0.8
+
+
+def test_exit_relative_route_renaming_covers_every_mode(oracle):
+    """E2E:345-385: under exit k a world route (start, end) is the mode of (start - k, end - k); checked through
+    eb_get_obs on single-candidate scenes against the name tables of the reference."""
+    names = dict(D=dict(do='1o', di='1i', ro='2o', ri='2i', uo='3o', ui='3i', lo='4o', li='4i'),
+                 R=dict(do='2o', di='2i', ro='3o', ri='3i', uo='4o', ui='4i', lo='1o', li='1i'),
+                 U=dict(do='3o', di='3i', ro='4o', ri='4i', uo='1o', ui='1i', lo='2o', li='2i'),
+                 L=dict(do='4o', di='4i', ro='1o', ri='1i', uo='2o', ui='2i', lo='3o', li='3i'))
+    route_of = {m: (names['D'][m[0] + 'o'], names['D'][m[1] + 'i']) for m in _capi.VMODES}
+    mode_of_route = {v: k for k, v in route_of.items()}
+    host = HostModel(oracle, 'straight', mode='selecting')          # slots: dl du ud ru ur
+    slots = VEHICLE_MODE_LIST['straight']
+    for k, ex in enumerate(_capi.EXITS):
+        for wm in _capi.VMODES:
+            rel = [m for m in _capi.VMODES if (names[ex][m[0] + 'o'], names[ex][m[1] + 'i']) == route_of[wm]]
+            assert len(rel) == 1
+            ego = np.array([[3., 0., 0., 5.6, -30., 90.]], np.float32)
+            # a candidate that passes every range filter once it is in the ego's frame: built there, rotated to the world
+            import math
+            lx, ly = 2.0, -10.0
+            a = math.radians({0: 0, 1: 90, 2: 180, 3: -90}[k])
+            wx, wy = lx * math.cos(a) - ly * math.sin(a), lx * math.sin(a) + ly * math.cos(a)
+            cand = np.array([[[wx, wy, 5.0, 33.0]]], np.float32)
+            cm = np.array([[_capi.VMODE_ID[wm]]], np.uint8)
+            # world phase 2 is what exits R / L see as green (multi_ego.py:89-92): no stop-line cars in either case
+            vl = np.array([2 if k & 1 else 0], np.uint8)
+            obs = host.get_obs(ego, cand, cm, vl, path_id=1, exit_id=np.array([k], np.uint8))
+            veh = obs[0, 9:].reshape(-1, 4)
+            hit = [slots[j] for j in range(len(slots)) if veh[j, 2] == 5.0]
+            assert hit == ([rel[0]] if rel[0] in slots else []), (ex, wm, rel, hit)
+    assert mode_of_route[('2o', '1i')] == 'rd'
+
+
+# ---- G11: init_traffic's conflict test (TRF:168-192) ------------------------------------------------
+def test_g11_init_conflict_predicate(oracle):
+    import ctypes as C
+    g = golden('g11_conflict')
+    n = len(g['hit'])
+    out = np.zeros(n, np.uint8)
+    fn = oracle.lib.eb_oracle_init_conflict
+    fn.restype, fn.argtypes = None, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    ego5, veh5 = np.ascontiguousarray(g['ego']), np.ascontiguousarray(g['veh'])     # (npz members are loaded per access)
+    fn(n, ego5.ctypes.data, veh5.ctypes.data, out.ctypes.data)
+    off = g['margin'] > 1e-3                                  # fp32 restatement of float64 Python: masks agree off-threshold
+    assert off.mean() > 0.95 and 0.2 < g['hit'].mean() < 0.5
+    assert np.array_equal(out[off], g['hit'][off])
+    assert (out != g['hit']).sum() <= 1
