@@ -77,11 +77,10 @@ class HierarchicalDecision(object):
         """[3, B, D]: the observation every env would see on each candidate path (:112-115)."""
         env, B = self.env, self.n_env
         out = torch.empty((len(self.path_list), B, env.obs_dim), dtype=torch.float32, device=self.device)
-        light = ((env._v_light != 0) | (env._virtual != 0)).to(torch.uint8)
         cand, cmode = env._cand.contiguous(), env._cand_mode.contiguous()
         for k in range(len(self.path_list)):
-            env.api.get_obs(env._h, B, _ptr(env._ego), None, k, env.n_cand, _ptr(cand), _ptr(cmode), _ptr(light),
-                            _ptr(out[k]), env._sp())
+            env.api.get_obs(env._h, B, _ptr(env._ego), None, k, env.n_cand, _ptr(cand), _ptr(cmode), _ptr(env._v_light),
+                            _ptr(env._virtual), None, _ptr(out[k]), env._sp())
         return out
 
     def select_path(self, path_values):

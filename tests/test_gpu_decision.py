@@ -55,7 +55,7 @@ def test_batched_decision_steps_match_oracle_composition(task):
     for t in range(8):
         ego, cand = env._ego.cpu().numpy(), env._cand.cpu().numpy()
         cmode = env._cand_mode.cpu().numpy()
-        light = ((env._v_light != 0) | (env._virtual != 0)).to(torch.uint8).cpu().numpy()
+        light = ((env._v_light != 0) | (env._virtual != 0)).to(torch.uint8).cpu().numpy()   # E2E:387-388, on the host
         if t % 2 == 1:        # start some envs from another path so that the hysteresis has something to decide
             hd.old_index = torch.from_numpy(np.random.default_rng(t).integers(0, 3, B)).to(hd.device)
         old = hd.old_index.cpu().numpy()
