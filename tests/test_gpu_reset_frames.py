@@ -135,12 +135,16 @@ def test_traffic_flow_reset_equals_oracle(task):
     for mdl in (host, dev):
         st = {k: mdl._in(v.copy(), v.dtype) for k, v in state0.items()}
         p = mdl._ptr
-        mdl.api.traffic_flow_reset(mdl.h, B, K, p(mdl._in(mask, np.uint8)), p(mdl._in(ego)), p(st['cand']), p(st['active']),
-                                   p(st['timer']), p(st['emitted']), p(st['sim_step']), p(st['phase0']), p(mdl._in(lane)),
-                                   p(mdl._in(period)), p(mdl._in(vmax)), p(mdl._in(vlen)), C.c_float(LANE_START - 25.0),
+        # (inputs are held in variables: a device tensor created inline would be freed before the kernel reads it)
+        mk, eg, ln, pe, vm, vl = (mdl._in(mask, np.uint8), mdl._in(ego), mdl._in(lane), mdl._in(period), mdl._in(vmax),
+                                  mdl._in(vlen))
+        mdl.api.traffic_flow_reset(mdl.h, B, K, p(mk), p(eg), p(st['cand']), p(st['active']),
+                                   p(st['timer']), p(st['emitted']), p(st['sim_step']), p(st['phase0']), p(ln),
+                                   p(pe), p(vm), p(vl), C.c_float(LANE_START - 25.0),
                                    1 if task == 'right' else 0, 1, C.c_uint64(4242), C.c_uint64(3), p(st['mode']), p(st['light']),
                                    mdl.stream)
         res.append({k: mdl._ret(v) for k, v in st.items()})
+        del mk, eg, ln, pe, vm, vl
     a, b = res
     on = b['active'] != 0
     for k in ('active', 'mode', 'timer', 'emitted', 'sim_step', 'phase0', 'light'):
@@ -198,9 +202,10 @@ def test_g11_conflict_fixture_through_the_flow_reset_kernel():
         vlen = np.full(M, veh5[i, 4], np.float32)
         # speed: u2 * v_max with u2 unknown -> the predicate's reach depends on it; use v_max = 0 and fold the fixture's
         # vehicle speed into the ego-frame test only through pairs whose outcome does not depend on it (checked below)
-        dev.api.traffic_flow_reset(dev.h, 1, K, None, p(dev._in(ego[i:i + 1])), p(st['cand']), p(st['active']), p(st['timer']),
-                                   p(st['emitted']), p(st['sim']), p(st['ph']), p(dev._in(ln)), p(dev._in(period)), p(dev._in(vmax)),
-                                   p(dev._in(vlen)), C.c_float(75.0), 0, 1, C.c_uint64(1), C.c_uint64(1), p(st['mode']), p(st['light']),
+        t_eg, t_ln, t_pe, t_vm, t_vl = dev._in(ego[i:i + 1]), dev._in(ln), dev._in(period), dev._in(vmax), dev._in(vlen)
+        dev.api.traffic_flow_reset(dev.h, 1, K, None, p(t_eg), p(st['cand']), p(st['active']), p(st['timer']),
+                                   p(st['emitted']), p(st['sim']), p(st['ph']), p(t_ln), p(t_pe), p(t_vm),
+                                   p(t_vl), C.c_float(75.0), 0, 1, C.c_uint64(1), C.c_uint64(1), p(st['mode']), p(st['light']),
                                    dev.stream)
         out[i] = 1 - dev._ret(st['active'])[0, 0]
     # the oracle's predicate with veh_v = 0 is the expectation; where the fixture's own speed does not matter, the
@@ -390,6 +395,7 @@ def test_env_step_validates_before_it_launches_and_set_paths_failure_keeps_the_o
                          p(c_io), p(dev._in(cmode, np.uint8)), None, None, None, p(sc), p(out5), None, p(obs_o), p(code), dev.stream)
     assert np.array_equal(dev._ret(e_io), ego) and np.array_equal(dev._ret(c_io), cand)
     dev.api.destroy(unset.h)
+    unset.h = None                                        # (its __del__ then destroys NULL: a no-op)
     # eb_set_paths with a non-finite point: error, and the handle still answers from the old tables
     before = dev.tracking_error(ego[:, 3], ego[:, 4], ego[:, 5], ego[:, 0], 0, ref_idx=ref)
     xs = np.concatenate([pp[0] for pp in dev.paths]).astype(np.float32).copy()

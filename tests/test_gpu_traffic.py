@@ -128,8 +128,8 @@ def test_traffic_respawn_equals_oracle_and_depends_on_its_key_only():
     along = (got[gone][:, 0] - np.broadcast_to(entry[:, 0], (B, M))[gone]) / np.broadcast_to(entry[:, 3], (B, M))[gone]
     assert np.all(got[gone][:, 2] >= 0) and np.all(got[gone][:, 2] < 8) and np.all(along > -1e-3) and np.all(along < 60.001)
     # the same (env, slot) rows inside a smaller batch draw the same values
-    c2 = dev._in(cand[:100].copy())
-    dev.api.traffic_respawn(dev.h, 100, M, dev._ptr(c2), dev._ptr(dev._in(entry)), C.c_float(65.0), C.c_float(60.0),
+    c2, en2 = dev._in(cand[:100].copy()), dev._in(entry)
+    dev.api.traffic_respawn(dev.h, 100, M, dev._ptr(c2), dev._ptr(en2), C.c_float(65.0), C.c_float(60.0),
                             C.c_float(8.0), C.c_uint64(12345678901234567), C.c_uint64(77), None, None, dev.stream)
     assert np.array_equal(dev._ret(c2), got[:100])
     u = got[gone][:, 2] / 8.0
