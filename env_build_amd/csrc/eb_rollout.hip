@@ -22,6 +22,8 @@
 // The hand-offs are LDS flags (see lds_publish / lds_wait_until), not barriers: neither role ever waits for
 // the other's HBM traffic.  HBM-bound: 104 + 32 n_veh algorithmic bytes per env-step; no MFMA (nothing here
 // is a dense contraction).
+#include <type_traits>
+
 #include "eb_device.h"
 #include "eb_kernels.h"
 
@@ -43,13 +45,6 @@ template <> struct Stored<float> {
     static EB_DEV void store4(float* p, f4u v) { *reinterpret_cast<f4u*>(p) = v; }
     static EB_DEV void store1(float* p, float v) { *p = v; }
     static EB_DEV float round(float v) { return v; }                    // what a store + load does to a value
-    // record store with a cache policy (wave-uniform `pol`): 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
-    static EB_DEV void store4_pol(float* p, f4u v, int pol) {
-        if (pol == 0) store4(p, v);
-        else if (pol == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
-        else if (pol == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
-    }
 };
 typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
 template <> struct Stored<_Float16> {
@@ -63,15 +58,6 @@ template <> struct Stored<_Float16> {
     }
     static EB_DEV void store1(_Float16* p, float v) { *p = (_Float16)v; }
     static EB_DEV float round(float v) { return (float)(_Float16)v; }
-    static EB_DEV void store4_pol(_Float16* p, f4u v, int pol) {
-        const h4u h = h4u{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        const u2v bits = __builtin_bit_cast(u2v, h);
-        if (pol == 0) store4(p, v);
-        else if (pol == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(bits) : "memory");
-        else if (pol == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(bits) : "memory");
-        else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(bits) : "memory");
-    }
 };
 
 // LDS-only workgroup barrier: orders this wave's LDS traffic, leaves global loads/stores in flight
@@ -116,7 +102,8 @@ EB_DEV int env_of_item(const FusedHot<ST>& H, int item) {
 // per-wave near-record queue: normally one drain at the end; in a crowded tile the in-loop tests stop while 64
 // slots are still free and the rest is tested record by record with a drain before each (see record_wave).  4 blocks of 2048 records must fit a CU's LDS with
 // room to spare: blocks above ~32 KB were seen to run 3 per CU, i.e. a second round of blocks.
-constexpr int QCAP = 192;
+constexpr int QCAP = 160;
+constexpr int TAPE_QCAP = 192;   // the tape kernel drains when more than 64 entries wait and adds at most 2 x 64 before the next check
 
 // ---- closest point of (px, py) on path p (DAM:702-715), tables in global memory (L1/L2 resident) ----
 // The cell of the position names the index range [lo, hi] that provably holds the reference's argmin for
@@ -160,7 +147,7 @@ struct FusedSmem {
     unsigned long long mask[64];          // per env: slots with a non-zero penalty sum
     float2 pen[ITEMS];                    // per record: (3.5 m sum, 2.5 m sum), DAM:228-229
     v2f qxy[RW][QCAP];                    // per record wave: queued near records: (x, y),
-    float qphi[RW][QCAP];                 //   heading,
+    v2f qsc[RW][QCAP];                    //   (sin, cos) of the heading — the prediction has just computed them (DAM:221 = DAM:413-414's angle),
     int qitem[RW][QCAP];                  //   item id
     int ego_ready;                        // set by the env wave once ego[] and mask[] are written
     int waves_done;                       // record waves that have published their partial sums
@@ -282,24 +269,37 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
 
 // ---- record waves -----------------------------------------------------------------------------------
 // one queue pass: entries [base, base + n) of this wave's queue, one per lane: DAM:218-229
+// the four circle-pair terms of one queued record (DAM:218-229) -> its partial sums + a bit in its env's slot mask
+template <typename SM, typename ST>
+EB_DEV void queue_terms(const FusedHot<ST>& H, SM& S, const float4* ego, int item, float x, float y, float vs, float vc) {
+    const int e2 = env_of_item(H, item), j2 = item - e2 * H.n_veh;
+    const float4 eg = ego[e2];
+    float t35[4], t25[4];
+    const float4 pts = make_float4(eg.x + LWS * eg.w, eg.y + LWS * eg.z, eg.x - LWS * eg.w, eg.y - LWS * eg.z);
+    veh2veh_terms(pts, x, y, vs, vc, t35, t25);
+    const float p35 = ((t35[0] + t35[1]) + t35[2]) + t35[3];
+    const float p25 = ((t25[0] + t25[1]) + t25[2]) + t25[3];
+    if (p35 != 0.0f) {   // p25 != 0 implies p35 != 0
+        S.pen[item] = make_float2(p35, p25);
+        atomicOr(&S.mask[e2], 1ull << j2);
+    }
+}
+// one queue pass: entries [base, base + n) of this wave's queue, one per lane.  The tape kernel queues a record's heading
+// (its near tests run before the prediction), the per-step kernel the heading's sin / cos (computed by the prediction).
 template <typename SM, typename ST>
 EB_DEV void queue_pass(const FusedHot<ST>& H, SM& S, const float4* ego, int w, int lane, int base, int n) {
     if (lane < n) {
         const v2f vxy = S.qxy[w][base + lane];
-        const float4 v = make_float4(vxy.x, vxy.y, S.qphi[w][base + lane], 0.0f);
-        const int item = S.qitem[w][base + lane];
-        const int e2 = env_of_item(H, item), j2 = item - e2 * H.n_veh;
-        const float4 eg = ego[e2];
-        float t35[4], t25[4], vs, vc;
-        const float4 pts = make_float4(eg.x + LWS * eg.w, eg.y + LWS * eg.z, eg.x - LWS * eg.w, eg.y - LWS * eg.z);
-        sincos_det(deg2rad(v.z), vs, vc);                                   // DAM:221
-        veh2veh_terms(pts, v.x, v.y, vs, vc, t35, t25);
-        const float p35 = ((t35[0] + t35[1]) + t35[2]) + t35[3];
-        const float p25 = ((t25[0] + t25[1]) + t25[2]) + t25[3];
-        if (p35 != 0.0f) {   // p25 != 0 implies p35 != 0
-            S.pen[item] = make_float2(p35, p25);
-            atomicOr(&S.mask[e2], 1ull << j2);
-        }
+        float vs, vc;
+        sincos_det(deg2rad(S.qphi[w][base + lane]), vs, vc);                // DAM:221
+        queue_terms(H, S, ego, S.qitem[w][base + lane], vxy.x, vxy.y, vs, vc);
+    }
+}
+template <typename SM, typename ST>
+EB_DEV void queue_pass_sc(const FusedHot<ST>& H, SM& S, const float4* ego, int w, int lane, int base, int n) {
+    if (lane < n) {
+        const v2f vxy = S.qxy[w][base + lane], sc = S.qsc[w][base + lane];
+        queue_terms(H, S, ego, S.qitem[w][base + lane], vxy.x, vxy.y, sc.x, sc.y);
     }
 }
 
@@ -318,8 +318,10 @@ EB_DEV TurnC turn_consts(int t) {
                                                                              : TurnC{1.0, 0.0f, 0.0f};
 }
 
+// sn_out / cs_out: sin / cos of the record's CURRENT heading, deg2rad(rec.w) — exactly sincos_det(deg2rad(phi)), the
+// pair the collision terms need too (DAM:221-224)
 template <typename ST>
-EB_DEV f4u predict_record_pk(const f4u rec, const TurnC tc) {
+EB_DEV f4u predict_record_pk(const f4u rec, const TurnC tc, float& sn_out, float& cs_out) {
     const v2f xy = {rec.x, rec.y};
     const float v = rec.z;
     const float v10 = div_const<C10>(v);                                     // DAM:413
@@ -339,6 +341,7 @@ EB_DEV f4u predict_record_pk(const f4u rec, const TurnC tc) {
     const float a = (k & 1) ? sc.y : sc.x;
     const float b = (k & 1) ? -sc.x : sc.y;
     const float sn = (k & 2) ? -a : a, cs = (k & 2) ? -b : b;
+    sn_out = sn; cs_out = cs;
     const v2f nxy = xy + v2f{v10, v10} * v2f{cs, sn};                        // DAM:413-414, 422
     const bool middle = (rec.x > -HALF_CROSS && rec.x < HALF_CROSS) && (rec.y > -HALF_CROSS && rec.y < HALF_CROSS);   // DAM:409-410
     const float u = div_by(v, tc.rc) * tc.sign;                              // +-(v / radius), DAM:417, 419
@@ -372,13 +375,20 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then every record
     const int turn_code = A.dt->turn[lane];
     f4u rec[RPT];
+    // A tile that holds its full RL * RPT records (every tile but a batch's last one) needs no per-record bounds
+    // checks: the two forms of each loop below differ only in that (wave-uniform choice, same results).
+    const bool full_tile = items == RL * RPT;
+    auto load_records = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        // lanes past the tile's last record re-read the tile's last record (branch-free loads; never stored)
-        const bool valid = item_of(k) < items;
-        rec[k] = Stored<ST>::load4(tin + (valid ? off_of(k) : 4 * (items - 1) + nE * HD));
-        if (!valid) rec[k].x = 1e30f;            // never near an ego (and never stored)
-    }
+        for (int k = 0; k < RPT; ++k) {
+            // lanes past the tile's last record re-read the tile's last record (branch-free loads; never stored)
+            const bool valid = FULL || item_of(k) < items;
+            rec[k] = Stored<ST>::load4(tin + (valid ? off_of(k) : 4 * (items - 1) + nE * HD));
+            if (!valid) rec[k].x = 1e30f;            // never near an ego (and never stored)
+        }
+    };
+    if (full_tile) load_records(std::true_type{}); else load_records(std::false_type{});
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
@@ -391,13 +401,12 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     // to the penalty sums (DAM:228-229).
     int qn = 0;
     auto drain = [&]() {
-        for (int base = 0; base < qn; base += 64) queue_pass(H, S, S.ego, w, lane, base, min(64, qn - base));
+        for (int base = 0; base < qn; base += 64) queue_pass_sc(H, S, S.ego, w, lane, base, min(64, qn - base));
         qn = 0;
     };
     // (lanes past the tile's last record carry x = 1e30 in `r`, see the loads: never near)
-    auto near_test = [&](int item, int env, const f4u r) {
-        const float4 eg = S.ego[env];
-        const v2f d = v2f{r.x, r.y} - v2f{eg.x, eg.y};
+    auto near_test = [&](int item, const v2f eg, const f4u r, const v2f sc) {
+        const v2f d = v2f{r.x, r.y} - eg;
         const v2f d2 = d * d;
         const bool near = d2.x + d2.y < 40.5f;
         const unsigned long long b = __builtin_amdgcn_ballot_w64(near);
@@ -406,7 +415,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
                 // queue slot = entries so far + near lanes below this one (v_mbcnt with the running count as its addend)
                 const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)qn));
                 S.qxy[w][pos] = v2f{r.x, r.y};          // three plain LDS writes straight from the record's registers
-                S.qphi[w][pos] = r.w;
+                S.qsc[w][pos] = sc;
                 S.qitem[w][pos] = item;
             }
             qn += __popcll(b);
@@ -422,30 +431,44 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         EB_MARK(A, trow, 3);                                                // ego seen
     }
     const bool test_near = H.do_rewards && !(A.ablate & 8);
-    const int store_pol = (A.ablate >> 5) & 3;          // profiling aid: cache policy of the record stores
     int k_late = test_near ? RPT : 0;
+    auto main_loop = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        // the ego positions of this lane's records, all LDS reads in flight at once (one wait instead of one per record)
+        v2f egoxy[RPT];
+        if (test_near) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        // Recompute this record's item id / env / offset from the lane's bases (an add each) instead of keeping the
-        // eight copies made for the loads alive through the whole loop: the empty asm hides the per-step constants.
-        int k_item = k * RL, k_env = k * epk, k_off = k * off_step;
-        asm volatile("" : "+s"(k_item), "+s"(k_env), "+s"(k_off));
-        const int item = k_item + rtid;
-        const int env = FAST ? e_first + k_env : env_of_item(H, item);
-        const int off = FAST ? off_first + k_off : 4 * item + (env + 1) * HD;
-        const bool valid = item < items;
-        if (k < k_late) {
-            near_test(item, valid ? env : 0, rec[k]);
-            if (qn > QCAP - 64) k_late = k + 1;
+            for (int k = 0; k < RPT; ++k) {
+                const int item = k * RL + rtid;
+                const int env = FAST ? e_first + k * epk : env_of_item(H, item);
+                egoxy[k] = *reinterpret_cast<const v2f*>(&S.ego[(FULL || item < items) ? env : 0]);
+            }
         }
-        if (valid) {
-            const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
-            Stored<ST>::store4_pol(tout + off, predict_record_pk<ST>(rec[k], tc), store_pol);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            // Recompute this record's item id / env / offset from the lane's bases (an add each) instead of keeping the
+            // eight copies made for the loads alive through the whole loop: the empty asm hides the per-step constants.
+            int k_item = k * RL, k_env = k * epk, k_off = k * off_step;
+            asm volatile("" : "+s"(k_item), "+s"(k_env), "+s"(k_off));
+            const int item = k_item + rtid;
+            const int env = FAST ? e_first + k_env : env_of_item(H, item);
+            const int off = FAST ? off_first + k_off : 4 * item + (env + 1) * HD;
+            const bool valid = FULL || item < items;
+            // the prediction first: it yields sin / cos of the record's heading, which a near record takes to the queue
+            const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[valid ? item - env * NV : 0]);
+            float sn, cs;
+            const f4u nv = predict_record_pk<ST>(rec[k], tc, sn, cs);
+            if (k < k_late) {
+                near_test(item, egoxy[k], rec[k], v2f{sn, cs});
+                if (qn > QCAP - 64) k_late = k + 1;
+            }
+            if (valid) Stored<ST>::store4(tout + off, (A.ablate & 256) ? rec[k] : nv);
+            if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
+            if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);   // two records at a time: bounds the live set, leaves some ILP
         }
-        if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
-        if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
-        if (k & 1) __builtin_amdgcn_sched_barrier(0);   // two records at a time: bounds the live set, leaves some ILP
-    }
+    };
+    if (full_tile) main_loop(std::true_type{}); else main_loop(std::false_type{});
     if (!H.do_rewards) return;
     if (test_near && k_late < RPT) {
         for (int k = k_late; k < RPT; ++k) {       // not unrolled: rare path
@@ -453,7 +476,9 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
             const bool valid = item_of(k) < items;
             f4u r = Stored<ST>::load4(tin + (valid ? off_of(k) : 4 * (items - 1) + nE * HD));
             if (!valid) r.x = 1e30f;
-            near_test(item_of(k), valid ? env_of(k) : 0, r);
+            float sn, cs;
+            sincos_det(deg2rad(r.w), sn, cs);
+            near_test(item_of(k), *reinterpret_cast<const v2f*>(&S.ego[valid ? env_of(k) : 0]), r, v2f{sn, cs});
         }
     }
     EB_MARK(A, trow, 4);                                                    // near tests done
@@ -480,9 +505,9 @@ struct TapeSmem {
     unsigned char turn[64];
     unsigned long long mask[64];
     float2 pen[ITEMS];
-    v2f qxy[RW][QCAP];
-    float qphi[RW][QCAP];
-    int qitem[RW][QCAP];
+    v2f qxy[RW][TAPE_QCAP];
+    float qphi[RW][TAPE_QCAP];
+    int qitem[RW][TAPE_QCAP];
     int ego_ready;
     int waves_done;
 };
@@ -637,7 +662,7 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
             asm volatile("" : "+s"(k_item), "+s"(k_env));
             const int item = k_item + rtid;
             const int env = FAST ? e_first + k_env : env_of_item(H, item);
-            if (k > 0 && (k & 1) == 0 && qn > 64) drain();                  // at most 64 + 2 * 64 = QCAP entries ever wait
+            if (k > 0 && (k & 1) == 0 && qn > 64) drain();                  // at most 64 + 2 * 64 = TAPE_QCAP entries ever wait
             const float4 eg = ego[item < items ? env : 0];
             const v2f d = v2f{rec[k].x, rec[k].y} - v2f{eg.x, eg.y};
             const v2f d2 = d * d;
@@ -665,7 +690,8 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
             if (item < items) {
                 const int env = FAST ? e_first + k_env : env_of_item(H, item);
                 const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
-                const f4u nv = predict_record_pk<ST>(rec[k], tc);
+                float sn_, cs_;
+                const f4u nv = predict_record_pk<ST>(rec[k], tc, sn_, cs_);
                 rec[k] = f4u{Stored<ST>::round(nv.x), Stored<ST>::round(nv.y), Stored<ST>::round(nv.z), Stored<ST>::round(nv.w)};
             }
             if (k & 1) __builtin_amdgcn_sched_barrier(0);

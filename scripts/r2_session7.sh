@@ -1,0 +1,16 @@
+#!/bin/bash
+OUT=gpurun_out/${1:-r2i}
+mkdir -p $OUT
+export TMPDIR=/tmp
+T="python scripts/time_rollout.py"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $OUT/parity.log 2>&1; echo "parity rc=$?"; tail -2 $OUT/parity.log
+{
+for i in 1 2; do
+  $T --iters 500 2>&1 | tail -1
+  $T --iters 500 --n-veh 64 --f16 2>&1 | tail -1
+  $T --iters 500 --n-veh 64 2>&1 | tail -1
+  $T --iters 400 --lanes 8 2>&1 | tail -1
+  $T --iters 1000 --n-env 4096 --n-veh 16 2>&1 | tail -1
+done
+} > $OUT/timing.txt 2>&1
+cat $OUT/timing.txt

@@ -10,9 +10,12 @@ from env_build_amd.synthetic import make_rollout_inputs
 ap = argparse.ArgumentParser()
 ap.add_argument('--task', default='left'); ap.add_argument('--n-env', type=int, default=65536)
 ap.add_argument('--n-veh', type=int, default=32); ap.add_argument('--mode', default='training')
-ap.add_argument('--iters', type=int, default=200); ap.add_argument('--lanes', type=int, default=1, help='independent env sets stepped round-robin (8: the working set leaves the Infinity Cache)'); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])')
+ap.add_argument('--iters', type=int, default=200); ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one'); ap.add_argument('--lanes', type=int, default=1, help='independent env sets stepped round-robin (8: the working set leaves the Infinity Cache)'); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
+if a.lib:
+    from env_build_amd import _capi
+    _capi._hip_api = _capi.CApi(a.lib)
 inp = make_rollout_inputs(a.task, a.n_env, a.n_veh, 25, seed=0)
 m = EnvironmentModel(a.task, 0, mode=a.mode, n_veh=a.n_veh, device=dev)
 ego = torch.from_numpy(inp['ego']).to(dev); ref = torch.from_numpy(inp['ref_idx']).to(dev)
