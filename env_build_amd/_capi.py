@@ -54,6 +54,9 @@ PROTOTYPES = {
     'eb_compute_next_obses': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P]),
     'eb_rollout_step': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    'eb_rollout_gated': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'eb_rollout_gated_blocks': (C.c_int, [_P, _I, C.POINTER(_I)]),
+    'eb_gate_feed': (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     'eb_rollout_step_f16': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape_f16': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_episode_summary': (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),

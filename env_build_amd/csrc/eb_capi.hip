@@ -54,6 +54,7 @@ struct eb_handle_s {
     int modes_set;
     long long* trace;         // profiling aid, see eb_debug_set_trace
     eb::ExitConsts xc;        // cos / sin of the exit angles (eb_get_obs with exit ids, eb_exit_frame)
+    hipStream_t gate_stream;  // producer stream of gated rollouts (high priority: a hardware queue of its own), made on first use
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
     int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
 };
@@ -180,6 +181,7 @@ int eb_destroy(eb_handle h) {
     if (h->d_cells) hipFree(h->d_cells);
     if (h->d_partials) hipFree(h->d_partials);
     if (h->d_pt) hipFree(h->d_pt);
+    if (h->gate_stream) hipStreamDestroy(h->gate_stream);
     delete h;
     return EB_OK;
 }
@@ -383,10 +385,33 @@ int eb_compute_rewards(eb_handle h, int32_t n_env, const float* obs, const float
 }
 
 // obs_in / obs_out point at fp32 rows, or at binary16 rows when storage_f16 is set
+struct GateArgs {
+    const uint32_t* ready;
+    uint32_t* done;
+    void* obs_steps;
+    uint32_t* status;
+    int spin;
+};
+
+static int pick_variant(eb_handle h, int32_t n_env) {
+    static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
+    int variant = h->tile_variant >= 0 ? h->tile_variant : forced;
+    if (variant < 0 || variant > 2) {
+        // the largest tile that still gives every CU two blocks; small batches take small tiles
+        variant = 2;
+        for (int v = 0; v < 2; ++v) {
+            const int e = std::max(1, std::min(64, eb::fused_tile_records(v) / h->cfg.n_veh));
+            if ((n_env + e - 1) / e >= 2 * h->n_cu) { variant = v; break; }
+        }
+    }
+    return variant;
+}
+
 static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* obs_in, const float* actions,
                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16,
-                         int tape_horizon = 0) {   // > 0: `actions` is a tape [H, n_env, 2], `out5` is [H, 5, n_env], one launch
+                         int tape_horizon = 0,   // > 0: `actions` is a tape [H, n_env, 2], `out5` is [H, 5, n_env], one launch
+                         const GateArgs* gate = nullptr) {
     const int NV = h->cfg.n_veh;
     eb::FusedArgs A;
     std::memset(&A, 0, sizeof A);
@@ -413,7 +438,18 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         A.ablate = ablate;
     }
     A.trace = h->trace;
+    if (gate) {
+        A.gate_ready = gate->ready; A.gate_done = gate->done; A.gate_obs = gate->obs_steps; A.gate_status = gate->status;
+        A.gate_spin = gate->spin;
+    }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
+    if (tape_horizon > 0) {
+        // Small grids (at most two blocks per CU) keep the stride-10 path tables in LDS for the whole launch: their steps are
+        // bound by the env wave's chain of dependent table reads, not by throughput.  Larger ones leave the LDS to occupancy.
+        static const int stage = std::getenv("EB_STAGE_PATHS") ? std::atoi(std::getenv("EB_STAGE_PATHS")) : -1;   // tuning aid: 0 / 1 force
+        const bool want = stage < 0 ? grid <= 2 * h->n_cu : stage != 0;
+        if (want) A.stage_entries = h->red_total + 4;
+    }
     if (tape_horizon > 0) EB_HIP(eb::launch_rollout_tape_fused(h->cfg.task, variant, A, tape_horizon, grid, s));
     else EB_HIP(eb::launch_rollout_fused(h->cfg.task, variant, A, grid, s));
     return EB_OK;
@@ -422,19 +458,19 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
 static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                           float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16 = 0,
-                          int tape_horizon = 0) {
-    static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
-    int variant = h->tile_variant >= 0 ? h->tile_variant : forced;
-    if (variant < 0 || variant > 2) {
-        // the largest tile that still gives every CU two blocks; small batches take small tiles
-        variant = 2;
-        for (int v = 0; v < 2; ++v) {
-            const int e = std::max(1, std::min(64, eb::fused_tile_records(v) / h->cfg.n_veh));
-            if ((n_env + e - 1) / e >= 2 * h->n_cu) { variant = v; break; }
-        }
-    }
-    return rollout_fused(h, variant, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
-                         actions_raw, do_rewards, s, storage_f16, tape_horizon);
+                          int tape_horizon = 0, const GateArgs* gate = nullptr) {
+    return rollout_fused(h, pick_variant(h, n_env), n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
+                         actions_raw, do_rewards, s, storage_f16, tape_horizon, gate);
+}
+
+// blocks of a gated rollout over n_env envs, or 0 when they cannot all be resident at once
+static int gated_blocks(eb_handle h, int32_t n_env) {
+    const int variant = pick_variant(h, n_env);
+    const int ept = std::max(1, std::min(64, eb::fused_tile_records(variant) / h->cfg.n_veh));
+    const int grid = (n_env + ept - 1) / ept;
+    const size_t dyn = grid <= 2 * h->n_cu ? (size_t)(h->red_total + 4) * 12 : 0;   // rollout_fused stages the path tables for small grids
+    const int per_cu = eb::tape_blocks_per_cu(h->cfg.task, variant, h->cfg.n_veh, 0, dyn);
+    return grid <= per_cu * h->n_cu ? grid : 0;
 }
 
 int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
@@ -506,6 +542,57 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
     EB_HIP(hipSetDevice(h->cfg.device));
     return rollout_tape_any(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps,
                             pick(h, stream), 0);
+}
+
+int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks) {
+    if (!h || n_env < 0 || !n_blocks) return fail(EB_EINVAL, "eb_rollout_gated_blocks: bad argument");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    *n_blocks = n_env == 0 ? 0 : gated_blocks(h, n_env);
+    return EB_OK;
+}
+
+int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
+                     const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
+                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, uint32_t* status,
+                     int32_t spin_limit, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_gated: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps || !step_ready || !step_done ||
+        !status || spin_limit < 1)
+        return fail(EB_EINVAL, "eb_rollout_gated: bad argument");
+    if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
+        return fail(EB_EINVAL, "eb_rollout_gated: obs_in, obs_work and obs_out must be distinct buffers");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    if (gated_blocks(h, n_env) == 0)
+        return fail(EB_EINVAL, "eb_rollout_gated: n_env needs more blocks than the device holds at once (a gated rollout must be fully resident)");
+    const GateArgs g{step_ready, step_done, obs_steps, status, spin_limit};
+    return rollout_common(h, n_env, obs_in, action_tape, ref_idx, path_id, obs_out, out5_steps, nullptr, 1, 1, pick(h, stream), 0,
+                          horizon, &g);
+}
+
+int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, const float* staged_tape,
+                 float* live_tape, uint32_t* step_ready, const uint32_t* step_done, uint32_t* status,
+                 int32_t spin_limit, void* stream) {
+    if (!h || n_env < 1 || (n_env & 1) || horizon < 1 || n_blocks < 1 || !staged_tape || !live_tape || !step_ready || !step_done ||
+        !status || spin_limit < 1 || staged_tape == live_tape)
+        return fail(EB_EINVAL, "eb_gate_feed: bad argument (n_env even: a step's actions are copied 16 bytes at a time)");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) {
+        // The producer has to run SIDE BY SIDE with the gated rollout.  Two streams of the same priority may share a
+        // hardware queue (then the second kernel would wait for the first to end, and each waits for the other's flags
+        // until both give up); a high-priority stream sits in a queue of its own.
+        if (!h->gate_stream) {
+            int lo = 0, hi = 0;
+            EB_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            EB_HIP(hipStreamCreateWithPriority(&h->gate_stream, hipStreamNonBlocking, hi));
+        }
+        s = h->gate_stream;
+    }
+    EB_HIP(eb::launch_gate_feed(horizon, n_blocks, (size_t)n_env * 8, staged_tape, live_tape, step_ready, step_done, status,
+                                spin_limit, s));
+    return EB_OK;
 }
 
 int eb_rollout_step_f16(eb_handle h, int32_t n_env, const uint16_t* obs_in, const float* actions, const int32_t* ref_idx,

@@ -39,12 +39,24 @@ struct FusedArgs {
     int do_rewards;            // 0: compute_next_obses only
     int ablate;                // profiling aid (EB_ABLATE)
     long long* trace;          // profiling aid (eb_debug_set_trace): [n_waves][8] s_memrealtime marks, or NULL
+    // step gates of eb_rollout_gated (tape kernel only; all NULL / 0 otherwise)
+    const unsigned* gate_ready;   // [horizon]: step t may start once gate_ready[t] != 0 (written by the action producer)
+    unsigned* gate_done;          // [horizon]: += 1 per block once step t's outputs are visible device-wide
+    void* gate_obs;               // [horizon, n_env, D] or NULL: the obs after every step, written through to memory
+    unsigned* gate_status;        // [0] = 1 when a gate was not opened within gate_spin polls (the launch gives up)
+    int gate_spin;
+    int stage_entries;            // tape / gated kernels: > 0 = copy this many stride-10 table entries (+ 4 readable past the end) into LDS
 };
 // variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 4 x 4 (1024), 2 = 1 x 4 (256)
 int fused_tile_records(int variant);
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s);
 // open-loop rollout of `horizon` steps in one launch: A.actions = tape [horizon, n_env, 2], A.out5 = [horizon, 5, n_env]
 hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, int horizon, int grid, hipStream_t s);
+// blocks of the tape kernel of `variant` that can be resident on one CU at once (a gated rollout needs its whole grid resident)
+int tape_blocks_per_cu(int task, int variant, int n_veh, int storage_f16, size_t dyn_bytes);
+// eb_gate_feed: the reference action producer of a gated rollout (one block)
+hipError_t launch_gate_feed(int horizon, int n_blocks, size_t step_bytes, const void* staged, void* live,
+                            unsigned* gate_ready, const unsigned* gate_done, unsigned* status, int spin, hipStream_t s);
 
 hipError_t launch_f_xu(int n, const float* st, const float* ac, float tau, float* nx, float* pr, hipStream_t s);
 hipError_t launch_action_transform(int n, const float* in, float* out, hipStream_t s);

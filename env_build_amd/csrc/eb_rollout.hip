@@ -45,6 +45,10 @@ template <> struct Stored<float> {
     static EB_DEV void store4(float* p, f4u v) { *reinterpret_cast<f4u*>(p) = v; }
     static EB_DEV void store1(float* p, float v) { *p = v; }
     static EB_DEV float round(float v) { return v; }                    // what a store + load does to a value
+    // write-through forms (sc1: the bytes leave this XCD's L2 at once, so another kernel can read them while this one
+    // runs; the issuing wave drains them with s_waitcnt vmcnt(0) before it raises a flag)
+    static EB_DEV void store4_wt(float* p, f4u v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+    static EB_DEV void store1_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 };
 typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
 template <> struct Stored<_Float16> {
@@ -58,6 +62,15 @@ template <> struct Stored<_Float16> {
     }
     static EB_DEV void store1(_Float16* p, float v) { *p = (_Float16)v; }
     static EB_DEV float round(float v) { return (float)(_Float16)v; }
+    static EB_DEV void store4_wt(_Float16* p, f4u v) {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        const u2v bits = __builtin_bit_cast(u2v, h4u{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w});
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(bits) : "memory");
+    }
+    static EB_DEV void store1_wt(_Float16* p, float v) {
+        const unsigned bits = __builtin_bit_cast(unsigned short, (_Float16)v);
+        asm volatile("global_store_short %0, %1, off sc1" :: "v"(p), "v"(bits) : "memory");
+    }
 };
 
 // LDS-only workgroup barrier: orders this wave's LDS traffic, leaves global loads/stores in flight
@@ -65,14 +78,33 @@ EB_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :::
 // The two hand-offs between the roles are LDS flags, not barriers: a barrier would hold the env wave until
 // every record wave has its HBM data, and the record waves until the env wave's chain is through.
 // (All waves of a block are resident together, so polling cannot deadlock.)
+// (The flags are accessed through LDS-typed pointers: a volatile access through a generic pointer stays a FLAT
+// instruction — the address-space inference pass leaves volatile operations alone — which is slower to poll.)
+typedef __attribute__((address_space(3))) int lds_int;
 EB_DEV void lds_publish(int* flag, int value) {   // everything this wave wrote to LDS before is visible first
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    *reinterpret_cast<volatile int*>(flag) = value;
+    *(volatile lds_int*)flag = value;
 }
 EB_DEV void lds_wait_until(int* flag, int value) {
-    while (*reinterpret_cast<volatile int*>(flag) != value) __builtin_amdgcn_s_sleep(2);
+    while (*(volatile lds_int*)flag != value) __builtin_amdgcn_s_sleep(2);
     asm volatile("" ::: "memory");
 }
+
+// Device-scope accesses of the gated rollout's flags and action words, spelled as global instructions with the sc1 bit
+// (served by L2 / memory, never by this CU's L1 — MI355X_MICROARCH.md, "inter-workgroup visibility").  Inline assembly:
+// the flat-pointer forms of the __hip_atomic builtins do not survive instruction selection here.
+EB_DEV unsigned agent_load_u32(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+EB_DEV unsigned long long agent_load_u64(const void* p) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+EB_DEV void agent_store_u32(unsigned* p, unsigned v) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+EB_DEV void agent_add_u32(unsigned* p, unsigned v) { asm volatile("global_atomic_add %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 
 // The arguments every wave needs before it can issue its first HBM load travel as separate kernel parameters:
 // with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave instead of behind an s_load.
@@ -111,9 +143,12 @@ constexpr int TAPE_QCAP = 192;   // the tape kernel drains when more than 64 ent
 // reference's fp32 expression and a strict '<' returns the index of the full scan after ~6-10 evaluations
 // instead of ~370.  Positions outside the grid (or NaN) take the pruned full search.
 // Returns the table index and the table point itself (x, y, heading).
-EB_DEV int closest_cell_index(const FusedArgs& A, int p, int roff, float px, float py, float& rx, float& ry, float& rphi) {
-    const float* xy = A.xy10 + 2 * roff;
-    const float* ph = A.phi10 + roff;
+// xy10 / phi10: the stride-10 tables — in global memory (the per-step kernel: L1/L2 resident), or the copy a block of the
+// tape / gated kernels keeps in LDS for its whole launch (north_star: "LDS staging of the reference path per block")
+EB_DEV int closest_cell_index(const FusedArgs& A, const float* xy10, const float* phi10, int p, int roff, float px, float py,
+                              float& rx, float& ry, float& rphi) {
+    const float* xy = xy10 + 2 * roff;
+    const float* ph = phi10 + roff;
     const float fx = (px - A.gx0) * CELL_INV, fy = (py - A.gy0) * CELL_INV;
     if (!(fx >= 0.0f && fx < (float)A.gnx && fy >= 0.0f && fy < (float)A.gny)) {
         const int n = p == 0 ? A.red_len[0] : p == 1 ? A.red_len[1] : A.red_len[2];
@@ -211,7 +246,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int roff = p == 0 ? A.red_off[0] : p == 1 ? A.red_off[1] : A.red_off[2];
         EB_MARK(A, trow, 2);                                                // bicycle step done
         float rx = 0.0f, ry = 0.0f, rphi = 0.0f;                            // == path[bi * 10]: bi * 10 < len always
-        const int bi = (A.ablate & 1) ? 0 : closest_cell_index(A, p, roff, nx[3], nx[4], rx, ry, rphi);
+        const int bi = (A.ablate & 1) ? 0 : closest_cell_index(A, A.xy10, A.phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
         t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                           // DAM:758
         if (A.trace) { asm volatile("" :: "v"(t0)); EB_MARK(A, trow, 3); }  // closest point found
         t1 = deal_with_phi_diff(nx[5] - rphi);                              // DAM:759
@@ -510,10 +545,22 @@ struct TapeSmem {
     int qitem[RW][TAPE_QCAP];
     int ego_ready;
     int waves_done;
+    int pub_done;                         // gated rollout: record waves whose step outputs have left for memory
+    int abort;                            // gated rollout: a gate timed out, every wave leaves
 };
+// wait for *flag >= value; false when the block is giving up (gated rollout only)
+EB_DEV bool lds_wait_or_abort(int* flag, int value, int* abort) {
+    while (*(volatile lds_int*)flag < value) {
+        if (*(volatile lds_int*)abort) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
 
-template <int TASK, int RW, int RPT, typename ST>
-EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, int e0, int nE, int horizon) {
+template <int TASK, int RW, int RPT, bool GATED, typename ST>
+EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, int e0, int nE, int horizon,
+                          const float* xy10, const float* phi10) {
     const int lane = threadIdx.x;   // wave 0
     const int D = H.obs_dim, NV = H.n_veh;
     const bool act = lane < nE;
@@ -530,14 +577,35 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
     }
     const int roff = p == 1 ? A.red_off[1] : p == 2 ? A.red_off[2] : A.red_off[0];
     const size_t n = (size_t)H.n_env;
-    f2u araw = *reinterpret_cast<const f2u*>(A.actions + 2 * (size_t)ge);
+    constexpr bool gated = GATED;
+    f2u araw = f2u{0.0f, 0.0f};
+    if (!gated) araw = *reinterpret_cast<const f2u*>(A.actions + 2 * (size_t)ge);
     const int trow = blockIdx.x * (RW + 1);
     long long waited = 0;
     EB_MARK(A, trow, 0);
     for (int t = 0; t < horizon; ++t) {
         float* out5 = A.out5 + (size_t)t * 5 * n;
         f2u araw_next = araw;
-        if (t + 1 < horizon) araw_next = *reinterpret_cast<const f2u*>(A.actions + 2 * ((size_t)(t + 1) * n + ge));   // prefetch
+        if (gated) {
+            // ---- the step gate: the producer of actions[t] (a policy kernel on another stream, eb_gate_feed, ...) raises
+            // gate_ready[t] after its stores have left for memory; every lane polls the same word (one request per poll)
+            unsigned open = 0;
+            for (int spins = 0; spins <= A.gate_spin; ++spins) {
+                open = agent_load_u32(A.gate_ready + t);
+                if (open) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!open) {                                                    // give up: tell the host and the record waves
+                if (lane == 0) agent_store_u32(A.gate_status, 1u);
+                lds_publish(&S.abort, 1);
+                return;
+            }
+            // the actions were written by another agent while this kernel runs: read them past this CU's L1
+            const unsigned long long bits = agent_load_u64(A.actions + 2 * ((size_t)t * n + ge));
+            araw = __builtin_bit_cast(f2u, bits);
+        } else if (t + 1 < horizon) {
+            araw_next = *reinterpret_cast<const f2u*>(A.actions + 2 * ((size_t)(t + 1) * n + ge));   // prefetch
+        }
         const float phi_rad = deg2rad(st[5]);
         float es, ec;
         sincos_det(phi_rad, es, ec);                                        // DAM:211 and DAM:79-80
@@ -546,14 +614,16 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         lds_publish(&S.ego_ready, t + 1);                                   // ---- hand-off 1 ----
         float steer, a_x;
         action_transform(araw.x, araw.y, steer, a_x);                       // DAM:120
+        // step outputs: plain stores, or written through when another kernel reads them while this one runs (gated)
+        auto put = [&](float* q, float v) { if (gated) Stored<float>::store1_wt(q, v); else *q = v; };
         if (act) {
             const float punish_steer = -sq(steer), punish_a_x = -sq(a_x);   // DAM:198-199
             const float punish_yaw_rate = -sq(st[2]);                       // DAM:202
             const float devi_y = -sq(trk[0]);                               // DAM:205
             const float devi_phi = -sq(deg2rad(trk[1]));                    // DAM:206
             const float devi_v = -sq(trk[2]);                               // DAM:207
-            out5[ge] = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
-                       5.0f * punish_steer + 0.05f * punish_a_x;            // DAM:297-298
+            put(out5 + ge, 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                           5.0f * punish_steer + 0.05f * punish_a_x);       // DAM:297-298
         }
         float nx[6];
         f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);              // DAM:387
@@ -562,16 +632,20 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         int bi = 0;
         if (p >= 0) {                                                       // DAM:334-353
             float rx = 0.0f, ry = 0.0f, rphi = 0.0f;
-            bi = closest_cell_index(A, p, roff, nx[3], nx[4], rx, ry, rphi);
+            bi = closest_cell_index(A, xy10, phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
             t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                       // DAM:758
             t1 = deal_with_phi_diff(nx[5] - rphi);                          // DAM:759
             t2 = nx[0] - EXP_V;                                             // DAM:760
         }
-        if (t == horizon - 1 && act) {     // the final obs: head (+ look-ahead columns, which feed nothing on the way)
-            Stored<ST>::store4(hout, f4u{nx[0], nx[1], nx[2], nx[3]});
-            Stored<ST>::store4(hout + 4, f4u{nx[4], nx[5], t0, t1});
-            Stored<ST>::store1(hout + 8, t2);
-            ST* otrk = hout + 9;
+        // the head of the next obs: (+ look-ahead columns, which feed nothing on the way): to the final obs after the
+        // last step, and to obs_steps[t] after every step of a gated rollout that publishes its states
+        auto store_head = [&](ST* row, bool wt) {
+            auto s4 = [&](ST* q, f4u v) { if (wt) Stored<ST>::store4_wt(q, v); else Stored<ST>::store4(q, v); };
+            auto s1 = [&](ST* q, float v) { if (wt) Stored<ST>::store1_wt(q, v); else Stored<ST>::store1(q, v); };
+            s4(row, f4u{nx[0], nx[1], nx[2], nx[3]});
+            s4(row + 4, f4u{nx[4], nx[5], t0, t1});
+            s1(row + 8, t2);
+            ST* otrk = row + 9;
             if (p >= 0) {                                                   // DAM:717-724, 763-768
                 const PathTables& pt = *A.dt;
                 const int len = pt.len[p];
@@ -580,16 +654,19 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
                     cur += 80;
                     if (cur >= len - 2) cur = len - 2;
                     const int fi = clamp_index(cur, len);
-                    Stored<ST>::store1(otrk + 3 * k, pt.x[p][fi] - nx[3]);
-                    Stored<ST>::store1(otrk + 3 * k + 1, pt.y[p][fi] - nx[4]);
-                    Stored<ST>::store1(otrk + 3 * k + 2, deal_with_phi_diff(nx[5] - pt.phi[p][fi]));
+                    s1(otrk + 3 * k, pt.x[p][fi] - nx[3]);
+                    s1(otrk + 3 * k + 1, pt.y[p][fi] - nx[4]);
+                    s1(otrk + 3 * k + 2, deal_with_phi_diff(nx[5] - pt.phi[p][fi]));
                 }
             } else {
-                for (int c = 0; c < 3 * A.n_future; ++c) Stored<ST>::store1(otrk + c, 0.0f);   // DAM:342, 352
+                for (int c = 0; c < 3 * A.n_future; ++c) s1(otrk + c, 0.0f);   // DAM:342, 352
             }
-        }
+        };
+        if (t == horizon - 1 && act) store_head(hout, false);
+        if (GATED && A.gate_obs && act) store_head(reinterpret_cast<ST*>(A.gate_obs) + ((size_t)t * n + ge) * D, true);
         const long long w0 = A.trace ? wall_clock64() : 0;
-        lds_wait_until(&S.waves_done, RW * (t + 1));                        // ---- hand-off 2 ----
+        if (GATED) { if (!lds_wait_or_abort(&S.waves_done, RW * (t + 1), &S.abort)) return; }
+        else lds_wait_until(&S.waves_done, RW * (t + 1));                    // ---- hand-off 2 ----
         if (A.trace) waited += wall_clock64() - w0;
         if (act) {                                                          // DAM:231-295, 299-300
             float a35 = 0.0f, a25 = 0.0f;
@@ -604,10 +681,17 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
             float road_t = 0.0f, road_r = 0.0f;
             road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
             road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
-            out5[n + ge] = a35 + road_t;       // DAM:299
-            out5[2 * n + ge] = a25 + road_r;   // DAM:300
-            out5[3 * n + ge] = a25;
-            out5[4 * n + ge] = road_r;
+            put(out5 + n + ge, a35 + road_t);       // DAM:299
+            put(out5 + 2 * n + ge, a25 + road_r);   // DAM:300
+            put(out5 + 3 * n + ge, a25);
+            put(out5 + 4 * n + ge, road_r);
+        }
+        if (gated) {
+            // ---- step t is out: this wave's stores have left (vmcnt), the record waves' too (pub_done) -> one count on
+            // gate_done[t]; a consumer that sees it reach the grid size may read out5[t] (and obs_steps[t])
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (A.gate_obs && !lds_wait_or_abort(&S.pub_done, RW * (t + 1), &S.abort)) return;
+            if (lane == 0) agent_add_u32(A.gate_done + t, 1u);
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) st[c] = Stored<ST>::round(nx[c]);
@@ -618,7 +702,7 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
     if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 2] = waited;
 }
 
-template <int TASK, int RW, int RPT, bool FAST, typename ST>
+template <int TASK, int RW, int RPT, bool FAST, bool GATED, typename ST>
 EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, int e0, int nE, int horizon) {
     constexpr int RL = RW * 64;
     const int rtid = threadIdx.x - 64, w = rtid >> 6, lane = rtid & 63;
@@ -653,7 +737,8 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
             qn = 0;
         };
         const long long w0 = A.trace ? wall_clock64() : 0;
-        lds_wait_until(&S.ego_ready, t + 1);                                // ---- hand-off 1 ----
+        if (GATED) { if (!lds_wait_or_abort(&S.ego_ready, t + 1, &S.abort)) return; }
+        else lds_wait_until(&S.ego_ready, t + 1);                            // ---- hand-off 1 ----
         if (A.trace) waited += wall_clock64() - w0;
         // near tests of step t on the records as they stand, then the queue, then hand-off 2 ...
 #pragma unroll
@@ -693,8 +778,14 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
                 float sn_, cs_;
                 const f4u nv = predict_record_pk<ST>(rec[k], tc, sn_, cs_);
                 rec[k] = f4u{Stored<ST>::round(nv.x), Stored<ST>::round(nv.y), Stored<ST>::round(nv.z), Stored<ST>::round(nv.w)};
+                // a gated rollout that publishes its states: the record of obs_steps[t], written through
+                if (GATED && A.gate_obs) Stored<ST>::store4_wt(reinterpret_cast<ST*>(A.gate_obs) + ((size_t)t * H.n_env + e0) * D + off_of(k), rec[k]);
             }
             if (k & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (GATED && A.gate_obs) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this step's records have left for memory
+            if (lane == 0) atomicAdd(&S.pub_done, 1);
         }
     }
 #pragma unroll
@@ -704,18 +795,29 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
     if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 2] = waited;
 }
 
-template <int TASK, int RW, int RPT, bool FAST, typename ST>
+template <int TASK, int RW, int RPT, bool FAST, bool GATED, typename ST>
 EB_DEV void tape_body(const FusedHot<ST>& H, const FusedArgs& A, int horizon) {
     __shared__ TapeSmem<RW, RPT> S;
+    extern __shared__ __attribute__((aligned(16))) float staged[];   // A.stage_entries > 0: [2 * entries] (x, y) pairs, then [entries] headings
     const int e0 = blockIdx.x * H.envs_per_tile;
     const int nE = min(H.envs_per_tile, H.n_env - e0);
-    if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
+    if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; S.pub_done = 0; S.abort = 0; }
+    // The stride-10 path tables (DAM:704-706: <= 3 x 512 points, 12 bytes each) into LDS once per launch: the closest-point
+    // scan of every step then reads LDS instead of L2 — the env wave's per-step chain is the serial part of a small batch.
+    const float* xy10 = A.xy10;
+    const float* phi10 = A.phi10;
+    if (A.stage_entries > 0) {
+        const int n_xy = 2 * A.stage_entries, n_all = 3 * A.stage_entries;
+        for (int i = threadIdx.x; i < n_all; i += (RW + 1) * 64) staged[i] = i < n_xy ? A.xy10[i] : A.phi10[i - n_xy];
+        xy10 = staged;
+        phi10 = staged + n_xy;
+    }
     lds_barrier();
     if (threadIdx.x < 64) {
         __builtin_amdgcn_s_setprio(3);   // the env wave's per-step chain is the serial part of a step: it goes first
-        env_wave_tape<TASK, RW, RPT, ST>(H, A, S, e0, nE, horizon);
+        env_wave_tape<TASK, RW, RPT, GATED, ST>(H, A, S, e0, nE, horizon, xy10, phi10);
     }
-    else record_wave_tape<TASK, RW, RPT, FAST, ST>(H, A, S, e0, nE, horizon);
+    else record_wave_tape<TASK, RW, RPT, FAST, GATED, ST>(H, A, S, e0, nE, horizon);
 }
 
 template <int TASK, int RW, int RPT, bool FAST, typename ST>
@@ -753,17 +855,21 @@ EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
 EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 8, 64)
 EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 8, 64)
 
-#define EB_TAPE_KERNEL(NAME, RW, RPT, WAVES)                                                             \
+#define EB_TAPE_KERNEL(NAME, RW, RPT, GATED, WAVES)                                                      \
     template <int TASK, bool FAST, typename ST>                                                          \
     __global__ __launch_bounds__((RW + 1) * 64, WAVES) void NAME(                                        \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
         unsigned nv_magic, int horizon, const FusedArgs A) {                                             \
         const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1};        \
-        tape_body<TASK, RW, RPT, FAST, ST>(H, A, horizon);                                               \
+        tape_body<TASK, RW, RPT, FAST, GATED, ST>(H, A, horizon);                                        \
     }
-EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, 6)
-EB_TAPE_KERNEL(rollout_tape_4x4, 4, 4, 1)
-EB_TAPE_KERNEL(rollout_tape_1x4, 1, 4, 1)
+EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, false, 6)
+EB_TAPE_KERNEL(rollout_tape_4x4, 4, 4, false, 1)
+EB_TAPE_KERNEL(rollout_tape_1x4, 1, 4, false, 1)
+// the same with step gates (eb_rollout_gated): its whole grid has to be resident, so it may as well take the registers
+EB_TAPE_KERNEL(rollout_gated_4x8, 4, 8, true, 4)
+EB_TAPE_KERNEL(rollout_gated_4x4, 4, 4, true, 1)
+EB_TAPE_KERNEL(rollout_gated_1x4, 1, 4, true, 1)
 
 int fused_tile_records(int variant) {
     switch (variant) {
@@ -793,20 +899,94 @@ int fused_tile_records(int variant) {
                          A.envs_per_tile, A.nv_magic, horizon
 #define EB_TAPE_TASK(KERNEL, FAST_, ST)                                                                         \
     switch (task) {                                                                                             \
-        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, 0, s, EB_TAPE_ARGS(ST), A); break; \
-        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, ST>), g, b, 0, s, EB_TAPE_ARGS(ST), A); break; \
-        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, ST>), g, b, 0, s, EB_TAPE_ARGS(ST), A); break;    \
+        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, dyn, s, EB_TAPE_ARGS(ST), A); break; \
+        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, ST>), g, b, dyn, s, EB_TAPE_ARGS(ST), A); break; \
+        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, ST>), g, b, dyn, s, EB_TAPE_ARGS(ST), A); break;    \
     }
 #define EB_TAPE_FAST(KERNEL, RW, ST)                                                                            \
     if ((RW * 64) % A.n_veh == 0) { EB_TAPE_TASK(KERNEL, true, ST) } else { EB_TAPE_TASK(KERNEL, false, ST) }
 #define EB_TAPE_LAUNCH(KERNEL, RW)                                                                              \
     {                                                                                                           \
         const dim3 g(grid), b((RW + 1) * 64);                                                                   \
+        const size_t dyn = (size_t)A.stage_entries * 12;                                                        \
         if (A.storage_f16) { EB_TAPE_FAST(KERNEL, RW, _Float16) } else { EB_TAPE_FAST(KERNEL, RW, float) }       \
     }
 
+#define EB_TAPE_OCC(KERNEL, RW)                                                                                  \
+    {                                                                                                           \
+        int nb = 0;                                                                                             \
+        const bool fast = (RW * 64) % n_veh == 0;                                                               \
+        hipError_t e;                                                                                           \
+        if (storage_f16) e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, true, _Float16>, (RW + 1) * 64, dyn_bytes) \
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, false, _Float16>, (RW + 1) * 64, dyn_bytes); \
+        else e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, true, float>, (RW + 1) * 64, dyn_bytes)       \
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, false, float>, (RW + 1) * 64, dyn_bytes);     \
+        return e == hipSuccess ? nb : 0;                                                                        \
+    }
+// resident blocks per CU of the tape kernel (the three tasks compile to the same resources; `left` stands for all)
+int tape_blocks_per_cu(int task, int variant, int n_veh, int storage_f16, size_t dyn_bytes) {
+    (void)task;
+    switch (variant) {
+        case 0: EB_TAPE_OCC(rollout_gated_4x8, 4)
+        case 1: EB_TAPE_OCC(rollout_gated_4x4, 4)
+        default: EB_TAPE_OCC(rollout_gated_1x4, 1)
+    }
+}
+
+// eb_gate_feed: the reference producer of a gated rollout — one block that hands the staged action tape over step by
+// step: waits until every block of the rollout has reported step t - 1, copies actions[t] (written through), raises
+// gate_ready[t].  What a policy kernel in the loop does, minus the policy.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gate_feed_kernel(int horizon, unsigned n_blocks, size_t step_words, const u4v* __restrict__ staged,
+                                                        u4v* live, unsigned* gate_ready, const unsigned* gate_done,
+                                                        unsigned* status, int spin) {
+    __shared__ int ok;
+    for (int t = 0; t < horizon; ++t) {
+        if (threadIdx.x == 0) {
+            int good = 1;
+            if (t > 0) {
+                good = 0;
+                for (int spins = 0; spins <= spin; ++spins) {
+                    if (agent_load_u32(gate_done + t - 1) >= n_blocks) { good = 1; break; }
+                    if (agent_load_u32(status)) break;   // the rollout gave up
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            ok = good;
+        }
+        __syncthreads();
+        if (!ok) {
+            if (threadIdx.x == 0) agent_store_u32(status + 1, 1u);
+            return;
+        }
+        for (size_t i = threadIdx.x; i < step_words; i += blockDim.x) {
+            const u4v v = staged[(size_t)t * step_words + i];
+            u4v* q = live + (size_t)t * step_words + i;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) agent_store_u32(gate_ready + t, 1u);
+    }
+}
+
+hipError_t launch_gate_feed(int horizon, int n_blocks, size_t step_bytes, const void* staged, void* live,
+                            unsigned* gate_ready, const unsigned* gate_done, unsigned* status, int spin, hipStream_t s) {
+    hipLaunchKernelGGL(gate_feed_kernel, dim3(1), dim3(256), 0, s, horizon, (unsigned)n_blocks, step_bytes / 16,
+                       reinterpret_cast<const u4v*>(staged), reinterpret_cast<u4v*>(live), gate_ready, gate_done, status, spin);
+    return hipGetLastError();
+}
+
 // A.actions = the tape [horizon, n_env, 2], A.out5 = [horizon, 5, n_env]
 hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, int horizon, int grid, hipStream_t s) {
+    if (A.gate_ready) {
+        switch (variant) {
+            case 0: EB_TAPE_LAUNCH(rollout_gated_4x8, 4) break;
+            case 1: EB_TAPE_LAUNCH(rollout_gated_4x4, 4) break;
+            default: EB_TAPE_LAUNCH(rollout_gated_1x4, 1) break;
+        }
+        return hipGetLastError();
+    }
     switch (variant) {
         case 0: EB_TAPE_LAUNCH(rollout_tape_4x8, 4) break;
         case 1: EB_TAPE_LAUNCH(rollout_tape_4x4, 4) break;

@@ -668,6 +668,53 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
     return EB_OK;
 }
 
+/* gated rollout (include/envbuild.h): on the CPU there is nobody to wait for, so every gate must already be open; the
+ * steps then run as in eb_rollout_tape, obs_steps[t] = the obs after step t, step_done[t] += 1 (one "block"). */
+int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks) {
+    if (!h || n_env < 0 || !n_blocks) return fail(EB_EINVAL, "eb_rollout_gated_blocks: bad argument");
+    *n_blocks = n_env > 0 ? 1 : 0;
+    return EB_OK;
+}
+
+int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
+                     const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
+                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, uint32_t* status,
+                     int32_t spin_limit, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_gated: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps || !step_ready || !step_done ||
+        !status || spin_limit < 1)
+        return fail(EB_EINVAL, "eb_rollout_gated: bad argument");
+    if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
+        return fail(EB_EINVAL, "eb_rollout_gated: obs_in, obs_work and obs_out must be distinct buffers");
+    const size_t row = (size_t)obs_dim(&h->cfg) * n_env;
+    const float* cur = obs_in;
+    for (int t = 0; t < horizon; ++t) {
+        if (!step_ready[t]) { status[0] = 1; return EB_OK; }              /* the launch "gives up" at a shut gate */
+        float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
+        rc = eb_rollout_step(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
+                             out5_steps + (size_t)t * 5 * n_env, NULL, stream);
+        if (rc) return rc;
+        if (obs_steps) memcpy(obs_steps + (size_t)t * row, dst, row * sizeof(float));
+        step_done[t] += 1;
+        cur = dst;
+    }
+    return EB_OK;
+}
+
+int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, const float* staged_tape,
+                 float* live_tape, uint32_t* step_ready, const uint32_t* step_done, uint32_t* status,
+                 int32_t spin_limit, void* stream) {
+    (void)stream; (void)step_done; (void)status;
+    if (!h || n_env < 1 || (n_env & 1) || horizon < 1 || n_blocks < 1 || !staged_tape || !live_tape || !step_ready || !step_done ||
+        !status || spin_limit < 1 || staged_tape == live_tape)
+        return fail(EB_EINVAL, "eb_gate_feed: bad argument (n_env even: a step's actions are copied 16 bytes at a time)");
+    memcpy(live_tape, staged_tape, (size_t)horizon * n_env * 2 * sizeof(float));   /* sequential host: the whole tape at once */
+    for (int t = 0; t < horizon; ++t) step_ready[t] = 1;
+    return EB_OK;
+}
+
 /* fp16 state storage (BASELINE.json configs[4]): rows are widened to fp32 (exact), stepped by the fp32 code above and
  * rounded to binary16, nearest-even, on the way out.  Software conversions: no F16C dependency. */
 static float half_to_float(uint16_t hbits) {

@@ -165,6 +165,24 @@ class HostModel(object):
         self.api.rollout_tape(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work), self._ptr(out), self._ptr(out5), self.stream)
         return self._ret(out), self._ret(out5)
 
+    def gated_blocks(self, n_env):
+        nb = C.c_int32()
+        self.api.rollout_gated_blocks(self.h, int(n_env), C.byref(nb))
+        return nb.value
+
+    def rollout_gated(self, obs, tape, ref_idx=None, path_id=0, publish_obs=True, ready=None, spin_limit=1 << 22):
+        """eb_rollout_gated with every gate already open (`ready` None) or as given -> (obs_out, out5, obs_steps, done, status)"""
+        ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
+        H, n = tp.shape[0], len(ob)
+        work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
+        steps = self._out((H,) + tuple(ob.shape)) if publish_obs else None
+        rd = self._in(np.ones(H, np.int32) if ready is None else np.asarray(ready, np.int32), np.int32)
+        dn, st = self._in(np.zeros(H, np.int32), np.int32), self._in(np.zeros(2, np.int32), np.int32)
+        self.api.rollout_gated(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work),
+                               self._ptr(out), self._ptr(out5), self._ptr(steps), self._ptr(rd), self._ptr(dn), self._ptr(st),
+                               int(spin_limit), self.stream)
+        return (self._ret(out), self._ret(out5), self._ret(steps) if publish_obs else None, self._ret(dn), self._ret(st))
+
     # ---- policy network + shield (eb_mlp_*, eb_policy_run_batch, eb_shield_is_safe) ----
     def make_mlp(self, obs_dim, n_hidden, n_units, out_dim, hidden_act, out_act, layers, obs_scale=None):
         return self.api.mlp_create_from(obs_dim, n_hidden, n_units, out_dim, hidden_act, out_act, layers, obs_scale, 0)
