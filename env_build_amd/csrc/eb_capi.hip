@@ -433,10 +433,6 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     A.training = h->cfg.mode == EB_MODE_TRAINING;
     A.actions_raw = actions_raw;
     A.do_rewards = do_rewards;
-    {
-        static const int ablate = std::getenv("EB_ABLATE") ? std::atoi(std::getenv("EB_ABLATE")) : 0;   // profiling aid
-        A.ablate = ablate;
-    }
     A.trace = h->trace;
     if (gate) {
         A.gate_ready = gate->ready; A.gate_done = gate->done; A.gate_obs = gate->obs_steps; A.gate_status = gate->status;

@@ -37,7 +37,6 @@ struct FusedArgs {
     int path_id, training;
     int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
     int do_rewards;            // 0: compute_next_obses only
-    int ablate;                // profiling aid (EB_ABLATE)
     long long* trace;          // profiling aid (eb_debug_set_trace): [n_waves][8] s_memrealtime marks, or NULL
     // step gates of eb_rollout_gated (tape kernel only; all NULL / 0 otherwise)
     const unsigned* gate_ready;   // [horizon]: step t may start once gate_ready[t] != 0 (written by the action producer)

@@ -235,18 +235,15 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
                      5.0f * punish_steer + 0.05f * punish_a_x;              // DAM:297-298
     }
     float nx[6];
-    if (A.ablate & 4) { for (int c = 0; c < 6; ++c) nx[c] = st[c]; }
-    else {
     f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);                  // DAM:387
     nx[0] = __builtin_fminf(__builtin_fmaxf(nx[0], 0.0f), 35.0f);           // DAM:390
-    }
     // tracking error of the next pose on the env's path (DAM:334-353)
     float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
-    if (p >= 0 && !(A.ablate & 4)) {
+    if (p >= 0) {
         const int roff = p == 0 ? A.red_off[0] : p == 1 ? A.red_off[1] : A.red_off[2];
         EB_MARK(A, trow, 2);                                                // bicycle step done
         float rx = 0.0f, ry = 0.0f, rphi = 0.0f;                            // == path[bi * 10]: bi * 10 < len always
-        const int bi = (A.ablate & 1) ? 0 : closest_cell_index(A, A.xy10, A.phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
+        const int bi = closest_cell_index(A, A.xy10, A.phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
         t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                           // DAM:758
         if (A.trace) { asm volatile("" :: "v"(t0)); EB_MARK(A, trow, 3); }  // closest point found
         t1 = deal_with_phi_diff(nx[5] - rphi);                              // DAM:759
@@ -338,55 +335,65 @@ EB_DEV void queue_pass_sc(const FusedHot<ST>& H, SM& S, const float4* ego, int w
     }
 }
 
-// predict_for_a_mode (DAM:405-427) on one record with the independent fp32 ops issued in pairs
-// (v_pk_mul/add/fma_f32: two IEEE fp32 results per instruction, each rounded exactly like its scalar
-// twin in eb_device.h:predict_record, so the bits are the same):
-//   (v, phi*pi) -> (v/10, phi_rad)      one 3-op exact constant division for both
-//   sin / cos polynomials                both Horner chains in one register pair
-//   (dx, dy), (x + dx, y + dy)           one multiply, one add
-// The heading chain (turn rate, wrap, back to degrees) is sequential and stays scalar.
+// predict_for_a_mode (DAM:405-427) on one record: the operations of eb_device.h:predict_record with the slot's turn
+// constants passed in (so the same bits).  Scalar fp32 throughout: v_pk_*_f32 issues at half the rate of its scalar
+// twins on this chip, so pairing the two polynomial chains saved nothing and cost four register moves per record
+// plus two constant loads (the pair forms take no literals) — 9 full-rate instructions now instead of 4 paired + 5.
 // slot turn constants (predict_for_a_mode, DAM:416-421): 1 / turn radius in double (for the exact division), the
 // sign of the heading rate, and whether the slot turns at all
-struct TurnC { double rc; float sign, enabled; };
+// (the sign rides on the reciprocal: rounding to nearest is symmetric, so fl(v * -rc) == -fl(v * rc) bit for bit)
+struct TurnC { double rc; float enabled; };
 EB_DEV TurnC turn_consts(int t) {
-    return t == TURN_LEFT ? TurnC{1.0 / 26.875, 1.0f, 1.0f} : t == TURN_RIGHT ? TurnC{1.0 / 15.625, -1.0f, 1.0f}
-                                                                             : TurnC{1.0, 0.0f, 0.0f};
+    return t == TURN_LEFT ? TurnC{1.0 / 26.875, 1.0f} : t == TURN_RIGHT ? TurnC{-1.0 / 15.625, 1.0f} : TurnC{1.0, 0.0f};
+}
+// The two polynomial constants of sincos_det that are added to a product of two registers: as literals each costs a
+// v_mov per use (a VOP3 fma takes no literal on gfx950); a record wave keeps them in two VGPRs for its whole loop.
+struct SinCosK { float s2, c2; };
+EB_DEV SinCosK sincos_consts() {
+    SinCosK k{8.3321608736e-3f, -1.388731625493765e-3f};
+    asm volatile("" : "+v"(k.s2), "+v"(k.c2));        // opaque to the compiler: stays in registers instead of being rematerialised
+    return k;
+}
+// sincos_det (eb_device.h) with those two constants from registers — same operations, same bits
+EB_DEV void sincos_det_k(float x, const SinCosK K, float& s_out, float& c_out) {
+    const float kf = __builtin_rintf(x * 0.636619747f);
+    const int k = (int)kf;
+    float r = __builtin_fmaf(-kf, 1.5703125f, x);
+    r = __builtin_fmaf(-kf, 4.83751296997070312e-4f, r);
+    r = __builtin_fmaf(-kf, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(-1.9515295891e-4f, z, K.s2);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(2.443315711809948e-5f, z, K.c2);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    const float a = (k & 1) ? c : s;
+    const float b = (k & 1) ? -s : c;
+    s_out = (k & 2) ? -a : a;
+    c_out = (k & 2) ? -b : b;
 }
 
 // sn_out / cs_out: sin / cos of the record's CURRENT heading, deg2rad(rec.w) — exactly sincos_det(deg2rad(phi)), the
 // pair the collision terms need too (DAM:221-224)
 template <typename ST>
-EB_DEV f4u predict_record_pk(const f4u rec, const TurnC tc, float& sn_out, float& cs_out) {
-    const v2f xy = {rec.x, rec.y};
+EB_DEV f4u predict_record_tc(const f4u rec, const TurnC tc, const SinCosK K, float& sn_out, float& cs_out) {
     const float v = rec.z;
     const float v10 = div_const<C10>(v);                                     // DAM:413
     const float phi_rad = div_const<C180>(rec.w * PI_F);                     // DAM:407
-    // sincos_det(phi_rad), same operations as eb_device.h
-    const float kf = __builtin_rintf(phi_rad * 0.636619747f);
-    const int k = (int)kf;
-    float r = __builtin_fmaf(-kf, 1.5703125f, phi_rad);
-    r = __builtin_fmaf(-kf, 4.83751296997070312e-4f, r);
-    r = __builtin_fmaf(-kf, 7.54978995489188216e-8f, r);
-    const float z = r * r;
-    const v2f zz = {z, z};
-    v2f pl = fma2(v2f{-1.9515295891e-4f, 2.443315711809948e-5f}, zz, v2f{8.3321608736e-3f, -1.388731625493765e-3f});
-    pl = fma2(pl, zz, v2f{-1.6666654611e-1f, 4.166664568298827e-2f});
-    const float t = __builtin_fmaf(-0.5f, z, 1.0f);
-    const v2f sc = fma2(v2f{r, z} * zz, pl, v2f{r, t});                      // (sin r, cos r)
-    const float a = (k & 1) ? sc.y : sc.x;
-    const float b = (k & 1) ? -sc.x : sc.y;
-    const float sn = (k & 2) ? -a : a, cs = (k & 2) ? -b : b;
+    float sn, cs;
+    sincos_det_k(phi_rad, K, sn, cs);
     sn_out = sn; cs_out = cs;
-    const v2f nxy = xy + v2f{v10, v10} * v2f{cs, sn};                        // DAM:413-414, 422
+    const float nx_ = rec.x + v10 * cs, ny_ = rec.y + v10 * sn;              // DAM:413-414, 422
     const bool middle = (rec.x > -HALF_CROSS && rec.x < HALF_CROSS) && (rec.y > -HALF_CROSS && rec.y < HALF_CROSS);   // DAM:409-410
-    const float u = div_by(v, tc.rc) * tc.sign;                              // +-(v / radius), DAM:417, 419
+    const float u = div_by(v, tc.rc);                                        // +-(v / radius), DAM:417, 419
     const float u10 = div_const<C10>(u);
     const float dphi = (middle && tc.enabled != 0.0f) ? u10 : 0.0f;          // DAM:416-421
     float nphi = phi_rad + dphi;                                             // DAM:423
     if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                 // DAM:424
     if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                               // DAM:425
     const float nphi_deg = div_const<CPi>(nphi * 180.0f);                    // DAM:426
-    return f4u{nxy.x, nxy.y, v, nphi_deg};                                   // DAM:422-427
+    return f4u{nx_, ny_, v, nphi_deg};                                       // DAM:422-427
 }
 
 // FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
@@ -429,6 +436,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     EB_MARK_PLACE(A, trow);
     S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
     const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
+    const SinCosK SK = sincos_consts();
 
     // ---- near-ego records -> this wave's queue ----
     // A circle pair can only be closer than 3.5 m when the two vehicle centres are within 3.5 + 2*1.4 = 6.3 m;
@@ -465,7 +473,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         lds_wait_until(&S.ego_ready, 1);                                    // ---- hand-off 1: ego poses are in LDS ----
         EB_MARK(A, trow, 3);                                                // ego seen
     }
-    const bool test_near = H.do_rewards && !(A.ablate & 8);
+    const bool test_near = H.do_rewards;
     int k_late = test_near ? RPT : 0;
     auto main_loop = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -492,12 +500,14 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
             // the prediction first: it yields sin / cos of the record's heading, which a near record takes to the queue
             const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[valid ? item - env * NV : 0]);
             float sn, cs;
-            const f4u nv = predict_record_pk<ST>(rec[k], tc, sn, cs);
+            const f4u nv = predict_record_tc<ST>(rec[k], tc, SK, sn, cs);
             if (k < k_late) {
                 near_test(item, egoxy[k], rec[k], v2f{sn, cs});
                 if (qn > QCAP - 64) k_late = k + 1;
             }
-            if (valid) Stored<ST>::store4(tout + off, (A.ablate & 256) ? rec[k] : nv);
+            // a 32-bit byte offset from the tile's (wave-uniform) base: the store then takes the base from SGPRs and the
+            // offset from one VGPR (an element offset would be widened to a 64-bit address in three VALU instructions)
+            if (valid) Stored<ST>::store4(reinterpret_cast<ST*>(reinterpret_cast<char*>(tout) + (unsigned)off * (unsigned)sizeof(ST)), nv);
             if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
             if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
             if (k & 1) __builtin_amdgcn_sched_barrier(0);   // two records at a time: bounds the live set, leaves some ILP
@@ -517,7 +527,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         }
     }
     EB_MARK(A, trow, 4);                                                    // near tests done
-    if (!(A.ablate & 16)) drain();
+    drain();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // ---- hand-off 2: partial sums are in LDS ----
     if (lane == 0) atomicAdd(&S.waves_done, 1);
     EB_MARK(A, trow, 5);                                                    // end
@@ -726,6 +736,7 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
     }
     S.turn[lane] = (unsigned char)turn_code;
     const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
+    const SinCosK SK = sincos_consts();
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
     long long waited = 0;
     EB_MARK(A, trow, 0);
@@ -776,7 +787,7 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
                 const int env = FAST ? e_first + k_env : env_of_item(H, item);
                 const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[item - env * NV]);
                 float sn_, cs_;
-                const f4u nv = predict_record_pk<ST>(rec[k], tc, sn_, cs_);
+                const f4u nv = predict_record_tc<ST>(rec[k], tc, SK, sn_, cs_);
                 rec[k] = f4u{Stored<ST>::round(nv.x), Stored<ST>::round(nv.y), Stored<ST>::round(nv.z), Stored<ST>::round(nv.w)};
                 // a gated rollout that publishes its states: the record of obs_steps[t], written through
                 if (GATED && A.gate_obs) Stored<ST>::store4_wt(reinterpret_cast<ST*>(A.gate_obs) + ((size_t)t * H.n_env + e0) * D + off_of(k), rec[k]);

@@ -10,6 +10,7 @@ tail -3 $OUT/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
 python bench.py --eager --no-cpu-baseline > $OUT/bench_eager.json 2>> $OUT/bench.err; cat $OUT/bench_eager.json
-rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+# headline line only (--no-side), so that the per-kernel average below is the headline kernel's alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-side > $OUT/prof_bench.json 2> $OUT/prof.err
 cat $OUT/prof_bench.json
 ls $OUT/prof | head; find $OUT/prof -name '*stats*' | head

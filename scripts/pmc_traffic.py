@@ -11,11 +11,14 @@ out = sys.argv[1]
 COPY_BYTES = 65536 * 137 * 4
 
 
-def mean_counter(sub, counter, kernel_substr):
+HEADLINE_GRID = 1024 * 320   # the 65 536 x 32 launch: 1024 tiles of 64 envs, 5 waves each (bench.py also runs larger batches)
+
+
+def mean_counter(sub, counter, kernel_substr, grid=None):
     vals = []
     for f in glob.glob(os.path.join(out, sub, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            if kernel_substr in r['Kernel_Name'] and r['Counter_Name'] == counter:
+            if kernel_substr in r['Kernel_Name'] and r['Counter_Name'] == counter and (grid is None or int(r['Grid_Size']) == grid):
                 vals.append(float(r['Counter_Value']))
     if not vals:
         raise SystemExit('no %s rows for %s in %s' % (counter, kernel_substr, sub))
@@ -24,7 +27,7 @@ def mean_counter(sub, counter, kernel_substr):
 
 res = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    k_kib, n_k = mean_counter('bench_' + c, c, 'rollout_fused')
+    k_kib, n_k = mean_counter('bench_' + c, c, 'rollout_fused_4x8<0, true, float>', HEADLINE_GRID)
     c_kib, n_c = mean_counter('copy_' + c, c, 'copy_one')
     factor = COPY_BYTES / (c_kib * 1024.0)
     res[c] = {'rollout_kib_per_launch': k_kib, 'rollout_launches': n_k, 'copy_kib_per_launch': c_kib,

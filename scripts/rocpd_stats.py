@@ -12,7 +12,7 @@ ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
 rows = cur.execute(
     f"select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
     f"max(s.arch_vgpr_count), max(s.sgpr_count), max(d.group_segment_size), max(d.grid_size_x), max(d.workgroup_size_x) "
-    f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name order by 3 desc").fetchall()
+    f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name, d.grid_size_x order by 3 desc").fetchall()
 total = sum(r[2] for r in rows) or 1
 lines = ['Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage,VGPRs,SGPRs,LDS_bytes,GridSizeX,WorkgroupSizeX']
 for r in rows:

@@ -50,11 +50,15 @@ def gated_open(publish):
     done.zero_()
     api.rollout_gated(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), p(steps) if publish else None, p(ready1), p(done),
                       p(status), 1 << 20, sp)
+R = a.reps + 5
+ready_r = torch.zeros((R, H), dtype=torch.int32, device=dev)      # one set of flags per repetition: nothing to reset in between
+done_r = torch.zeros((R, H), dtype=torch.int32, device=dev)
+fed_i = [0]
 def gated_fed():
-    done.zero_(); ready.zero_()
-    torch.cuda.current_stream().synchronize()
-    api.gate_feed(h, B, H, nb, p(tape), p(live), p(ready), p(done), p(status), 1 << 20, None)
-    api.rollout_gated(h, B, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready), p(done), p(status), 1 << 20, sp)
+    i = fed_i[0] % R
+    fed_i[0] += 1
+    api.gate_feed(h, B, H, nb, p(tape), p(live), p(ready_r[i]), p(done_r[i]), p(status), 1 << 20, None)
+    api.rollout_gated(h, B, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready_r[i]), p(done_r[i]), p(status), 1 << 20, sp)
 
 def timeit(name, fn, sync_each=False):
     for _ in range(5): fn()
@@ -72,6 +76,6 @@ timeit('one launch per step, eager', eager)
 timeit('one launch per step, hipGraph replay', graph)
 timeit('gated, every gate open, obs published every step', lambda: gated_open(True))
 timeit('gated, every gate open, obs not published', lambda: gated_open(False))
-timeit('gated, fed step by step by eb_gate_feed (2nd stream)', gated_fed, sync_each=True)
+timeit('gated, fed step by step by eb_gate_feed (2nd stream)', gated_fed)
 timeit('open-loop tape kernel (no gates, nothing published)', tape_kernel)
 assert status.cpu().tolist() == [0, 0], status
