@@ -459,14 +459,24 @@ static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const
                          actions_raw, do_rewards, s, storage_f16, tape_horizon, gate);
 }
 
-// blocks of a gated rollout over n_env envs, or 0 when they cannot all be resident at once
-static int gated_blocks(eb_handle h, int32_t n_env) {
-    const int variant = pick_variant(h, n_env);
-    const int ept = std::max(1, std::min(64, eb::fused_tile_records(variant) / h->cfg.n_veh));
-    const int grid = (n_env + ept - 1) / ept;
-    const size_t dyn = grid <= 2 * h->n_cu ? (size_t)(h->red_total + 4) * 12 : 0;   // rollout_fused stages the path tables for small grids
-    const int per_cu = eb::tape_blocks_per_cu(h->cfg.task, variant, h->cfg.n_veh, 0, dyn);
-    return grid <= per_cu * h->n_cu ? grid : 0;
+// blocks of a gated rollout over n_env envs, or 0 when they cannot all be resident at once next to a producer: a gated
+// rollout may take HALF of the device's block slots — whatever opens its gates has to run beside it, and a grid that
+// fills every CU leaves the producer's workgroups nowhere to go (both sides would then wait until they give up)
+static int gated_blocks(eb_handle h, int32_t n_env, int* variant_out = nullptr) {
+    // the tile shape the per-step kernel would take for this batch, or the next larger one whose grid fits (a forced shape stays)
+    const int first = pick_variant(h, n_env);
+    for (int variant = first; variant >= 0; --variant) {
+        const int ept = std::max(1, std::min(64, eb::fused_tile_records(variant) / h->cfg.n_veh));
+        const int grid = (n_env + ept - 1) / ept;
+        const size_t dyn = grid <= 2 * h->n_cu ? (size_t)(h->red_total + 4) * 12 : 0;   // rollout_fused stages the path tables for small grids
+        const int per_cu = eb::tape_blocks_per_cu(h->cfg.task, variant, h->cfg.n_veh, 0, dyn);
+        if (grid <= per_cu * h->n_cu / 2) {
+            if (variant_out) *variant_out = variant;
+            return grid;
+        }
+        if (h->tile_variant >= 0) break;
+    }
+    return 0;
 }
 
 int eb_compute_next_obses(eb_handle h, int32_t n_env, const float* obs, const float* actions,
@@ -560,11 +570,12 @@ int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* o
     if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
         return fail(EB_EINVAL, "eb_rollout_gated: obs_in, obs_work and obs_out must be distinct buffers");
     EB_HIP(hipSetDevice(h->cfg.device));
-    if (gated_blocks(h, n_env) == 0)
-        return fail(EB_EINVAL, "eb_rollout_gated: n_env needs more blocks than the device holds at once (a gated rollout must be fully resident)");
+    int variant = 0;
+    if (gated_blocks(h, n_env, &variant) == 0)
+        return fail(EB_EINVAL, "eb_rollout_gated: n_env needs more than half of the device's block slots (a gated rollout must be fully resident, next to its producer)");
     const GateArgs g{step_ready, step_done, obs_steps, status, spin_limit};
-    return rollout_common(h, n_env, obs_in, action_tape, ref_idx, path_id, obs_out, out5_steps, nullptr, 1, 1, pick(h, stream), 0,
-                          horizon, &g);
+    return rollout_fused(h, variant, n_env, obs_in, action_tape, ref_idx, path_id, obs_out, out5_steps, nullptr, 1, 1, pick(h, stream), 0,
+                         horizon, &g);
 }
 
 int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, const float* staged_tape,

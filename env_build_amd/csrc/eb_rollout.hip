@@ -47,7 +47,9 @@ template <> struct Stored<float> {
     static EB_DEV float round(float v) { return v; }                    // what a store + load does to a value
     // write-through forms (sc1: the bytes leave this XCD's L2 at once, so another kernel can read them while this one
     // runs; the issuing wave drains them with s_waitcnt vmcnt(0) before it raises a flag)
-    static EB_DEV void store4_wt(float* p, f4u v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+    // (the s_nop: a store of more than 64 bits reads its data registers a little after it issues, and the compiler's hazard
+    // check — which would keep the next instruction from overwriting them — does not look inside an asm statement)
+    static EB_DEV void store4_wt(float* p, f4u v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
     static EB_DEV void store1_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 };
 typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
@@ -568,8 +570,125 @@ EB_DEV bool lds_wait_or_abort(int* flag, int value, int* abort) {
     return true;
 }
 
+// Gated rollout: the env wave never waits for memory inside the step loop.  Two COURIER waves of the block do that: the
+// in-courier polls gate_ready[t], fetches the tile's actions[t] past the L1 and hands them over in LDS; the out-courier
+// takes a step's outputs from LDS, writes them through to memory, waits for them (and the record waves' rows) to have
+// arrived and raises the block's word of gate_done[t].  Both run a step or two apart from the env wave (double buffers), so
+// with open gates a step costs what it costs the open-loop tape kernel, and with a producer in the loop the memory
+// round trips of the hand-off are the only thing on the critical path.
+struct GateSmem {
+    f2u act[2][64];                       // actions[t] of the tile's envs, by t & 1
+    float out5[2][5][64];                 // the five outputs of step t
+    float head[2][9][64];                 // the next obs head (6 ego + 3 tracking) of step t — only used with obs_steps
+    int bi[2][64];                        //   and the closest-point index its look-ahead columns start from
+    int act_ready;                        // in-courier -> env wave: actions of step (value - 1) are in LDS
+    int out_ready;                        // env wave -> couriers: outputs of step (value - 1) are in LDS
+    int sent;                             // out-courier -> env wave: outputs of step (value - 1) have been shipped
+};
+
+// obs head row: 6 ego + 3 tracking columns, then 3 * n_future look-ahead columns from table index bi * 10 (DAM:717-724,
+// 763-768); WT: written through (another kernel reads the row while this one runs)
+template <typename ST, bool WT>
+EB_DEV void store_head_row(const FusedArgs& A, ST* row, const float (&hv)[9], int bi, int p) {
+    auto s4 = [&](ST* q, f4u v) { if (WT) Stored<ST>::store4_wt(q, v); else Stored<ST>::store4(q, v); };
+    auto s1 = [&](ST* q, float v) { if (WT) Stored<ST>::store1_wt(q, v); else Stored<ST>::store1(q, v); };
+    s4(row, f4u{hv[0], hv[1], hv[2], hv[3]});
+    s4(row + 4, f4u{hv[4], hv[5], hv[6], hv[7]});
+    s1(row + 8, hv[8]);
+    ST* otrk = row + 9;
+    if (p >= 0) {
+        const PathTables& pt = *A.dt;
+        const int len = pt.len[p];
+        int cur = bi * 10;                                                  // DAM:714
+        for (int k = 0; k < A.n_future; ++k) {
+            cur += 80;
+            if (cur >= len - 2) cur = len - 2;
+            const int fi = clamp_index(cur, len);
+            s1(otrk + 3 * k, pt.x[p][fi] - hv[3]);
+            s1(otrk + 3 * k + 1, pt.y[p][fi] - hv[4]);
+            s1(otrk + 3 * k + 2, deal_with_phi_diff(hv[5] - pt.phi[p][fi]));
+        }
+    } else {
+        for (int c = 0; c < 3 * A.n_future; ++c) s1(otrk + c, 0.0f);       // DAM:342, 352
+    }
+}
+
+// the path an env follows: its own ref_idx in training mode (out of range: none, DAM:342, 352), else the handle's
+EB_DEV int env_path(const FusedArgs& A, int ge) {
+    if (!A.training) return A.path_id;
+    const int pr = A.ref_idx[ge];
+    return (pr >= 0 && pr < A.n_paths) ? pr : -1;
+}
+
+template <int RW, int RPT>
+EB_DEV void in_courier(const FusedArgs& A, TapeSmem<RW, RPT>& S, GateSmem& G, int e0, int nE, int n_env, int horizon) {
+    const int lane = threadIdx.x & 63;
+    const int ge = e0 + (lane < nE ? lane : 0);
+    for (int t = 0; t < horizon; ++t) {
+        // act[t & 1] is free once the env wave has taken step t - 2's actions, which it has when that step's outputs are out
+        if (t >= 2 && !lds_wait_or_abort(&G.out_ready, t - 1, &S.abort)) return;
+        // the step gate: the producer of actions[t] raises gate_ready[t] after its stores have left for memory.  One look
+        // right away (a producer that runs ahead has opened it already); if it is shut, the producer is presumably waiting
+        // for step t - 1's results, so polling starts once those are on their way out — a few hundred blocks polling one
+        // word through a whole step would only stand in the way of the stores that open it.
+        unsigned open = agent_load_u32(A.gate_ready + t);
+        if (!open && t >= 1 && !lds_wait_or_abort(&G.out_ready, t, &S.abort)) return;
+        for (int spins = 0; !open && spins <= A.gate_spin; ++spins) {
+            open = agent_load_u32(A.gate_ready + t);
+            if (open || *(volatile lds_int*)&S.abort) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!open) {                                                        // give up: tell the host and the other waves
+            if (lane == 0) agent_store_u32(A.gate_status, 1u);
+            lds_publish(&S.abort, 1);
+            return;
+        }
+        const unsigned long long bits = agent_load_u64(A.actions + 2 * ((size_t)t * n_env + ge));
+        G.act[t & 1][lane] = __builtin_bit_cast(f2u, bits);
+        lds_publish(&G.act_ready, t + 1);
+    }
+}
+
+template <int RW, int RPT, typename ST>
+EB_DEV void out_courier(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, GateSmem& G, int e0, int nE, int horizon) {
+    const int lane = threadIdx.x & 63;
+    const bool act = lane < nE;
+    const int ge = e0 + (act ? lane : 0);
+    const size_t n = (size_t)H.n_env;
+    const int p = env_path(A, ge);
+    for (int t = 0; t < horizon; ++t) {
+        if (!lds_wait_or_abort(&G.out_ready, t + 1, &S.abort)) return;
+        if (act) {
+            float* out5 = A.out5 + (size_t)t * 5 * n + ge;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) Stored<float>::store1_wt(out5 + c * n, G.out5[t & 1][c][lane]);
+            if (A.gate_obs) {
+                float hv[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) hv[c] = G.head[t & 1][c][lane];
+                store_head_row<ST, true>(A, reinterpret_cast<ST*>(A.gate_obs) + ((size_t)t * n + ge) * H.obs_dim, hv, G.bi[t & 1][lane], p);
+            }
+        }
+        // step t is out once these stores have arrived (vmcnt) and the record waves' rows too (pub_done): the block raises
+        // its own 64-byte record gate_done[t][block][0..15] — four lanes write the whole record in one instruction, so the
+        // memory side sees one full write per block; one shared counter would serialise the device's few hundred atomics
+        // in one memory channel (13 ns each, measured: more than the step itself), and neighbouring 4-byte flags would do
+        // the same to their partial writes.  A consumer that finds word 0 of all gridDim.x records of step t set may read
+        // out5[t] (and obs_steps[t]).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (A.gate_obs && !lds_wait_or_abort(&S.pub_done, RW * (t + 1), &S.abort)) return;
+        if (lane < 4) {
+            typedef unsigned u4w __attribute__((ext_vector_type(4)));
+            const u4w ones = {1u, 1u, 1u, 1u};
+            unsigned* rec = A.gate_done + ((size_t)t * gridDim.x + blockIdx.x) * 16 + 4 * lane;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(rec), "v"(ones) : "memory");
+        }
+        lds_publish(&G.sent, t + 1);
+    }
+}
+
 template <int TASK, int RW, int RPT, bool GATED, typename ST>
-EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, int e0, int nE, int horizon,
+EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW, RPT>& S, GateSmem* Gp, int e0, int nE, int horizon,
                           const float* xy10, const float* phi10) {
     const int lane = threadIdx.x;   // wave 0
     const int D = H.obs_dim, NV = H.n_veh;
@@ -580,11 +699,7 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
     const f4u h0 = Stored<ST>::load4(hin), h1 = Stored<ST>::load4(hin + 4);
     float st[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
     float trk[3] = {h1.z, h1.w, Stored<ST>::load1(hin + 8)};
-    int p = A.path_id;
-    if (A.training) {
-        const int pr = A.ref_idx[ge];
-        p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
-    }
+    const int p = env_path(A, ge);
     const int roff = p == 1 ? A.red_off[1] : p == 2 ? A.red_off[2] : A.red_off[0];
     const size_t n = (size_t)H.n_env;
     constexpr bool gated = GATED;
@@ -597,22 +712,10 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         float* out5 = A.out5 + (size_t)t * 5 * n;
         f2u araw_next = araw;
         if (gated) {
-            // ---- the step gate: the producer of actions[t] (a policy kernel on another stream, eb_gate_feed, ...) raises
-            // gate_ready[t] after its stores have left for memory; every lane polls the same word (one request per poll)
-            unsigned open = 0;
-            for (int spins = 0; spins <= A.gate_spin; ++spins) {
-                open = agent_load_u32(A.gate_ready + t);
-                if (open) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (!open) {                                                    // give up: tell the host and the record waves
-                if (lane == 0) agent_store_u32(A.gate_status, 1u);
-                lds_publish(&S.abort, 1);
-                return;
-            }
-            // the actions were written by another agent while this kernel runs: read them past this CU's L1
-            const unsigned long long bits = agent_load_u64(A.actions + 2 * ((size_t)t * n + ge));
-            araw = __builtin_bit_cast(f2u, bits);
+            // actions[t] come from the in-courier; out5 / head of step t go to buffer t & 1, free once step t - 2 is shipped
+            if (!lds_wait_or_abort(&Gp->act_ready, t + 1, &S.abort)) return;
+            araw = Gp->act[t & 1][lane];
+            if (t >= 2 && !lds_wait_or_abort(&Gp->sent, t - 1, &S.abort)) return;
         } else if (t + 1 < horizon) {
             araw_next = *reinterpret_cast<const f2u*>(A.actions + 2 * ((size_t)(t + 1) * n + ge));   // prefetch
         }
@@ -624,16 +727,16 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         lds_publish(&S.ego_ready, t + 1);                                   // ---- hand-off 1 ----
         float steer, a_x;
         action_transform(araw.x, araw.y, steer, a_x);                       // DAM:120
-        // step outputs: plain stores, or written through when another kernel reads them while this one runs (gated)
-        auto put = [&](float* q, float v) { if (gated) Stored<float>::store1_wt(q, v); else *q = v; };
+        // step outputs: plain stores, or handed to the out-courier through LDS (gated)
+        auto put = [&](int c, float v) { if (gated) Gp->out5[t & 1][c][lane] = v; else out5[(size_t)c * n + ge] = v; };
         if (act) {
             const float punish_steer = -sq(steer), punish_a_x = -sq(a_x);   // DAM:198-199
             const float punish_yaw_rate = -sq(st[2]);                       // DAM:202
             const float devi_y = -sq(trk[0]);                               // DAM:205
             const float devi_phi = -sq(deg2rad(trk[1]));                    // DAM:206
             const float devi_v = -sq(trk[2]);                               // DAM:207
-            put(out5 + ge, 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
-                           5.0f * punish_steer + 0.05f * punish_a_x);       // DAM:297-298
+            put(0, 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                   5.0f * punish_steer + 0.05f * punish_a_x);               // DAM:297-298
         }
         float nx[6];
         f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);              // DAM:387
@@ -647,33 +750,15 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
             t1 = deal_with_phi_diff(nx[5] - rphi);                          // DAM:759
             t2 = nx[0] - EXP_V;                                             // DAM:760
         }
-        // the head of the next obs: (+ look-ahead columns, which feed nothing on the way): to the final obs after the
-        // last step, and to obs_steps[t] after every step of a gated rollout that publishes its states
-        auto store_head = [&](ST* row, bool wt) {
-            auto s4 = [&](ST* q, f4u v) { if (wt) Stored<ST>::store4_wt(q, v); else Stored<ST>::store4(q, v); };
-            auto s1 = [&](ST* q, float v) { if (wt) Stored<ST>::store1_wt(q, v); else Stored<ST>::store1(q, v); };
-            s4(row, f4u{nx[0], nx[1], nx[2], nx[3]});
-            s4(row + 4, f4u{nx[4], nx[5], t0, t1});
-            s1(row + 8, t2);
-            ST* otrk = row + 9;
-            if (p >= 0) {                                                   // DAM:717-724, 763-768
-                const PathTables& pt = *A.dt;
-                const int len = pt.len[p];
-                int cur = bi * 10;                                          // DAM:714
-                for (int k = 0; k < A.n_future; ++k) {
-                    cur += 80;
-                    if (cur >= len - 2) cur = len - 2;
-                    const int fi = clamp_index(cur, len);
-                    s1(otrk + 3 * k, pt.x[p][fi] - nx[3]);
-                    s1(otrk + 3 * k + 1, pt.y[p][fi] - nx[4]);
-                    s1(otrk + 3 * k + 2, deal_with_phi_diff(nx[5] - pt.phi[p][fi]));
-                }
-            } else {
-                for (int c = 0; c < 3 * A.n_future; ++c) s1(otrk + c, 0.0f);   // DAM:342, 352
-            }
-        };
-        if (t == horizon - 1 && act) store_head(hout, false);
-        if (GATED && A.gate_obs && act) store_head(reinterpret_cast<ST*>(A.gate_obs) + ((size_t)t * n + ge) * D, true);
+        // the head of the next obs (+ look-ahead columns, which feed nothing on the way): to the final obs after the last
+        // step; a gated rollout that publishes its states hands it to the out-courier after every step
+        const float hv[9] = {nx[0], nx[1], nx[2], nx[3], nx[4], nx[5], t0, t1, t2};
+        if (t == horizon - 1 && act) store_head_row<ST, false>(A, hout, hv, bi, p);
+        if (GATED && A.gate_obs) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Gp->head[t & 1][c][lane] = hv[c];
+            Gp->bi[t & 1][lane] = bi;
+        }
         const long long w0 = A.trace ? wall_clock64() : 0;
         if (GATED) { if (!lds_wait_or_abort(&S.waves_done, RW * (t + 1), &S.abort)) return; }
         else lds_wait_until(&S.waves_done, RW * (t + 1));                    // ---- hand-off 2 ----
@@ -691,18 +776,12 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
             float road_t = 0.0f, road_r = 0.0f;
             road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
             road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
-            put(out5 + n + ge, a35 + road_t);       // DAM:299
-            put(out5 + 2 * n + ge, a25 + road_r);   // DAM:300
-            put(out5 + 3 * n + ge, a25);
-            put(out5 + 4 * n + ge, road_r);
+            put(1, a35 + road_t);                   // DAM:299
+            put(2, a25 + road_r);                   // DAM:300
+            put(3, a25);
+            put(4, road_r);
         }
-        if (gated) {
-            // ---- step t is out: this wave's stores have left (vmcnt), the record waves' too (pub_done) -> one count on
-            // gate_done[t]; a consumer that sees it reach the grid size may read out5[t] (and obs_steps[t])
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (A.gate_obs && !lds_wait_or_abort(&S.pub_done, RW * (t + 1), &S.abort)) return;
-            if (lane == 0) agent_add_u32(A.gate_done + t, 1u);
-        }
+        if (gated) lds_publish(&Gp->out_ready, t + 1);                      // ---- step t is in LDS: over to the out-courier
 #pragma unroll
         for (int c = 0; c < 6; ++c) st[c] = Stored<ST>::round(nx[c]);
         trk[0] = Stored<ST>::round(t0); trk[1] = Stored<ST>::round(t1); trk[2] = Stored<ST>::round(t2);
@@ -812,23 +891,30 @@ EB_DEV void tape_body(const FusedHot<ST>& H, const FusedArgs& A, int horizon) {
     extern __shared__ __attribute__((aligned(16))) float staged[];   // A.stage_entries > 0: [2 * entries] (x, y) pairs, then [entries] headings
     const int e0 = blockIdx.x * H.envs_per_tile;
     const int nE = min(H.envs_per_tile, H.n_env - e0);
-    if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; S.pub_done = 0; S.abort = 0; }
+    __shared__ std::conditional_t<GATED, GateSmem, int> Gs;   // the couriers' hand-off buffers (gated rollout only)
+    GateSmem* Gp = GATED ? reinterpret_cast<GateSmem*>(&Gs) : nullptr;
+    if (threadIdx.x == 0) {
+        S.ego_ready = 0; S.waves_done = 0; S.pub_done = 0; S.abort = 0;
+        if (GATED) { Gp->act_ready = 0; Gp->out_ready = 0; Gp->sent = 0; }
+    }
     // The stride-10 path tables (DAM:704-706: <= 3 x 512 points, 12 bytes each) into LDS once per launch: the closest-point
     // scan of every step then reads LDS instead of L2 — the env wave's per-step chain is the serial part of a small batch.
     const float* xy10 = A.xy10;
     const float* phi10 = A.phi10;
     if (A.stage_entries > 0) {
         const int n_xy = 2 * A.stage_entries, n_all = 3 * A.stage_entries;
-        for (int i = threadIdx.x; i < n_all; i += (RW + 1) * 64) staged[i] = i < n_xy ? A.xy10[i] : A.phi10[i - n_xy];
+        for (int i = threadIdx.x; i < n_all; i += (RW + (GATED ? 3 : 1)) * 64) staged[i] = i < n_xy ? A.xy10[i] : A.phi10[i - n_xy];
         xy10 = staged;
         phi10 = staged + n_xy;
     }
     lds_barrier();
     if (threadIdx.x < 64) {
         __builtin_amdgcn_s_setprio(3);   // the env wave's per-step chain is the serial part of a step: it goes first
-        env_wave_tape<TASK, RW, RPT, GATED, ST>(H, A, S, e0, nE, horizon, xy10, phi10);
+        env_wave_tape<TASK, RW, RPT, GATED, ST>(H, A, S, Gp, e0, nE, horizon, xy10, phi10);
     }
-    else record_wave_tape<TASK, RW, RPT, FAST, GATED, ST>(H, A, S, e0, nE, horizon);
+    else if (threadIdx.x < (RW + 1) * 64) record_wave_tape<TASK, RW, RPT, FAST, GATED, ST>(H, A, S, e0, nE, horizon);
+    else if (GATED && threadIdx.x < (RW + 2) * 64) in_courier<RW, RPT>(A, S, *Gp, e0, nE, H.n_env, horizon);
+    else if (GATED) out_courier<RW, RPT, ST>(H, A, S, *Gp, e0, nE, horizon);
 }
 
 template <int TASK, int RW, int RPT, bool FAST, typename ST>
@@ -868,7 +954,7 @@ EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 8, 64)
 
 #define EB_TAPE_KERNEL(NAME, RW, RPT, GATED, WAVES)                                                      \
     template <int TASK, bool FAST, typename ST>                                                          \
-    __global__ __launch_bounds__((RW + 1) * 64, WAVES) void NAME(                                        \
+    __global__ __launch_bounds__((RW + (GATED ? 3 : 1)) * 64, WAVES) void NAME(                          \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
         unsigned nv_magic, int horizon, const FusedArgs A) {                                             \
         const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1};        \
@@ -916,9 +1002,9 @@ int fused_tile_records(int variant) {
     }
 #define EB_TAPE_FAST(KERNEL, RW, ST)                                                                            \
     if ((RW * 64) % A.n_veh == 0) { EB_TAPE_TASK(KERNEL, true, ST) } else { EB_TAPE_TASK(KERNEL, false, ST) }
-#define EB_TAPE_LAUNCH(KERNEL, RW)                                                                              \
+#define EB_TAPE_LAUNCH(KERNEL, RW, EXTRA_WAVES)                                                                 \
     {                                                                                                           \
-        const dim3 g(grid), b((RW + 1) * 64);                                                                   \
+        const dim3 g(grid), b((RW + 1 + EXTRA_WAVES) * 64);                                                               \
         const size_t dyn = (size_t)A.stage_entries * 12;                                                        \
         if (A.storage_f16) { EB_TAPE_FAST(KERNEL, RW, _Float16) } else { EB_TAPE_FAST(KERNEL, RW, float) }       \
     }
@@ -928,10 +1014,10 @@ int fused_tile_records(int variant) {
         int nb = 0;                                                                                             \
         const bool fast = (RW * 64) % n_veh == 0;                                                               \
         hipError_t e;                                                                                           \
-        if (storage_f16) e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, true, _Float16>, (RW + 1) * 64, dyn_bytes) \
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, false, _Float16>, (RW + 1) * 64, dyn_bytes); \
-        else e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, true, float>, (RW + 1) * 64, dyn_bytes)       \
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, false, float>, (RW + 1) * 64, dyn_bytes);     \
+        if (storage_f16) e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, true, _Float16>, (RW + 3) * 64, dyn_bytes) \
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, false, _Float16>, (RW + 3) * 64, dyn_bytes); \
+        else e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, true, float>, (RW + 3) * 64, dyn_bytes)       \
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<TASK_LEFT, false, float>, (RW + 3) * 64, dyn_bytes);     \
         return e == hipSuccess ? nb : 0;                                                                        \
     }
 // resident blocks per CU of the tape kernel (the three tasks compile to the same resources; `left` stands for all)
@@ -951,29 +1037,38 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void gate_feed_kernel(int horizon, unsigned n_blocks, size_t step_words, const u4v* __restrict__ staged,
                                                         u4v* live, unsigned* gate_ready, const unsigned* gate_done,
                                                         unsigned* status, int spin) {
-    __shared__ int ok;
+    constexpr int PRE = 8;   // 16-byte words per thread fetched from the staged tape BEFORE the wait (the "policy" is instantaneous)
     for (int t = 0; t < horizon; ++t) {
-        if (threadIdx.x == 0) {
-            int good = 1;
-            if (t > 0) {
-                good = 0;
-                for (int spins = 0; spins <= spin; ++spins) {
-                    if (agent_load_u32(gate_done + t - 1) >= n_blocks) { good = 1; break; }
-                    if (agent_load_u32(status)) break;   // the rollout gave up
-                    __builtin_amdgcn_s_sleep(8);
+        const u4v* src = staged + (size_t)t * step_words;
+        u4v* dst = live + (size_t)t * step_words;
+        u4v pre[PRE];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const size_t i = threadIdx.x + (size_t)k * blockDim.x;
+            pre[k] = src[i < step_words ? i : 0];
+        }
+        int good = 1;
+        if (t > 0) {                                     // word 0 of every block's 64-byte record of step t - 1, 256 at a time
+            for (unsigned b = threadIdx.x; b < n_blocks && good; b += blockDim.x) {
+                const unsigned* w = gate_done + ((size_t)(t - 1) * n_blocks + b) * 16;
+                for (int spins = 0; !agent_load_u32(w); ++spins) {
+                    if (spins >= spin || ((spins & 31) == 31 && agent_load_u32(status))) { good = 0; break; }   // or the rollout gave up
+                    __builtin_amdgcn_s_sleep(2);
                 }
             }
-            ok = good;
         }
-        __syncthreads();
-        if (!ok) {
+        if (!__syncthreads_and(good)) {
             if (threadIdx.x == 0) agent_store_u32(status + 1, 1u);
             return;
         }
-        for (size_t i = threadIdx.x; i < step_words; i += blockDim.x) {
-            const u4v v = staged[(size_t)t * step_words + i];
-            u4v* q = live + (size_t)t * step_words + i;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const size_t i = threadIdx.x + (size_t)k * blockDim.x;
+            if (i < step_words) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst + i), "v"(pre[k]) : "memory");
+        }
+        for (size_t i = threadIdx.x + (size_t)PRE * blockDim.x; i < step_words; i += blockDim.x) {   // long steps: the rest
+            const u4v v = src[i];
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst + i), "v"(v) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -992,16 +1087,16 @@ hipError_t launch_gate_feed(int horizon, int n_blocks, size_t step_bytes, const 
 hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, int horizon, int grid, hipStream_t s) {
     if (A.gate_ready) {
         switch (variant) {
-            case 0: EB_TAPE_LAUNCH(rollout_gated_4x8, 4) break;
-            case 1: EB_TAPE_LAUNCH(rollout_gated_4x4, 4) break;
-            default: EB_TAPE_LAUNCH(rollout_gated_1x4, 1) break;
+            case 0: EB_TAPE_LAUNCH(rollout_gated_4x8, 4, 2) break;
+            case 1: EB_TAPE_LAUNCH(rollout_gated_4x4, 4, 2) break;
+            default: EB_TAPE_LAUNCH(rollout_gated_1x4, 1, 2) break;
         }
         return hipGetLastError();
     }
     switch (variant) {
-        case 0: EB_TAPE_LAUNCH(rollout_tape_4x8, 4) break;
-        case 1: EB_TAPE_LAUNCH(rollout_tape_4x4, 4) break;
-        default: EB_TAPE_LAUNCH(rollout_tape_1x4, 1) break;
+        case 0: EB_TAPE_LAUNCH(rollout_tape_4x8, 4, 0) break;
+        case 1: EB_TAPE_LAUNCH(rollout_tape_4x4, 4, 0) break;
+        default: EB_TAPE_LAUNCH(rollout_tape_1x4, 1, 0) break;
     }
     return hipGetLastError();
 }

@@ -171,24 +171,26 @@ int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint1
 /* The same H-step rollout in ONE launch with a GATE in front of every step — the closed-loop form without a host round
  * trip or a kernel boundary per step: step t starts once step_ready[t] != 0, which the producer of actions[t] (a policy
  * kernel on another stream; eb_gate_feed below is the reference producer) sets after its action stores have left for
- * memory; after step t every block adds 1 to step_done[t] once out5_steps[t] — and obs_steps[t], when given — are
- * visible device-wide (written through, drained, then counted).  A consumer that sees step_done[t] reach
- * eb_rollout_gated_blocks() may read them and produce actions[t + 1].
+ * memory; after step t every block b sets its own 64-byte record step_done[(t * n_blocks + b) * 16 + 0..15] = 1 (n_blocks =
+ * eb_rollout_gated_blocks()) once its part of out5_steps[t] — and obs_steps[t], when given — is visible device-wide
+ * (written through, drained, then flagged; one full 64-byte write per block: a shared counter would serialise a few
+ * hundred atomics in one memory channel).  A consumer that finds word 0 of all n_blocks records of step t set may read
+ * them and produce actions[t + 1].
  *   action_tape [horizon, n_env, 2] is read step by step, each step after its gate (device-scope loads);
  *   obs_steps (nullable) [horizon, n_env, D]: the obs after every step; obs_work / obs_out / out5_steps as in
- *   eb_rollout_tape; step_ready, step_done: uint32 [horizon] in device memory, step_done zeroed by the caller;
+ *   eb_rollout_tape; step_ready: uint32 [horizon], step_done: uint32 [horizon, n_blocks, 16], device memory, step_done zeroed by the caller;
  *   status: uint32 [2] zeroed by the caller — [0] becomes 1 when a gate stayed shut for spin_limit polls (the launch
  *   then ends early and the results are void), [1] when eb_gate_feed gave up.
- * The whole grid has to be resident at once (otherwise a block that has not started would hold every gate shut):
- * n_env beyond that capacity is refused with EB_EINVAL.  Results equal `horizon` calls of eb_rollout_step bit for bit. */
+ * The whole grid has to be resident at once (otherwise a block that has not started would hold every gate shut), and
+ * the producer beside it: n_env beyond HALF of the device's block slots is refused with EB_EINVAL.  Results equal `horizon` calls of eb_rollout_step bit for bit. */
 int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                      const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
                      float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, uint32_t* status,
                      int32_t spin_limit, void* stream);
-/* number of blocks eb_rollout_gated launches for n_env envs = the value step_done[t] reaches (0 if n_env is too large) */
+/* number of blocks eb_rollout_gated launches for n_env envs = the 64-byte records per step of step_done (0 if n_env is too large) */
 int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks);
 /* The reference action producer for eb_rollout_gated, to be enqueued on ANOTHER stream before it: for t = 0 .. horizon - 1
- * wait until step_done[t - 1] == n_blocks (t > 0), copy staged_tape[t] -> live_tape[t] ([n_env, 2] floats, n_env even),
+ * wait until all n_blocks records of step_done[t - 1] are set (t > 0), copy staged_tape[t] -> live_tape[t] ([n_env, 2] floats, n_env even),
  * raise step_ready[t].  What a policy kernel in the loop does, minus the policy.  stream = NULL: the handle's own
  * producer stream — a HIGH-PRIORITY stream, i.e. a hardware queue of its own: two streams of equal priority may share
  * one, and a producer queued behind the rollout it feeds (or the other way round) would never meet it. */

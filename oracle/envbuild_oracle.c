@@ -669,7 +669,7 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
 }
 
 /* gated rollout (include/envbuild.h): on the CPU there is nobody to wait for, so every gate must already be open; the
- * steps then run as in eb_rollout_tape, obs_steps[t] = the obs after step t, step_done[t] += 1 (one "block"). */
+ * steps then run as in eb_rollout_tape, obs_steps[t] = the obs after step t, step_done[t][0][0..15] = 1 (one "block": one 64-byte record per step). */
 int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks) {
     if (!h || n_env < 0 || !n_blocks) return fail(EB_EINVAL, "eb_rollout_gated_blocks: bad argument");
     *n_blocks = n_env > 0 ? 1 : 0;
@@ -697,7 +697,7 @@ int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* o
                              out5_steps + (size_t)t * 5 * n_env, NULL, stream);
         if (rc) return rc;
         if (obs_steps) memcpy(obs_steps + (size_t)t * row, dst, row * sizeof(float));
-        step_done[t] += 1;
+        for (int w = 0; w < 16; ++w) step_done[(size_t)t * 16 + w] = 1;
         cur = dst;
     }
     return EB_OK;

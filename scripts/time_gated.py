@@ -28,11 +28,12 @@ work, out = torch.empty_like(obs0), torch.empty_like(obs0)
 out5 = torch.empty((H, 5, B), device=dev)
 steps = torch.empty((H,) + tuple(obs0.shape), device=dev)
 ready1 = torch.ones(H, dtype=torch.int32, device=dev)
-ready, done, status = (torch.zeros(H, dtype=torch.int32, device=dev) for _ in range(2)) + (torch.zeros(2, dtype=torch.int32, device=dev),) if False else (torch.zeros(H, dtype=torch.int32, device=dev), torch.zeros(H, dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev))
+status = torch.zeros(2, dtype=torch.int32, device=dev)
 p = lambda t: C.c_void_p(t.data_ptr())
 api, lib, h = m.api, m.api.lib, m.handle
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 nb = C.c_int32(); api.rollout_gated_blocks(h, B, C.byref(nb)); nb = nb.value
+done = torch.zeros((H, nb, 16), dtype=torch.int32, device=dev)   # the rollout only ever sets these words: no reset between repetitions
 plan = C.c_void_p()
 api.plan_create(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), None, C.byref(plan))
 dst = [out if (H - 1 - t) % 2 == 0 else work for t in range(H)]
@@ -47,12 +48,11 @@ def graph():
 def tape_kernel():
     lib.eb_rollout_tape(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), sp)
 def gated_open(publish):
-    done.zero_()
     api.rollout_gated(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), p(steps) if publish else None, p(ready1), p(done),
                       p(status), 1 << 20, sp)
 R = a.reps + 5
 ready_r = torch.zeros((R, H), dtype=torch.int32, device=dev)      # one set of flags per repetition: nothing to reset in between
-done_r = torch.zeros((R, H), dtype=torch.int32, device=dev)
+done_r = torch.zeros((R, H, nb, 16), dtype=torch.int32, device=dev)
 fed_i = [0]
 def gated_fed():
     i = fed_i[0] % R

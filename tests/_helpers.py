@@ -177,7 +177,7 @@ class HostModel(object):
         work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
         steps = self._out((H,) + tuple(ob.shape)) if publish_obs else None
         rd = self._in(np.ones(H, np.int32) if ready is None else np.asarray(ready, np.int32), np.int32)
-        dn, st = self._in(np.zeros(H, np.int32), np.int32), self._in(np.zeros(2, np.int32), np.int32)
+        dn, st = self._in(np.zeros((H, max(1, self.gated_blocks(n)), 16), np.int32), np.int32), self._in(np.zeros(2, np.int32), np.int32)
         self.api.rollout_gated(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work),
                                self._ptr(out), self._ptr(out5), self._ptr(steps), self._ptr(rd), self._ptr(dn), self._ptr(st),
                                int(spin_limit), self.stream)

@@ -45,17 +45,17 @@ def test_gated_rollout_with_open_gates_equals_stepwise(task, N, B, tile, nf):
     assert nb >= 1
     for publish in (True, False):
         out, o5, steps, done, status = dev.rollout_gated(obs0, inp['actions'], inp['ref_idx'], publish_obs=publish)
-        assert status.tolist() == [0, 0] and done.tolist() == [nb] * H
+        assert status.tolist() == [0, 0] and done.shape == (H, nb, 16) and done.all()
         assert np.array_equal(out, want_obs)
         _check(o5, want_o5)
         if publish:
             assert np.array_equal(steps, want_states)
     # the oracle's twin of the entry point
     out_h, o5_h, steps_h, done_h, st_h = host.rollout_gated(obs0, inp['actions'], inp['ref_idx'])
-    assert np.array_equal(out_h, want_obs) and np.array_equal(steps_h, want_states) and done_h.tolist() == [1] * H
+    assert np.array_equal(out_h, want_obs) and np.array_equal(steps_h, want_states) and done_h.shape == (H, 1, 16) and done_h.all()
 
 
-@pytest.mark.parametrize('B,N', [(4096, 16), (2048, 32), (1024, 8), (8192, 16), (32768, 32)])
+@pytest.mark.parametrize('B,N', [(4096, 16), (2048, 32), (1024, 8), (8192, 16), (16384, 32)])
 def test_gated_rollout_fed_step_by_step_from_another_stream(B, N):
     """The closed loop without the host: a producer kernel on a second stream releases actions[t] only after every block
     has published step t - 1; the rollout's blocks wait at their gates in between."""
@@ -71,8 +71,8 @@ def test_gated_rollout_fed_step_by_step_from_another_stream(B, N):
     live = t.full_like(staged, float('nan'))                 # nothing usable until the feeder has delivered it
     work, out, out5 = t.empty_like(ob), t.empty_like(ob), t.empty((H, 5, B), device=d)
     steps = t.empty((H,) + tuple(ob.shape), device=d)
-    ready, done, status = (t.zeros(H, dtype=t.int32, device=d), t.zeros(H, dtype=t.int32, device=d), t.zeros(2, dtype=t.int32, device=d))
     nb = dev.gated_blocks(B)
+    ready, done, status = (t.zeros(H, dtype=t.int32, device=d), t.zeros((H, nb, 16), dtype=t.int32, device=d), t.zeros(2, dtype=t.int32, device=d))
     t.cuda.synchronize()
     p = lambda x: C.c_void_p(x.data_ptr())
     spin = 1 << 18                                           # ~ a second of polling at most, then both sides give up
@@ -82,7 +82,7 @@ def test_gated_rollout_fed_step_by_step_from_another_stream(B, N):
                           spin, dev.stream)
     t.cuda.synchronize()
     assert status.cpu().tolist() == [0, 0]
-    assert done.cpu().tolist() == [nb] * H and ready.cpu().tolist() == [1] * H
+    assert bool(done.cpu().all()) and ready.cpu().tolist() == [1] * H
     assert np.array_equal(live.cpu().numpy(), inp['actions'])
     assert np.array_equal(out.cpu().numpy(), want_obs) and np.array_equal(steps.cpu().numpy(), want_states)
     _check(out5.cpu().numpy(), want_o5)
@@ -97,7 +97,7 @@ def test_gated_rollout_gives_up_at_a_shut_gate_and_refuses_oversized_batches():
     ready[3] = 0                                             # nobody will ever open gate 3
     out, o5, steps, done, status = dev.rollout_gated(obs0, inp['actions'], inp['ref_idx'], ready=ready, spin_limit=2000)
     nb = dev.gated_blocks(B)
-    assert status[0] == 1 and done[:3].tolist() == [nb] * 3 and done[3:].tolist() == [0] * 3
+    assert status[0] == 1 and done.shape == (H, nb, 16) and done[:3].all() and not done[3:].any()
     _, want_o5, want_states = _stepwise(host, obs0, inp, 3)
     assert np.array_equal(steps[:3], want_states)            # what was published before the gate is good
     _check(o5[:3], want_o5)
@@ -105,7 +105,8 @@ def test_gated_rollout_gives_up_at_a_shut_gate_and_refuses_oversized_batches():
     o1, _, _ = dev.rollout_step(obs0, inp['actions'][0], inp['ref_idx'])
     assert np.array_equal(o1, want_states[0])
     big = DeviceModel(task, n_veh=32)
-    assert big.gated_blocks(32768) == 512                    # 64 envs per 2048-record tile
+    assert big.gated_blocks(16384) == 256                    # 64 envs per 2048-record tile, half of the device's block slots
+    assert big.gated_blocks(32768) == 0                      # the other half is the producer's
     assert big.gated_blocks(1 << 20) == 0                    # more blocks than the device holds at once
     with pytest.raises(ValueError):
         big.api.rollout_gated(big.h, 1 << 20, 2, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 0, C.c_void_p(16), C.c_void_p(24),
