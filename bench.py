@@ -25,7 +25,8 @@ a short untimed trial picks the faster form and `config.workload` names the one 
                 and its re-read, 0.9 GB footprint), (b) one batch of 524 288 envs (290 MB per obs buffer);
   strong        BASELINE configs[3]: 262 144 envs in total, split 262 144 / N per rank (strong scaling; at N = 1 the
                 one-GPU reference point of that curve);
-  extra         configs[1] (4 096 x 16, fp32) and configs[4] (65 536 x 64, fp16 state) on rank 0 at N = 1;
+  extra         configs[1] (4 096 x 16, fp32; + `one_launch_forms`: the same 25 steps as ONE gated launch with open gates /
+                fed by a second stream, and the open-loop tape) and configs[4] (65 536 x 64, fp16 state) on rank 0 at N = 1;
   cpu_baseline  the CPU oracle (oracle/, plain-C port of the reference path, OpenMP over envs) timed on this box's host
                 cores on a bounded sample of the same workload; never part of the GPU path.
 """
@@ -332,6 +333,70 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
     return out
 
 
+def one_launch_forms(torch, model, n_env, n_veh, seed, reps=100):
+    """configs[1] is launch-bound as one kernel per step; the same H = 25 closed-loop-capable rollout in ONE launch:
+    eb_rollout_gated (a device-side gate in front of every step) with every gate open and the states published after
+    every step, the same fed step by step by a producer kernel on a second stream (eb_gate_feed: what a policy kernel
+    in the loop does, minus the policy), and — for reference — the open-loop tape kernel.  Wall clock over `reps`
+    back-to-back rollouts, bracketed by synchronize."""
+    from env_build_amd.synthetic import make_rollout_inputs
+    dev, H = model.device, HORIZON
+    api, lib, h = model.api, model.api.lib, model.handle
+    inp = make_rollout_inputs(TASK, n_env, n_veh, H, seed=seed)
+    ego = torch.from_numpy(inp['ego']).to(dev)
+    ref = torch.from_numpy(inp['ref_idx']).to(dev)
+    trk = model.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(),
+                                                       ego[:, 0].contiguous(), 0, ref_indexes=ref).t
+    obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous()
+    tape = torch.from_numpy(inp['actions']).to(dev)
+    live = torch.empty_like(tape)
+    work, out = torch.empty_like(obs0), torch.empty_like(obs0)
+    out5 = torch.empty((H, 5, n_env), device=dev)
+    steps = torch.empty((H,) + tuple(obs0.shape), device=dev)
+    nb = C.c_int32()
+    api.rollout_gated_blocks(h, n_env, C.byref(nb))
+    nb = nb.value
+    if nb == 0:
+        return None
+    R = reps + 3
+    i32 = dict(dtype=torch.int32, device=dev)
+    open_gates, status = torch.ones(H, **i32), torch.zeros(2, **i32)
+    ready, done = torch.zeros((R, H), **i32), torch.zeros((R, H, nb, 16), **i32)   # one set of flags per repetition
+    p = lambda t: C.c_void_p(t.data_ptr())
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    spin = 1 << 20
+    k = [0]
+
+    def gated_open():
+        api.rollout_gated(h, n_env, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), p(steps), p(open_gates), p(done[0]),
+                          p(status), spin, sp)
+
+    def gated_fed():
+        i = k[0] % R
+        k[0] += 1
+        api.gate_feed(h, n_env, H, nb, p(tape), p(live), p(ready[i]), p(done[i]), p(status), spin, None)
+        api.rollout_gated(h, n_env, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready[i]), p(done[i]),
+                          p(status), spin, sp)
+
+    def tape_kernel():
+        api.rollout_tape(h, n_env, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), sp)
+
+    res = {'horizon': H, 'gated_blocks': nb, 'rollouts_timed': reps}
+    for name, fn in (('gated_open_gates', gated_open), ('gated_fed_by_second_stream', gated_fed), ('open_loop_tape', tape_kernel)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[name] = {'us_per_step': dt * 1e6 / H, 'value': n_env * H / dt, 'unit': 'env-steps/s'}
+    if status.cpu().tolist() != [0, 0]:
+        raise RuntimeError('gated rollout gave up at a gate: status %s' % status.cpu().tolist())
+    return res
+
+
 def shield_bench(args):
     """The model-predictive safety shield with the policy network on the GPU (hier_decision.py:89-97): one JSON line in
     the same format; the roofline object is the policy kernel's (f32 matrix cores), the bound of this loop."""
@@ -507,8 +572,10 @@ def main():
                                              '— 290 MB per obs buffer, footprint %.0f MB; Infinity Cache = 268 MB'
                                              % (a['footprint_MB'], b['footprint_MB']),
                    'lanes8_x_65536': a, 'single_524288': b}
-            extra.append(dict(side_config(torch, dist, model_for(torch, EnvironmentModel, dev, 16), 4096, 16, 11, side_steps, side_warm,
-                                          side_rep), workload='configs[1]: N_env=4096, N_veh=16, horizon=25, fp32'))
+            m16 = model_for(torch, EnvironmentModel, dev, 16)
+            extra.append(dict(side_config(torch, dist, m16, 4096, 16, 11, side_steps, side_warm, side_rep),
+                              workload='configs[1]: N_env=4096, N_veh=16, horizon=25, fp32 (value: one launch per step)',
+                              one_launch_forms=one_launch_forms(torch, m16, 4096, 16, 11)))
             extra.append(dict(side_config(torch, dist, model_for(torch, EnvironmentModel, dev, 64), N_ENV, 64, 12, side_steps, side_warm,
                                           side_rep, f16=True), workload='configs[4]: N_env=65536, N_veh=64, fp16 state / fp32 reward accumulate'))
 
