@@ -36,3 +36,17 @@ def test_driver_invocation_times_events_summary_and_repeats():
     assert s[6] == 8192 and s[7] == 20 and s[0] != 0.0                  # n_env, horizon, sum of rewards
     assert ('eager' in line['config']['workload']) != ('hipGraph' in line['config']['workload'])
     assert abs(line['value'] - 8192 * 20 / (line['ms_per_step'] * 1e-3 * 20)) / line['value'] < 1e-9
+
+
+@pytest.mark.gpu
+def test_one_launch_forms_of_configs1_run_and_report():
+    """the configs[1] side measurement: gated with open gates, gated fed by the second stream, open-loop tape"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    from env_build_amd.dynamics_and_models import EnvironmentModel
+    model = EnvironmentModel(bench.TASK, num_future_data=0, mode='training', n_veh=16, device=torch.device('cuda', 0))
+    r = bench.one_launch_forms(torch, model, 4096, 16, 11, reps=3)
+    assert r['horizon'] == bench.HORIZON and r['gated_blocks'] >= 1
+    for k in ('gated_open_gates', 'gated_fed_by_second_stream', 'open_loop_tape'):
+        assert r[k]['value'] > 0 and r[k]['us_per_step'] > 0 and r[k]['unit'] == 'env-steps/s'
