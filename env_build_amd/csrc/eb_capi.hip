@@ -290,6 +290,7 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     }
     pt.n_paths = n_paths;
     pt.cells = d_cells;
+    pt.rad = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + rad_byte_off);
     pt.gx0 = (float)grid.x0; pt.gy0 = (float)grid.y0;   // integers: exact in fp32
     pt.gnx = grid.nx; pt.gny = grid.ny;
     const eb::PathTables old_pt = h->pt;

@@ -254,6 +254,7 @@ struct PathTables {
     const uint32_t* cells;
     float gx0, gy0;         // lower-left corner of the grid
     int gnx, gny;
+    const float* rad;       // 3 x 32 block radii of the pruned full search (positions outside the grid), closest_reduced_index
 };
 constexpr float CELL_INV = 2.0f;   // 1 / cell size (0.5 m): exact in fp32
 

@@ -394,6 +394,25 @@ def test_env_kernels_random_scenes_bit_exact(task):
 
 
 @pytest.mark.parametrize('task', TASKS)
+def test_get_obs_egos_off_the_map(task):
+    """egos that have left the closest-point cell grid (far outside the junction, +-inf, NaN) take the pruned full search
+    of the observation kernel: same table index as the oracle's full scan, so the same tracking columns bit for bit"""
+    B, M = 300, 9
+    host, dev = _pair(task, n_veh=VEH_NUM[task])
+    ego, cand, cmode, lw, light, act, ref = _random_scene(task, B, M, 77)
+    rng = np.random.default_rng(5)
+    ego[:, 3] = rng.uniform(-900, 900, B).astype(np.float32)
+    ego[:, 4] = rng.uniform(-900, 900, B).astype(np.float32)
+    ego[::7, 3] = rng.uniform(-45, 45, len(ego[::7]))               # a few back on the map, in the same waves
+    ego[::7, 4] = rng.uniform(-45, 45, len(ego[::7]))
+    ego[5, 3], ego[11, 4], ego[17, 3], ego[23, 4] = np.nan, np.nan, np.inf, -np.inf
+    o_h = host.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    o_d = dev.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    assert np.array_equal(o_h, o_d, equal_nan=True)
+    assert np.isfinite(o_h[:, 6]).mean() > 0.9
+
+
+@pytest.mark.parametrize('task', TASKS)
 @pytest.mark.parametrize('M,NV', [(1, None), (4, None), (33, None), (64, None), (48, 32), (64, 64)])
 def test_get_obs_candidate_and_slot_counts(task, M, NV):
     """The observation kernel's LDS-staged form over candidate counts (odd / even row strides, one per env, the
