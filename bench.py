@@ -289,7 +289,7 @@ class Timer(object):
                 self.api.event_elapsed_ms(self.ev[2 * k], self.ev[2 * k + 1], C.byref(ms))
                 ev_ms += ms.value
                 ev_launches += (1 if self.open_loop else h * self.s.lanes)
-        t = torch.tensor(dts, dtype=torch.float64, device=self.s.model.device)
+        t = torch.tensor(dts, dtype=torch.float64, device=self.s.model.device if not self.use_dist or dist.get_backend() == 'nccl' else 'cpu')
         if self.use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return dict(dt=[float(x) for x in t.tolist()], launch_us=ev_ms * 1e3 / max(1, ev_launches), launches_timed=ev_launches)
@@ -520,12 +520,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # Test aids for a 1-GPU box: EB_BENCH_DEVICE pins every rank to one device index and EB_BENCH_BACKEND=gloo replaces
+    # RCCL (which refuses two ranks on one GPU) — the N > 1 control flow (sharding, barriers, max over ranks, strong split)
+    # then runs end to end with the ranks time-sharing the GPU; the numbers of such a run mean nothing.
+    dev_index = int(os.environ.get('EB_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('EB_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     use_dist = world > 1 or os.environ.get('EB_BENCH_FORCE_DIST') == '1'   # the latter: exercise the RCCL calls on one GPU
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- headline: this rank's synthetic shard (seed = rank: independent envs per GPU), resident in HBM ----
     model = EnvironmentModel(TASK, num_future_data=0, mode='training', n_veh=n_veh, device=dev)
@@ -541,7 +549,7 @@ def main():
     else:
         tm.pick_form()
         if use_dist:                       # every rank runs the same form: rank 0's pick
-            flag = torch.tensor([1 if tm.eager else 0], dtype=torch.int32, device=dev)
+            flag = torch.tensor([1 if tm.eager else 0], dtype=torch.int32, device=dev if backend == 'nccl' else 'cpu')
             dist.broadcast(flag, 0)
             tm.eager = bool(flag.item())
     r = tm.measure(args.steps, args.warmup, args.repeats)

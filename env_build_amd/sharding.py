@@ -57,6 +57,11 @@ def gather_summaries_async(summary8, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return PendingGather(None, summary8.reshape(1, SUMMARY_LEN).clone(), None)
     world = dist.get_world_size(group)
+    if summary8.is_cuda and dist.get_backend(group) != 'nccl':
+        # a backend without device collectives (gloo in tests): through host memory, synchronously
+        host = torch.empty((world, SUMMARY_LEN), dtype=summary8.dtype)
+        dist.all_gather_into_tensor(host.view(-1), summary8.detach().reshape(-1).cpu(), group=group)
+        return PendingGather(None, host.to(summary8.device), None)
     out = torch.empty((world, SUMMARY_LEN), dtype=summary8.dtype, device=summary8.device)
     src = summary8.reshape(-1).contiguous()
     work = dist.all_gather_into_tensor(out.view(-1), src, group=group, async_op=True)

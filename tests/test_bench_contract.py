@@ -50,3 +50,23 @@ def test_one_launch_forms_of_configs1_run_and_report():
     assert r['horizon'] == bench.HORIZON and r['gated_blocks'] >= 1
     for k in ('gated_open_gates', 'gated_fed_by_second_stream', 'open_loop_tape'):
         assert r[k]['value'] > 0 and r[k]['us_per_step'] > 0 and r[k]['unit'] == 'env-steps/s'
+
+
+@pytest.mark.gpu
+def test_two_rank_control_flow_over_gloo_on_one_gpu():
+    """RCCL refuses two ranks on one GPU, so on a 1-GPU box the N > 1 path of bench.py runs with EB_BENCH_BACKEND=gloo
+    and both ranks pinned to device 0: sharded seeds, barriers, max over ranks, the summary all-gather and its fold, the
+    strong-scaling split — everything but the RCCL transport.  (The numbers of such a run mean nothing.)"""
+    env = dict(os.environ, EB_BENCH_DEVICE='0', EB_BENCH_BACKEND='gloo')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20',
+                          '--warmup', '5', '--n-env', '8192', '--no-cpu-baseline', '--repeats', '3'],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                              # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and 'x2' in line['config']['parallelism']
+    assert line['summary'][6] == 2 * 8192 and line['summary'][7] == 20  # both shards' envs in the gathered summary
+    assert line['strong']['n_gpus'] == 2 and line['strong']['n_env_per_gpu'] == 262144 // 2 and line['strong']['scaling'] == 'strong'
+    assert line['cpu_baseline'] is None and line['roofline']['hbm_resident'] is None and line['extra'] == []
