@@ -175,7 +175,10 @@ int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint1
  * eb_rollout_gated_blocks()) once its part of out5_steps[t] — and obs_steps[t], when given — is visible device-wide
  * (written through, drained, then flagged; one full 64-byte write per block: a shared counter would serialise a few
  * hundred atomics in one memory channel).  A consumer that finds word 0 of all n_blocks records of step t set may read
- * them and produce actions[t + 1].
+ * them and produce actions[t + 1].  Both sides of the hand-off go past the per-XCD L2: a consumer KERNEL polls the records
+ * and reads out5_steps[t] / obs_steps[t] with device-scope loads (sc1 on gfx950; __hip_atomic_load at agent scope) — a plain
+ * load may be served from a stale line of its own XCD's L2 — and a producer writes actions[t] with device-scope stores (or
+ * writes back its L2) and waits for them (s_waitcnt vmcnt(0)) before it raises step_ready[t].
  *   action_tape [horizon, n_env, 2] is read step by step, each step after its gate (device-scope loads);
  *   obs_steps (nullable) [horizon, n_env, D]: the obs after every step; obs_work / obs_out / out5_steps as in
  *   eb_rollout_tape; step_ready: uint32 [horizon], step_done: uint32 [horizon, n_blocks, 16], device memory, step_done zeroed by the caller;
