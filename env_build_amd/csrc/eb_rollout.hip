@@ -275,10 +275,14 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     }
     EB_MARK(A, trow, 4);                                                    // head stored
     if (!H.do_rewards) return;
+    // the road walls (DAM:231-295) need nothing from the record waves: done while those are still at work
+    float road_t = 0.0f, road_r = 0.0f;
+    road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
+    road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
     lds_wait_until(&S.waves_done, RW);                                      // ---- hand-off 2 ----
     EB_MARK(A, trow, 5);                                                    // record waves done
 
-    // per env: penalty sums in vehicle order + road walls (DAM:231-295, 299-300)
+    // per env: penalty sums in vehicle order (DAM:218-229, 299-300)
     if (act) {
         float a35 = 0.0f, a25 = 0.0f;
         unsigned long long m = S.mask[lane];
@@ -289,9 +293,6 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
             a35 += ps.x;
             a25 += ps.y;
         }
-        float road_t = 0.0f, road_r = 0.0f;
-        road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
-        road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
         const size_t n = (size_t)H.n_env;
         A.out5[n + ge] = a35 + road_t;       // DAM:299
         A.out5[2 * n + ge] = a25 + road_r;   // DAM:300
@@ -759,11 +760,14 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
             for (int c = 0; c < 9; ++c) Gp->head[t & 1][c][lane] = hv[c];
             Gp->bi[t & 1][lane] = bi;
         }
+        float road_t = 0.0f, road_r = 0.0f;                                 // the road walls, DAM:231-295: while the record waves work
+        road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
+        road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
         const long long w0 = A.trace ? wall_clock64() : 0;
         if (GATED) { if (!lds_wait_or_abort(&S.waves_done, RW * (t + 1), &S.abort)) return; }
         else lds_wait_until(&S.waves_done, RW * (t + 1));                    // ---- hand-off 2 ----
         if (A.trace) waited += wall_clock64() - w0;
-        if (act) {                                                          // DAM:231-295, 299-300
+        if (act) {                                                          // DAM:218-229, 299-300
             float a35 = 0.0f, a25 = 0.0f;
             unsigned long long m = S.mask[lane];
             while (m) {
@@ -773,9 +777,6 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
                 a35 += ps.x;
                 a25 += ps.y;
             }
-            float road_t = 0.0f, road_r = 0.0f;
-            road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
-            road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
             put(1, a35 + road_t);                   // DAM:299
             put(2, a25 + road_r);                   // DAM:300
             put(3, a25);
