@@ -319,10 +319,17 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
             const unsigned c = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
             const int lo = (int)(c & 0xffffu), hi = (int)(c >> 16);
             float best = __builtin_inff();
-            for (int r = lo; r <= hi; ++r) {
-                const float2 q = red[r];
-                const float d = sq(ex - q.x) + sq(ey - q.y);
-                if (d < best) { best = d; bi = r; }
+            // four table points per trip (two 16-byte loads in flight instead of one dependent 8-byte load per point; the
+            // table is readable four entries past its end, eb_set_paths); same order, same strict '<': same index
+            for (int r = lo; r <= hi; r += 4) {
+                typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));   // two table entries: 8-byte aligned
+                const f4a8 q01 = *reinterpret_cast<const f4a8*>(red + r), q23 = *reinterpret_cast<const f4a8*>(red + r + 2);
+                const float d0 = sq(ex - q01.x) + sq(ey - q01.y), d1 = sq(ex - q01.z) + sq(ey - q01.w);
+                const float d2 = sq(ex - q23.x) + sq(ey - q23.y), d3 = sq(ex - q23.z) + sq(ey - q23.w);
+                if (d0 < best) { best = d0; bi = r; }
+                if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; }
+                if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; }
+                if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; }
             }
         } else {
             // an ego that has left the map (or NaN): the exact pruned search over block centres and radii — the index of
