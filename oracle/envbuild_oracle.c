@@ -1546,9 +1546,12 @@ int eb_traffic_flow_step(eb_handle h, int32_t n_env, int32_t per_route, float* c
  * (hierarchical_decision/hier_decision.py:89-97, multi_env/multi_ego.py:187-197).
  * TensorFlow's matmul / exp / tanh kernels are third-party code absent from /root/reference (unpinned,
  * README.md:37) and leave the summation order unspecified; the contract stated in include/envbuild.h fixes it:
- * every output is a chain of fused multiply-adds over k = 0, 1, ... starting from the bias.  PARITY UNPINNED
- * against the reference for this block (it holds no test vectors for the network); tests/ check it against
- * torch fp32 within 1e-5 and the HIP kernel against this file bit for bit.
+ * every output is a chain of fused multiply-adds over k = 0, 1, ... starting from the bias.  Pinning: the reference
+ * holds no weights or test vectors for the network; fixture G13 (oracle/gen_golden.py:g13_policy) runs the reference's
+ * own MLPNet / Policy4Toyota / Preprocessor / LoadPolicy.run_batch classes over a NumPy stand-in of the tf.keras slice
+ * they use, on seeded weights, and tests/test_policy_oracle.py holds this file to those outputs (rtol 1e-5, atol 5e-6;
+ * observed excess 2.5e-7); at TensorFlow's own matmul / exp / tanh kernels parity stays UNPINNED, as for the path.
+ * tests/ also check it against torch fp32 within 1e-5 and the HIP kernel against this file bit for bit.
  * ================================================================================================ */
 struct eb_mlp_s {
     eb_mlp_config cfg;

@@ -232,8 +232,52 @@ class _Threading(object):
         pass
 
 
+class _Experimental(object):
+    @staticmethod
+    def set_visible_devices(devices, kind=None):
+        pass
+
+
 class _Config(object):
     threading = _Threading()
+    experimental = _Experimental()
 
 
 config = _Config()
+
+
+# ---- the inference surface of utils/model.py / utils/policy.py / utils/load_policy.py (tensorflow/keras holds the layers) ----
+def tanh(x): return Tensor(np.tanh(_f(x)).astype(np.float32))
+def exp(x): return Tensor(np.exp(_f(x)).astype(np.float32))
+
+
+def split(x, num_or_size_splits, axis=0):
+    return [Tensor(p) for p in np.split(_f(x), num_or_size_splits, axis=axis)]
+
+
+def squeeze(x, axis=None):
+    return Tensor(np.squeeze(_f(x), axis=axis))
+
+
+class Module(object):
+    def __init__(self, *a, **k):
+        pass
+
+
+class _Checkpoint(object):
+    def __init__(self, **objects):
+        self.objects = objects
+
+    def save(self, path):
+        raise RuntimeError('the stand-in has no checkpoint format')
+
+    def restore(self, path):       # LoadPolicy.__init__ restores unconditionally; the fixtures set weights afterwards
+        return self
+
+
+class _Train(object):
+    Checkpoint = _Checkpoint
+
+
+train = _Train()
+from . import keras  # noqa: E402  (tf.keras.* attribute access)

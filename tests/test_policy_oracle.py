@@ -2,6 +2,7 @@
 eb_shield_is_safe) against a plain torch fp32 restatement of utils/model.py:18-43 + utils/policy.py:85-92, and
 its deterministic exp / tanh against NumPy.  Tolerance 1e-5 (relative to the layer scale): the reference's
 TensorFlow matmul leaves the summation order open, the contract of include/envbuild.h fixes one."""
+import glob
 import os
 import sys
 
@@ -13,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from env_build_amd.policy import orthogonal  # noqa: E402
 from env_build_amd.synthetic import assemble_obs, make_rollout_inputs  # noqa: E402
-from tests._helpers import HostModel, oracle_lib  # noqa: E402
+from tests._helpers import GOLDEN, HostModel, close, golden, oracle_lib  # noqa: E402
 
 ACTS = {'linear': lambda x: x, 'relu': torch.relu, 'elu': torch.nn.functional.elu, 'tanh': torch.tanh}
 
@@ -129,3 +130,28 @@ def test_mlp_argument_errors():
         host.policy_run_batch(m, 1, np.zeros((4, 8), np.float32), 1.0)      # odd out_dim has no (mean | log_std) split
     assert host.mlp_forward(m, 3, np.zeros((0, 8), np.float32)).shape == (0, 3)
     api.mlp_destroy(m)
+
+
+# ---- G13: the reference's own MLPNet / Policy4Toyota / Preprocessor / LoadPolicy.run_batch over the tf.keras stand-in ----
+G13 = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, 'g13_policy_*.npz')))
+
+
+def g13_layers(g, model):
+    n = 2 * (int(g['hidden']) + 1)
+    ws = [g['%s_w%d' % (model, i)] for i in range(n)]
+    return [(ws[2 * i], ws[2 * i + 1]) for i in range(n // 2)]        # Keras order: kernel, bias per layer
+
+
+@pytest.mark.parametrize('name', G13)
+def test_g13_policy_network_against_the_reference_classes(name):
+    """actions = action_range * tanh(first act_dim logits of MLPNet(obs * obs_scale)), values = relu head of obj_v:
+    the oracle's MLP (fmaf chain, deterministic exp / tanh) against the reference's classes on NumPy fp32 matmuls"""
+    g = golden(name)
+    api = oracle_lib()
+    host = HostModel(api, 'left')
+    obs, scale, hidden, units, act = g['obs'], g['obs_scale'], int(g['hidden']), int(g['units']), str(g['act'])
+    pol = host.make_mlp(obs.shape[1], hidden, units, 4, act, 'linear', g13_layers(g, 'policy'), scale)
+    val = host.make_mlp(obs.shape[1], hidden, units, 1, act, 'relu', g13_layers(g, 'obj_v'), scale)
+    close(host.policy_run_batch(pol, 2, obs, 1.0), g['actions'], 1e-5, 5e-6, 'G13 policy actions')
+    close(host.mlp_forward(val, 1, obs)[:, 0], g['values'], 1e-5, 5e-6, 'G13 obj_v values')
+    api.mlp_destroy(pol); api.mlp_destroy(val)
