@@ -243,3 +243,37 @@ def test_g13_policy_fixtures_on_gpu_through_the_kernel_and_the_facade(name):
     lp.policy.set_weights([[g['obj_v_w%d' % i] for i in range(n)], [g['policy_w%d' % i] for i in range(n)]])
     close(lp.run_batch(obs).numpy(), g['actions'], 1e-5, 5e-6, 'GPU G13 facade run_batch')
     close(lp.obj_value_batch(obs).numpy(), g['values'], 1e-5, 5e-6, 'GPU G13 facade obj_value_batch')
+
+
+from tests.test_policy_oracle import G14, g14_check  # noqa: E402
+
+
+@pytest.mark.parametrize('name', G14)
+def test_g14_shield_fixtures_on_gpu_through_the_kernels_and_the_facade(name):
+    """eb_shield_is_safe (policy kernel -> rollout kernel -> accumulate, 5 steps) and the drop-in safe_shield of
+    env_build_amd.shield against HierarchicalDecision.is_safe / safe_shield of the reference (fixture G14)"""
+    from types import SimpleNamespace
+    import torch
+    from env_build_amd.dynamics_and_models import EnvironmentModel
+    from env_build_amd.policy import LoadPolicy
+    from env_build_amd.shield import safe_shield
+    g = golden(name)
+    task = name.split('_')[-1]
+    n = len([k for k in g.files if k.startswith('policy_w')])
+    layers = [(g['policy_w%d' % (2 * i)], g['policy_w%d' % (2 * i + 1)]) for i in range(n // 2)]
+    hidden, units, D = n // 2 - 1, layers[0][0].shape[1], g['obs'].shape[1]
+    dev = DeviceModel(task, mode='selecting')
+    mlp = dev.make_mlp(D, hidden, units, 4, 'elu', 'linear', layers, g['obs_scale'])
+    g14_check(dev, g, mlp)
+    dev.api.mlp_destroy(mlp)
+    # the classes a user of the reference would switch to
+    cuda = torch.device('cuda', 0)
+    args = SimpleNamespace(obs_dim=D, act_dim=2, num_hidden_layers=hidden, num_hidden_units=units, hidden_activation='elu',
+                           policy_out_activation='linear', action_range=1.0, deterministic_policy=True,
+                           obs_preprocess_type='scale', obs_scale=[float(x) for x in g['obs_scale']])
+    lp = LoadPolicy(args=args, device=cuda)
+    lp.policy.policy.set_weights([g['policy_w%d' % i] for i in range(n)])
+    model = EnvironmentModel(task, num_future_data=0, mode='selecting', device=cuda)
+    act, started = safe_shield(model, lp, g['obs'], path_index=int(g['path_index']))
+    assert np.array_equal(started.numpy().astype(np.uint8), g['shield_started'])
+    close(act.numpy(), g['safe_action'], 1e-5, 5e-6, 'GPU G14 facade safe_shield actions')

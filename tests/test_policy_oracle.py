@@ -155,3 +155,35 @@ def test_g13_policy_network_against_the_reference_classes(name):
     close(host.policy_run_batch(pol, 2, obs, 1.0), g['actions'], 1e-5, 5e-6, 'G13 policy actions')
     close(host.mlp_forward(val, 1, obs)[:, 0], g['values'], 1e-5, 5e-6, 'G13 obj_v values')
     api.mlp_destroy(pol); api.mlp_destroy(val)
+
+
+# ---- G14: HierarchicalDecision.is_safe / safe_shield (hier_decision.py:89-107) from the reference's own method bodies ----
+G14 = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, 'g14_shield_*.npz')))
+
+
+def g14_check(model, g, mlp):
+    """eb_shield_is_safe over the fixture's start states: the safe flags must equal the reference's, and the action
+    the shield lets through (the policy's, or (0, -1) when it starts) must match"""
+    obs, path = g['obs'], int(g['path_index'])
+    safe, punish, _, _ = model.shield_is_safe(mlp, obs, ref_idx=None, path_id=path, steps=5, penalty=0)
+    assert np.array_equal(safe, g['safe']), 'safe flags differ from the reference at %s' % np.flatnonzero(safe != g['safe'])
+    assert np.array_equal(punish > 0, g['safe'] == 0)
+    act = model.policy_run_batch(mlp, 2, obs, 1.0)
+    want = g['safe_action']
+    assert np.array_equal(g['shield_started'], 1 - g['safe'])
+    ok = g['safe'] == 1
+    close(act[ok], want[ok], 1e-5, 5e-6, 'G14 actions let through')
+    assert (want[~ok] == np.array([0., -1.], np.float32)).all()          # hier_decision.py:100, 105
+
+
+@pytest.mark.parametrize('name', G14)
+def test_g14_shield_against_the_reference_methods(name):
+    g = golden(name)
+    task = name.split('_')[-1]
+    api = oracle_lib()
+    host = HostModel(api, task, mode='selecting')
+    n = len([k for k in g.files if k.startswith('policy_w')])
+    layers = [(g['policy_w%d' % (2 * i)], g['policy_w%d' % (2 * i + 1)]) for i in range(n // 2)]
+    mlp = host.make_mlp(g['obs'].shape[1], n // 2 - 1, layers[0][0].shape[1], 4, 'elu', 'linear', layers, g['obs_scale'])
+    g14_check(host, g, mlp)
+    api.mlp_destroy(mlp)
