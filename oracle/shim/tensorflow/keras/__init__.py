@@ -3,6 +3,7 @@ Sequential, Dense with string activations, two initializers, a do-nothing Adam),
 activation(x @ kernel + bias) with float32 operands (utils/model.py:21-36 asks for dtype=tf.float32); weights are listed
 kernel-then-bias per layer in construction order, as Keras' get_weights() does.  Container-only, see ../__init__.py."""
 import types
+import zlib
 
 import numpy as np
 
@@ -109,7 +110,7 @@ class Model(Layer):
         return [w for l in self._sub for w in l.weights]
 
     def build(self, input_shape):
-        rng = np.random.default_rng(abs(hash(self.name)) % (1 << 32))
+        rng = np.random.default_rng(zlib.crc32(str(self.name).encode()))   # deterministic per model name
         d = int(input_shape[-1])
         for l in self._sub:          # MLPNet chains its sub-layers in construction order (utils/model.py:39-43)
             d = l.build_for(d, rng)
