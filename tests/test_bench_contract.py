@@ -57,9 +57,13 @@ def test_two_rank_control_flow_over_gloo_on_one_gpu():
     """RCCL refuses two ranks on one GPU, so on a 1-GPU box the N > 1 path of bench.py runs with EB_BENCH_BACKEND=gloo
     and both ranks pinned to device 0: sharded seeds, barriers, max over ranks, the summary all-gather and its fold, the
     strong-scaling split — everything but the RCCL transport.  (The numbers of such a run mean nothing.)"""
+    import socket
+    with socket.socket() as sk:                                          # a free rendezvous port
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, EB_BENCH_DEVICE='0', EB_BENCH_BACKEND='gloo')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                          '127.0.0.1', '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20',
                           '--warmup', '5', '--n-env', '8192', '--no-cpu-baseline', '--repeats', '3'],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
