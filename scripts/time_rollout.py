@@ -48,5 +48,5 @@ t2 = time.perf_counter()
 print('wall: enqueue %.2f us/step, enqueue+drain %.2f us/step; torch events %.2f us/step' % ((t1 - t0) * 1e6 / a.iters, (t2 - t0) * 1e6 / a.iters, e0.elapsed_time(e1) * 1e3 / a.iters))
 us = (t2 - t0) * 1e6 / a.iters
 alg = ((68 + 16 * a.n_veh) if a.f16 else (104 + 32 * a.n_veh)) * a.n_env
-print(('f16 ' if a.f16 else '') + 'lanes=%d ' % L + 'ablate=%s task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
-      % (os.environ.get('EB_ABLATE', '0'), a.task, a.n_env, a.n_veh, a.mode, us, a.n_env / us / 1e3, alg / us / 1e3, alg / us / 1e3 / 80))
+print(('f16 ' if a.f16 else '') + 'lanes=%d ' % L + 'task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
+      % (a.task, a.n_env, a.n_veh, a.mode, us, a.n_env / us / 1e3, alg / us / 1e3, alg / us / 1e3 / 80))
