@@ -10,6 +10,10 @@ all-gather (RCCL) of the 8-float episodic-return summary at the end of every hor
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started WITHOUT a launcher and with --gpus N > 1, bench.py starts its own N ranks: it re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>`
+(self_launch_argv); rank 0 still prints the one line.
+
 The K timed steps run as rollouts of min(K, 25) launches (+ a shorter last one when 25 does not divide K), each followed
 by the episodic summary (two small kernels) and its all-gather; the K-step region is bracketed by barrier +
 synchronize, measured `--repeats` times (default 11) and the MEDIAN is `value` (min / max are reported too).  The
@@ -28,7 +32,10 @@ a short untimed trial picks the faster form and `config.workload` names the one 
   extra         configs[1] (4 096 x 16, fp32; + `one_launch_forms`: the same 25 steps as ONE gated launch with open gates /
                 fed by a second stream, and the open-loop tape) and configs[4] (65 536 x 64, fp16 state) on rank 0 at N = 1;
   cpu_baseline  the CPU oracle (oracle/, plain-C port of the reference path, OpenMP over envs) timed on this box's host
-                cores on a bounded sample of the same workload; never part of the GPU path.
+                cores on a bounded sample of the same workload, on rank 0 after every timed GPU region (at any N: "next to
+                the reference CPU path ... in the same run"); never part of the GPU path.
+  At N > 1 also: roofline.aggregate (sum over ranks of the per-rank achieved GB/s against N x 8 TB/s, with the per-rank
+                launch durations' min / max) and rccl_ranks / backend = what torch.distributed reports for the job.
 """
 import argparse
 import ctypes as C
@@ -64,6 +71,26 @@ def median(xs):
     s = sorted(xs)
     n = len(s)
     return s[n // 2] if n & 1 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+
+
+def self_launch_argv(argv, n_gpus, port=None):
+    """The command bench.py re-executes itself with when it is started without a launcher and --gpus N > 1: one rank
+    per GPU under torch.distributed.run on a free local port (the bench contract's own form)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(n_gpus)),
+            '--master-addr', '127.0.0.1', '--master-port', str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def gather_floats(torch, dist, values, device):
+    """[world, len(values)] float64: every rank's values (all-gather on the job's backend)"""
+    t = torch.tensor(values, dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.tolist()] for o in out]
 
 
 def cpu_baseline(inp, obs0, n_veh, budget_s=18.0):
@@ -496,6 +523,7 @@ def main():
     ap.add_argument('--eager', action='store_true', help='one host launch per step instead of hipGraph replays')
     ap.add_argument('--graph', action='store_true', help='hipGraph replays (default: whichever of the two an untimed trial finds faster)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget-s', type=float, default=18.0, help='seconds of host time the cpu_baseline leg may use')
     ap.add_argument('--no-side', action='store_true', help='skip hbm_resident / strong / extra (headline line only)')
     ap.add_argument('--open-loop', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
@@ -515,11 +543,18 @@ def main():
     from env_build_amd.dynamics_and_models import EnvironmentModel
     from env_build_amd.sharding import combine_summaries
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        # started without a launcher: become the launcher (one rank per GPU over RCCL; rank 0 prints the line)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = self_launch_argv(sys.argv[1:], args.gpus)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os.execv(cmd[0], cmd)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (the launcher started a different number of ranks)' % (args.gpus, world))
     # Test aids for a 1-GPU box: EB_BENCH_DEVICE pins every rank to one device index and EB_BENCH_BACKEND=gloo replaces
     # RCCL (which refuses two ranks on one GPU) — the N > 1 control flow (sharding, barriers, max over ranks, strong split)
     # then runs end to end with the ranks time-sharing the GPU; the numbers of such a run mean nothing.
@@ -555,6 +590,10 @@ def main():
     r = tm.measure(args.steps, args.warmup, args.repeats)
     dt = median(r['dt'])
     summary = [float(x) for x in combine_summaries(tm.gathered).tolist()]
+    per_rank = gather_floats(torch, dist, [r['launch_us'], float(r['launches_timed'])], dev) if use_dist else \
+        [[r['launch_us'], float(r['launches_timed'])]]
+    job = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')} \
+        if use_dist else {'rccl_ranks': 1, 'backend': 'none (single process)'}
     headline_form = 'eager host launches' if tm.eager else 'hipGraph replays of <= %d launches' % HORIZON
 
     # ---- side measurements (untimed for `value`) ----
@@ -629,12 +668,20 @@ def main():
                          'residency': ('working set %.0f MB < 268 MB Infinity Cache: this fraction is cache-assisted; see hbm_resident'
                                        % (ws / 1e6)) if ws < MALL_BYTES else 'working set exceeds the Infinity Cache',
                          'hbm_resident': hbm},
+            'rccl_ranks': job['rccl_ranks'], 'backend': job['backend'],
             'summary': summary,
             'strong': strong,
             'extra': extra,
         }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
-            line['cpu_baseline'] = cpu_baseline(shard.inp, shard.obs0_f32.cpu().numpy(), n_veh)
+        us = [x[0] for x in per_rank]
+        agg = sum(alg / (u * 1e-6) / 1e9 for u in us)
+        line['roofline']['aggregate'] = {
+            'achieved': agg, 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': agg / (HBM_PEAK_GBS * world),
+            'ranks': world, 'avg_launch_us_min': min(us), 'avg_launch_us_max': max(us), 'avg_launch_us_by_rank': us,
+            'note': 'sum over ranks of alg_bytes_per_launch / that rank\'s own event-timed launch duration; `achieved` / `frac` '
+                    'above are rank 0\'s'}
+        if not args.no_cpu_baseline:   # rank 0, after every timed GPU region (the other ranks wait at the final barrier)
+            line['cpu_baseline'] = cpu_baseline(shard.inp, shard.obs0_f32.cpu().numpy(), n_veh, budget_s=args.cpu_budget_s)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))

@@ -20,6 +20,18 @@ def test_segments_cover_exactly_the_requested_steps():
     assert bench.alg_bytes_per_env_step(32) == 1128 and bench.alg_bytes_per_env_step(64, f16=True) == 1092
 
 
+def test_self_launch_command_is_the_contract_form():
+    """`python bench.py --gpus N` without a launcher re-executes itself as the driver would have started it"""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.self_launch_argv(['--gpus', '4', '--steps', '20', '--warmup', '5'], 4, port=29511)
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert cmd[3:10] == ['--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1', '--master-port', '29511']
+    assert cmd[10] == os.path.join(ROOT, 'bench.py') and cmd[11:] == ['--gpus', '4', '--steps', '20', '--warmup', '5']
+    free = bench.self_launch_argv([], 2)
+    assert 1024 < int(free[9]) < 65536
+
+
 @pytest.mark.gpu
 def test_driver_invocation_times_events_summary_and_repeats():
     """`--steps 20 --warmup 5` (fewer steps than one horizon): the rollout is planned with horizon 20, so the event
@@ -56,21 +68,25 @@ def test_one_launch_forms_of_configs1_run_and_report():
 def test_two_rank_control_flow_over_gloo_on_one_gpu():
     """RCCL refuses two ranks on one GPU, so on a 1-GPU box the N > 1 path of bench.py runs with EB_BENCH_BACKEND=gloo
     and both ranks pinned to device 0: sharded seeds, barriers, max over ranks, the summary all-gather and its fold, the
-    strong-scaling split — everything but the RCCL transport.  (The numbers of such a run mean nothing.)"""
-    import socket
-    with socket.socket() as sk:                                          # a free rendezvous port
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
+    strong-scaling split — everything but the RCCL transport.  (The numbers of such a run mean nothing.)
+    Started as PLAIN `python bench.py --gpus 2`: bench.py launches its own two ranks (round 3)."""
     env = dict(os.environ, EB_BENCH_DEVICE='0', EB_BENCH_BACKEND='gloo')
-    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                          '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20',
-                          '--warmup', '5', '--n-env', '8192', '--no-cpu-baseline', '--repeats', '3'],
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20',
+                          '--warmup', '5', '--n-env', '8192', '--cpu-budget-s', '2', '--repeats', '3'],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1                                              # rank 0 alone prints
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and 'x2' in line['config']['parallelism']
+    assert line['rccl_ranks'] == 2 and line['backend'] == 'gloo'        # what torch.distributed saw
     assert line['summary'][6] == 2 * 8192 and line['summary'][7] == 20  # both shards' envs in the gathered summary
     assert line['strong']['n_gpus'] == 2 and line['strong']['n_env_per_gpu'] == 262144 // 2 and line['strong']['scaling'] == 'strong'
-    assert line['cpu_baseline'] is None and line['roofline']['hbm_resident'] is None and line['extra'] == []
+    assert line['roofline']['hbm_resident'] is None and line['extra'] == []
+    agg = line['roofline']['aggregate']
+    assert agg['ranks'] == 2 and len(agg['avg_launch_us_by_rank']) == 2 and agg['peak'] == 2 * 8000.0
+    assert agg['avg_launch_us_min'] <= line['roofline']['avg_launch_us'] <= agg['avg_launch_us_max']
+    cb = line['cpu_baseline']                                           # the CPU leg runs at N > 1 too, on rank 0
+    assert cb is not None and cb['value'] > 0 and cb['kind'] == 'port' and cb['cores'] >= 1

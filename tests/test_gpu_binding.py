@@ -1,0 +1,64 @@
+"""GPU (-m gpu): the reference-side binding that INTEGRATION.md §2 shows (examples/envbuild_binding.py) is driven for
+real — three closed-loop rollout_out steps and one compute_rewards through the stub, against the CPU oracle."""
+import importlib.util
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from env_build_amd.endtoend_env_utils import VEHICLE_MODE_LIST
+from env_build_amd.ref_path_tables import build_ref_paths
+from env_build_amd.synthetic import assemble_obs, make_rollout_inputs
+from tests._helpers import ROOT, HostModel, oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _binding():
+    spec = importlib.util.spec_from_file_location('envbuild_binding', os.path.join(ROOT, 'examples', 'envbuild_binding.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('task', ['left', 'straight', 'right'])
+def test_binding_rollout_out_three_steps_against_the_oracle(task):
+    import torch
+    from env_build_amd import _capi
+    _capi.hip_api()                                  # builds the library when the box has none yet
+    eb = _binding()
+    paths, _, _ = build_ref_paths(task)
+    ref_path = SimpleNamespace(path_list=paths)      # what the reference's ReferencePath exposes (DAM:592, 633)
+    modes = VEHICLE_MODE_LIST[task]
+    model = eb.HipEnvironmentModel(task, 0, 'training', ref_path, modes)
+    host = HostModel(oracle_lib(), task)
+    B, N = 300, len(modes)
+    inp = make_rollout_inputs(task, B, N, 3, seed=5)
+    trk = host.tracking_error(inp['ego'][:, 3], inp['ego'][:, 4], inp['ego'][:, 5], inp['ego'][:, 0], 0, ref_idx=inp['ref_idx'])
+    obs_h = assemble_obs(inp['ego'], trk, inp['veh'])
+    dev = torch.device('cuda', 0)
+    obs_d = torch.from_numpy(obs_h).to(dev)
+    ref_d = torch.from_numpy(inp['ref_idx']).to(dev)
+    assert model.D == obs_h.shape[1]
+    for t in range(3):
+        act = torch.from_numpy(inp['actions'][t]).to(dev)
+        obs_d, rew, p_train, p_real, v2v, v2r, scaled = model.rollout_out(obs_d, act, ref_d, 0)
+        obs_h, o5, sc = host.rollout_step(obs_h, inp['actions'][t], inp['ref_idx'])
+        torch.cuda.synchronize()
+        assert np.array_equal(obs_d.cpu().numpy(), obs_h)
+        assert np.array_equal(scaled.cpu().numpy(), sc) and np.array_equal(rew.cpu().numpy(), o5[0])
+        got = np.stack([x.cpu().numpy() for x in (p_train, p_real, v2v, v2r)])
+        assert np.allclose(got, o5[1:], rtol=1e-6, atol=0)
+    out5, d16 = model.compute_rewards(obs_d, scaled)
+    o5_h, d16_h = host.compute_rewards(obs_h, sc)
+    torch.cuda.synchronize()
+    assert np.allclose(out5.cpu().numpy(), o5_h, rtol=1e-6, atol=0) and np.allclose(d16.cpu().numpy(), d16_h, rtol=1e-6, atol=0)
+    model.close()
+
+
+def test_binding_reports_errors_as_exceptions():
+    eb = _binding()
+    paths, _, _ = build_ref_paths('left')
+    with pytest.raises(RuntimeError):
+        eb.HipEnvironmentModel('left', 0, 'training', SimpleNamespace(path_list=paths), ['dl'] * 65)     # n_veh > EB_MAX_VEH

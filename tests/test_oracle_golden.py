@@ -19,14 +19,11 @@ import pytest
 from env_build_amd import _capi
 from env_build_amd.endtoend_env_utils import VEH_NUM, VEHICLE_MODE_LIST
 from env_build_amd.ref_path_tables import build_ref_paths
+from tests import _golden_checks as CK
 from tests._helpers import GOLDEN, HostModel, close, golden
 
 TASKS = ('left', 'straight', 'right')
-RTOL = 1e-5
-# absolute slack next to north_star's rtol 1e-5, per check — set from the OBSERVED excess (printed at the end of a run
-# under "parity margins"), not the other way round.  1 step = the transcendental kernels' <= 2 ulp; closed loops compound it.
-ATOL = dict(g2=1e-6, g2_cancel=5e-6, g3=5e-6, g4=5e-6, g5_teacher=5e-6, g5_closed_loop=5e-6, g7_reward=5e-6, g7_state=5e-6,
-            g8=5e-6, g9=5e-6)
+RTOL, ATOL = CK.RTOL, CK.ATOL      # tolerances: tests/_golden_checks.py
 
 
 # ---- G1: path tables ---------------------------------------------------------------------------
@@ -42,62 +39,24 @@ def test_g1_path_tables_bit_identical(task):
         assert hashlib.sha256(full.tobytes()).hexdigest() == str(g['path%d_sha256' % k])
 
 
-# ---- G2: f_xu ----------------------------------------------------------------------------------
+# ---- G2 / G3 / G4: single ops (bodies shared with the GPU suite: tests/_golden_checks.py) ----------
 def test_g2_f_xu(oracle):
-    g = golden('g2_f_xu')
-    host = HostModel(oracle, 'left')
-    for name, tau in zip(('tau0p1', 'tau0p05'), g['taus']):
-        nxt, par = host.f_xu(g['states'], g['actions'], float(tau))
-        # v_x, x, y: no cancellation -> tight; v_y, r: sums of 1e4..1e5-magnitude terms that cancel
-        close(nxt[:, [0, 3, 4, 5]], g['next_' + name][:, [0, 3, 4, 5]], RTOL, ATOL['g2'], 'G2 f_xu next (v_x, x, y, phi)')
-        close(nxt[:, 1:3], g['next_' + name][:, 1:3], RTOL, ATOL['g2_cancel'], 'G2 f_xu next (v_y, r)')
-        close(par, g['params_' + name], RTOL, ATOL['g2'], 'G2 f_xu params')
+    CK.check_g2_f_xu(lambda task, **kw: HostModel(oracle, task, **kw))
 
 
-# ---- G3: compute_rewards -----------------------------------------------------------------------
 @pytest.mark.parametrize('task', TASKS)
 def test_g3_compute_rewards(oracle, task):
-    g = golden('g3_rewards_%s' % task)
-    host = HostModel(oracle, task)
-    out5, d16 = host.compute_rewards(g['obs'], g['actions'])
-    assert [str(k) for k in g['dict_keys']] == list(REWARD_KEYS)
-    close(out5, g['out5'], RTOL, ATOL['g3'], 'G3 compute_rewards out5 (%s)' % task)
-    close(d16, g['dict16'], RTOL, ATOL['g3'], 'G3 compute_rewards dict16 (%s)' % task)
-    # the penalty MASKS (which envs are penalised at all) are bit-exact
-    assert np.array_equal(out5[1:] > 0, g['out5'][1:] > 0)
+    CK.check_g3_compute_rewards(lambda task, **kw: HostModel(oracle, task, **kw), task)
 
 
-REWARD_KEYS = ('punish_steer', 'punish_a_x', 'punish_yaw_rate', 'devi_v', 'devi_y', 'devi_phi',
-               'scaled_punish_steer', 'scaled_punish_a_x', 'scaled_punish_yaw_rate', 'scaled_devi_v',
-               'scaled_devi_y', 'scaled_devi_phi', 'veh2veh4training', 'veh2road4training', 'veh2veh4real',
-               'veh2road4real')  # DAM:302-318
-
-
-# ---- G4: closest point + tracking error --------------------------------------------------------
 def test_g4_reference_own_vector(oracle):
     """The reference's only known-input vector (DAM:803-811, task 'straight', n = 10)."""
-    g = golden('g4_tracking')
-    host = HostModel(oracle, 'straight')
-    for k in range(3):
-        out = host.tracking_error(g['ref_xs'], g['ref_ys'], g['ref_phis'], g['ref_vs'], 10, path_id=k)
-        close(out, g['ref_out_path%d_n10' % k], RTOL, ATOL['g4'], 'G4 reference own vector (DAM:805-808)')
+    CK.check_g4_reference_own_vector(lambda task, **kw: HostModel(oracle, task, **kw))
 
 
 @pytest.mark.parametrize('task', TASKS)
 def test_g4_tracking(oracle, task):
-    g = golden('g4_tracking')
-    host = HostModel(oracle, task)
-    for k in range(3):
-        tag = '%s_p%d' % (task, k)
-        x, y, phi, v = g['x_' + tag], g['y_' + tag], g['phi_' + tag], g['v_' + tag]
-        idx, pts = host.find_closest_point(x, y, path_id=k)
-        assert np.array_equal(idx.astype(np.int64), g['index_' + tag])        # argmin: bit-exact
-        assert np.array_equal(pts, g['points_' + tag])                         # gather: bit-exact
-        for nf in (0, 3):
-            out = host.tracking_error(x, y, phi, v, nf, path_id=k)
-            ref = g['out_%s_n%d' % (tag, nf)]
-            close(out, ref, RTOL, ATOL['g4'], 'G4 tracking_error_vector (%s)' % task)
-            assert np.array_equal(out[:, 2], ref[:, 2])                        # v - 8: exact
+    CK.check_g4_tracking(lambda task, **kw: HostModel(oracle, task, **kw), task)
 
 
 # ---- G5: closed-loop rollouts ------------------------------------------------------------------
@@ -140,12 +99,7 @@ def test_g5_teacher_forced_native(oracle, name):
 
 @pytest.mark.parametrize('task', TASKS)
 def test_g5t_teacher_forced_n32(oracle, task):
-    g = golden('g5t_teacher_%s_N32' % task)
-    host = HostModel(oracle, task, n_veh=32, mode='training', modes=[str(m) for m in g['modes']])
-    for t in range(g['actions'].shape[0]):
-        obs, o5, _ = host.rollout_step(g['obs_all'][t], g['actions'][t], g['ref_idx'])
-        close(obs, g['obs_all'][t + 1], RTOL, ATOL['g5_teacher'], 'G5T teacher-forced: obs (N = 32)')
-        close(o5, g['out5'][t], RTOL, ATOL['g5_teacher'], 'G5T teacher-forced: out5 (N = 32)')
+    CK.check_g5t_teacher_forced_n32(lambda task, **kw: HostModel(oracle, task, **kw), task)
 
 
 def test_g5_covers_every_task_mode_and_size():
@@ -159,11 +113,11 @@ def test_g5_covers_every_task_mode_and_size():
 # ---- G9: ss ------------------------------------------------------------------------------------
 @pytest.mark.parametrize('task', TASKS)
 def test_g9_ss(oracle, task):
-    g = golden('g9_ss_%s' % task)
-    host = HostModel(oracle, task)
-    out = host.ss(g['obs'], g['actions'], g['ref_idx'], 0, float(g['lam']))
-    close(out, g['out'], RTOL, ATOL['g9'], 'G9 ss (%s)' % task)
-    assert np.array_equal(out > 0, g['out'] > 0)
+    CK.check_g9_ss(lambda task, **kw: HostModel(oracle, task, **kw), task)
+
+
+def test_g12_exit_frames_through_the_kernel_entry(oracle):
+    CK.check_g12_exit_frames(lambda task, **kw: HostModel(oracle, task, **kw))
 
 
 # ---- G6: env-side logic (endtoend.py) ----------------------------------------------------------
