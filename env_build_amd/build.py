@@ -19,14 +19,15 @@ HASH_FILE = LIB + '.srchash'
 SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip', 'eb_policy.hip']
 HEADERS = ['eb_device.h', 'eb_kernels.h', os.path.join('..', '..', 'include', 'envbuild.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
-         '-fPIC', '-shared', '-Wno-unused-value', '-Wno-pass-failed',
+         '-fPIC', '-Wno-unused-value', '-Wno-pass-failed',
          '-mllvm', '-amdgpu-kernarg-preload-count=12']   # the rollout kernel's leading arguments arrive in SGPRs
+LINK_FLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC']
 
 
 def source_hash():
     """SHA-256 over the compiler flags and the bytes of every source and header, in a fixed order."""
     h = hashlib.sha256()
-    h.update('\0'.join(FLAGS).encode())
+    h.update('\0'.join(FLAGS + ['|'] + LINK_FLAGS).encode())
     for f in SOURCES + HEADERS:
         h.update(b'\0' + f.encode() + b'\0')
         with open(os.path.join(CSRC, f), 'rb') as fh:
@@ -57,17 +58,46 @@ def check_fresh():
 
 
 def build(force=False, verbose=False):
+    """Compile the translation units in parallel (one hipcc per .hip file: a fresh GPU box builds the library in the time
+    of its slowest file), then link; the library and its source hash are replaced atomically at the end."""
     if not force and not needs_build():
         return LIB
+    import fcntl
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    # one builder at a time: the ranks of a multi-GPU job on a fresh box all arrive here; the first one compiles, the
+    # others wait for the lock and find the library fresh
+    with open(LIB + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose):
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    tmp = LIB + '.tmp%d' % os.getpid()
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ['-o', tmp]
-    if verbose:
-        print(' '.join(cmd))
     digest = source_hash()           # of what the compiler is about to read
-    subprocess.check_call(cmd)
-    os.replace(tmp, LIB)
+    objdir = tempfile.mkdtemp(prefix='eb_build_', dir=os.path.dirname(LIB))
+    try:
+        def compile_one(f):
+            obj = os.path.join(objdir, os.path.splitext(f)[0] + '.o')
+            cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, f), '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        tmp = LIB + '.tmp%d' % os.getpid()
+        cmd = [hipcc] + LINK_FLAGS + objs + ['-o', tmp]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     with open(HASH_FILE, 'w') as fh:
         fh.write(digest + '\n')
     return LIB
