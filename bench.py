@@ -30,7 +30,9 @@ a short untimed trial picks the faster form and `config.workload` names the one 
   strong        BASELINE configs[3]: 262 144 envs in total, split 262 144 / N per rank (strong scaling; at N = 1 the
                 one-GPU reference point of that curve);
   extra         configs[1] (4 096 x 16, fp32; + `one_launch_forms`: the same 25 steps as ONE gated launch with open gates /
-                fed by a second stream, and the open-loop tape) and configs[4] (65 536 x 64, fp16 state) on rank 0 at N = 1;
+                fed by a second stream, and the open-loop tape), configs[4] (65 536 x 64, fp16 state) and `env_step` — the
+                env-side step of endtoend.py (CrossroadEnd2end.step through eb_env_step, one launch) at 65 536 and 4 096 envs
+                x 16 candidates with its own algorithmic bytes and roofline fraction — on rank 0 at N = 1;
   cpu_baseline  the CPU oracle (oracle/, plain-C port of the reference path, OpenMP over envs) timed on this box's host
                 cores on a bounded sample of the same workload, on rank 0 after every timed GPU region (at any N: "next to
                 the reference CPU path ... in the same run"); never part of the GPU path.
@@ -396,14 +398,14 @@ def one_launch_forms(torch, model, n_env, n_veh, seed, reps=100):
 
     def gated_open():
         api.rollout_gated(h, n_env, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), p(steps), p(open_gates), p(done[0]),
-                          p(status), spin, sp)
+                          nb, p(status), spin, sp)
 
     def gated_fed():
         i = k[0] % R
         k[0] += 1
-        api.gate_feed(h, n_env, H, nb, p(tape), p(live), p(ready[i]), p(done[i]), p(status), spin, None)
+        api.gate_feed(h, n_env, H, nb, p(tape), p(live), p(ready[i]), p(done[i]), p(status), spin, sp, 1, None)
         api.rollout_gated(h, n_env, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready[i]), p(done[i]),
-                          p(status), spin, sp)
+                          nb, p(status), spin, sp)
 
     def tape_kernel():
         api.rollout_tape(h, n_env, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), sp)
@@ -422,6 +424,91 @@ def one_launch_forms(torch, model, n_env, n_veh, seed, reps=100):
     if status.cpu().tolist() != [0, 0]:
         raise RuntimeError('gated rollout gave up at a gate: status %s' % status.cpu().tolist())
     return res
+
+
+def env_step_alg_bytes(D, m_cand):
+    """Algorithmic bytes of one CrossroadEnd2end.step per env (env-side step): read obs 4D + ego 24 + raw action 8
+    + ref index 4 + candidates 16M + their modes M; write obs 4D + ego 24 + params 16 + scaled action 8 + candidates 16M +
+    five outputs 20 + done code 1  ->  8D + 32M + M + 105  (961 B at D = 41, M = 16).  The 16-term reward dict (64 B) is
+    optional in the C-ABI and not requested here; path tables, slot modes and the re-entry table are L2-resident."""
+    return 8 * D + 33 * m_cand + 105
+
+
+def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
+    """The env-side step (E2E:132-144 = action scaling, reward, ego step, traffic step, observation,
+    done code, pool re-entry) through the raw C entry eb_env_step: pre-allocated ping-pong observation buffers, no Python
+    allocation in the loop.  `reps` segments of `seg` steps from the same reset state (restored between segments, outside
+    the event pairs, so that the egos stay on the map as they do under a driver that resets finished envs), mild random
+    actions; HIP event pairs around every segment."""
+    from env_build_amd import _capi
+    from env_build_amd.endtoend import CrossroadEnd2end
+    env = CrossroadEnd2end(TASK, n_env=n_env, multi_display=True, traffic='pool', n_cand=n_cand, device=dev)
+    env.seed(0)
+    env.reset()
+    api, lib = env.api, env.api.lib
+    B, M, D = n_env, env.n_cand, env.obs_dim
+    g = torch.Generator(device='cpu').manual_seed(3)
+    tape = torch.stack([torch.rand((seg, B), generator=g) * 0.6 - 0.3, torch.rand((seg, B), generator=g) * 0.8 - 0.2], 2).to(dev).contiguous()
+    keep = {k: getattr(env, k).clone() for k in ('_obs', '_ego', '_params', '_cand')}
+    obs = [torch.empty_like(env._obs) for _ in range(2)]
+    ego, params, cand = env._ego, env._params, env._cand.contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    scaled, out5, code = torch.empty((B, 2), **f32), torch.empty((5, B), **f32), torch.empty((B,), dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rule = _capi.EbRespawn(env._entry5.data_ptr(), 65.0, 60.0, 8.0, 12345, 0)
+    fn = lib.eb_env_step
+    h, ht = env._h, env._traffic.h
+    argsets = []
+    for t in range(seg):
+        src, dst = obs[t & 1], obs[(t + 1) & 1]
+        argsets.append((h, ht, B, p(src), p(tape[t]), p(env._ref_idx), 0, p(ego), p(params), M, p(cand), p(env._cand_mode), None,
+                        p(env._v_light), p(env._virtual), p(scaled), p(out5), None, p(dst), p(code), C.byref(rule), sp))
+    ev = []
+    for _ in range(2 * reps):
+        e = C.c_void_p()
+        api.event_create(h, C.byref(e))
+        ev.append(e)
+
+    def restore():
+        obs[0].copy_(keep['_obs']); ego.copy_(keep['_ego']); params.copy_(keep['_params']); cand.copy_(keep['_cand'])
+
+    def segment(k):
+        for a in argsets:
+            rule.counter = k = k + 1
+            rc = fn(*a)
+            if rc != 0:
+                api.check(rc)
+        return k
+
+    k = 0
+    for _ in range(3):
+        restore(); k = segment(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        restore()
+        lib.eb_event_record(ev[2 * r], sp)
+        k = segment(k)
+        lib.eb_event_record(ev[2 * r + 1], sp)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms, tot = C.c_float(), 0.0
+    for r in range(reps):
+        api.event_elapsed_ms(ev[2 * r], ev[2 * r + 1], C.byref(ms))
+        tot += ms.value
+    for e in ev:
+        api.event_destroy(e)
+    us = tot * 1e3 / (reps * seg)
+    alg = env_step_alg_bytes(D, M) * B
+    achieved, frac = roofline_of(alg, us)
+    done_frac = float((code != 0).float().mean().item())
+    return {'workload': 'env_step: CrossroadEnd2end.step for N_env=%d single-ego envs x %d traffic candidates (task %s, D=%d): eb_env_step '
+                        '= ONE launch (action scaling, reward, ego step, traffic step, observation, done code, pool re-entry)' % (B, M, TASK, D),
+            'n_env_per_gpu': B, 'n_cand': M, 'obs_dim': D, 'dtype': 'f32', 'value': B / (us * 1e-6), 'unit': 'env-steps/s',
+            'avg_launch_us': us, 'launches_timed': reps * seg, 'wall_us_per_step_incl_state_restores': wall * 1e6 / (reps * seg),
+            'alg_bytes_per_env_step': env_step_alg_bytes(D, M), 'alg_bytes_per_launch': alg, 'achieved_GBs': achieved, 'frac': frac,
+            'kernel': 'eb::env_step_kernel<0>', 'done_fraction_after_segment': done_frac}
 
 
 def shield_bench(args):
@@ -528,6 +615,7 @@ def main():
     ap.add_argument('--open-loop', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
                          'state in registers — VALU-bound, not the HBM-bound closed-loop headline')
+    ap.add_argument('--env-step', action='store_true', help='only the env-side step entries of `extra` (profiling aid), as JSON lines')
     ap.add_argument('--shield', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)2): eb_shield_is_safe — 5 x [policy MLP (137 -> 256 -> 256 -> 4, ELU) -> '
                          'rollout step] per start state; a "step" is one shield pass over the batch; N = 1 only')
@@ -537,6 +625,11 @@ def main():
         raise SystemExit('--steps and --repeats must be >= 1')
     if args.shield:
         return shield_bench(args)
+    if args.env_step:
+        import torch
+        for b in (N_ENV, 4096):
+            print(json.dumps(env_step_bench(torch, torch.device('cuda', 0), b)))
+        return
 
     import torch
     import torch.distributed as dist
@@ -625,6 +718,8 @@ def main():
                               one_launch_forms=one_launch_forms(torch, m16, 4096, 16, 11)))
             extra.append(dict(side_config(torch, dist, model_for(torch, EnvironmentModel, dev, 64), N_ENV, 64, 12, side_steps, side_warm,
                                           side_rep, f16=True), workload='configs[4]: N_env=65536, N_veh=64, fp16 state / fp32 reward accumulate'))
+            extra.append(env_step_bench(torch, dev, N_ENV))      # the env-side step (endtoend.py), one launch per step
+            extra.append(env_step_bench(torch, dev, 4096))
 
     if rank == 0:
         value = n_env * world * args.steps / dt

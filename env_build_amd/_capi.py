@@ -8,7 +8,7 @@ with the same class to compare the two libraries call-for-call.)
 import ctypes as C
 import os
 
-EB_ABI_VERSION = 2
+EB_ABI_VERSION = 3
 TASK_ID = {'left': 0, 'straight': 1, 'right': 2}
 MODE_TRAINING, MODE_SELECTING = 0, 1
 # vehicle mode ids (EB_VMODE_*), in the order of the twelve lists of E2E:354
@@ -30,6 +30,11 @@ class EbConfig(C.Structure):
 class EbMlpConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('abi_version', 'obs_dim', 'n_hidden', 'n_units', 'out_dim',
                                          'hidden_act', 'out_act', 'device')]
+
+
+class EbRespawn(C.Structure):     # struct eb_respawn: the pool's re-entry rule as the last stage of eb_env_step
+    _fields_ = [('entry', C.c_void_p), ('limit', C.c_float), ('span', C.c_float), ('v_max', C.c_float),
+                ('seed', C.c_uint64), ('counter', C.c_uint64)]
 
 
 ACT_ID = {'linear': 0, None: 0, 'relu': 1, 'elu': 2, 'tanh': 3}        # EB_ACT_*
@@ -54,9 +59,9 @@ PROTOTYPES = {
     'eb_compute_next_obses': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P]),
     'eb_rollout_step': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
-    'eb_rollout_gated': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'eb_rollout_gated': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'eb_rollout_gated_blocks': (C.c_int, [_P, _I, C.POINTER(_I)]),
-    'eb_gate_feed': (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    'eb_gate_feed': (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'eb_rollout_step_f16': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape_f16': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_episode_summary': (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
@@ -78,7 +83,7 @@ PROTOTYPES = {
     'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'eb_exit_frame': (C.c_int, [_P, _I, _P, _I, _P, _P, _P]),
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
-    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P]),
     'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, _P]),
     'eb_traffic_flow_reset': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I,

@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libenvbuild_hip.so')
 HASH_FILE = LIB + '.srchash'
-SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip', 'eb_policy.hip']
-HEADERS = ['eb_device.h', 'eb_kernels.h', os.path.join('..', '..', 'include', 'envbuild.h')]
+SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip', 'eb_env_step.hip', 'eb_policy.hip']
+HEADERS = ['eb_device.h', 'eb_kernels.h', 'eb_env_device.h', os.path.join('..', '..', 'include', 'envbuild.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
          '-fPIC', '-Wno-unused-value', '-Wno-pass-failed',
          '-mllvm', '-amdgpu-kernarg-preload-count=12']   # the rollout kernel's leading arguments arrive in SGPRs

@@ -55,6 +55,9 @@ struct eb_handle_s {
     long long* trace;         // profiling aid, see eb_debug_set_trace
     eb::ExitConsts xc;        // cos / sin of the exit angles (eb_get_obs with exit ids, eb_exit_frame)
     hipStream_t gate_stream;  // producer stream of gated rollouts (high priority: a hardware queue of its own), made on first use
+    hipEvent_t gate_event;    // orders eb_gate_feed behind the caller's stream (after_stream)
+    float* d_scratch;         // eb_env_step's scaled actions when the caller passes none (separate-launch path only)
+    size_t scratch_floats;
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
     int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
 };
@@ -182,6 +185,8 @@ int eb_destroy(eb_handle h) {
     if (h->d_partials) hipFree(h->d_partials);
     if (h->d_pt) hipFree(h->d_pt);
     if (h->gate_stream) hipStreamDestroy(h->gate_stream);
+    if (h->gate_event) hipEventDestroy(h->gate_event);
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
     delete h;
     return EB_OK;
 }
@@ -408,6 +413,14 @@ static int pick_variant(eb_handle h, int32_t n_env) {
     return variant;
 }
 
+// Small grids (at most two blocks per CU) keep the stride-10 path tables in LDS for the whole launch: their steps are bound
+// by the env wave's chain of dependent table reads, not by throughput.  Larger ones leave the LDS to occupancy.  ONE
+// decision for the launch (rollout_fused) and for the residency query (gated_blocks): EB_STAGE_PATHS=0 / 1 forces it.
+static bool stage_paths_in_lds(eb_handle h, int grid) {
+    static const int stage = std::getenv("EB_STAGE_PATHS") ? std::atoi(std::getenv("EB_STAGE_PATHS")) : -1;   // tuning aid
+    return stage < 0 ? grid <= 2 * h->n_cu : stage != 0;
+}
+
 static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* obs_in, const float* actions,
                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16,
@@ -440,13 +453,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         A.gate_spin = gate->spin;
     }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
-    if (tape_horizon > 0) {
-        // Small grids (at most two blocks per CU) keep the stride-10 path tables in LDS for the whole launch: their steps are
-        // bound by the env wave's chain of dependent table reads, not by throughput.  Larger ones leave the LDS to occupancy.
-        static const int stage = std::getenv("EB_STAGE_PATHS") ? std::atoi(std::getenv("EB_STAGE_PATHS")) : -1;   // tuning aid: 0 / 1 force
-        const bool want = stage < 0 ? grid <= 2 * h->n_cu : stage != 0;
-        if (want) A.stage_entries = h->red_total + 4;
-    }
+    if (tape_horizon > 0 && stage_paths_in_lds(h, grid)) A.stage_entries = h->red_total + 4;
     if (tape_horizon > 0) EB_HIP(eb::launch_rollout_tape_fused(h->cfg.task, variant, A, tape_horizon, grid, s));
     else EB_HIP(eb::launch_rollout_fused(h->cfg.task, variant, A, grid, s));
     return EB_OK;
@@ -469,7 +476,7 @@ static int gated_blocks(eb_handle h, int32_t n_env, int* variant_out = nullptr) 
     for (int variant = first; variant >= 0; --variant) {
         const int ept = std::max(1, std::min(64, eb::fused_tile_records(variant) / h->cfg.n_veh));
         const int grid = (n_env + ept - 1) / ept;
-        const size_t dyn = grid <= 2 * h->n_cu ? (size_t)(h->red_total + 4) * 12 : 0;   // rollout_fused stages the path tables for small grids
+        const size_t dyn = stage_paths_in_lds(h, grid) ? (size_t)(h->red_total + 4) * 12 : 0;   // as rollout_fused will launch it
         const int per_cu = eb::tape_blocks_per_cu(h->cfg.task, variant, h->cfg.n_veh, 0, dyn);
         if (grid <= per_cu * h->n_cu / 2) {
             if (variant_out) *variant_out = variant;
@@ -553,6 +560,10 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
 
 int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks) {
     if (!h || n_env < 0 || !n_blocks) return fail(EB_EINVAL, "eb_rollout_gated_blocks: bad argument");
+    // the answer depends on the staged table size and the slot count: the handle must be configured as for the launch
+    int rc = check_paths(h, "eb_rollout_gated_blocks: null handle");
+    if (!rc) rc = check_modes(h);
+    if (rc) return rc;
     EB_HIP(hipSetDevice(h->cfg.device));
     *n_blocks = n_env == 0 ? 0 : gated_blocks(h, n_env);
     return EB_OK;
@@ -560,8 +571,8 @@ int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks) {
 
 int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                      const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
-                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, uint32_t* status,
-                     int32_t spin_limit, void* stream) {
+                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, int32_t n_blocks,
+                     uint32_t* status, int32_t spin_limit, void* stream) {
     if (h && n_env == 0) return EB_OK;
     int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_gated: null handle");
     if (rc) return rc;
@@ -572,8 +583,14 @@ int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* o
         return fail(EB_EINVAL, "eb_rollout_gated: obs_in, obs_work and obs_out must be distinct buffers");
     EB_HIP(hipSetDevice(h->cfg.device));
     int variant = 0;
-    if (gated_blocks(h, n_env, &variant) == 0)
+    const int grid = gated_blocks(h, n_env, &variant);
+    if (grid == 0)
         return fail(EB_EINVAL, "eb_rollout_gated: n_env needs more than half of the device's block slots (a gated rollout must be fully resident, next to its producer)");
+    // step_done was sized by the caller from an earlier eb_rollout_gated_blocks: the grid about to be launched (tile
+    // shape, staging, occupancy — all re-derived from the handle's present state) has to be THAT grid, or the done
+    // records would be written past the buffer and the consumer would count the wrong number of them
+    if (n_blocks != grid)
+        return fail(EB_EINVAL, "eb_rollout_gated: n_blocks does not match the grid this handle launches now (call eb_rollout_gated_blocks again)");
     const GateArgs g{step_ready, step_done, obs_steps, status, spin_limit};
     return rollout_fused(h, variant, n_env, obs_in, action_tape, ref_idx, path_id, obs_out, out5_steps, nullptr, 1, 1, pick(h, stream), 0,
                          horizon, &g);
@@ -581,7 +598,7 @@ int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* o
 
 int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, const float* staged_tape,
                  float* live_tape, uint32_t* step_ready, const uint32_t* step_done, uint32_t* status,
-                 int32_t spin_limit, void* stream) {
+                 int32_t spin_limit, void* after_stream, int32_t wait_after, void* stream) {
     if (!h || n_env < 1 || (n_env & 1) || horizon < 1 || n_blocks < 1 || !staged_tape || !live_tape || !step_ready || !step_done ||
         !status || spin_limit < 1 || staged_tape == live_tape)
         return fail(EB_EINVAL, "eb_gate_feed: bad argument (n_env even: a step's actions are copied 16 bytes at a time)");
@@ -597,6 +614,13 @@ int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, 
             EB_HIP(hipStreamCreateWithPriority(&h->gate_stream, hipStreamNonBlocking, hi));
         }
         s = h->gate_stream;
+    }
+    if (wait_after && (hipStream_t)after_stream != s) {
+        // the feed reads staged_tape and the zeroed flags: whatever the caller enqueued on `after_stream` to produce them
+        // (asynchronous fills included) must be complete first — an event, not a host wait
+        if (!h->gate_event) EB_HIP(hipEventCreateWithFlags(&h->gate_event, hipEventDisableTiming));
+        EB_HIP(hipEventRecord(h->gate_event, (hipStream_t)after_stream));
+        EB_HIP(hipStreamWaitEvent(s, h->gate_event, 0));
     }
     EB_HIP(eb::launch_gate_feed(horizon, n_blocks, (size_t)n_env * 8, staged_tape, live_tape, step_ready, step_done, status,
                                 spin_limit, s));
@@ -761,12 +785,15 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
-                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream) {
+                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
+                const eb_respawn* respawn, void* stream) {
     // every check first: an error return leaves ego / params / cand untouched
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
-    if (n_env < 0 || !obs || !actions || !ego || !params || !scaled_actions || !out5 || !obs_out || !done_code || obs == obs_out ||
+    if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
         m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)))
         return fail(EB_EINVAL, "eb_env_step: bad argument");
+    if (respawn && (!respawn->entry || !(respawn->limit >= 0.0f) || m_cand < 1 || m_cand > 64))
+        return fail(EB_EINVAL, "eb_env_step: bad respawn rule");
     if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_step: the traffic handle must have n_veh == m_cand");
     if (traffic->cfg.device != h->cfg.device) return fail(EB_EINVAL, "eb_env_step: the two handles live on different devices");
     int rc = check_paths(h, "eb_env_step: null handle");
@@ -776,24 +803,58 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (n_env == 0) return EB_OK;
     hipStream_t s = pick(h, stream);
-    // E2E:133-135 in one launch: action scaling, reward on the current obs, ego step in place (the same device
-    // functions eb_action_transform / eb_compute_rewards / eb_env_ego_step run)
     EB_HIP(hipSetDevice(h->cfg.device));
-    EB_HIP(eb::launch_env_pre(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, obs, actions,
-                              scaled_actions, out5, out_dict16, ego, params, s));
-    if (m_cand > 0) EB_HIP(eb::launch_veh_predict(n_env, m_cand, traffic->modes, cand, cand, s));   /* TRF:220-238's role */
-    if (m_cand > 0 && eb::get_obs_is_staged(obs_dim(h->cfg), m_cand, cand)) {
-        // E2E:140-141 in one launch: the observation kernel keeps the tile's candidates and the new delta_y in LDS and
-        // appends _judge_done (the same device functions eb_judge_done runs)
-        EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
-                                  ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, s, params,
-                                  cand_lw, done_code));
+    const int D = obs_dim(h->cfg);
+    if (eb::env_step_is_fused(D, h->cfg.n_veh, m_cand, cand)) {
+        // the whole step — the six calls and the pool's re-entry — as ONE launch (csrc/eb_env_step.hip)
+        eb::EnvStepArgs A;
+        std::memset(&A, 0, sizeof A);
+        auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+        A.n_env = n_env; A.D = D; A.n_future = h->cfg.n_future; A.NV = h->cfg.n_veh; A.m_cand = m_cand; A.path_id = path_id;
+        A.d_magic = magic(D); A.m_magic = magic(m_cand); A.nv_magic = magic(h->cfg.n_veh);
+        A.pt = h->pt; A.modes = h->modes;
+        std::memcpy(A.tturn.t, traffic->modes.turn, sizeof A.tturn.t);
+        A.obs = obs; A.raw = actions; A.ref_idx = ref_idx; A.ego = ego; A.params = params; A.cand = cand; A.cand_mode = cand_mode;
+        A.cand_lw = cand_lw; A.v_light = v_light; A.virtual_flag = virtual_flag; A.scaled = scaled_actions; A.out5 = out5;
+        A.d16 = out_dict16; A.obs_out = obs_out; A.done_code = done_code;
+        if (respawn) {
+            A.respawn_entry = respawn->entry; A.limit = respawn->limit; A.span = respawn->span; A.v_max = respawn->v_max;
+            A.seed = respawn->seed; A.counter = respawn->counter;
+        }
+        EB_HIP(eb::launch_env_step(h->cfg.task, A, s));
         return EB_OK;
     }
-    EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
-                              ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, s));   /* E2E:140 */
-    EB_HIP(eb::launch_judge_done(h->cfg.task, n_env, obs_dim(h->cfg), ego, params, obs_out, m_cand, cand, cand_mode,
-                                 cand_lw, v_light, done_code, s));                                          /* E2E:141 */
+    // separate launches (no candidates, a tile that does not fit the LDS, an unaligned candidate buffer)
+    float* scaled = scaled_actions;
+    if (!scaled) {
+        if (h->scratch_floats < (size_t)n_env * 2) {
+            if (h->d_scratch) (void)hipFree(h->d_scratch);
+            h->d_scratch = nullptr; h->scratch_floats = 0;
+            EB_HIP(hipMalloc(&h->d_scratch, (size_t)n_env * 2 * sizeof(float)));
+            h->scratch_floats = (size_t)n_env * 2;
+        }
+        scaled = h->d_scratch;
+    }
+    // E2E:133-135 in one launch: action scaling, reward on the current obs, ego step in place (the same device
+    // functions eb_action_transform / eb_compute_rewards / eb_env_ego_step run)
+    EB_HIP(eb::launch_env_pre(h->cfg.task, n_env, D, h->cfg.n_future, h->cfg.n_veh, obs, actions,
+                              scaled, out5, out_dict16, ego, params, s));
+    if (m_cand > 0) EB_HIP(eb::launch_veh_predict(n_env, m_cand, traffic->modes, cand, cand, s));   /* TRF:220-238's role */
+    if (m_cand > 0 && eb::get_obs_is_staged(D, m_cand, cand)) {
+        // E2E:140-141 in one launch: the observation kernel keeps the tile's candidates and the new delta_y in LDS and
+        // appends _judge_done (the same device functions eb_judge_done runs)
+        EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, D, h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
+                                  ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, s, params,
+                                  cand_lw, done_code));
+    } else {
+        EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, D, h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
+                                  ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, s));   /* E2E:140 */
+        EB_HIP(eb::launch_judge_done(h->cfg.task, n_env, D, ego, params, obs_out, m_cand, cand, cand_mode,
+                                     cand_lw, v_light, done_code, s));                                          /* E2E:141 */
+    }
+    if (respawn)
+        EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
+                                          respawn->seed, respawn->counter, nullptr, nullptr, s));
     return EB_OK;
 }
 

@@ -110,6 +110,37 @@ hipError_t launch_judge_done(int task, int n_env, int D, const float* ego, const
                              int m_cand, const float* cand, const uint8_t* cand_mode, const float* cand_lw,
                              const uint8_t* v_light, uint8_t* done_code, hipStream_t s);
 
+// CrossroadEnd2end.step as one launch (eb_env_step.hip)
+struct SlotTurns { uint8_t t[64]; };
+struct EnvStepArgs {
+    int n_env, D, n_future, NV, m_cand, path_id;
+    unsigned d_magic, m_magic, nv_magic;   // ceil(2^32 / d) for d = D, m_cand, NV (0 when d == 1): item / d == umulhi(item, magic)
+    PathTables pt;
+    VehModes modes;                        // the observation's slot modes (handle h)
+    SlotTurns tturn;                       // turn class of every candidate slot (the traffic handle's modes)
+    const float* obs;                      // [n_env, D] current observation
+    const float* raw;                      // [n_env, 2] raw actions
+    const int* ref_idx;
+    float* ego;                            // [n_env, 6] in place
+    float* params;                         // [n_env, 4] out
+    float* cand;                           // [n_env, m_cand, 4] in place, 16-byte aligned
+    const uint8_t* cand_mode;
+    const float* cand_lw;                  // nullable
+    const uint8_t* v_light;                // nullable
+    const uint8_t* virtual_flag;           // nullable
+    float* scaled;                         // nullable
+    float* out5;
+    float* d16;                            // nullable
+    float* obs_out;
+    uint8_t* done_code;
+    const float* respawn_entry;            // NULL: no re-entry stage
+    float limit, span, v_max;
+    uint64_t seed, counter;
+};
+size_t env_step_lds_bytes(int D, int NV, int m_cand);
+bool env_step_is_fused(int D, int NV, int m_cand, const float* cand);
+hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s);
+
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
                                   float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask, uint8_t* respawned,
                                   hipStream_t s);

@@ -102,6 +102,84 @@ def _unwrap_action(action, B, dev):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(t, np.float32).reshape(B, 2))).to(dev)
 
 
+class _RewardInfo(dict):
+    """info['reward_info'] of a batch (E2E:142-143): the 16 reward terms are rows of one [16, B] device array; a row is
+    wrapped as a DevArray when it is first read, so a driver that never looks pays nothing per step."""
+
+    def __init__(self, keys, d16, final_rew):
+        dict.__init__(self)
+        self._rows = {k: i for i, k in enumerate(keys)}
+        self._d16 = d16
+        dict.__setitem__(self, 'final_rew', final_rew)
+
+    def __missing__(self, k):
+        v = DevArray(self._d16[self._rows[k]])
+        dict.__setitem__(self, k, v)
+        return v
+
+    def _fill(self):
+        for k in self._rows:
+            self[k]
+
+    def keys(self):
+        self._fill(); return dict.keys(self)
+
+    def items(self):
+        self._fill(); return dict.items(self)
+
+    def values(self):
+        self._fill(); return dict.values(self)
+
+    def __iter__(self):
+        self._fill(); return dict.__iter__(self)
+
+    def __len__(self):
+        return len(self._rows) + 1
+
+    def __contains__(self, k):
+        return k in self._rows or dict.__contains__(self, k)
+
+
+class _LazyInitState(dict):
+    """init_state of a batch (E2E:487-499 builds it for the one env of the reference): env 0's start values, read from the
+    device when somebody asks — a masked reset of a vectorised driver must not sync the stream for a dict nobody reads."""
+
+    def __init__(self, ego, l, w, route):
+        dict.__init__(self)
+        self._src = (ego, l, w, route)
+
+    def __missing__(self, k):
+        if k != 'ego':
+            raise KeyError(k)
+        ego, l, w, route = self._src
+        e0 = ego[0].cpu().numpy()
+        v = dict(v_x=e0[0], v_y=0, r=0, x=e0[3], y=e0[4], phi=e0[5], l=l, w=w, routeID=route)
+        dict.__setitem__(self, k, v)
+        return v
+
+    def __contains__(self, k):
+        return k == 'ego'
+
+
+class _LazyDone(DevArray):
+    """done of a batch: uint8 0 / 1 per env = (done code != 0) — the one small kernel that makes it runs when the value
+    is first read (`.t`, `.numpy()`, indexing, reset(mask=done), ...), not on every step."""
+
+    def __init__(self, code):
+        self._code = code
+        self._t = None
+
+    @property
+    def t(self):
+        if self._t is None:
+            self._t = self._code.clamp(max=1)
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = v
+
+
 class CrossroadEnd2end(object):
     def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
                  device=None, respawn=True, traffic='pool', per_route=5, **kwargs):
@@ -180,6 +258,8 @@ class CrossroadEnd2end(object):
         self.done_code = torch.zeros((B,), dtype=torch.uint8, device=dev)
         self._injected = False
         self._flows = None
+        self._bufs, self._buf_i = None, 0
+        self._respawn_rule = _capi.EbRespawn(self._entry5.data_ptr(), CROSSROAD_SIZE / 2 + 40., 60.0, EXPECTED_V, 0, 0)
         if traffic == 'flows':
             from .traffic import FlowTraffic
             self._flows = FlowTraffic(B, dev, None, self.training_task, mode=self.mode, per_route=per_route,
@@ -199,6 +279,7 @@ class CrossroadEnd2end(object):
         self._respawn_seed = int(self.np_random.integers(0, 2 ** 62))     # keys: (seed, counter, env, slot)
         if getattr(self, '_flows', None) is not None:
             self._flows.seed = self._respawn_seed
+            self._flows.counter = self._flows.reset_counter = 0      # a reseed reproduces the same flow traffic
         self._respawn_counter = 0
         self._reset_counter = 0
         return [seed]
@@ -248,7 +329,7 @@ class CrossroadEnd2end(object):
                                C.c_uint64(self._reset_counter), 1 if self.mode == 'training' else 0, _ptr(self._ego),
                                _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual_next), _ptr(self.done_code),
                                self._sp())
-            e0 = self._ego[0].cpu().numpy()
+            return _LazyInitState(self._ego, self.ego_l, self.ego_w, route)     # env 0's values, copied from the device on first access
         return dict(ego=dict(v_x=e0[0], v_y=0, r=0, x=e0[3], y=e0[4], phi=e0[5], l=self.ego_l,
                              w=self.ego_w, routeID=route))
 
@@ -279,6 +360,10 @@ class CrossroadEnd2end(object):
             self.api.traffic_respawn(self._traffic.h, B, self.n_cand, _ptr(self._cand), _ptr(self._entry5), C.c_float(-1.0),
                                      C.c_float(60.0), C.c_float(EXPECTED_V), C.c_uint64(self._respawn_seed ^ self._POOL_SALT),
                                      C.c_uint64(self._reset_counter), _ptr(mask8), None, sp)
+            if mask8 is None:                      # the pool has no light programme: a reset env starts at phase 0
+                self._v_light.zero_()              # (a value injected through the multi_display seam does not survive reset)
+            else:
+                self._v_light.masked_fill_(mask8.bool(), 0)
         self._injected = False
         self._publish_state()                                                            # E2E:104-115
         self.obs = self._get_obs()                                                       # E2E:116 (with the OLD flag)
@@ -460,38 +545,53 @@ class CrossroadEnd2end(object):
         """done_type strings of the last step for every env of a batch (E2E:208-221)."""
         return [_capi.DONE_NAMES[int(c)] for c in self.done_code.cpu().numpy()]
 
+    def _step_buffers(self):
+        """Two pre-allocated sets of step outputs used in turn: what step() hands out stays valid until the step after
+        the next one, and the step loop itself allocates nothing on the device."""
+        if self._bufs is None:
+            B, dev = self.n_env, self.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            self._bufs = [dict(act=torch.empty((B, 2), **f32), out5=torch.empty((5, B), **f32), d16=torch.empty((16, B), **f32),
+                               obs=torch.empty((B, self.obs_dim), **f32), code=torch.empty((B,), dtype=torch.uint8, device=dev))
+                          for _ in range(2)]
+            self._ri1 = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self._buf_i ^= 1
+        return self._bufs[self._buf_i]
+
     def step(self, action):
-        """E2E:132-144 through ONE C-ABI call (eb_env_step): action scaling -> reward on the current obs -> ego step ->
-        traffic step -> observation -> done code; afterwards the traffic pool re-enters the vehicles that left the map
-        (the observation saw the pool as this step left it, the way the reference sees SUMO's state of the step)."""
+        """E2E:132-144 through ONE C-ABI call and — when the candidate tile fits the LDS — ONE kernel launch (eb_env_step,
+        csrc/eb_env_step.hip): action scaling -> reward on the current obs -> ego step -> traffic step -> observation ->
+        done code -> the traffic pool re-enters the vehicles that left the map (the observation saw the pool as this step
+        left it, the way the reference sees SUMO's state of the step).  Outputs live in two pre-allocated buffer sets used
+        in turn (valid until the step after next)."""
         B, dev = self.n_env, self.device
         raw = _unwrap_action(action, B, dev)
-        act = torch.empty_like(raw)
-        out5 = torch.empty((5, B), dtype=torch.float32, device=dev)
-        d16 = torch.empty((16, B), dtype=torch.float32, device=dev)
-        obs_out = torch.empty_like(self._obs)
-        code = torch.empty((B,), dtype=torch.uint8, device=dev)
+        bufs = self._step_buffers()
+        act, out5, d16, obs_out, code = bufs['act'], bufs['out5'], bufs['d16'], bufs['obs'], bufs['code']
+        if obs_out.data_ptr() == self._obs.data_ptr():          # (after a reset wrote into the same buffer)
+            self._obs = self._obs.clone()
         ri = self._ref_idx
         if B == 1:
-            ri = torch.tensor([int(self.ref_path.ref_index)], dtype=torch.int32, device=dev)
+            self._ri1.fill_(int(self.ref_path.ref_index))
+            ri = self._ri1
         if not self._cand.is_contiguous():
             self._cand = self._cand.contiguous()
         lw = self._flows.cand_lw() if self._flows is not None else None      # the vTypes' (l, w): TRF:263-295
         sp = self._sp()
+        rs = None
+        if self._flows is None and self.respawn:     # vehicles that left the map re-enter on their lane, counter-based draws
+            self._respawn_counter += 1
+            rs = self._respawn_rule
+            rs.seed, rs.counter = self._respawn_seed, self._respawn_counter
         self.api.env_step(self._h, self._traffic.h, B, _ptr(self._obs), _ptr(raw), _ptr(ri), 0, _ptr(self._ego),
                           _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(lw),
                           _ptr(self._v_light), _ptr(self._virtual), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out),
-                          _ptr(code), sp)
+                          _ptr(code), C.byref(rs) if rs is not None else None, sp)
         self._obs, self.done_code = obs_out, code
         if self._flows is not None:       # exits, emissions and the light for the NEXT step (the obs saw this step's state)
             self._flows.cand = self._cand
             self._flows.after_step(self.api, self._traffic.h, sp)
             self._cand, self._cand_mode, self._v_light = self._flows.cand, self._flows.mode(), self._flows.v_light()
-        elif self.respawn:                # vehicles that left the map re-enter on their lane (one kernel, counter-based draws)
-            self._respawn_counter += 1
-            self.api.traffic_respawn(self._traffic.h, B, self.n_cand, _ptr(self._cand), _ptr(self._entry5),
-                                     C.c_float(CROSSROAD_SIZE / 2 + 40.), C.c_float(60.0), C.c_float(EXPECTED_V),
-                                     C.c_uint64(self._respawn_seed), C.c_uint64(self._respawn_counter), None, None, sp)
         self._publish_state()                                                           # E2E:136, 139
         keys = EnvironmentModel.REWARD_KEYS
         if B == 1:
@@ -500,13 +600,13 @@ class CrossroadEnd2end(object):
             reward = out5[0].cpu().numpy()[0]
             d16h = d16[:, 0].cpu().numpy()
             self.reward_info = {k: d16h[i] for i, k in enumerate(keys)}                # E2E:505-507
+            self.reward_info.update({'final_rew': reward})                              # E2E:142
             c = int(code[0].item())
             self.done_type, done = _capi.DONE_NAMES[c], int(c != 0)                     # E2E:141
         else:
             self.action, self.obs, reward = DevArray(act), DevArray(obs_out), DevArray(out5[0])
-            self.reward_info = {k: DevArray(d16[i]) for i, k in enumerate(keys)}
-            self.done_type, done = DevArray(code), DevArray(code.clamp(max=1))      # 0 / 1 per env: one small kernel
-        self.reward_info.update({'final_rew': reward})                                  # E2E:142
+            self.reward_info = _RewardInfo(keys, d16, reward)                           # rows of d16, wrapped on access
+            self.done_type, done = DevArray(code), _LazyDone(code)                      # 0 / 1 per env, computed when read
         all_info = dict(all_vehicles=self.all_vehicles, ego_dynamics=self.ego_dynamics, v_light=self.v_light)
         all_info.update({'reward_info': self.reward_info,
                          'ref_index': self.ref_path.ref_index if B == 1 else DevArray(self._ref_idx)})   # E2E:143

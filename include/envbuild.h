@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EB_ABI_VERSION 2
+#define EB_ABI_VERSION 3
 
 /* error codes */
 #define EB_OK 0
@@ -188,18 +188,26 @@ int eb_rollout_tape_f16(eb_handle h, int32_t n_env, int32_t horizon, const uint1
  * the producer beside it: n_env beyond HALF of the device's block slots is refused with EB_EINVAL.  Results equal `horizon` calls of eb_rollout_step bit for bit. */
 int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                      const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
-                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, uint32_t* status,
-                     int32_t spin_limit, void* stream);
-/* number of blocks eb_rollout_gated launches for n_env envs = the 64-byte records per step of step_done (0 if n_env is too large) */
+                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, int32_t n_blocks,
+                     uint32_t* status, int32_t spin_limit, void* stream);
+/* number of blocks eb_rollout_gated launches for n_env envs = the 64-byte records per step of step_done (0 if n_env is too
+ * large).  The handle must be configured (paths and slot modes set) as for the launch: the answer depends on both.
+ * eb_rollout_gated takes the number back as `n_blocks` and refuses (EB_EINVAL, nothing launched) when the grid it would
+ * launch NOW differs — the tile shape (eb_debug_set_tile), the staging of the path tables and the occupancy are
+ * re-derived from the handle's state at every call, and step_done was sized from the earlier answer. */
 int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks);
 /* The reference action producer for eb_rollout_gated, to be enqueued on ANOTHER stream before it: for t = 0 .. horizon - 1
  * wait until all n_blocks records of step_done[t - 1] are set (t > 0), copy staged_tape[t] -> live_tape[t] ([n_env, 2] floats, n_env even),
  * raise step_ready[t].  What a policy kernel in the loop does, minus the policy.  stream = NULL: the handle's own
  * producer stream — a HIGH-PRIORITY stream, i.e. a hardware queue of its own: two streams of equal priority may share
- * one, and a producer queued behind the rollout it feeds (or the other way round) would never meet it. */
+ * one, and a producer queued behind the rollout it feeds (or the other way round) would never meet it.
+ * Ordering: the feed reads staged_tape and the flags the caller zeroed; that stream has no order against the stream the
+ * caller produced them on.  wait_after != 0: the feed is ordered (event record + stream wait, no host wait) behind
+ * everything enqueued so far on `after_stream` (a hipStream_t; NULL = the null stream).  wait_after == 0: the caller
+ * guarantees that staged_tape and the zero fills of step_ready / step_done / status are COMPLETE before the call. */
 int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, const float* staged_tape,
                  float* live_tape, uint32_t* step_ready, const uint32_t* step_done, uint32_t* status,
-                 int32_t spin_limit, void* stream);
+                 int32_t spin_limit, void* after_stream, int32_t wait_after, void* stream);
 
 /* Episodic-return summary of one shard of envs after a rollout of `horizon` steps — the only
  * quantity north_star exchanges between GPUs (one all-gather of this vector per rollout; the
@@ -290,7 +298,9 @@ int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actio
  *   multi_ego.py:89-92 (exits R / L see phase 2 as 0 and every other phase as 2); `ego` must already be in the
  *   exit's frame (eb_exit_frame).  Filters and sort keys use the float64 transformed values the way the reference's
  *   Python does (against ego-derived fp32 values after rounding to fp32, against constants in float64); the
- *   observation holds them rounded to fp32.  obs_out [n_env, D]. */
+ *   observation holds them rounded to fp32.  obs_out [n_env, D].
+ *   An exit id above 3 is an error: the oracle (host arguments) returns EB_EINVAL; the HIP library cannot read device
+ *   memory on the host and writes NaN into every column of that env's row instead (eb_exit_frame: NaN x, y, phi). */
 int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx,
                int32_t path_id, int32_t m_cand, const float* cand, const uint8_t* cand_mode,
                const uint8_t* v_light, const uint8_t* virtual_flag, const uint8_t* exit_id,
@@ -321,12 +331,26 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
  * (its slot modes = their modes) and the candidates move by the model's own prediction step (eb_veh_predict).
  * In-place state: ego [n_env,6], cand [n_env, m_cand, 4]; params [n_env,4] is written.  obs [n_env,D] is the
  * current observation (input), obs_out the next one; they must differ.  cand_lw (nullable) as in eb_judge_done,
- * v_light / virtual_flag (nullable) as in eb_get_obs.  Every argument is validated before the first launch: an
- * error return leaves the state untouched.  Equivalent to the six calls in that order. */
+ * v_light / virtual_flag (nullable) as in eb_get_obs.  scaled_actions and out_dict16 are nullable.
+ * respawn (nullable): the traffic pool's re-entry rule applied AFTER the observation and the done code were taken (the
+ * observation sees the pool as this step left it, the way the reference sees SUMO's state of the step) =
+ * eb_traffic_respawn(traffic, n_env, m_cand, cand, entry, limit, span, v_max, seed, counter, NULL, NULL) as a seventh call.
+ * Every argument is validated before the first launch: an error return leaves the state untouched.  Equivalent to the
+ * six (seven) calls in that order; the HIP library runs them as ONE launch (csrc/eb_env_step.hip) when the candidate
+ * tile fits the LDS, m_cand <= 64 and cand is 16-byte aligned, and as separate launches otherwise. */
+typedef struct eb_respawn {
+    const float* entry; /* [m_cand, 5] = (x, y, phi, dx, dy) per slot, as eb_traffic_respawn */
+    float limit;        /* a candidate with |x| or |y| beyond it re-enters (>= 0) */
+    float span;
+    float v_max;
+    uint64_t seed;
+    uint64_t counter;
+} eb_respawn;
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
-                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream);
+                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
+                const eb_respawn* respawn, void* stream);
 
 /* CrossroadEnd2end.reset (E2E:99-127) with _reset_init_state (E2E:472-499) for the envs of a batch whose mask byte is
  * non-zero (mask NULL = every env); the other envs keep their state.  Per env, with u_k in [0, 1) the counter-based

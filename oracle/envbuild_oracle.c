@@ -672,17 +672,21 @@ int eb_rollout_tape(eb_handle h, int32_t n_env, int32_t horizon, const float* ob
  * steps then run as in eb_rollout_tape, obs_steps[t] = the obs after step t, step_done[t][0][0..15] = 1 (one "block": one 64-byte record per step). */
 int eb_rollout_gated_blocks(eb_handle h, int32_t n_env, int32_t* n_blocks) {
     if (!h || n_env < 0 || !n_blocks) return fail(EB_EINVAL, "eb_rollout_gated_blocks: bad argument");
+    int rc = check_paths(h, "eb_rollout_gated_blocks: null handle");
+    if (!rc) rc = check_modes(h);
+    if (rc) return rc;
     *n_blocks = n_env > 0 ? 1 : 0;
     return EB_OK;
 }
 
 int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                      const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
-                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, uint32_t* status,
-                     int32_t spin_limit, void* stream) {
+                     float* obs_steps, const uint32_t* step_ready, uint32_t* step_done, int32_t n_blocks,
+                     uint32_t* status, int32_t spin_limit, void* stream) {
     if (h && n_env == 0) return EB_OK;
     int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_gated: null handle");
     if (rc) return rc;
+    if (n_blocks != 1) return fail(EB_EINVAL, "eb_rollout_gated: n_blocks does not match the grid this handle launches now (call eb_rollout_gated_blocks again)");
     if (n_env < 0 || horizon < 1 || !obs_in || !action_tape || !obs_work || !obs_out || !out5_steps || !step_ready || !step_done ||
         !status || spin_limit < 1)
         return fail(EB_EINVAL, "eb_rollout_gated: bad argument");
@@ -705,8 +709,8 @@ int eb_rollout_gated(eb_handle h, int32_t n_env, int32_t horizon, const float* o
 
 int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, const float* staged_tape,
                  float* live_tape, uint32_t* step_ready, const uint32_t* step_done, uint32_t* status,
-                 int32_t spin_limit, void* stream) {
-    (void)stream; (void)step_done; (void)status;
+                 int32_t spin_limit, void* after_stream, int32_t wait_after, void* stream) {
+    (void)stream; (void)step_done; (void)status; (void)after_stream; (void)wait_after;
     if (!h || n_env < 1 || (n_env & 1) || horizon < 1 || n_blocks < 1 || !staged_tape || !live_tape || !step_ready || !step_done ||
         !status || spin_limit < 1 || staged_tape == live_tape)
         return fail(EB_EINVAL, "eb_gate_feed: bad argument (n_env even: a step's actions are copied 16 bytes at a time)");
@@ -1243,11 +1247,14 @@ int eb_event_destroy(eb_event e) {
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
-                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code, void* stream) {
+                float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
+                const eb_respawn* respawn, void* stream) {
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
-    if (n_env < 0 || !obs || !actions || !ego || !params || !scaled_actions || !out5 || !obs_out || !done_code || obs == obs_out ||
+    if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
         m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)))
         return fail(EB_EINVAL, "eb_env_step: bad argument");
+    if (respawn && (!respawn->entry || !(respawn->limit >= 0.0f) || m_cand < 1 || m_cand > 64))
+        return fail(EB_EINVAL, "eb_env_step: bad respawn rule");
     if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_step: the traffic handle must have n_veh == m_cand");
     int rc = check_paths(h, "eb_env_step: null handle");
     if (!rc) rc = check_modes(h);
@@ -1255,12 +1262,22 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (rc) return rc;
     if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (n_env == 0) return EB_OK;
+    float* own_scaled = NULL;
+    if (!scaled_actions) {                                                                       /* nullable output */
+        own_scaled = (float*)malloc((size_t)n_env * 2 * sizeof(float));
+        if (!own_scaled) return fail(EB_ENOMEM, "eb_env_step: out of memory");
+        scaled_actions = own_scaled;
+    }
     rc = eb_action_transform(h, n_env, actions, scaled_actions, stream);                         /* E2E:133 */
     if (!rc) rc = eb_compute_rewards(h, n_env, obs, scaled_actions, out5, out_dict16, stream);      /* E2E:134 */
     if (!rc) rc = eb_env_ego_step(h, n_env, ego, scaled_actions, ego, params, stream);           /* E2E:135 */
+    free(own_scaled);
     if (!rc) rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                            /* TRF:220-238's role */
     if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, NULL, obs_out, stream);   /* E2E:140 */
     if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, cand_lw, v_light, done_code, stream);   /* E2E:141 */
+    if (!rc && respawn)   /* the pool's re-entry, after the observation saw this step's state */
+        rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
+                                respawn->seed, respawn->counter, NULL, NULL, stream);
     return rc;
 }
 

@@ -29,8 +29,8 @@ torch.cuda.synchronize()
 import time
 for i in range(R):
     t0 = time.perf_counter()
-    api.gate_feed(h, B, H, nb, p(tape), p(live), p(ready[i]), p(done[i]), p(status[i]), 1 << 18, None)
-    api.rollout_gated(h, B, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready[i]), p(done[i]), p(status[i]), 1 << 18, sp)
+    api.gate_feed(h, B, H, nb, p(tape), p(live), p(ready[i]), p(done[i]), p(status[i]), 1 << 18, sp, 1, None)
+    api.rollout_gated(h, B, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready[i]), p(done[i]), nb, p(status[i]), 1 << 18, sp)
     if sync_each:
         torch.cuda.synchronize(); print(i, 'ms %.2f' % ((time.perf_counter() - t0) * 1e3), status[i].cpu().tolist(), 'steps done', int(done[i, :, :, 0].all(dim=1).sum()))
 torch.cuda.synchronize()

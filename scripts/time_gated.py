@@ -49,7 +49,7 @@ def tape_kernel():
     lib.eb_rollout_tape(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), sp)
 def gated_open(publish):
     api.rollout_gated(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), p(steps) if publish else None, p(ready1), p(done),
-                      p(status), 1 << 20, sp)
+                      nb, p(status), 1 << 20, sp)
 R = a.reps + 5
 ready_r = torch.zeros((R, H), dtype=torch.int32, device=dev)      # one set of flags per repetition: nothing to reset in between
 done_r = torch.zeros((R, H, nb, 16), dtype=torch.int32, device=dev)
@@ -57,8 +57,8 @@ fed_i = [0]
 def gated_fed():
     i = fed_i[0] % R
     fed_i[0] += 1
-    api.gate_feed(h, B, H, nb, p(tape), p(live), p(ready_r[i]), p(done_r[i]), p(status), 1 << 20, None)
-    api.rollout_gated(h, B, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready_r[i]), p(done_r[i]), p(status), 1 << 20, sp)
+    api.gate_feed(h, B, H, nb, p(tape), p(live), p(ready_r[i]), p(done_r[i]), p(status), 1 << 20, sp, 1, None)
+    api.rollout_gated(h, B, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready_r[i]), p(done_r[i]), nb, p(status), 1 << 20, sp)
 
 def timeit(name, fn, sync_each=False):
     for _ in range(5): fn()

@@ -177,9 +177,10 @@ class HostModel(object):
         work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
         steps = self._out((H,) + tuple(ob.shape)) if publish_obs else None
         rd = self._in(np.ones(H, np.int32) if ready is None else np.asarray(ready, np.int32), np.int32)
-        dn, st = self._in(np.zeros((H, max(1, self.gated_blocks(n)), 16), np.int32), np.int32), self._in(np.zeros(2, np.int32), np.int32)
+        nb = self.gated_blocks(n)
+        dn, st = self._in(np.zeros((H, max(1, nb), 16), np.int32), np.int32), self._in(np.zeros(2, np.int32), np.int32)
         self.api.rollout_gated(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work),
-                               self._ptr(out), self._ptr(out5), self._ptr(steps), self._ptr(rd), self._ptr(dn), self._ptr(st),
+                               self._ptr(out), self._ptr(out5), self._ptr(steps), self._ptr(rd), self._ptr(dn), nb, self._ptr(st),
                                int(spin_limit), self.stream)
         return (self._ret(out), self._ret(out5), self._ret(steps) if publish_obs else None, self._ret(dn), self._ret(st))
 
@@ -312,19 +313,37 @@ class HostModel(object):
         return self._ret(out)
 
     def env_step(self, traffic, obs, raw, ego, cand, cand_mode, ref_idx=None, path_id=0, cand_lw=None, v_light=None,
-                 virtual=None):
-        """eb_env_step on copies of the state -> (scaled, out5, d16, ego, params, cand, obs_out, done_code)"""
+                 virtual=None, respawn=None, want_scaled=True, want_dict=True):
+        """eb_env_step on copies of the state -> (scaled, out5, d16, ego, params, cand, obs_out, done_code).
+        respawn: dict(entry [M, 5], limit, span, v_max, seed, counter) — the pool's re-entry as the step's last stage."""
         B, M = len(ego), cand.shape[1]
         e_io, c_io = self._in(np.array(ego, np.float32)), self._in(np.array(cand, np.float32))
         ob, rw, ri = self._in(obs), self._in(raw), self._in(ref_idx, np.int32)
         cm, lw = self._in(cand_mode, np.uint8), self._in(cand_lw)
         vl, vf = self._in(v_light, np.uint8), self._in(virtual, np.uint8)
-        par, sc, out5, dd = self._out((B, 4)), self._out((B, 2)), self._out((5, B)), self._out((16, B))
+        par, out5 = self._out((B, 4)), self._out((5, B))
+        sc = self._out((B, 2)) if want_scaled else None
+        dd = self._out((16, B)) if want_dict else None
         obs_o, code = self._out(np.asarray(obs).shape), self._out((B,), np.uint8)
+        rs, entry = None, None
+        if respawn is not None:
+            entry = self._in(respawn['entry'])
+            rs = _capi.EbRespawn(self._ptr(entry).value, float(respawn['limit']),
+                                 float(respawn['span']), float(respawn['v_max']), int(respawn['seed']), int(respawn['counter']))
         self.api.env_step(self.h, traffic.h, B, self._ptr(ob), self._ptr(rw), self._ptr(ri), int(path_id), self._ptr(e_io),
                           self._ptr(par), M, self._ptr(c_io), self._ptr(cm), self._ptr(lw), self._ptr(vl), self._ptr(vf),
-                          self._ptr(sc), self._ptr(out5), self._ptr(dd), self._ptr(obs_o), self._ptr(code), self.stream)
-        return [self._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code)]
+                          self._ptr(sc), self._ptr(out5), self._ptr(dd), self._ptr(obs_o), self._ptr(code),
+                          C.byref(rs) if rs is not None else None, self.stream)
+        return [None if x is None else self._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code)]
+
+    def traffic_respawn(self, cand, entry, limit, span, v_max, seed, counter, mask=None):
+        """eb_traffic_respawn on a copy of the candidates -> (cand, respawned)"""
+        cd, en, mk = self._in(np.array(cand, np.float32)), self._in(entry), self._in(mask, np.uint8)
+        B, M = cd.shape[0], cd.shape[1]
+        flags = self._out((B, M), np.uint8)
+        self.api.traffic_respawn(self.h, B, M, self._ptr(cd), self._ptr(en), C.c_float(limit), C.c_float(span), C.c_float(v_max),
+                                 C.c_uint64(seed), C.c_uint64(counter), self._ptr(mk), self._ptr(flags), self.stream)
+        return self._ret(cd), self._ret(flags)
 
     def judge_done(self, ego, params, obs, cand, cand_mode, cand_lw, v_light):
         eg, pr, ob, cd = self._in(ego), self._in(params), self._in(obs), self._in(cand)

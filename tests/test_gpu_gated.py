@@ -7,6 +7,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from env_build_amd import _capi
+
 from env_build_amd.synthetic import assemble_obs, make_rollout_inputs
 from tests._helpers import DeviceModel, HostModel, oracle_lib
 
@@ -73,12 +75,12 @@ def test_gated_rollout_fed_step_by_step_from_another_stream(B, N):
     steps = t.empty((H,) + tuple(ob.shape), device=d)
     nb = dev.gated_blocks(B)
     ready, done, status = (t.zeros(H, dtype=t.int32, device=d), t.zeros((H, nb, 16), dtype=t.int32, device=d), t.zeros(2, dtype=t.int32, device=d))
-    t.cuda.synchronize()
     p = lambda x: C.c_void_p(x.data_ptr())
     spin = 1 << 18                                           # ~ a second of polling at most, then both sides give up
     # the producer on the handle's own (high-priority) stream — a hardware queue of its own —, the rollout on torch's
-    dev.api.gate_feed(dev.h, B, H, nb, p(staged), p(live), p(ready), p(done), p(status), spin, None)
-    dev.api.rollout_gated(dev.h, B, H, p(ob), p(live), p(ri), 0, p(work), p(out), p(out5), p(steps), p(ready), p(done), p(status),
+    # (wait_after = 1: the feed is ordered behind torch's stream, where the zero fills above were enqueued — no host sync needed)
+    dev.api.gate_feed(dev.h, B, H, nb, p(staged), p(live), p(ready), p(done), p(status), spin, dev.stream, 1, None)
+    dev.api.rollout_gated(dev.h, B, H, p(ob), p(live), p(ri), 0, p(work), p(out), p(out5), p(steps), p(ready), p(done), nb, p(status),
                           spin, dev.stream)
     t.cuda.synchronize()
     assert status.cpu().tolist() == [0, 0]
@@ -110,4 +112,20 @@ def test_gated_rollout_gives_up_at_a_shut_gate_and_refuses_oversized_batches():
     assert big.gated_blocks(1 << 20) == 0                    # more blocks than the device holds at once
     with pytest.raises(ValueError):
         big.api.rollout_gated(big.h, 1 << 20, 2, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 0, C.c_void_p(16), C.c_void_p(24),
-                              C.c_void_p(8), None, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 10, None)
+                              C.c_void_p(8), None, C.c_void_p(8), C.c_void_p(8), 1, C.c_void_p(8), 10, None)
+    # a block count that is not the grid this handle launches: refused before anything is written (the done records
+    # of a larger grid would land past the caller's buffer)
+    nb_ok = big.gated_blocks(4096)
+    other = [v for v in (0, 1, 2) if (big.set_tile(v), big.gated_blocks(4096))[1] not in (0, nb_ok)]
+    assert other                                             # some forced tile shape gives a different (resident) grid
+    big.set_tile(other[0])
+    assert big.gated_blocks(4096) != nb_ok
+    with pytest.raises(ValueError):
+        big.api.rollout_gated(big.h, 4096, 2, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 0, C.c_void_p(16), C.c_void_p(24),
+                              C.c_void_p(8), None, C.c_void_p(8), C.c_void_p(8), nb_ok, C.c_void_p(8), 10, None)
+    big.set_tile(-1)
+    # the query needs a configured handle (its answer depends on the table size and the slot count)
+    bare = big.api.create(task, 32, 0, _capi.MODE_TRAINING)
+    with pytest.raises(_capi.EbError):
+        big.api.rollout_gated_blocks(bare, 4096, C.byref(C.c_int32()))
+    big.api.destroy(bare)
