@@ -63,6 +63,36 @@ EB_DEV int veh_cmp(int task, int m, const V4& a, const V4& b) {
 #undef EB_DESC
 }
 
+// The same sort keys as data, for a wave-uniform mode: key = (s1 * f1, s2 * f2) with f in {x, y, none}; DESC(f) is ASC(-f)
+// (negation is exact and order-reversing, ties and NaN included), a missing key is the constant 0.  key_less == veh_cmp < 0,
+// key_before == "sorts before under (key, insertion index)".
+struct KeySpec { int f1, f2; float s1, s2; };   // f: 0 = none, 1 = x, 2 = y
+EB_DEV KeySpec key_spec(int task, int m) {
+    switch (m) {
+        case EB_VMODE_DL: return KeySpec{2, 1, 1.0f, -1.0f};
+        case EB_VMODE_DU: return KeySpec{2, 0, 1.0f, 1.0f};
+        case EB_VMODE_DR: return KeySpec{2, 1, 1.0f, 1.0f};
+        case EB_VMODE_RU: return KeySpec{1, 2, 1.0f, -1.0f};
+        case EB_VMODE_UR:
+            if (task == TASK_STRAIGHT) return KeySpec{2, 0, 1.0f, 1.0f};
+            if (task == TASK_RIGHT) return KeySpec{2, 1, 1.0f, -1.0f};
+            return KeySpec{0, 0, 1.0f, 1.0f};
+        case EB_VMODE_UD: return KeySpec{2, 0, 1.0f, 1.0f};
+        case EB_VMODE_UL: return KeySpec{2, 1, 1.0f, 1.0f};
+        case EB_VMODE_LR: return KeySpec{1, 0, -1.0f, 1.0f};
+        default: return KeySpec{0, 0, 1.0f, 1.0f};
+    }
+}
+EB_DEV float2 key_of(const KeySpec& k, float x, float y) {
+    const float a = k.f1 == 1 ? x : k.f1 == 2 ? y : 0.0f, b = k.f2 == 1 ? x : k.f2 == 2 ? y : 0.0f;
+    return make_float2(k.s1 < 0.0f ? -a : a, k.s2 < 0.0f ? -b : b);
+}
+EB_DEV bool key_less(const float2 a, const float2 b) { return a.x < b.x || (!(a.x > b.x) && a.y < b.y); }
+EB_DEV bool key_before(const float2 a, int ia, const float2 b, int ib) {
+    const bool lt1 = a.x < b.x, gt1 = a.x > b.x, lt2 = a.y < b.y, gt2 = a.y > b.y;
+    return lt1 || (!gt1 && (lt2 || (!gt2 && ia < ib)));
+}
+
 EB_DEV V4 veh_fill_value(int m) {   // mode2fillvalue, E2E:439-447
     const float C2 = HALF_CROSS, LW = LANE_W;
     V4 f = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -125,9 +155,10 @@ EB_DEV bool collision_with(const EgoCircles& E, float x, float y, const float4 v
            sq(E.x1 - sx1) + sq(E.y1 - sy1) < thr || sq(E.x1 - sx0) + sq(E.y1 - sy0) < thr;
 }
 
-// the rest of _judge_done (E2E:200-256) once the collision flag is known
-EB_DEV uint8_t judge_code(int task, bool collision, float v_x, float r, float x, float y, float phi, float miu_r,
-                          float delta_y, bool red_light) {
+// the rest of _judge_done (E2E:200-256) in two parts: the predicates that need only the ego state (a bit set) and the
+// priority chain once the collision flag and delta_y are known — the one-launch step evaluates the parts on different waves
+enum { JB_FEASIBLE = 1, JB_STABLE = 2, JB_RED = 4, JB_GOAL = 8 };
+EB_DEV unsigned judge_bits(int task, float v_x, float r, float x, float y, float phi, float miu_r, bool red_light) {
     const float EGO_L = 4.8f, EGO_W = 2.0f;
     // corner points (E2E:171-176, UTL:120-157) through judge_feasible
     float rs, rc;
@@ -146,13 +177,58 @@ EB_DEV uint8_t judge_code(int task, bool collision, float v_x, float r, float x,
     if (task == TASK_LEFT) goal = x < -HALF_CROSS - 10.0f && 0.0f < y && y < 3.0f * LANE_W;
     else if (task == TASK_RIGHT) goal = x > HALF_CROSS + 10.0f && -3.0f * LANE_W < y && y < 0.0f;
     else goal = y > HALF_CROSS + 10.0f && 0.0f < x && x < 3.0f * LANE_W;
+    return (feasible ? JB_FEASIBLE : 0u) | ((-r_bound < r && r < r_bound) ? JB_STABLE : 0u) |
+           ((red_light && y > -HALF_CROSS && task != TASK_RIGHT) ? JB_RED : 0u) | (goal ? JB_GOAL : 0u);
+}
+EB_DEV uint8_t judge_merge(unsigned bits, bool collision, float delta_y) {
     if (collision) return EB_DONE_COLLISION;
-    if (!feasible) return EB_DONE_BREAK_ROAD;
+    if (!(bits & JB_FEASIBLE)) return EB_DONE_BREAK_ROAD;
     if (__builtin_fabsf(delta_y) > 15.0f) return EB_DONE_DEVIATE;                 // E2E:224
-    if (!(-r_bound < r && r < r_bound)) return EB_DONE_STABILITY;
-    if (red_light && y > -HALF_CROSS && task != TASK_RIGHT) return EB_DONE_RED_LIGHT;
-    if (goal) return EB_DONE_GOOD;
+    if (!(bits & JB_STABLE)) return EB_DONE_STABILITY;
+    if (bits & JB_RED) return EB_DONE_RED_LIGHT;
+    if (bits & JB_GOAL) return EB_DONE_GOOD;
     return EB_DONE_NOT_YET;
+}
+EB_DEV uint8_t judge_code(int task, bool collision, float v_x, float r, float x, float y, float phi, float miu_r,
+                          float delta_y, bool red_light) {
+    return judge_merge(judge_bits(task, v_x, r, x, y, phi, miu_r, red_light), collision, delta_y);
+}
+
+// veh_in_range (E2E:393-411) as data: every mode's filter is a conjunction of up to four strict comparisons
+//   x > xlo,  x < xhi,  y > ylo,  y < yhi      with constant or ego-relative bounds,
+// so one branch-free evaluation serves lanes whose candidates have different modes (the one-launch step tests one
+// candidate per lane).  Same fp32 operations as veh_in_range: ego_x + 5.0f, ego_y - 2.0f (== ego_y + (-2.0f)), ...
+struct RangeRow {
+    unsigned flags;   // bit 0..3: the four comparisons are active; 4: xhi = ego_x + cxh; 5: ylo = ego_y + cyl; 6: ylo = max25(ylo)
+    float cxl, cxh, cyl, cyh;
+    float pad[3];
+};
+enum { RR_XLO = 1, RR_XHI = 2, RR_YLO = 4, RR_YHI = 8, RR_XHI_EGO = 16, RR_YLO_EGO = 32, RR_YLO_MAX25 = 64 };
+EB_DEV RangeRow range_row(int task, int m) {
+    const float C2 = HALF_CROSS;
+    RangeRow r = {0u, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f, 0.0f}};
+    switch (m) {
+        case EB_VMODE_DL: r.flags = RR_XLO | RR_YLO | RR_YLO_EGO; r.cxl = -C2 - 10.0f; r.cyl = -2.0f; break;
+        case EB_VMODE_DU: r.flags = RR_YLO | RR_YLO_EGO | RR_YHI | RR_XHI | RR_XHI_EGO; r.cyl = -2.0f; r.cyh = C2 + 10.0f; r.cxh = 5.0f; break;
+        case EB_VMODE_DR: r.flags = RR_XHI | RR_YLO | RR_YLO_EGO; r.cxh = C2 + 10.0f; r.cyl = 0.0f; break;
+        case EB_VMODE_RU: r.flags = RR_XHI | RR_YHI; r.cxh = C2 + 10.0f; r.cyh = C2 + 10.0f; break;
+        case EB_VMODE_UR:
+            if (task == TASK_STRAIGHT) { r.flags = RR_XHI | RR_XHI_EGO | RR_YLO | RR_YLO_EGO | RR_YHI; r.cxh = 7.0f; r.cyl = 0.0f; r.cyh = C2 + 10.0f; }
+            else if (task == TASK_RIGHT) { r.flags = RR_XHI | RR_YHI; r.cxh = C2 + 10.0f; r.cyh = C2; }
+            break;
+        case EB_VMODE_UD: r.flags = RR_YLO | RR_YLO_EGO | RR_YLO_MAX25 | RR_YHI | RR_XHI | RR_XHI_EGO; r.cyl = -2.0f; r.cyh = C2; r.cxh = 0.0f; break;
+        case EB_VMODE_UL: r.flags = RR_XLO | RR_XHI | RR_XHI_EGO | RR_YHI; r.cxl = -C2 - 10.0f; r.cxh = 0.0f; r.cyh = C2; break;
+        case EB_VMODE_LR: r.flags = RR_XLO | RR_XHI; r.cxl = -C2 - 10.0f; r.cxh = C2 + 10.0f; break;
+        default: break;
+    }
+    return r;
+}
+EB_DEV bool in_range_row(const RangeRow& r, float x, float y, float ego_x, float ego_y) {
+    const unsigned f = r.flags;
+    const float xhi = (f & RR_XHI_EGO) ? ego_x + r.cxh : r.cxh;
+    float ylo = (f & RR_YLO_EGO) ? ego_y + r.cyl : r.cyl;
+    if (f & RR_YLO_MAX25) ylo = __builtin_fmaxf(ylo, -HALF_CROSS);      // as veh_in_range's UD row
+    return (!(f & RR_XLO) || x > r.cxl) && (!(f & RR_XHI) || x < xhi) && (!(f & RR_YLO) || y > ylo) && (!(f & RR_YHI) || y < r.cyh);
 }
 
 // the same for a candidate row staged in LDS as float4s

@@ -3,30 +3,33 @@
 // eb_env_step used to be four launches (action scaling + reward + ego step | traffic step | observation + done code |
 // pool re-entry): 62.5 MB of algorithmic traffic in 76-81 us at 65 536 envs x 16 candidates, i.e. ~10 % of the HBM peak —
 // the candidates crossed HBM three times, the old observation was read by one thread per row (64 cache lines per load
-// instruction), and every launch boundary cost its ~2 us.  Here a block owns a tile of 64 envs for the whole step:
+// instruction), and every launch boundary cost its ~2 us.  Here a block owns a tile of 64 envs for the whole step, every
+// record crosses HBM once in each direction, and the work is laid out so that no phase is one lane per env walking its
+// candidates (the first one-launch version was: its slot-building phase alone took 8-10 us per block, a chain of
+// dependent LDS reads and divergent branches):
 //
-//   wave 0 (one lane per env)                           waves 1-3 (192 lanes over the tile's records)
-//   -------------------------------------------------   -----------------------------------------------------------
-//   head loads: old obs columns 0..8, raw action, ego   traffic step: 16 B per candidate record, coalesced;
-//   old ego circle centres -> LDS                       predict_for_a_mode (TRF:220-238's role) -> LDS
-//   ------------------------------------------------- barrier 0 ----------------------------------------------------
-//   action scaling (E2E:133), reward scalars, road      reward's per-vehicle terms (DAM:218-229), one lane per
-//   walls, ego step (E2E:135) -> ego / params in        (env, slot) of the OLD observation -> LDS partials
-//   place, new pose -> LDS
-//   ------------------------------------------------- barrier 1 ----------------------------------------------------
-//   penalty sums in vehicle order -> out5 / dict16;     observation slots (E2E:340-464): the distinct slot modes are
-//   closest point (cell grid) + tracking error          dealt to the waves (wave 0 joins last); per mode one walk over
-//   (E2E:293-297) -> LDS row; then its share of modes   the candidates -> in-range list -> repeated selection
-//   ------------------------------------------------- barrier 2 ----------------------------------------------------
-//   collision test shared by the four waves (TRF:263-295) -> LDS flags
-//   ------------------------------------------------- barrier 3 ----------------------------------------------------
-//   done code (E2E:200-221)                             all: observation rows -> HBM (coalesced); candidates -> HBM,
-//                                                       with the pool's re-entry rule applied on the way out
+//   phase 1   wave 0, lane = env: ego state + raw action -> action scaling (E2E:133), ego step (E2E:135: f_xu core, floor,
+//             wrap) -> new pose to LDS and to HBM.   wave 1, lane = env: old observation head -> ego circle centres
+//             (DAM:210-214) to LDS; tyre parameters (DAM:65-71, two atan) -> HBM; reward scalars and road walls (E2E:134).
+//             Whoever is free: the traffic step (TRF:220-238's role) — 16-byte candidate records in coalesced chunks,
+//             predict_for_a_mode, staged in LDS with their mode byte.                                       barrier
+//   phase 2   wave 0: closest point through the cell grid + tracking error (E2E:293-297) -> observation row head.
+//             waves 1-3, one lane per (env, old slot): compute_rewards' vehicle terms (DAM:218-229) — a centre-distance
+//             test first, the few pairs inside 6.364 m are compacted (ballot / mbcnt) into a per-wave queue and evaluated
+//             densely, everything else contributes exact zeros.  One lane per (env, candidate): the range filter of
+//             E2E:393-411 as a table-driven, branch-free test -> a tag byte (mode or 0xFF); the 10 m box test of
+//             TRF:263-295 -> per-wave queue -> two-circle test -> per-env collision flag.                   barrier
+//   phase 3   the distinct slot modes are dealt to waves 2, 3, 1, 0; per mode (wave-uniform) and env (lane): the tag row
+//             becomes a 64-bit candidate set (4 tags per LDS dword, zero-byte trick), the mode's slots are filled by
+//             repeated selection over that set (E2E:414-437; typically 0-3 members).  wave 1 first adds up the penalty
+//             partials in vehicle order -> out5 / dict16, then the done predicates that need only the ego (E2E:223-256).
+//                                                                                                           barrier
+//   phase 4   wave 0: priority chain -> done code (E2E:200-221).  all: observation rows -> HBM (coalesced); candidates ->
+//             HBM with the pool's re-entry rule applied on the way out (eb_traffic_respawn).
 //
-// Every record crosses HBM once in each direction; nothing but the tile's LDS is shared between waves, so there is no
-// cross-block traffic and no XCD consideration beyond "a tile's lines belong to one workgroup".  The arithmetic is the
-// same device functions the single-entry kernels run (eb_env_device.h, eb_device.h): bit-identical to the six (seven)
-// calls, which tests/test_gpu_parity.py::test_env_step_composite_equals_the_six_calls holds it to.
+// Nothing but the tile's LDS is shared between waves: no cross-block traffic, no XCD consideration beyond "a tile's lines
+// belong to one workgroup".  The arithmetic is the same device functions the single-entry kernels run (eb_env_device.h,
+// eb_device.h): bit-identical to the six (seven) calls — tests/_env_step_check.py holds it to that.
 #include "eb_env_device.h"
 
 #pragma clang fp contract(off)
@@ -34,19 +37,23 @@
 namespace eb {
 
 typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment (obs rows: D is odd)
+typedef __attribute__((address_space(3))) int lds_int;
+typedef float f2a4 __attribute__((ext_vector_type(2), aligned(4)));    // 8-byte access at 4-byte alignment
 
 EB_DEV int es_obs_stride(int D) { return D | 1; }                       // floats per LDS row, odd: no bank conflicts
+EB_DEV int es_tag_stride4(int m_cand) { return ((m_cand + 3) >> 2) | 1; }   // dwords per tag row, odd
 EB_DEV int fast_div(int item, unsigned magic) { return magic ? (int)__umulhi((unsigned)item, magic) : item; }   // magic 0: / 1
+constexpr int ES_QCAP = 128;   // per-wave queue: flushed whenever 64 entries are waiting, so 64 + 64 suffice
 
 size_t env_step_lds_bytes(int D, int NV, int m_cand) {
-    const int rs4 = m_cand + ((m_cand & 1) ? 2 : 1), os = D | 1;
+    const int rs4 = m_cand + ((m_cand & 1) ? 2 : 1), os = D | 1, ts4 = ((m_cand + 3) >> 2) | 1;
     size_t b = (size_t)64 * rs4 * 16;            // s_cand
     b += (size_t)64 * os * 4;                    // s_out
     b += (size_t)64 * NV * 8;                    // s_part
-    b += (size_t)64 * 16;                        // s_pts
-    b += (size_t)64 * 16;                        // s_ego
-    b += (size_t)64 * (m_cand + 4);              // s_mode
-    b += (size_t)256 * (m_cand + 1);             // s_list
+    b += (size_t)64 * 16 * 2;                    // s_pts, s_ego
+    b += (size_t)64 * 8;                         // s_oldc
+    b += (size_t)64 * ts4 * 4;                   // s_tag
+    b += (size_t)4 * ES_QCAP * 2;                // s_queue
     return (b + 15) & ~(size_t)15;
 }
 
@@ -55,121 +62,174 @@ bool env_step_is_fused(int D, int NV, int m_cand, const float* cand) {
            (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
 }
 
+// profiling aid (eb_debug_set_trace on the model handle): slot k of this wave's row [8] <- the 100 MHz wall clock, lane 0 only
+#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)
+
+// A per-wave queue of 16-bit item ids: `hit` lanes append (ballot / mbcnt), and whenever 64 are waiting the wave runs
+// `body(item)` on a full set of lanes; flush() runs the rest.
+template <class Body>
+struct WaveQueue {
+    unsigned short* q;
+    int n;
+    Body body;
+    EB_DEV void push(bool hit, int item) {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(hit);
+        if (b) {
+            if (hit) {
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, (unsigned)n));
+                q[pos] = (unsigned short)item;
+            }
+            n += __popcll(b);
+            if (n >= 64) { run(64); }
+        }
+    }
+    EB_DEV void run(int count) {
+        const int lane = threadIdx.x & 63;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int item = lane < count ? q[lane] : -1;
+        const int rest = lane < n - count ? q[count + lane] : 0;    // (n - count <= 64: push flushes at >= 64)
+        if (item >= 0) body(item);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < n - count) q[lane] = (unsigned short)rest;
+        n -= count;
+    }
+    EB_DEV void flush() { if (n > 0) run(n); }
+};
+
 template <int TASK>
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint8_t smode[64], sturn[64];
+    __shared__ uint8_t smode[64], sturn[64], s_col[64], s_jbits[64];
+    __shared__ float s_newr[64];                                                 // new yaw rate (the done predicates' input)
+    __shared__ RangeRow s_range[13];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * 64;
     const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
     const int nE = n_env - e0 < 64 ? n_env - e0 : 64;
     const int i = e0 + lane;
     const bool live = i < n_env;
-    const int RS4 = obs_cand_stride4(m_cand), OS = es_obs_stride(D), MS = m_cand + 4, T = 3 * (n_future + 1);
+    const int RS4 = obs_cand_stride4(m_cand), OS = es_obs_stride(D), TS4 = es_tag_stride4(m_cand), T = 3 * (n_future + 1);
     float4* s_cand = reinterpret_cast<float4*>(smem);                            // [64][RS4] candidates after the traffic step
     float* s_out = reinterpret_cast<float*>(s_cand + (size_t)64 * RS4);          // [64][OS]  next observation rows
     float2* s_part = reinterpret_cast<float2*>(s_out + (size_t)64 * OS);         // [64][NV]  (veh2veh4training, veh2veh4real) per old slot
     float4* s_pts = reinterpret_cast<float4*>(s_part + (size_t)64 * NV);         // [64]      old ego circle centres (DAM:210-214)
-    float4* s_ego = s_pts + 64;                                                  // [64]      new ego (x, y, phi, -)
-    uint8_t* s_mode = reinterpret_cast<uint8_t*>(s_ego + 64);                    // [64][MS]
-    uint8_t* s_list = s_mode + (size_t)64 * MS;                                  // [4][64][m_cand + 1]
-    if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
+    float4* s_ego = s_pts + 64;                                                  // [64]      new ego (x, y, phi, v_x)
+    float2* s_oldc = reinterpret_cast<float2*>(s_ego + 64);                      // [64]      old ego centre (obs columns 3, 4)
+    unsigned* s_tag32 = reinterpret_cast<unsigned*>(s_oldc + 64);                // [64][TS4] mode bytes, then range tags
+    uint8_t* s_tag = reinterpret_cast<uint8_t*>(s_tag32);
+    unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_tag32 + (size_t)64 * TS4);   // [4][ES_QCAP]
+    ES_MARK(0);
+    if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; s_col[tid] = 0; }
+    if (tid >= 64 && tid < 64 + 13) s_range[tid - 64] = range_row(TASK, tid - 64);     // row 12: no condition (modes without a filter)
+    for (int w = tid; w < 64 * TS4; w += 256) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
     __syncthreads();   // (kernel-argument tables only: nobody waits for memory here)
 
-    // ---- wave 0: the env's head; waves 1-3: the traffic step ---------------------------------------------------
-    float o9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st[6] = {0, 0, 0, 0, 0, 0}, raw0 = 0.0f, raw1 = 0.0f;
-    float4 pts = make_float4(0, 0, 0, 0);
-    if (wave == 0 && live) {
-        const float* o = A.obs + (size_t)D * i;
-        const f4a4 a = *reinterpret_cast<const f4a4*>(o), b = *reinterpret_cast<const f4a4*>(o + 4);
-        o9[0] = a.x; o9[1] = a.y; o9[2] = a.z; o9[3] = a.w; o9[4] = b.x; o9[5] = b.y; o9[6] = b.z; o9[7] = b.w; o9[8] = o[8];
+    // ---- phase 1 ---------------------------------------------------------------------------------------------
+    // Loads first, all of them: the candidate records of this thread (16 bytes each, consecutive threads on consecutive
+    // records), the per-env flags and — lane = slot — the slot modes; the role work of waves 0 / 1 runs under their latency.
+    const float4* csrc = reinterpret_cast<const float4*>(A.cand) + (size_t)e0 * m_cand;
+    const uint8_t* msrc = A.cand_mode + (size_t)e0 * m_cand;
+    const int n_rec = nE * m_cand;
+    float4 cv[4];
+    unsigned cm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k;
+        cv[k] = make_float4(0, 0, 0, 0); cm[k] = EB_VMODE_EMPTY;
+        if (idx < n_rec) { cv[k] = csrc[idx]; cm[k] = msrc[idx]; }
+    }
+    // (waves 1-3) the first batch of compute_rewards' (env, old slot) pairs: their (x, y) are needed in phase 2 only
+    const int n_pairs = nE * NV, pt_ = tid - 64;
+    float2 pxy[4];
+    auto load_pairs = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = base + pt_ + 192 * k;
+            pxy[k] = make_float2(1e30f, 1e30f);                                  // (past the end: never near)
+            if (wave > 0 && p < n_pairs) {
+                const int e = fast_div(p, A.nv_magic), j = p - e * NV;
+                const f2a4 q = *reinterpret_cast<const f2a4*>(A.obs + (size_t)D * (e0 + e) + 6 + T + 4 * j);
+                pxy[k] = make_float2(q.x, q.y);
+            }
+        }
+    };
+    load_pairs(0);
+    const int slot_mode = lane < NV ? A.modes.mode[lane] : 0xff;                        // lane = slot
+    const bool red_light = live && A.v_light && A.v_light[i] != 0;
+    const bool light = red_light || (live && A.virtual_flag && A.virtual_flag[i] != 0);   // E2E:387-388
+    float nx[6] = {0, 0, 0, 0, 0, 0};                                        // wave 0
+    float steer = 0.0f, a_x = 0.0f, o9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // wave 1
+    float road_t = 0.0f, road_r = 0.0f, miu_r = 0.0f;
+    if (wave < 2 && live) {
         const float2 r2 = reinterpret_cast<const float2*>(A.raw)[i];
-        raw0 = r2.x; raw1 = r2.y;
         const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
         const float2 g0 = eg[0], g1 = eg[1], g2 = eg[2];
-        st[0] = g0.x; st[1] = g0.y; st[2] = g1.x; st[3] = g1.y; st[4] = g2.x; st[5] = g2.y;
-        float es, ec;
-        sincos_det(deg2rad(o9[5]), es, ec);                                        // DAM:211
-        pts = make_float4(o9[3] + LWS * ec, o9[4] + LWS * es, o9[3] - LWS * ec, o9[4] - LWS * es);
-        s_pts[lane] = pts;
-    } else if (wave != 0) {
-        // the traffic step (TRF:220-238's role): the model's own prediction step per candidate, staged for the rest
-        const int t = tid - 64;
-        const float4* src = reinterpret_cast<const float4*>(A.cand) + (size_t)e0 * m_cand;
-        const uint8_t* msrc = A.cand_mode + (size_t)e0 * m_cand;
-        const int total = nE * m_cand;
-        for (int idx = t; idx < total; idx += 192) {
+        const float st[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
+        if (wave == 1) {
+            const float* o = A.obs + (size_t)D * i;
+            const f4a4 a = *reinterpret_cast<const f4a4*>(o), b = *reinterpret_cast<const f4a4*>(o + 4);
+            o9[0] = a.x; o9[1] = a.y; o9[2] = a.z; o9[3] = a.w; o9[4] = b.x; o9[5] = b.y; o9[6] = b.z; o9[7] = b.w; o9[8] = o[8];
+        }
+        action_transform(r2.x, r2.y, steer, a_x);                              // E2E:133
+        if (wave == 0) {
+            // E2E:135 = env_ego_step_row without the tyre parameters (wave 1 has those)
+            const float phi_rad = deg2rad(st[5]);
+            float sn, cs;
+            sincos_det(phi_rad, sn, cs);
+            f_xu_core(st, steer, a_x, TAU10, phi_rad, sn, cs, nx);             // E2E:279
+            nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;                              // E2E:281
+            nx[5] = wrap_deal_with_phi(nx[5]);                                 // E2E:282
+            s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
+            s_newr[lane] = nx[2];
+            float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
+            ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
+            if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
+        } else {
+            float es, ec;
+            sincos_det(deg2rad(o9[5]), es, ec);                                // DAM:211
+            const float4 pts = make_float4(o9[3] + LWS * ec, o9[4] + LWS * es, o9[3] - LWS * ec, o9[4] - LWS * es);
+            s_pts[lane] = pts;
+            s_oldc[lane] = make_float2(o9[3], o9[4]);
+            float pr[4];
+            f_xu_params(st, steer, a_x, pr);                                   // E2E:279 (the parameters of the same f_xu call)
+            reinterpret_cast<float4*>(A.params)[i] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+            miu_r = pr[3];
+            road_terms<TASK>(pts.x, pts.y, road_t, road_r);                    // DAM:231-295
+            road_terms<TASK>(pts.z, pts.w, road_t, road_r);
+        }
+    }
+    {   // the traffic step (TRF:220-238's role): the model's own prediction step per candidate, staged for the rest
+        auto stage = [&](int idx, const float4 v, unsigned mode) {
             const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
-            const float4 v = src[idx];
             const float phi_rad = deg2rad(v.w);
             float sn, cs;
             sincos_det(phi_rad, sn, cs);
             s_cand[e * RS4 + c] = veh_predict_one(v.x, v.y, v.z, phi_rad, sn, cs, sturn[c]);
-            s_mode[e * MS + c] = msrc[idx];
+            s_tag[e * TS4 * 4 + c] = (uint8_t)mode;
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < n_rec) stage(tid + 256 * k, cv[k], cm[k]);
+        for (int base = 1024; base < n_rec; base += 1024) {                    // more than 16 candidates per env: further batches of 4
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + tid + 256 * k;
+                if (idx < n_rec) { cv[k] = csrc[idx]; cm[k] = msrc[idx]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (base + tid + 256 * k < n_rec) stage(base + tid + 256 * k, cv[k], cm[k]);
         }
     }
-    __syncthreads();   // barrier 0: s_pts, s_cand, s_mode
+    ES_MARK(1);
+    __syncthreads();   // barrier: s_ego, s_pts, s_oldc, s_cand, mode bytes
 
-    float steer = 0.0f, a_x = 0.0f, nx[6] = {0, 0, 0, 0, 0, 0}, pr[4] = {0, 0, 0, 0};
-    float road_t = 0.0f, road_r = 0.0f;
+    // ---- phase 2 ---------------------------------------------------------------------------------------------
+    float delta_y = 0.0f;
     if (wave == 0) {
         if (live) {
-            action_transform(raw0, raw1, steer, a_x);                              // E2E:133
-            if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
-            road_terms<TASK>(pts.x, pts.y, road_t, road_r);                        // DAM:231-295
-            road_terms<TASK>(pts.z, pts.w, road_t, road_r);
-            env_ego_step_row(st, steer, a_x, nx, pr);                              // E2E:135
-            float2* eg = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
-            eg[0] = make_float2(nx[0], nx[1]); eg[1] = make_float2(nx[2], nx[3]); eg[2] = make_float2(nx[4], nx[5]);
-            reinterpret_cast<float4*>(A.params)[i] = make_float4(pr[0], pr[1], pr[2], pr[3]);
-            s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
-        }
-    } else {
-        const int t = tid - 64;
-        // compute_rewards' vehicle loop on the CURRENT observation (DAM:218-229), one lane per (env, slot)
-        const int pairs = nE * NV;
-        for (int p = t; p < pairs; p += 192) {
-            const int e = fast_div(p, A.nv_magic), j = p - e * NV;
-            const f4a4 v = *reinterpret_cast<const f4a4*>(A.obs + (size_t)D * (e0 + e) + 6 + T + 4 * j);
-            float vs, vc, t35[4], t25[4];
-            sincos_det(deg2rad(v.w), vs, vc);
-            veh2veh_terms(s_pts[e], v.x, v.y, vs, vc, t35, t25);
-            s_part[e * NV + j] = make_float2(((t35[0] + t35[1]) + t35[2]) + t35[3], ((t25[0] + t25[1]) + t25[2]) + t25[3]);
-        }
-    }
-    __syncthreads();   // barrier 1: s_cand, s_mode, s_part, s_ego
-
-    if (live) {
-        float* orow = s_out + lane * OS;
-        const float4 eg = s_ego[lane];
-        const float ex = eg.x, ey = eg.y;
-        if (wave == 0) {
-            // E2E:134: the reward of the step taken from the CURRENT observation
-            float v2v_train = 0.0f, v2v_real = 0.0f;
-            for (int j = 0; j < NV; ++j) {
-                const float2 q = s_part[lane * NV + j];
-                v2v_train += q.x;
-                v2v_real += q.y;
-            }
-            const float punish_steer = -sq(steer), punish_a_x = -sq(a_x), punish_yaw_rate = -sq(o9[2]);
-            const float devi_y = -sq(o9[6]), devi_phi = -sq(deg2rad(o9[7])), devi_v = -sq(o9[8]);
-            const float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
-                                  5.0f * punish_steer + 0.05f * punish_a_x;
-            const size_t n = (size_t)n_env;
-            float* out5 = A.out5;
-            out5[i] = rewards;
-            out5[n + i] = v2v_train + road_t;
-            out5[2 * n + i] = v2v_real + road_r;
-            out5[3 * n + i] = v2v_real;
-            out5[4 * n + i] = road_r;
-            if (float* d16 = A.d16) {   // DAM:302-318
-                d16[i] = punish_steer; d16[n + i] = punish_a_x; d16[2 * n + i] = punish_yaw_rate;
-                d16[3 * n + i] = devi_v; d16[4 * n + i] = devi_y; d16[5 * n + i] = devi_phi;
-                d16[6 * n + i] = 5.0f * punish_steer; d16[7 * n + i] = 0.05f * punish_a_x;
-                d16[8 * n + i] = 0.02f * punish_yaw_rate; d16[9 * n + i] = 0.05f * devi_v;
-                d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
-                d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
-            }
             // E2E:329-338 ego vector, E2E:293-297 tracking error on the env's path
+            float* orow = s_out + lane * OS;
+            const float ex = nx[3], ey = nx[4];
 #pragma unroll
             for (int c = 0; c < 6; ++c) orow[c] = nx[c];
             const PathTables& pt = A.pt;
@@ -198,9 +258,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                 }
                 const int idx = bi * 10, len = pt.len[p];
                 const int ci = clamp_index(idx, len);
-                orow[6] = two2one<TASK>(ex, ey, pt.x[p][ci], pt.y[p][ci]);
-                orow[7] = deal_with_phi_diff(eg.z - pt.phi[p][ci]);
-                orow[8] = eg.w - EXP_V;
+                delta_y = two2one<TASK>(ex, ey, pt.x[p][ci], pt.y[p][ci]);
+                orow[6] = delta_y;
+                orow[7] = deal_with_phi_diff(nx[5] - pt.phi[p][ci]);
+                orow[8] = nx[0] - EXP_V;
                 int cur = idx;
                 for (int k = 0; k < n_future; ++k) {
                     cur += 80;
@@ -208,105 +269,268 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                     const int fi = clamp_index(cur, len);
                     orow[9 + 3 * k] = pt.x[p][fi] - ex;
                     orow[10 + 3 * k] = pt.y[p][fi] - ey;
-                    orow[11 + 3 * k] = deal_with_phi_diff(eg.z - pt.phi[p][fi]);
+                    orow[11 + 3 * k] = deal_with_phi_diff(nx[5] - pt.phi[p][fi]);
                 }
             }
         }
-        // E2E:340-464: the distinct modes of the slot list are dealt to the waves, wave 0 (which has the chain above) last
-        const float4* crow = s_cand + lane * RS4;
-        const uint8_t* mrow = s_mode + lane * MS;
-        const bool light = (A.v_light && A.v_light[i] != 0) || (A.virtual_flag && A.virtual_flag[i] != 0);   // E2E:387-388
-        const bool virt = TASK != TASK_RIGHT && light && ey < -HALF_CROSS;                                   // E2E:386-388
-        float* ov = orow + 6 + T;
-        uint8_t* list = s_list + (wave * 64 + lane) * (m_cand + 1);
-        int distinct = 0;
-        for (int s = 0; s < NV; ++s) {
-            const int m = smode[s];
-            bool first = true;
-            for (int t2 = 0; t2 < s; ++t2) first = first && smode[t2] != m;
-            if (!first) continue;
-            if (((++distinct) & 3) != wave) continue;
-            int L = 0;
-            for (int c = 0; c <= m_cand; ++c) {
-                V4 v;
-                if (!fetch_candidate_lds(m, c, m_cand, crow, mrow, virt, v)) continue;
-                if (!veh_in_range(TASK, m, v, ex, ey)) continue;
-                list[L++] = (uint8_t)c;
+    } else {
+        unsigned short* myq = s_queue + wave * ES_QCAP;
+        {   // compute_rewards' vehicle loop on the CURRENT observation (DAM:218-229), one lane per (env, slot).  A circle pair
+            // can only be closer than 3.5 m when the two centres are within 3.5 + 2 * 1.4 = 6.3 m: pairs inside 6.364 m
+            // (slack >> fp32 rounding; the rollout kernel's test) are queued, every other pair contributes exact zeros.
+            auto body = [&](int item) {
+                const int e = item >> 6, j = item & 63;
+                const f4a4 v = *reinterpret_cast<const f4a4*>(A.obs + (size_t)D * (e0 + e) + 6 + T + 4 * j);
+                float vs, vc, t35[4], t25[4];
+                sincos_det(deg2rad(v.w), vs, vc);
+                veh2veh_terms(s_pts[e], v.x, v.y, vs, vc, t35, t25);
+                s_part[e * NV + j] = make_float2(((t35[0] + t35[1]) + t35[2]) + t35[3], ((t25[0] + t25[1]) + t25[2]) + t25[3]);
+            };
+            WaveQueue<decltype(body)> Q{myq, 0, body};
+            for (int base = 0; base < n_pairs; base += 192 * 4) {              // four pairs per lane per batch
+                if (base > 0) load_pairs(base);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = base + pt_ + 192 * k;
+                    const bool valid = p < n_pairs;
+                    const int e = valid ? fast_div(p, A.nv_magic) : 0, j = valid ? p - e * NV : 0;
+                    const float2 c = s_oldc[e];
+                    const float dx = pxy[k].x - c.x, dy = pxy[k].y - c.y;
+                    const bool near = valid && dx * dx + dy * dy < 40.5f;
+                    if (valid && !near) s_part[e * NV + j] = make_float2(0.0f, 0.0f);
+                    Q.push(near, e * 64 + j);
+                }
             }
-            V4 prev = {0, 0, 0, 0};
+            Q.flush();
+        }
+        ES_MARK(5);
+        {   // one lane per (env, candidate): range tag (E2E:393-411) and the collision test (TRF:263-295: 10 m box first)
+            auto body = [&](int item) {
+                const int e = item >> 6, c = item & 63;
+                const float4 eg = s_ego[e];
+                const EgoCircles E = ego_circles(eg.x, eg.y, eg.z);
+                const size_t ck = (size_t)(e0 + e) * m_cand + c;
+                if (collision_with(E, eg.x, eg.y, s_cand[e * RS4 + c], A.cand_lw ? A.cand_lw[ck * 2] : 4.8f,
+                                   A.cand_lw ? A.cand_lw[ck * 2 + 1] : 2.0f))
+                    s_col[e] = 1;
+            };
+            WaveQueue<decltype(body)> Q{myq, 0, body};
+            const int t = tid - 64;
+            for (int base = 0; base < n_rec; base += 192 * 2) {                // two records per lane in flight
+                float4 v2[2], eg2[2];
+                int m2[2], e2[2], c2[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = base + t + 192 * k;
+                    e2[k] = 0; c2[k] = 0;
+                    if (idx < n_rec) { e2[k] = fast_div(idx, A.m_magic); c2[k] = idx - e2[k] * m_cand; }
+                    v2[k] = s_cand[e2[k] * RS4 + c2[k]];
+                    eg2[k] = s_ego[e2[k]];
+                    m2[k] = s_tag[e2[k] * TS4 * 4 + c2[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bool valid = base + t + 192 * k < n_rec;
+                    const int m = m2[k];
+                    const bool ok = in_range_row(s_range[m < 12 ? m : 12], v2[k].x, v2[k].y, eg2[k].x, eg2[k].y);
+                    if (valid) s_tag[e2[k] * TS4 * 4 + c2[k]] = (uint8_t)(ok ? m : 0xff);
+                    const bool box = valid && m != EB_VMODE_EMPTY && __builtin_fabsf(v2[k].x - eg2[k].x) < 10.0f &&
+                                     __builtin_fabsf(v2[k].y - eg2[k].y) < 10.0f;
+                    Q.push(box, e2[k] * 64 + c2[k]);
+                }
+            }
+            Q.flush();
+        }
+    }
+    ES_MARK(2);
+    __syncthreads();   // barrier: s_part, tags, s_col, the row heads
+
+    // ---- phase 3 ---------------------------------------------------------------------------------------------
+    if (wave == 1 && live) {
+        // E2E:134: the reward of the step taken from the CURRENT observation; penalty partials in vehicle order
+        float v2v_train = 0.0f, v2v_real = 0.0f;
+        for (int j = 0; j < NV; ++j) {
+            const float2 q = s_part[lane * NV + j];
+            v2v_train += q.x;
+            v2v_real += q.y;
+        }
+        const float punish_steer = -sq(steer), punish_a_x = -sq(a_x), punish_yaw_rate = -sq(o9[2]);
+        const float devi_y = -sq(o9[6]), devi_phi = -sq(deg2rad(o9[7])), devi_v = -sq(o9[8]);
+        const float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                              5.0f * punish_steer + 0.05f * punish_a_x;
+        const size_t n = (size_t)n_env;
+        float* out5 = A.out5;
+        out5[i] = rewards;
+        out5[n + i] = v2v_train + road_t;
+        out5[2 * n + i] = v2v_real + road_r;
+        out5[3 * n + i] = v2v_real;
+        out5[4 * n + i] = road_r;
+        if (float* d16 = A.d16) {   // DAM:302-318
+            d16[i] = punish_steer; d16[n + i] = punish_a_x; d16[2 * n + i] = punish_yaw_rate;
+            d16[3 * n + i] = devi_v; d16[4 * n + i] = devi_y; d16[5 * n + i] = devi_phi;
+            d16[6 * n + i] = 5.0f * punish_steer; d16[7 * n + i] = 0.05f * punish_a_x;
+            d16[8 * n + i] = 0.02f * punish_yaw_rate; d16[9 * n + i] = 0.05f * devi_v;
+            d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
+            d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
+        }
+        // the done predicates that need only the new ego state (E2E:223-256)
+        const float4 eg = s_ego[lane];
+        s_jbits[lane] = (uint8_t)judge_bits(TASK, eg.w, s_newr[lane], eg.x, eg.y, eg.z, miu_r, red_light);
+    }
+    ES_MARK(6);
+    {
+        // E2E:340-464.  The slot plan is scalar: lane s of `slot_mode` holds the mode of slot s, so the distinct modes (first
+        // occurrences: A.first_mask), their owners (waves 2, 3, 1, 0 in turn) and a mode's slots (a ballot) cost no memory
+        // access; per mode (wave-uniform) and env (lane) the tag row becomes a candidate set and the slots are filled by
+        // repeated selection over it with branch-free key comparisons.
+        const float4 eg = s_ego[lane];
+        const float ex = eg.x, ey = eg.y;
+        const float4* crow = s_cand + lane * RS4;
+        const unsigned* trow = s_tag32 + lane * TS4;
+        const bool virt = TASK != TASK_RIGHT && light && ey < -HALF_CROSS;                                   // E2E:386-388
+        float* ov = s_out + lane * OS + 6 + T;
+        const int nw = (m_cand + 3) >> 2;
+        unsigned long long firsts = A.first_mask;
+        for (int k = 0; firsts; ++k) {
+            const int s = __builtin_ctzll(firsts);
+            firsts &= firsts - 1ull;
+            if (((0x1e >> (2 * (k & 3))) & 3) != wave) continue;               // owners in turn: waves 2, 3, 1, 0
+            const int m = __builtin_amdgcn_readlane(slot_mode, s);
+            unsigned long long slots = __builtin_amdgcn_ballot_w64(slot_mode == m);   // the mode's slots, ascending
+            if (!live) continue;
+            const KeySpec ks = key_spec(TASK, m);
+            // the env's in-range candidates of this mode as a bit set (tag == m), 4 tags per dword
+            unsigned long long elig = 0ull;
+            const unsigned mm = (unsigned)m * 0x01010101u;
+            for (int w = 0; w < nw; ++w) {
+                const unsigned x = trow[w] ^ mm;
+                const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
+                const unsigned nib = (((z >> 7) * 0x01020408u) >> 24) & 0xfu;
+                elig |= (unsigned long long)nib << (4 * w);
+            }
+            // the virtual red-light car of the mode (E2E:386-390), candidate index m_cand
+            const V4 vv = {m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f};
+            const bool has_virt = virt && (m == EB_VMODE_DL || m == EB_VMODE_DU) && veh_in_range(TASK, m, vv, ex, ey);
+            const float2 vk = key_of(ks, vv.x, vv.y);
+            const V4 fill = veh_fill_value(m);
+            const float4 fill4 = make_float4(fill.x, fill.y, fill.v, fill.phi);   // slice_or_fill, E2E:431-437
+            const float4 vv4 = make_float4(vv.x, vv.y, vv.v, vv.phi);
+            if (__popcll(slots) <= 2) {
+                // the usual case (the native lists have at most two slots per mode, VEHICLE_MODE_DICT UTL:21-23): the first
+                // two of the candidate set under (key, insertion index) in ONE walk, each record read once
+                float2 k1 = make_float2(0.0f, 0.0f), k2 = k1;
+                float4 r1 = fill4, r2 = fill4;
+                int i1 = -1, i2 = -1;
+                unsigned long long rest = elig;
+                float4 nxt = make_float4(0, 0, 0, 0);
+                int nc = -1;
+                if (rest) { nc = __builtin_ctzll(rest); rest &= rest - 1ull; nxt = crow[nc]; }
+                while (nc >= 0) {
+                    const float4 q = nxt;
+                    const int c = nc;
+                    nc = -1;
+                    if (rest) { nc = __builtin_ctzll(rest); rest &= rest - 1ull; nxt = crow[nc]; }   // the next read under this compare
+                    const float2 kk = key_of(ks, q.x, q.y);
+                    // candidates arrive in ascending index: c sorts before an earlier one only with a strictly smaller key
+                    if (i1 < 0 || key_less(kk, k1)) { k2 = k1; r2 = r1; i2 = i1; k1 = kk; r1 = q; i1 = c; }
+                    else if (i2 < 0 || key_less(kk, k2)) { k2 = kk; r2 = q; i2 = c; }
+                }
+                if (has_virt) {                                                    // index m_cand: after every real candidate
+                    if (i1 < 0 || key_less(vk, k1)) { k2 = k1; r2 = r1; i2 = i1; k1 = vk; r1 = vv4; i1 = m_cand; }
+                    else if (i2 < 0 || key_less(vk, k2)) { k2 = vk; r2 = vv4; i2 = m_cand; }
+                }
+                const int sa = __builtin_ctzll(slots);
+                *reinterpret_cast<f4a4*>(ov + 4 * sa) = f4a4{r1.x, r1.y, r1.z, r1.w};
+                slots &= slots - 1ull;
+                if (slots) {
+                    const int sb = __builtin_ctzll(slots);
+                    *reinterpret_cast<f4a4*>(ov + 4 * sb) = f4a4{r2.x, r2.y, r2.z, r2.w};
+                }
+                continue;
+            }
+            float2 prev_k = make_float2(0.0f, 0.0f);
             int prev_i = -1;
             bool found = true;
-            for (int s2 = s; s2 < NV; ++s2) {
-                if (smode[s2] != m) continue;
+            while (slots) {
+                const int s2 = __builtin_ctzll(slots);
+                slots &= slots - 1ull;
+                float4 r = fill4;
                 if (found) {
-                    V4 best = {0, 0, 0, 0};
+                    float2 best_k = make_float2(0.0f, 0.0f);
                     int best_i = -1;
-                    for (int q = 0; q < L; ++q) {
-                        const int c = list[q];
-                        V4 v;
-                        fetch_candidate_lds(m, c, m_cand, crow, mrow, virt, v);
-                        if (prev_i >= 0) {
-                            const int cp = veh_cmp(TASK, m, prev, v);
-                            if (!(cp < 0 || (cp == 0 && prev_i < c))) continue;   // not after the previous pick
-                        }
-                        if (best_i < 0 || veh_cmp(TASK, m, v, best) < 0) { best = v; best_i = c; }
+                    unsigned long long rest = elig;
+                    while (rest) {
+                        const int c = __builtin_ctzll(rest);
+                        rest &= rest - 1ull;
+                        const float2 xy = *reinterpret_cast<const float2*>(crow + c);
+                        const float2 kk = key_of(ks, xy.x, xy.y);
+                        const bool after = prev_i < 0 || key_before(prev_k, prev_i, kk, c);      // not yet picked
+                        const bool better = best_i < 0 || key_less(kk, best_k);
+                        if (after && better) { best_k = kk; best_i = c; }
+                    }
+                    if (has_virt) {
+                        const bool after = prev_i < 0 || key_before(prev_k, prev_i, vk, m_cand);
+                        const bool better = best_i < 0 || key_less(vk, best_k);
+                        if (after && better) { best_k = vk; best_i = m_cand; }
                     }
                     if (best_i < 0) found = false;
-                    else { prev = best; prev_i = best_i; }
+                    else {
+                        prev_k = best_k; prev_i = best_i;
+                        r = best_i < m_cand ? crow[best_i] : vv4;
+                    }
                 }
-                const V4 r = found ? prev : veh_fill_value(m);                 // slice_or_fill, E2E:431-437
-                ov[4 * s2] = r.x; ov[4 * s2 + 1] = r.y; ov[4 * s2 + 2] = r.v; ov[4 * s2 + 3] = r.phi;
+                *reinterpret_cast<f4a4*>(ov + 4 * s2) = f4a4{r.x, r.y, r.z, r.w};
             }
         }
     }
-    __syncthreads();   // barrier 2: s_out complete, index lists dead
+    ES_MARK(3);
+    __syncthreads();   // barrier: s_out complete, s_jbits
 
-    {   // E2E:141: the collision test shared by the four waves (candidates w, w + 4, ...)
-        bool col = false;
-        if (live) {
-            const float4 eg = s_ego[lane];
-            const EgoCircles E = ego_circles(eg.x, eg.y, eg.z);
-            const float4* crow = s_cand + lane * RS4;
-            const uint8_t* mrow = s_mode + lane * MS;
-            for (int c = wave; c < m_cand; c += 4) {
-                if (mrow[c] == EB_VMODE_EMPTY) continue;
-                const size_t ck = (size_t)i * m_cand + c;
-                col = col || collision_with(E, eg.x, eg.y, crow[c], A.cand_lw ? A.cand_lw[ck * 2] : 4.8f,
-                                            A.cand_lw ? A.cand_lw[ck * 2 + 1] : 2.0f);
-            }
-        }
-        s_list[wave * 64 + lane] = col ? 1 : 0;
-    }
-    __syncthreads();   // barrier 3
-    if (wave == 0 && live) {
-        const bool collision = (s_list[lane] | s_list[64 + lane] | s_list[128 + lane] | s_list[192 + lane]) != 0;
-        A.done_code[i] = judge_code(TASK, collision, nx[0], nx[2], nx[3], nx[4], nx[5], pr[3], s_out[lane * OS + 6],
-                                    A.v_light && A.v_light[i] != 0);
-    }
-    {   // observation rows out: the tile's rows are contiguous in memory
+    // ---- phase 4 ---------------------------------------------------------------------------------------------
+    if (wave == 0 && live) A.done_code[i] = judge_merge(s_jbits[lane], s_col[lane] != 0, delta_y);        // E2E:200-221
+    {   // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane)
         float* dst = A.obs_out + (size_t)e0 * D;
         const int total = nE * D;
-        for (int idx = tid; idx < total; idx += 256) {
-            const int e = fast_div(idx, A.d_magic), c = idx - e * D;
-            dst[idx] = s_out[e * OS + c];
+        for (int base = tid; base < total; base += 1024) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + 256 * k < total ? base + 256 * k : 0;
+                const int e = fast_div(idx, A.d_magic), c = idx - e * D;
+                v[k] = s_out[e * OS + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (base + 256 * k < total) dst[base + 256 * k] = v[k];
         }
     }
     {   // candidates out, the pool's re-entry rule on the way (eb_traffic_respawn: after the observation saw this step's state)
         float4* dst = reinterpret_cast<float4*>(A.cand) + (size_t)e0 * m_cand;
-        const int total = nE * m_cand;
-        for (int idx = tid; idx < total; idx += 256) {
-            const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
-            float4 v = s_cand[e * RS4 + c];
-            if (A.respawn_entry && (__builtin_fabsf(v.x) > A.limit || __builtin_fabsf(v.y) > A.limit)) {
-                const uint64_t base = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
-                const float u1 = u01(A.seed, base), u2 = u01(A.seed, base + 1);
-                const float* en = A.respawn_entry + 5 * c;
-                const float along = u1 * A.span;
-                v = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
+        for (int base = tid; base < n_rec; base += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + 256 * k < n_rec ? base + 256 * k : 0;
+                const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
+                v[k] = s_cand[e * RS4 + c];
             }
-            dst[idx] = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + 256 * k;
+                if (idx >= n_rec) continue;
+                if (A.respawn_entry && (__builtin_fabsf(v[k].x) > A.limit || __builtin_fabsf(v[k].y) > A.limit)) {
+                    const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
+                    const uint64_t ub = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
+                    const float u1 = u01(A.seed, ub), u2 = u01(A.seed, ub + 1);
+                    const float* en = A.respawn_entry + 5 * c;
+                    const float along = u1 * A.span;
+                    v[k] = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
+                }
+                dst[idx] = v[k];
+            }
         }
     }
+    ES_MARK(4);
 }
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {

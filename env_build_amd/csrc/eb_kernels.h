@@ -118,6 +118,7 @@ struct EnvStepArgs {
     PathTables pt;
     VehModes modes;                        // the observation's slot modes (handle h)
     SlotTurns tturn;                       // turn class of every candidate slot (the traffic handle's modes)
+    unsigned long long first_mask;         // bit s: slot s is the first slot of its mode
     const float* obs;                      // [n_env, D] current observation
     const float* raw;                      // [n_env, 2] raw actions
     const int* ref_idx;
@@ -136,6 +137,7 @@ struct EnvStepArgs {
     const float* respawn_entry;            // NULL: no re-entry stage
     float limit, span, v_max;
     uint64_t seed, counter;
+    long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * 4][8] wall-clock marks, or NULL
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand);
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand);
