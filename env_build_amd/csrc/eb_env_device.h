@@ -194,43 +194,6 @@ EB_DEV uint8_t judge_code(int task, bool collision, float v_x, float r, float x,
     return judge_merge(judge_bits(task, v_x, r, x, y, phi, miu_r, red_light), collision, delta_y);
 }
 
-// veh_in_range (E2E:393-411) as data: every mode's filter is a conjunction of up to four strict comparisons
-//   x > xlo,  x < xhi,  y > ylo,  y < yhi      with constant or ego-relative bounds,
-// so one branch-free evaluation serves lanes whose candidates have different modes (the one-launch step tests one
-// candidate per lane).  Same fp32 operations as veh_in_range: ego_x + 5.0f, ego_y - 2.0f (== ego_y + (-2.0f)), ...
-struct RangeRow {
-    unsigned flags;   // bit 0..3: the four comparisons are active; 4: xhi = ego_x + cxh; 5: ylo = ego_y + cyl; 6: ylo = max25(ylo)
-    float cxl, cxh, cyl, cyh;
-    float pad[3];
-};
-enum { RR_XLO = 1, RR_XHI = 2, RR_YLO = 4, RR_YHI = 8, RR_XHI_EGO = 16, RR_YLO_EGO = 32, RR_YLO_MAX25 = 64 };
-EB_DEV RangeRow range_row(int task, int m) {
-    const float C2 = HALF_CROSS;
-    RangeRow r = {0u, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f, 0.0f}};
-    switch (m) {
-        case EB_VMODE_DL: r.flags = RR_XLO | RR_YLO | RR_YLO_EGO; r.cxl = -C2 - 10.0f; r.cyl = -2.0f; break;
-        case EB_VMODE_DU: r.flags = RR_YLO | RR_YLO_EGO | RR_YHI | RR_XHI | RR_XHI_EGO; r.cyl = -2.0f; r.cyh = C2 + 10.0f; r.cxh = 5.0f; break;
-        case EB_VMODE_DR: r.flags = RR_XHI | RR_YLO | RR_YLO_EGO; r.cxh = C2 + 10.0f; r.cyl = 0.0f; break;
-        case EB_VMODE_RU: r.flags = RR_XHI | RR_YHI; r.cxh = C2 + 10.0f; r.cyh = C2 + 10.0f; break;
-        case EB_VMODE_UR:
-            if (task == TASK_STRAIGHT) { r.flags = RR_XHI | RR_XHI_EGO | RR_YLO | RR_YLO_EGO | RR_YHI; r.cxh = 7.0f; r.cyl = 0.0f; r.cyh = C2 + 10.0f; }
-            else if (task == TASK_RIGHT) { r.flags = RR_XHI | RR_YHI; r.cxh = C2 + 10.0f; r.cyh = C2; }
-            break;
-        case EB_VMODE_UD: r.flags = RR_YLO | RR_YLO_EGO | RR_YLO_MAX25 | RR_YHI | RR_XHI | RR_XHI_EGO; r.cyl = -2.0f; r.cyh = C2; r.cxh = 0.0f; break;
-        case EB_VMODE_UL: r.flags = RR_XLO | RR_XHI | RR_XHI_EGO | RR_YHI; r.cxl = -C2 - 10.0f; r.cxh = 0.0f; r.cyh = C2; break;
-        case EB_VMODE_LR: r.flags = RR_XLO | RR_XHI; r.cxl = -C2 - 10.0f; r.cxh = C2 + 10.0f; break;
-        default: break;
-    }
-    return r;
-}
-EB_DEV bool in_range_row(const RangeRow& r, float x, float y, float ego_x, float ego_y) {
-    const unsigned f = r.flags;
-    const float xhi = (f & RR_XHI_EGO) ? ego_x + r.cxh : r.cxh;
-    float ylo = (f & RR_YLO_EGO) ? ego_y + r.cyl : r.cyl;
-    if (f & RR_YLO_MAX25) ylo = __builtin_fmaxf(ylo, -HALF_CROSS);      // as veh_in_range's UD row
-    return (!(f & RR_XLO) || x > r.cxl) && (!(f & RR_XHI) || x < xhi) && (!(f & RR_YLO) || y > ylo) && (!(f & RR_YHI) || y < r.cyh);
-}
-
 // the same for a candidate row staged in LDS as float4s
 EB_DEV bool fetch_candidate_lds(int m, int i, int m_cand, const float4* row, const uint8_t* mrow, bool virt, V4& v) {
     if (i < m_cand) {

@@ -45,20 +45,24 @@ EB_DEV int es_tag_stride4(int m_cand) { return ((m_cand + 3) >> 2) | 1; }   // d
 EB_DEV int fast_div(int item, unsigned magic) { return magic ? (int)__umulhi((unsigned)item, magic) : item; }   // magic 0: / 1
 constexpr int ES_QCAP = 128;   // per-wave queue: flushed whenever 64 entries are waiting, so 64 + 64 suffice
 
-size_t env_step_lds_bytes(int D, int NV, int m_cand) {
+size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs) {
     const int rs4 = m_cand + ((m_cand & 1) ? 2 : 1), os = D | 1, ts4 = ((m_cand + 3) >> 2) | 1;
-    size_t b = (size_t)64 * rs4 * 16;            // s_cand
-    b += (size_t)64 * os * 4;                    // s_out
-    b += (size_t)64 * NV * 8;                    // s_part
-    b += (size_t)64 * 16 * 2;                    // s_pts, s_ego
-    b += (size_t)64 * 8;                         // s_oldc
-    b += (size_t)64 * ts4 * 4;                   // s_tag
+    const size_t E = (size_t)tile_envs;
+    size_t b = E * rs4 * 16;                     // s_cand
+    b += E * os * 4;                             // s_out
+    b += E * NV * 8;                             // s_part
+    b += E * 16 * 2;                             // s_pts, s_ego
+    b += E * 8;                                  // s_oldc
+    b += E * ts4 * 4;                            // s_tag
     b += (size_t)4 * ES_QCAP * 2;                // s_queue
     return (b + 15) & ~(size_t)15;
 }
+// envs per block: 64 for throughput; small batches take 16-env tiles so that four times as many blocks (and a quarter of
+// the records per lane) stand behind the same step — a step of 4 096 envs is latency, not bandwidth
+int env_step_tile_envs(int n_env) { return n_env <= 16384 ? 16 : 64; }
 
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand) {
-    return m_cand >= 1 && m_cand <= 64 && env_step_lds_bytes(D, NV, m_cand) <= 150 * 1024 &&
+    return m_cand >= 1 && m_cand <= 64 && env_step_lds_bytes(D, NV, m_cand, 64) <= 150 * 1024 &&
            (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
 }
 
@@ -96,31 +100,30 @@ struct WaveQueue {
     EB_DEV void flush() { if (n > 0) run(n); }
 };
 
-template <int TASK>
+template <int TASK, int ET>   // ET: envs per tile (64 or 16); lanes >= ET of the per-env roles idle
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint8_t smode[64], sturn[64], s_col[64], s_jbits[64];
-    __shared__ float s_newr[64];                                                 // new yaw rate (the done predicates' input)
-    __shared__ RangeRow s_range[13];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * 64;
+    __shared__ uint8_t smode[64], sturn[64], s_col[ET];
+    __shared__ float s_miu[ET];                                                  // miu_r of the step (the stability predicate's input)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * ET;
     const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
-    const int nE = n_env - e0 < 64 ? n_env - e0 : 64;
+    const int nE = n_env - e0 < ET ? n_env - e0 : ET;
     const int i = e0 + lane;
-    const bool live = i < n_env;
+    const bool live = lane < nE;
     const int RS4 = obs_cand_stride4(m_cand), OS = es_obs_stride(D), TS4 = es_tag_stride4(m_cand), T = 3 * (n_future + 1);
     float4* s_cand = reinterpret_cast<float4*>(smem);                            // [64][RS4] candidates after the traffic step
-    float* s_out = reinterpret_cast<float*>(s_cand + (size_t)64 * RS4);          // [64][OS]  next observation rows
-    float2* s_part = reinterpret_cast<float2*>(s_out + (size_t)64 * OS);         // [64][NV]  (veh2veh4training, veh2veh4real) per old slot
-    float4* s_pts = reinterpret_cast<float4*>(s_part + (size_t)64 * NV);         // [64]      old ego circle centres (DAM:210-214)
-    float4* s_ego = s_pts + 64;                                                  // [64]      new ego (x, y, phi, v_x)
-    float2* s_oldc = reinterpret_cast<float2*>(s_ego + 64);                      // [64]      old ego centre (obs columns 3, 4)
-    unsigned* s_tag32 = reinterpret_cast<unsigned*>(s_oldc + 64);                // [64][TS4] mode bytes, then range tags
+    float* s_out = reinterpret_cast<float*>(s_cand + (size_t)ET * RS4);          // [64][OS]  next observation rows
+    float2* s_part = reinterpret_cast<float2*>(s_out + (size_t)ET * OS);         // [64][NV]  (veh2veh4training, veh2veh4real) per old slot
+    float4* s_pts = reinterpret_cast<float4*>(s_part + (size_t)ET * NV);         // [64]      old ego circle centres (DAM:210-214)
+    float4* s_ego = s_pts + ET;                                                  // [64]      new ego (x, y, phi, v_x)
+    float2* s_oldc = reinterpret_cast<float2*>(s_ego + ET);                      // [64]      old ego centre (obs columns 3, 4)
+    unsigned* s_tag32 = reinterpret_cast<unsigned*>(s_oldc + ET);                // [64][TS4] mode bytes, then range tags
     uint8_t* s_tag = reinterpret_cast<uint8_t*>(s_tag32);
-    unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_tag32 + (size_t)64 * TS4);   // [4][ES_QCAP]
+    unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_tag32 + (size_t)ET * TS4);   // [4][ES_QCAP]
     ES_MARK(0);
-    if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; s_col[tid] = 0; }
-    if (tid >= 64 && tid < 64 + 13) s_range[tid - 64] = range_row(TASK, tid - 64);     // row 12: no condition (modes without a filter)
-    for (int w = tid; w < 64 * TS4; w += 256) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
+    if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
+    if (tid < ET) s_col[tid] = 0;
+    for (int w = tid; w < ET * TS4; w += 256) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
     __syncthreads();   // (kernel-argument tables only: nobody waits for memory here)
 
     // ---- phase 1 ---------------------------------------------------------------------------------------------
@@ -129,14 +132,22 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     const float4* csrc = reinterpret_cast<const float4*>(A.cand) + (size_t)e0 * m_cand;
     const uint8_t* msrc = A.cand_mode + (size_t)e0 * m_cand;
     const int n_rec = nE * m_cand;
-    float4 cv[4];
-    unsigned cm[4];
+    // chunks of 64 records in groups of eight: waves 2 and 3 take three chunks of a group each, waves 0 and 1 — which
+    // have the ego step and the tyre parameters to do — one each
+    auto rec_index = [&](int group, int k) -> int {
+        const int chunk = wave == 2 ? 2 * k : wave == 3 ? 2 * k + 1 : (k == 0 ? 6 + wave : -1);
+        return chunk < 0 ? -1 : (group * 8 + chunk) * 64 + lane;
+    };
+    float4 cv[2][3];
+    unsigned cm[2][3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k;
-        cv[k] = make_float4(0, 0, 0, 0); cm[k] = EB_VMODE_EMPTY;
-        if (idx < n_rec) { cv[k] = csrc[idx]; cm[k] = msrc[idx]; }
-    }
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = rec_index(g, k);
+            cv[g][k] = make_float4(0, 0, 0, 0); cm[g][k] = EB_VMODE_EMPTY;
+            if (idx >= 0 && idx < n_rec) { cv[g][k] = csrc[idx]; cm[g][k] = msrc[idx]; }
+        }
     // (waves 1-3) the first batch of compute_rewards' (env, old slot) pairs: their (x, y) are needed in phase 2 only
     const int n_pairs = nE * NV, pt_ = tid - 64;
     float2 pxy[4];
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     const bool light = red_light || (live && A.virtual_flag && A.virtual_flag[i] != 0);   // E2E:387-388
     float nx[6] = {0, 0, 0, 0, 0, 0};                                        // wave 0
     float steer = 0.0f, a_x = 0.0f, o9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // wave 1
-    float road_t = 0.0f, road_r = 0.0f, miu_r = 0.0f;
+    float road_t = 0.0f, road_r = 0.0f;
     if (wave < 2 && live) {
         const float2 r2 = reinterpret_cast<const float2*>(A.raw)[i];
         const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
@@ -179,7 +190,6 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
             nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;                              // E2E:281
             nx[5] = wrap_deal_with_phi(nx[5]);                                 // E2E:282
             s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
-            s_newr[lane] = nx[2];
             float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
             ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
             if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
@@ -192,32 +202,38 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
             float pr[4];
             f_xu_params(st, steer, a_x, pr);                                   // E2E:279 (the parameters of the same f_xu call)
             reinterpret_cast<float4*>(A.params)[i] = make_float4(pr[0], pr[1], pr[2], pr[3]);
-            miu_r = pr[3];
+            s_miu[lane] = pr[3];
             road_terms<TASK>(pts.x, pts.y, road_t, road_r);                    // DAM:231-295
             road_terms<TASK>(pts.z, pts.w, road_t, road_r);
         }
     }
     {   // the traffic step (TRF:220-238's role): the model's own prediction step per candidate, staged for the rest
+        const SinCosK SK = sincos_consts();
         auto stage = [&](int idx, const float4 v, unsigned mode) {
             const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
-            const float phi_rad = deg2rad(v.w);
-            float sn, cs;
-            sincos_det(phi_rad, sn, cs);
-            s_cand[e * RS4 + c] = veh_predict_one(v.x, v.y, v.z, phi_rad, sn, cs, sturn[c]);
+            float sn, cs;     // (the record loop of the rollout kernel: one code path for every turn class, eb_device.h)
+            const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs);
+            s_cand[e * RS4 + c] = make_float4(r.x, r.y, r.z, r.w);
             s_tag[e * TS4 * 4 + c] = (uint8_t)mode;
         };
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (tid + 256 * k < n_rec) stage(tid + 256 * k, cv[k], cm[k]);
-        for (int base = 1024; base < n_rec; base += 1024) {                    // more than 16 candidates per env: further batches of 4
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = base + tid + 256 * k;
-                if (idx < n_rec) { cv[k] = csrc[idx]; cm[k] = msrc[idx]; }
+            for (int k = 0; k < 3; ++k) {
+                const int idx = rec_index(g, k);
+                if (idx >= 0 && idx < n_rec) stage(idx, cv[g][k], cm[g][k]);
+            }
+        for (int g = 2; g * 512 < n_rec; ++g) {                                // more than 16 candidates per env: one group at a time
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = rec_index(g, k);
+                if (idx >= 0 && idx < n_rec) { cv[0][k] = csrc[idx]; cm[0][k] = msrc[idx]; }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (base + tid + 256 * k < n_rec) stage(base + tid + 256 * k, cv[k], cm[k]);
+            for (int k = 0; k < 3; ++k) {
+                const int idx = rec_index(g, k);
+                if (idx >= 0 && idx < n_rec) stage(idx, cv[0][k], cm[0][k]);
+            }
         }
     }
     ES_MARK(1);
@@ -273,6 +289,33 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                 }
             }
         }
+        // candidates out (they are final since the barrier), the pool's re-entry rule on the way (eb_traffic_respawn: it
+        // applies after the observation and the done code saw this step's state — both read the LDS copy); this wave
+        // would otherwise idle here while the others test pairs
+        float4* cdst = reinterpret_cast<float4*>(A.cand) + (size_t)e0 * m_cand;
+        for (int base = lane; base < n_rec; base += 256) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + 64 * k < n_rec ? base + 64 * k : 0;
+                const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
+                v[k] = s_cand[e * RS4 + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + 64 * k;
+                if (idx >= n_rec) continue;
+                if (A.respawn_entry && (__builtin_fabsf(v[k].x) > A.limit || __builtin_fabsf(v[k].y) > A.limit)) {
+                    const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
+                    const uint64_t ub = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
+                    const float u1 = u01(A.seed, ub), u2 = u01(A.seed, ub + 1);
+                    const float* en = A.respawn_entry + 5 * c;
+                    const float along = u1 * A.span;
+                    v[k] = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
+                }
+                cdst[idx] = v[k];
+            }
+        }
     } else {
         unsigned short* myq = s_queue + wave * ES_QCAP;
         {   // compute_rewards' vehicle loop on the CURRENT observation (DAM:218-229), one lane per (env, slot).  A circle pair
@@ -304,7 +347,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
             Q.flush();
         }
         ES_MARK(5);
-        {   // one lane per (env, candidate): range tag (E2E:393-411) and the collision test (TRF:263-295: 10 m box first)
+        {   // one lane per (env, candidate): the collision test (TRF:263-295), its 10 m box first
             auto body = [&](int item) {
                 const int e = item >> 6, c = item & 63;
                 const float4 eg = s_ego[e];
@@ -315,28 +358,23 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                     s_col[e] = 1;
             };
             WaveQueue<decltype(body)> Q{myq, 0, body};
-            const int t = tid - 64;
-            for (int base = 0; base < n_rec; base += 192 * 2) {                // two records per lane in flight
-                float4 v2[2], eg2[2];
-                int m2[2], e2[2], c2[2];
+            for (int base = 0; base < n_rec; base += 192 * 3) {                // three records per lane in flight
+                float2 v3[3], eg3[3];
+                int m3[3], e3[3], c3[3];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int idx = base + t + 192 * k;
-                    e2[k] = 0; c2[k] = 0;
-                    if (idx < n_rec) { e2[k] = fast_div(idx, A.m_magic); c2[k] = idx - e2[k] * m_cand; }
-                    v2[k] = s_cand[e2[k] * RS4 + c2[k]];
-                    eg2[k] = s_ego[e2[k]];
-                    m2[k] = s_tag[e2[k] * TS4 * 4 + c2[k]];
+                for (int k = 0; k < 3; ++k) {
+                    const int idx = base + pt_ + 192 * k;
+                    e3[k] = 0; c3[k] = 0;
+                    if (idx < n_rec) { e3[k] = fast_div(idx, A.m_magic); c3[k] = idx - e3[k] * m_cand; }
+                    v3[k] = *reinterpret_cast<const float2*>(s_cand + e3[k] * RS4 + c3[k]);
+                    eg3[k] = *reinterpret_cast<const float2*>(s_ego + e3[k]);
+                    m3[k] = s_tag[e3[k] * TS4 * 4 + c3[k]];
                 }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const bool valid = base + t + 192 * k < n_rec;
-                    const int m = m2[k];
-                    const bool ok = in_range_row(s_range[m < 12 ? m : 12], v2[k].x, v2[k].y, eg2[k].x, eg2[k].y);
-                    if (valid) s_tag[e2[k] * TS4 * 4 + c2[k]] = (uint8_t)(ok ? m : 0xff);
-                    const bool box = valid && m != EB_VMODE_EMPTY && __builtin_fabsf(v2[k].x - eg2[k].x) < 10.0f &&
-                                     __builtin_fabsf(v2[k].y - eg2[k].y) < 10.0f;
-                    Q.push(box, e2[k] * 64 + c2[k]);
+                for (int k = 0; k < 3; ++k) {
+                    const bool box = base + pt_ + 192 * k < n_rec && m3[k] != EB_VMODE_EMPTY &&
+                                     __builtin_fabsf(v3[k].x - eg3[k].x) < 10.0f && __builtin_fabsf(v3[k].y - eg3[k].y) < 10.0f;
+                    Q.push(box, e3[k] * 64 + c3[k]);
                 }
             }
             Q.flush();
@@ -373,10 +411,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
             d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
             d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
         }
-        // the done predicates that need only the new ego state (E2E:223-256)
-        const float4 eg = s_ego[lane];
-        s_jbits[lane] = (uint8_t)judge_bits(TASK, eg.w, s_newr[lane], eg.x, eg.y, eg.z, miu_r, red_light);
     }
+    unsigned jbits = 0u;
+    if (wave == 0 && live)   // the done predicates that need only the new ego state (E2E:223-256)
+        jbits = judge_bits(TASK, nx[0], nx[2], nx[3], nx[4], nx[5], s_miu[lane], red_light);
     ES_MARK(6);
     {
         // E2E:340-464.  The slot plan is scalar: lane s of `slot_mode` holds the mode of slot s, so the distinct modes (first
@@ -399,7 +437,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
             unsigned long long slots = __builtin_amdgcn_ballot_w64(slot_mode == m);   // the mode's slots, ascending
             if (!live) continue;
             const KeySpec ks = key_spec(TASK, m);
-            // the env's in-range candidates of this mode as a bit set (tag == m), 4 tags per dword
+            // the env's candidates of this mode as a bit set (mode byte == m), 4 bytes per dword; the range filter of
+            // E2E:393-411 is applied in the walk below, where the mode is wave-uniform
             unsigned long long elig = 0ull;
             const unsigned mm = (unsigned)m * 0x01010101u;
             for (int w = 0; w < nw; ++w) {
@@ -430,6 +469,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                     const int c = nc;
                     nc = -1;
                     if (rest) { nc = __builtin_ctzll(rest); rest &= rest - 1ull; nxt = crow[nc]; }   // the next read under this compare
+                    if (!veh_in_range(TASK, m, V4{q.x, q.y, q.z, q.w}, ex, ey)) continue;
                     const float2 kk = key_of(ks, q.x, q.y);
                     // candidates arrive in ascending index: c sorts before an earlier one only with a strictly smaller key
                     if (i1 < 0 || key_less(kk, k1)) { k2 = k1; r2 = r1; i2 = i1; k1 = kk; r1 = q; i1 = c; }
@@ -447,6 +487,16 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                     *reinterpret_cast<f4a4*>(ov + 4 * sb) = f4a4{r2.x, r2.y, r2.z, r2.w};
                 }
                 continue;
+            }
+            {   // more than two slots of one mode: the range filter first, then one selection pass per slot
+                unsigned long long in = 0ull, rest = elig;
+                while (rest) {
+                    const int c = __builtin_ctzll(rest);
+                    rest &= rest - 1ull;
+                    const float4 q = crow[c];
+                    if (veh_in_range(TASK, m, V4{q.x, q.y, q.z, q.w}, ex, ey)) in |= 1ull << c;
+                }
+                elig = in;
             }
             float2 prev_k = make_float2(0.0f, 0.0f);
             int prev_i = -1;
@@ -487,7 +537,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     __syncthreads();   // barrier: s_out complete, s_jbits
 
     // ---- phase 4 ---------------------------------------------------------------------------------------------
-    if (wave == 0 && live) A.done_code[i] = judge_merge(s_jbits[lane], s_col[lane] != 0, delta_y);        // E2E:200-221
+    if (wave == 0 && live) A.done_code[i] = judge_merge(jbits, s_col[lane] != 0, delta_y);                // E2E:200-221
     {   // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane)
         float* dst = A.obs_out + (size_t)e0 * D;
         const int total = nE * D;
@@ -504,57 +554,34 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                 if (base + 256 * k < total) dst[base + 256 * k] = v[k];
         }
     }
-    {   // candidates out, the pool's re-entry rule on the way (eb_traffic_respawn: after the observation saw this step's state)
-        float4* dst = reinterpret_cast<float4*>(A.cand) + (size_t)e0 * m_cand;
-        for (int base = tid; base < n_rec; base += 1024) {
-            float4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = base + 256 * k < n_rec ? base + 256 * k : 0;
-                const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
-                v[k] = s_cand[e * RS4 + c];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = base + 256 * k;
-                if (idx >= n_rec) continue;
-                if (A.respawn_entry && (__builtin_fabsf(v[k].x) > A.limit || __builtin_fabsf(v[k].y) > A.limit)) {
-                    const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
-                    const uint64_t ub = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
-                    const float u1 = u01(A.seed, ub), u2 = u01(A.seed, ub + 1);
-                    const float* en = A.respawn_entry + 5 * c;
-                    const float along = u1 * A.span;
-                    v[k] = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
-                }
-                dst[idx] = v[k];
-            }
-        }
-    }
     ES_MARK(4);
 }
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
-    const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand);
+    const int ET = A.tile_envs == 16 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env);
+    const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET);
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;
     hipError_t e = hipSuccess;
-    const dim3 g((A.n_env + 63) / 64), b(256);
-#define EB_ENV_STEP(T)                                                                                               \
+    const dim3 g((A.n_env + ET - 1) / ET), b(256);
+#define EB_ENV_STEP(T, E)                                                                                            \
     do {                                                                                                             \
         static size_t granted[64];   /* the > 48 KB opt-in is per kernel and device, and sticky */                   \
         if (lds > 48 * 1024 && lds > granted[dev]) {                                                                 \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T>),                              \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T, E>),                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             if (e == hipSuccess) granted[dev] = lds;                                                                 \
         }                                                                                                            \
-        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T>), g, b, lds, s, A);                              \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E>), g, b, lds, s, A);                           \
     } while (0)
+#define EB_ENV_STEP_T(T) do { if (ET == 16) EB_ENV_STEP(T, 16); else EB_ENV_STEP(T, 64); } while (0)
     switch (task) {
-        case TASK_LEFT: EB_ENV_STEP(TASK_LEFT); break;
-        case TASK_STRAIGHT: EB_ENV_STEP(TASK_STRAIGHT); break;
-        default: EB_ENV_STEP(TASK_RIGHT); break;
+        case TASK_LEFT: EB_ENV_STEP_T(TASK_LEFT); break;
+        case TASK_STRAIGHT: EB_ENV_STEP_T(TASK_STRAIGHT); break;
+        default: EB_ENV_STEP_T(TASK_RIGHT); break;
     }
+#undef EB_ENV_STEP_T
 #undef EB_ENV_STEP
     return e != hipSuccess ? e : hipGetLastError();
 }

@@ -138,8 +138,10 @@ struct EnvStepArgs {
     float limit, span, v_max;
     uint64_t seed, counter;
     long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * 4][8] wall-clock marks, or NULL
+    int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 64: forced (eb_debug_set_tile 2 / 0)
 };
-size_t env_step_lds_bytes(int D, int NV, int m_cand);
+size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
+int env_step_tile_envs(int n_env);
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand);
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s);
 

@@ -31,7 +31,6 @@
 
 namespace eb {
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access, 4-byte aligned
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));                 // register pair for v_pk_*_f32
 EB_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -338,66 +337,7 @@ EB_DEV void queue_pass_sc(const FusedHot<ST>& H, SM& S, const float4* ego, int w
     }
 }
 
-// predict_for_a_mode (DAM:405-427) on one record: the operations of eb_device.h:predict_record with the slot's turn
-// constants passed in (so the same bits).  Scalar fp32 throughout: v_pk_*_f32 issues at half the rate of its scalar
-// twins on this chip, so pairing the two polynomial chains saved nothing and cost four register moves per record
-// plus two constant loads (the pair forms take no literals) — 9 full-rate instructions now instead of 4 paired + 5.
-// slot turn constants (predict_for_a_mode, DAM:416-421): 1 / turn radius in double (for the exact division), the
-// sign of the heading rate, and whether the slot turns at all
-// (the sign rides on the reciprocal: rounding to nearest is symmetric, so fl(v * -rc) == -fl(v * rc) bit for bit)
-struct TurnC { double rc; float enabled; };
-EB_DEV TurnC turn_consts(int t) {
-    return t == TURN_LEFT ? TurnC{1.0 / 26.875, 1.0f} : t == TURN_RIGHT ? TurnC{-1.0 / 15.625, 1.0f} : TurnC{1.0, 0.0f};
-}
-// The two polynomial constants of sincos_det that are added to a product of two registers: as literals each costs a
-// v_mov per use (a VOP3 fma takes no literal on gfx950); a record wave keeps them in two VGPRs for its whole loop.
-struct SinCosK { float s2, c2; };
-EB_DEV SinCosK sincos_consts() {
-    SinCosK k{8.3321608736e-3f, -1.388731625493765e-3f};
-    asm volatile("" : "+v"(k.s2), "+v"(k.c2));        // opaque to the compiler: stays in registers instead of being rematerialised
-    return k;
-}
-// sincos_det (eb_device.h) with those two constants from registers — same operations, same bits
-EB_DEV void sincos_det_k(float x, const SinCosK K, float& s_out, float& c_out) {
-    const float kf = __builtin_rintf(x * 0.636619747f);
-    const int k = (int)kf;
-    float r = __builtin_fmaf(-kf, 1.5703125f, x);
-    r = __builtin_fmaf(-kf, 4.83751296997070312e-4f, r);
-    r = __builtin_fmaf(-kf, 7.54978995489188216e-8f, r);
-    const float z = r * r;
-    float ps = __builtin_fmaf(-1.9515295891e-4f, z, K.s2);
-    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
-    const float s = __builtin_fmaf(r * z, ps, r);
-    float pc = __builtin_fmaf(2.443315711809948e-5f, z, K.c2);
-    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
-    const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
-    const float a = (k & 1) ? c : s;
-    const float b = (k & 1) ? -s : c;
-    s_out = (k & 2) ? -a : a;
-    c_out = (k & 2) ? -b : b;
-}
-
-// sn_out / cs_out: sin / cos of the record's CURRENT heading, deg2rad(rec.w) — exactly sincos_det(deg2rad(phi)), the
-// pair the collision terms need too (DAM:221-224)
-template <typename ST>
-EB_DEV f4u predict_record_tc(const f4u rec, const TurnC tc, const SinCosK K, float& sn_out, float& cs_out) {
-    const float v = rec.z;
-    const float v10 = div_const<C10>(v);                                     // DAM:413
-    const float phi_rad = div_const<C180>(rec.w * PI_F);                     // DAM:407
-    float sn, cs;
-    sincos_det_k(phi_rad, K, sn, cs);
-    sn_out = sn; cs_out = cs;
-    const float nx_ = rec.x + v10 * cs, ny_ = rec.y + v10 * sn;              // DAM:413-414, 422
-    const bool middle = (rec.x > -HALF_CROSS && rec.x < HALF_CROSS) && (rec.y > -HALF_CROSS && rec.y < HALF_CROSS);   // DAM:409-410
-    const float u = div_by(v, tc.rc);                                        // +-(v / radius), DAM:417, 419
-    const float u10 = div_const<C10>(u);
-    const float dphi = (middle && tc.enabled != 0.0f) ? u10 : 0.0f;          // DAM:416-421
-    float nphi = phi_rad + dphi;                                             // DAM:423
-    if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                 // DAM:424
-    if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                               // DAM:425
-    const float nphi_deg = div_const<CPi>(nphi * 180.0f);                    // DAM:426
-    return f4u{nx_, ny_, v, nphi_deg};                                       // DAM:422-427
-}
+// (predict_record_tc, TurnC / turn_consts, SinCosK / sincos_consts / sincos_det_k: eb_device.h — shared with eb_env_step.hip)
 
 // FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
 // fixed step, so slot constants are fetched once and addresses advance by a uniform stride.

@@ -30,7 +30,7 @@ def random_scene(task, B, M, seed):
     return ego, cand, cmode, lw, light, act, inp['ref_idx']
 
 
-def composite_case(make, task, B, M, NV, nf):
+def composite_case(make, task, B, M, NV, nf, tile=None):
     """make(task, **kw) -> a HostModel / DeviceModel; -> the composite's eight outputs (for cross-library comparison)"""
     native = VEHICLE_MODE_LIST[task]
     modes = [native[i % len(native)] for i in range(M)]
@@ -58,6 +58,8 @@ def composite_case(make, task, B, M, NV, nf):
     if NV is not None:
         kw.update(n_veh=NV)
     m, tr = make(task, **kw), make(task, n_veh=M, modes=modes)
+    if tile is not None:
+        m.set_tile(tile)          # the one-launch step: 0 = 64-env tiles, 2 = 16-env tiles (eb_debug_set_tile)
     obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
     # the six calls
     act = m.action_transform(raw)

@@ -415,7 +415,8 @@ def test_get_obs_candidate_and_slot_counts(task, M, NV):
 
 
 @pytest.mark.parametrize('task,B,M,NV,nf', __import__('tests._env_step_check', fromlist=['CASES']).CASES)
-def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf):
+@pytest.mark.parametrize('tile', [0, 2])
+def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf, tile):
     """eb_env_step == action_transform, compute_rewards, env_ego_step, veh_predict, get_obs, judge_done (+ traffic_respawn
     when a re-entry rule is given) in that order, on both libraries (bit for bit against the oracle's composite too).
     The HIP library runs the composite as ONE launch (csrc/eb_env_step.hip) — except the last case, whose tile does not
@@ -423,7 +424,7 @@ def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf):
     columns go through the same check (tests/_env_step_check.py)."""
     from tests._env_step_check import composite_case
     outs = [composite_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B, M, NV, nf),
-            composite_case(lambda t, **kw: DeviceModel(t, **kw), task, B, M, NV, nf)]
+            composite_case(lambda t, **kw: DeviceModel(t, **kw), task, B, M, NV, nf, tile=tile)]
     for a, b in zip(*outs):
         if a.dtype == np.float32 and a.shape == (5, B):
             _check_out5(b, a, 'composite')
