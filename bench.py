@@ -503,12 +503,18 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     alg = env_step_alg_bytes(D, M) * B
     achieved, frac = roofline_of(alg, us)
     done_frac = float((code != 0).float().mean().item())
+    traffic = None
+    for name in ('r3_pmc_traffic.json',):
+        tpath = os.path.join(ROOT, 'profiles', name)
+        if os.path.isfile(tpath) and (B, M) == (N_ENV, 16):
+            traffic = (json.load(open(tpath)).get('env_step') or {}).get('hbm_bytes_per_launch')
     return {'workload': 'env_step: CrossroadEnd2end.step for N_env=%d single-ego envs x %d traffic candidates (task %s, D=%d): eb_env_step '
                         '= ONE launch (action scaling, reward, ego step, traffic step, observation, done code, pool re-entry)' % (B, M, TASK, D),
             'n_env_per_gpu': B, 'n_cand': M, 'obs_dim': D, 'dtype': 'f32', 'value': B / (us * 1e-6), 'unit': 'env-steps/s',
             'avg_launch_us': us, 'launches_timed': reps * seg, 'wall_us_per_step_incl_state_restores': wall * 1e6 / (reps * seg),
             'alg_bytes_per_env_step': env_step_alg_bytes(D, M), 'alg_bytes_per_launch': alg, 'achieved_GBs': achieved, 'frac': frac,
-            'kernel': 'eb::env_step_kernel<0>', 'done_fraction_after_segment': done_frac}
+            'traffic': traffic, 'traffic_source': 'profiles/r3_pmc_traffic.json (separate rocprofv3 --pmc passes, scripts/pmc_traffic.sh)' if traffic else None,
+            'kernel': 'eb::env_step_kernel<0, %d>' % (16 if B <= 16384 else 64), 'done_fraction_after_segment': done_frac}
 
 
 def shield_bench(args):
@@ -726,7 +732,7 @@ def main():
         alg = alg_bytes_per_env_step(n_veh) * n_env
         launch_us = r['launch_us']
         traffic, traffic_src = None, None
-        for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):      # separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
+        for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):      # separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
             tpath = os.path.join(ROOT, 'profiles', name)
             if os.path.isfile(tpath) and n_env == N_ENV and n_veh == N_VEH and not args.open_loop:
                 traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')

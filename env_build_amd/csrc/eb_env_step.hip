@@ -59,10 +59,14 @@ size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs) {
 }
 // envs per block: 64 for throughput; small batches take 16-env tiles so that four times as many blocks (and a quarter of
 // the records per lane) stand behind the same step — a step of 4 096 envs is latency, not bandwidth
-int env_step_tile_envs(int n_env) { return n_env <= 16384 ? 16 : 64; }
+// Many candidates per env (the flow source: 60) make a 64-env tile too big for four blocks per CU (> 40 KB of LDS): 16-env
+// tiles then, at any batch size (measured at 65 536 envs x 60 candidates: 119 us with one 85 KB block per CU).
+int env_step_tile_envs(int n_env, int D, int NV, int m_cand) {
+    return (n_env <= 16384 || env_step_lds_bytes(D, NV, m_cand, 64) > 40 * 1024) ? 16 : 64;
+}
 
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand) {
-    return m_cand >= 1 && m_cand <= 64 && env_step_lds_bytes(D, NV, m_cand, 64) <= 150 * 1024 &&
+    return m_cand >= 1 && m_cand <= 64 && env_step_lds_bytes(D, NV, m_cand, 16) <= 150 * 1024 &&
            (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
 }
 
@@ -558,7 +562,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
 }
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
-    const int ET = A.tile_envs == 16 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env);
+    int ET = A.tile_envs == 16 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
+    if (ET == 64 && env_step_lds_bytes(A.D, A.NV, A.m_cand, 64) > 150 * 1024) ET = 16;     // a forced shape that does not fit
     const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET);
     int dev = 0;
     (void)hipGetDevice(&dev);

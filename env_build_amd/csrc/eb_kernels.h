@@ -141,7 +141,7 @@ struct EnvStepArgs {
     int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 64: forced (eb_debug_set_tile 2 / 0)
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
-int env_step_tile_envs(int n_env);
+int env_step_tile_envs(int n_env, int D, int NV, int m_cand);
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand);
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s);
 

@@ -41,7 +41,23 @@ summary = {'hbm_bytes_per_launch': read_b + write_b, 'read_bytes_per_launch': re
                      'calibration factor measured on a float4 copy of a known 35.9 MB buffer in the same run '
                      '(gfx950: FETCH_SIZE counts half of a wide coalesced read)',
            'counters': res}
+# the one-launch env step (bench.py --env-step: 65 536 envs x 16 candidates, 64-env tiles -> grid 1024 x 256), same calibration
+try:
+    es = {}
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        k_kib, n_k = mean_counter('envstep_' + c, c, 'env_step_kernel<0, 64>', 1024 * 256)
+        es[c] = {'kib_per_launch': k_kib, 'launches': n_k, 'bytes_per_launch': k_kib * 1024.0 * res[c]['calibration_factor']}
+    es_alg = (8 * 41 + 33 * 16 + 105) * 65536
+    es_total = es['FETCH_SIZE']['bytes_per_launch'] + es['WRITE_SIZE']['bytes_per_launch']
+    summary['env_step'] = {'hbm_bytes_per_launch': es_total, 'read_bytes_per_launch': es['FETCH_SIZE']['bytes_per_launch'],
+                           'write_bytes_per_launch': es['WRITE_SIZE']['bytes_per_launch'], 'algorithmic_bytes_per_launch': es_alg,
+                           'traffic_over_algorithmic': es_total / es_alg, 'kernel': 'eb::env_step_kernel<0, 64>', 'counters': es}
+except SystemExit as e:
+    summary['env_step'] = None
+    print('(no env-step passes: %s)' % e)
 json.dump(summary, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k != 'counters'}, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k not in ('counters', 'env_step')}, indent=1))
+if summary.get('env_step'):
+    print('env step:', json.dumps({k: v for k, v in summary['env_step'].items() if k != 'counters'}))
 for c, r in res.items():
     print('%s: rollout %.0f KiB x factor %.3f (copy: %.0f KiB for %d known bytes)' % (c, r['rollout_kib_per_launch'], r['calibration_factor'], r['copy_kib_per_launch'], COPY_BYTES))

@@ -419,9 +419,9 @@ def test_get_obs_candidate_and_slot_counts(task, M, NV):
 def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf, tile):
     """eb_env_step == action_transform, compute_rewards, env_ego_step, veh_predict, get_obs, judge_done (+ traffic_respawn
     when a re-entry rule is given) in that order, on both libraries (bit for bit against the oracle's composite too).
-    The HIP library runs the composite as ONE launch (csrc/eb_env_step.hip) — except the last case, whose tile does not
-    fit the LDS and takes the separate launches: partial tiles, 1..64 candidates, non-native slot counts and look-ahead
-    columns go through the same check (tests/_env_step_check.py)."""
+    The HIP library runs the composite as ONE launch (csrc/eb_env_step.hip) with 64-env (tile 0) or 16-env (tile 2) tiles;
+    the last case does not fit 64-env tiles and takes the small ones either way: partial tiles, 1..64 candidates,
+    non-native slot counts and look-ahead columns go through the same check (tests/_env_step_check.py)."""
     from tests._env_step_check import composite_case
     outs = [composite_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B, M, NV, nf),
             composite_case(lambda t, **kw: DeviceModel(t, **kw), task, B, M, NV, nf, tile=tile)]
@@ -432,6 +432,44 @@ def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf, tile):
             np.testing.assert_allclose(b, a, rtol=PEN_RTOL, atol=0)
         else:
             assert np.array_equal(a, b)
+
+
+def test_env_step_separate_launches_equal_the_one_launch_kernel():
+    """A candidate buffer that is not 16-byte aligned (or more than 64 candidates) takes eb_env_step's separate launches
+    — same outputs, bit for bit, as the one-launch kernel on the same scene."""
+    import ctypes as C
+    import torch
+    task, B, M = 'left', 333, 12
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    ego, cand, _, _, light, _, ref = _random_scene(task, B, M, 91)
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    rng = np.random.default_rng(6)
+    raw = rng.uniform(-1.1, 1.1, (B, 2)).astype(np.float32)
+    cand[:, :3, 0] = 70.0                                                # three per env have left the map
+    entry = rng.uniform(-50, 50, (M, 5)).astype(np.float32)
+    m, tr = DeviceModel(task, mode='training'), DeviceModel(task, n_veh=M, modes=modes)
+    obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    rule = dict(entry=entry, limit=65.0, span=60.0, v_max=8.0, seed=77, counter=3)
+    want = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=light, respawn=rule)
+    # the same call with the candidates one float into a larger buffer: 4-byte aligned only
+    t, dev = torch, m.dev
+    p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+    big = t.zeros(B * M * 4 + 1, dtype=t.float32, device=dev)
+    c_io = big[1:].view(B, M, 4)
+    c_io.copy_(t.from_numpy(cand))
+    assert c_io.data_ptr() % 16 != 0
+    e_io, ob, rw, ri = m._in(ego.copy()), m._in(obs0), m._in(raw), m._in(ref, np.int32)
+    cm, vl, en = m._in(cmode, np.uint8), m._in(light, np.uint8), m._in(entry)
+    par, sc, out5, dd = m._out((B, 4)), m._out((B, 2)), m._out((5, B)), m._out((16, B))
+    obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
+    rs = _capi.EbRespawn(en.data_ptr(), 65.0, 60.0, 8.0, 77, 3)
+    m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), None, p(sc), p(out5), p(dd),
+                   p(obs_o), p(code), C.byref(rs), m.stream)
+    t.cuda.synchronize()
+    got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code)]
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w), k
 
 
 @pytest.mark.parametrize('task,n_env', [('left', 1), ('straight', 1), ('right', 64), ('left', 300)])
