@@ -6,6 +6,8 @@
 // through LDS — candidates in, observation rows out, both as coalesced 16-byte accesses — because a
 // thread walks its env's candidates a dozen times.  fp32 throughout (see the oracle's note on the
 // reference's NumPy-version-dependent scalar promotion).
+#include <cstring>
+
 #include "eb_env_device.h"
 
 #pragma clang fp contract(off)
@@ -542,6 +544,24 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
             default: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_RIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, obs_out); break;
         }
         return hipGetLastError();
+    }
+    if (!done_code && env_step_is_fused(D, NV, m_cand, cand)) {
+        // the observation alone through the one-launch step's machinery (eb_env_step.hip, OBS variant): pair-parallel
+        // staging and the bit-set slot selection instead of one lane per env walking its candidates
+        EnvStepArgs A;
+        std::memset(&A, 0, sizeof A);
+        auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+        A.n_env = n_env; A.D = D; A.n_future = n_future; A.NV = NV; A.m_cand = m_cand; A.path_id = path_id;
+        A.d_magic = magic(D); A.m_magic = magic(m_cand); A.nv_magic = magic(NV);
+        A.pt = pt; A.modes = modes;
+        for (int sl = 0; sl < NV; ++sl) {
+            bool first = true;
+            for (int t = 0; t < sl; ++t) first = first && modes.mode[t] != modes.mode[sl];
+            if (first) A.first_mask |= 1ull << sl;
+        }
+        A.ref_idx = ref_idx; A.ego = const_cast<float*>(ego); A.cand = const_cast<float*>(cand); A.cand_mode = cand_mode;
+        A.v_light = v_light; A.virtual_flag = virtual_flag; A.obs_out = obs_out; A.obs_only = 1;
+        return launch_env_step(task, A, s);
     }
     const size_t lds = get_obs_lds_bytes(D, m_cand);
     const bool staged = get_obs_is_staged(D, m_cand, cand);

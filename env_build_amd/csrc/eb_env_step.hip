@@ -104,7 +104,10 @@ struct WaveQueue {
     EB_DEV void flush() { if (n > 0) run(n); }
 };
 
-template <int TASK, int ET>   // ET: envs per tile (64 or 16); lanes >= ET of the per-env roles idle
+// ET: envs per tile (64 or 16); lanes >= ET of the per-env roles idle.  OBS: the observation alone (eb_get_obs on an ego and
+// candidates given as they are: no action, reward, ego step, traffic step, collision test or done code — phases 1-4 shrink to
+// staging, tracking, slots and the row store; the arithmetic of what remains is the same code).
+template <int TASK, int ET, bool OBS>
 __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET];
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
         for (int k = 0; k < 4; ++k) {
             const int p = base + pt_ + 192 * k;
             pxy[k] = make_float2(1e30f, 1e30f);                                  // (past the end: never near)
-            if (wave > 0 && p < n_pairs) {
+            if (!OBS && wave > 0 && p < n_pairs) {
                 const int e = fast_div(p, A.nv_magic), j = p - e * NV;
                 const f2a4 q = *reinterpret_cast<const f2a4*>(A.obs + (size_t)D * (e0 + e) + 6 + T + 4 * j);
                 pxy[k] = make_float2(q.x, q.y);
@@ -174,7 +177,14 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     float nx[6] = {0, 0, 0, 0, 0, 0};                                        // wave 0
     float steer = 0.0f, a_x = 0.0f, o9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // wave 1
     float road_t = 0.0f, road_r = 0.0f;
-    if (wave < 2 && live) {
+    if (OBS) {
+        if (wave == 0 && live) {                                                // the ego as given (eb_get_obs)
+            const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
+            const float2 g0 = eg[0], g1 = eg[1], g2 = eg[2];
+            nx[0] = g0.x; nx[1] = g0.y; nx[2] = g1.x; nx[3] = g1.y; nx[4] = g2.x; nx[5] = g2.y;
+            s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
+        }
+    } else if (wave < 2 && live) {
         const float2 r2 = reinterpret_cast<const float2*>(A.raw)[i];
         const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
         const float2 g0 = eg[0], g1 = eg[1], g2 = eg[2];
@@ -216,8 +226,11 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
         auto stage = [&](int idx, const float4 v, unsigned mode) {
             const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
             float sn, cs;     // (the record loop of the rollout kernel: one code path for every turn class, eb_device.h)
-            const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs);
-            s_cand[e * RS4 + c] = make_float4(r.x, r.y, r.z, r.w);
+            if (OBS) s_cand[e * RS4 + c] = v;
+            else {
+                const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs);
+                s_cand[e * RS4 + c] = make_float4(r.x, r.y, r.z, r.w);
+            }
             s_tag[e * TS4 * 4 + c] = (uint8_t)mode;
         };
 #pragma unroll
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
         // applies after the observation and the done code saw this step's state — both read the LDS copy); this wave
         // would otherwise idle here while the others test pairs
         float4* cdst = reinterpret_cast<float4*>(A.cand) + (size_t)e0 * m_cand;
-        for (int base = lane; base < n_rec; base += 256) {
+        for (int base = lane; !OBS && base < n_rec; base += 256) {
             float4 v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                 cdst[idx] = v[k];
             }
         }
-    } else {
+    } else if (!OBS) {
         unsigned short* myq = s_queue + wave * ES_QCAP;
         {   // compute_rewards' vehicle loop on the CURRENT observation (DAM:218-229), one lane per (env, slot).  A circle pair
             // can only be closer than 3.5 m when the two centres are within 3.5 + 2 * 1.4 = 6.3 m: pairs inside 6.364 m
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     __syncthreads();   // barrier: s_part, tags, s_col, the row heads
 
     // ---- phase 3 ---------------------------------------------------------------------------------------------
-    if (wave == 1 && live) {
+    if (!OBS && wave == 1 && live) {
         // E2E:134: the reward of the step taken from the CURRENT observation; penalty partials in vehicle order
         float v2v_train = 0.0f, v2v_real = 0.0f;
         for (int j = 0; j < NV; ++j) {
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
         }
     }
     unsigned jbits = 0u;
-    if (wave == 0 && live)   // the done predicates that need only the new ego state (E2E:223-256)
+    if (!OBS && wave == 0 && live)   // the done predicates that need only the new ego state (E2E:223-256)
         jbits = judge_bits(TASK, nx[0], nx[2], nx[3], nx[4], nx[5], s_miu[lane], red_light);
     ES_MARK(6);
     {
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     __syncthreads();   // barrier: s_out complete, s_jbits
 
     // ---- phase 4 ---------------------------------------------------------------------------------------------
-    if (wave == 0 && live) A.done_code[i] = judge_merge(jbits, s_col[lane] != 0, delta_y);                // E2E:200-221
+    if (!OBS && wave == 0 && live) A.done_code[i] = judge_merge(jbits, s_col[lane] != 0, delta_y);                // E2E:200-221
     {   // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane)
         float* dst = A.obs_out + (size_t)e0 * D;
         const int total = nE * D;
@@ -570,17 +583,21 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     dev = dev < 0 || dev >= 64 ? 0 : dev;
     hipError_t e = hipSuccess;
     const dim3 g((A.n_env + ET - 1) / ET), b(256);
-#define EB_ENV_STEP(T, E)                                                                                            \
+#define EB_ENV_STEP(T, E, O)                                                                                          \
     do {                                                                                                             \
         static size_t granted[64];   /* the > 48 KB opt-in is per kernel and device, and sticky */                   \
         if (lds > 48 * 1024 && lds > granted[dev]) {                                                                 \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T, E>),                           \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T, E, O>),                        \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             if (e == hipSuccess) granted[dev] = lds;                                                                 \
         }                                                                                                            \
-        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E>), g, b, lds, s, A);                           \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O>), g, b, lds, s, A);                        \
     } while (0)
-#define EB_ENV_STEP_T(T) do { if (ET == 16) EB_ENV_STEP(T, 16); else EB_ENV_STEP(T, 64); } while (0)
+#define EB_ENV_STEP_T(T)                                                                                             \
+    do {                                                                                                             \
+        if (A.obs_only) { if (ET == 16) EB_ENV_STEP(T, 16, true); else EB_ENV_STEP(T, 64, true); }                   \
+        else { if (ET == 16) EB_ENV_STEP(T, 16, false); else EB_ENV_STEP(T, 64, false); }                            \
+    } while (0)
     switch (task) {
         case TASK_LEFT: EB_ENV_STEP_T(TASK_LEFT); break;
         case TASK_STRAIGHT: EB_ENV_STEP_T(TASK_STRAIGHT); break;

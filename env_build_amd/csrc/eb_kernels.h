@@ -138,6 +138,7 @@ struct EnvStepArgs {
     float limit, span, v_max;
     uint64_t seed, counter;
     long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * 4][8] wall-clock marks, or NULL
+    int obs_only;                          // 1: eb_get_obs — ego / cand are inputs, only obs_out is written
     int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 64: forced (eb_debug_set_tile 2 / 0)
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
