@@ -80,7 +80,7 @@ PROTOTYPES = {
     'eb_veh_predict': (C.c_int, [_P, _I, _P, _P, _P]),
     'eb_ss': (C.c_int, [_P, _I, _P, _P, _P, _I, C.c_double, _P, _P]),
     'eb_env_ego_step': (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
-    'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_exit_frame': (C.c_int, [_P, _I, _P, _I, _P, _P, _P]),
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

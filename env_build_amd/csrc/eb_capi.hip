@@ -744,7 +744,7 @@ int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actio
 
 int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx, int32_t path_id,
                int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* v_light,
-               const uint8_t* virtual_flag, const uint8_t* exit_id, float* obs_out, void* stream) {
+               const uint8_t* virtual_flag, const uint8_t* exit_id, const uint8_t* row_mask, float* obs_out, void* stream) {
     int rc = check_paths(h, "eb_get_obs: null handle");
     if (rc) return rc;
     rc = check_modes(h);
@@ -757,7 +757,7 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
     // (exit ids live in device memory: the kernel masks them to 0..3 instead of a host-side range check)
     EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
                               ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, pick(h, stream),
-                              nullptr, nullptr, nullptr, exit_id, &h->xc));
+                              nullptr, nullptr, nullptr, exit_id, &h->xc, row_mask));
     return EB_OK;
 }
 

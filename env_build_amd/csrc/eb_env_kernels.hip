@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
                                const float* __restrict__ ego, const int* __restrict__ ref_idx, int path_id,
                                int m_cand, const float* __restrict__ cand_all, const uint8_t* __restrict__ cmode_all,
                                const uint8_t* __restrict__ v_light, const uint8_t* __restrict__ virtual_flag,
-                               float* __restrict__ obs_out, const JudgeArgs J) {
+                               float* __restrict__ obs_out, const JudgeArgs J, const uint8_t* __restrict__ row_mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // The slot modes come in the kernel-argument block; indexed with a loop variable they would be fetched from there by a
     // vector load each time — a memory round trip per access inside the slot loops below, which is what this kernel
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
         }
         __syncthreads();
     }
-    if (i < n_env) {
+    if (i < n_env && (STAGED || !row_mask || row_mask[i])) {
     const float* e = ego + 6 * (size_t)i;
     float* o = STAGED ? s_out + lane * OS : obs_out + (size_t)D * i;
     const int T = 3 * (n_future + 1);
@@ -419,12 +419,14 @@ __global__ __launch_bounds__(64) void get_obs_exit_kernel(int n_env, int D, int 
                                     const float* __restrict__ ego, const int* __restrict__ ref_idx, int path_id,
                                     int m_cand, const float* __restrict__ cand_all, const uint8_t* __restrict__ cmode_all,
                                     const uint8_t* __restrict__ v_light, const uint8_t* __restrict__ virtual_flag,
-                                    const uint8_t* __restrict__ exit_id, const ExitConsts xc, float* __restrict__ obs_out) {
+                                    const uint8_t* __restrict__ exit_id, const ExitConsts xc, const uint8_t* __restrict__ row_mask,
+                                    float* __restrict__ obs_out) {
     __shared__ uint8_t smode[64];                                           // see get_obs_kernel
     smode[threadIdx.x] = modes.mode[threadIdx.x];
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_env) return;
+    if (row_mask && !row_mask[i]) return;
     const float* e = ego + 6 * (size_t)i;
     float* o = obs_out + (size_t)D * i;
     const int T = 3 * (n_future + 1);
@@ -534,14 +536,14 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
                           const float* cand, const uint8_t* cand_mode, const uint8_t* v_light, const uint8_t* virtual_flag,
                           float* obs_out, hipStream_t s, const float* params, const float* cand_lw,
-                          uint8_t* done_code, const uint8_t* exit_id, const ExitConsts* xc) {
+                          uint8_t* done_code, const uint8_t* exit_id, const ExitConsts* xc, const uint8_t* row_mask) {
     if (exit_id) {
         if (done_code || !xc) return hipErrorInvalidValue;
         const dim3 g((n_env + 63) / 64), b(64);
         switch (task) {
-            case TASK_LEFT: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_LEFT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, obs_out); break;
-            case TASK_STRAIGHT: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_STRAIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, obs_out); break;
-            default: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_RIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, obs_out); break;
+            case TASK_LEFT: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_LEFT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, row_mask, obs_out); break;
+            case TASK_STRAIGHT: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_STRAIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, row_mask, obs_out); break;
+            default: hipLaunchKernelGGL(get_obs_exit_kernel<TASK_RIGHT>, g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, exit_id, *xc, row_mask, obs_out); break;
         }
         return hipGetLastError();
     }
@@ -560,11 +562,11 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
             if (first) A.first_mask |= 1ull << sl;
         }
         A.ref_idx = ref_idx; A.ego = const_cast<float*>(ego); A.cand = const_cast<float*>(cand); A.cand_mode = cand_mode;
-        A.v_light = v_light; A.virtual_flag = virtual_flag; A.obs_out = obs_out; A.obs_only = 1;
+        A.v_light = v_light; A.virtual_flag = virtual_flag; A.obs_out = obs_out; A.obs_only = 1; A.row_mask = row_mask;
         return launch_env_step(task, A, s);
     }
     const size_t lds = get_obs_lds_bytes(D, m_cand);
-    const bool staged = get_obs_is_staged(D, m_cand, cand);
+    const bool staged = !row_mask && get_obs_is_staged(D, m_cand, cand);   // (a masked pass outside the one-launch machinery: one thread per env)
     if (done_code && !staged) return hipErrorInvalidValue;
     const JudgeArgs J{params, cand_lw, done_code};
     int dev = 0;
@@ -583,10 +585,10 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
             }                                                                                                        \
             if (e == hipSuccess)                                                                                     \
                 hipLaunchKernelGGL((get_obs_kernel<T, true>), g, b, lds, s, n_env, D, n_future, NV, pt, modes, ego,  \
-                                   ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, J);    \
+                                   ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, J, row_mask); \
         } else {                                                                                                     \
             hipLaunchKernelGGL((get_obs_kernel<T, false>), g, b, 0, s, n_env, D, n_future, NV, pt, modes, ego,       \
-                               ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, J);        \
+                               ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, J, row_mask); \
         }                                                                                                            \
     } while (0)
     switch (task) {

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
     const int nE = n_env - e0 < ET ? n_env - e0 : ET;
     const int i = e0 + lane;
-    const bool live = lane < nE;
+    const bool live = lane < nE && !(OBS && A.row_mask && A.row_mask[i] == 0);   // (a masked observation pass: the other rows are left alone)
+    if (OBS && A.row_mask && __builtin_amdgcn_ballot_w64(live) == 0ull) return;   // same lanes -> envs in every wave: the whole block leaves
     const int RS4 = obs_cand_stride4(m_cand), OS = es_obs_stride(D), TS4 = es_tag_stride4(m_cand), T = 3 * (n_future + 1);
     float4* s_cand = reinterpret_cast<float4*>(smem);                            // [64][RS4] candidates after the traffic step
     float* s_out = reinterpret_cast<float*>(s_cand + (size_t)ET * RS4);          // [64][OS]  next observation rows
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_tag32 + (size_t)ET * TS4);   // [4][ES_QCAP]
     ES_MARK(0);
     if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
-    if (tid < ET) s_col[tid] = 0;
+    if (tid < ET) s_col[tid] = (OBS && A.row_mask && !(tid < nE && A.row_mask[e0 + tid] != 0)) ? 1 : 0;   // OBS: 1 = row not to be written
     for (int w = tid; w < ET * TS4; w += 256) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
     __syncthreads();   // (kernel-argument tables only: nobody waits for memory here)
 
@@ -567,8 +568,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
                 v[k] = s_out[e * OS + c];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (base + 256 * k < total) dst[base + 256 * k] = v[k];
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + 256 * k;
+                if (idx < total && !(OBS && A.row_mask && s_col[fast_div(idx, A.d_magic)])) dst[idx] = v[k];
+            }
         }
     }
     ES_MARK(4);

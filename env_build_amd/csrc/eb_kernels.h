@@ -95,7 +95,8 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
                           const float* cand, const uint8_t* cand_mode, const uint8_t* v_light, const uint8_t* virtual_flag,
                           float* obs_out, hipStream_t s, const float* params = nullptr, const float* cand_lw = nullptr,
-                          uint8_t* done_code = nullptr, const uint8_t* exit_id = nullptr, const ExitConsts* xc = nullptr);
+                          uint8_t* done_code = nullptr, const uint8_t* exit_id = nullptr, const ExitConsts* xc = nullptr,
+                          const uint8_t* row_mask = nullptr);
 hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const ExitConsts& xc, const float* ego, float* out,
                              hipStream_t s);
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
@@ -139,6 +140,7 @@ struct EnvStepArgs {
     uint64_t seed, counter;
     long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * 4][8] wall-clock marks, or NULL
     int obs_only;                          // 1: eb_get_obs — ego / cand are inputs, only obs_out is written
+    const uint8_t* row_mask;               // obs_only: nullable [n_env]; rows with a zero byte are left alone
     int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 64: forced (eb_debug_set_tile 2 / 0)
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);

@@ -324,7 +324,6 @@ class CrossroadEnd2end(object):
             e0 = ego[0]
         else:
             self._reset_counter += 1
-            self._virtual_next.copy_(self._virtual)                                      # unmasked envs keep their flag
             self.api.env_reset(self._h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
                                C.c_uint64(self._reset_counter), 1 if self.mode == 'training' else 0, _ptr(self._ego),
                                _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual_next), _ptr(self.done_code),
@@ -346,6 +345,7 @@ class CrossroadEnd2end(object):
             mt = mask.t if isinstance(mask, DevArray) else mask
             mt = mt if isinstance(mt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(mt)))
             mask8 = mt.to(device=dev).reshape(B).to(torch.uint8).contiguous()
+            mask_b = mask8 != 0
         if B > 1:
             self.done_code = self.done_code.clone()      # the array handed out by the last step stays as it was
         self.init_state = self._reset_init_state(mask8)                                 # E2E:101
@@ -363,10 +363,10 @@ class CrossroadEnd2end(object):
             if mask8 is None:                      # the pool has no light programme: a reset env starts at phase 0
                 self._v_light.zero_()              # (a value injected through the multi_display seam does not survive reset)
             else:
-                self._v_light.masked_fill_(mask8.bool(), 0)
+                self._v_light.masked_fill_(mask_b, 0)
         self._injected = False
         self._publish_state()                                                            # E2E:104-115
-        self.obs = self._get_obs()                                                       # E2E:116 (with the OLD flag)
+        self.obs = self._get_obs(row_mask=mask8)                                         # E2E:116 (with the OLD flag)
         self.action = None
         self.reward_info = None
         if B == 1:
@@ -375,7 +375,11 @@ class CrossroadEnd2end(object):
             self._virtual.fill_(1 if flag else 0)
             self.virtual_red_light_vehicle = flag
         else:
-            self._virtual.copy_(self._virtual_next)                                      # E2E:120-126, drawn by eb_env_reset
+            # E2E:120-126: the flag drawn by eb_env_reset replaces the old one AFTER the reset observation, for the reset envs only
+            if mask8 is None:
+                self._virtual.copy_(self._virtual_next)
+            else:
+                torch.where(mask_b, self._virtual_next, self._virtual, out=self._virtual)
             self.virtual_red_light_vehicle = None
             self.done_type = DevArray(self.done_code)
         return self.obs
@@ -444,7 +448,7 @@ class CrossroadEnd2end(object):
         self.api.exit_frame(self._h, self.n_env, _ptr(self._exit_ids(exit_)), 1 if inverse else 0, _ptr(e), _ptr(out), self._sp())
         return DevArray(out)
 
-    def _get_obs(self, exit_='D'):
+    def _get_obs(self, exit_='D', row_mask=None):
         """n_env == 1: the reference's call — with multi_display the caller has put ego_dynamics / all_vehicles /
         v_light (already in the ego's frame, multi_ego.py:94-96) on the object and exit_ only renames the routes.
         A batch with exit_ other than 'D' is the 12-ego scene in one call: `_ego`, the candidates and the light are
@@ -465,8 +469,9 @@ class CrossroadEnd2end(object):
         ri = self._ref_idx
         if self.n_env == 1:
             ri = torch.tensor([int(self.ref_path.ref_index)], dtype=torch.int32, device=self.device)
+        # row_mask (a masked reset): only those rows are recomputed, the others keep the observation they have
         self.api.get_obs(self._h, self.n_env, _ptr(ego), _ptr(ri), 0, m, _ptr(cand.contiguous()),
-                         _ptr(cmode.contiguous()), _ptr(self._v_light), _ptr(self._virtual), _ptr(exit_ids),
+                         _ptr(cmode.contiguous()), _ptr(self._v_light), _ptr(self._virtual), _ptr(exit_ids), _ptr(row_mask),
                          _ptr(self._obs), self._sp())
         return self._ret(self._obs.clone())
 

@@ -80,7 +80,7 @@ class HierarchicalDecision(object):
         cand, cmode = env._cand.contiguous(), env._cand_mode.contiguous()
         for k in range(len(self.path_list)):
             env.api.get_obs(env._h, B, _ptr(env._ego), None, k, env.n_cand, _ptr(cand), _ptr(cmode), _ptr(env._v_light),
-                            _ptr(env._virtual), None, _ptr(out[k]), env._sp())
+                            _ptr(env._virtual), None, None, _ptr(out[k]), env._sp())
         return out
 
     def select_path(self, path_values):

@@ -300,11 +300,14 @@ int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actio
  *   Python does (against ego-derived fp32 values after rounding to fp32, against constants in float64); the
  *   observation holds them rounded to fp32.  obs_out [n_env, D].
  *   An exit id above 3 is an error: the oracle (host arguments) returns EB_EINVAL; the HIP library cannot read device
- *   memory on the host and writes NaN into every column of that env's row instead (eb_exit_frame: NaN x, y, phi). */
+ *   memory on the host and writes NaN into every column of that env's row instead (eb_exit_frame: NaN x, y, phi).
+ *   row_mask (nullable, uint8 [n_env]): only the rows with a non-zero byte are computed and written, the others keep
+ *   what obs_out holds — the observation pass of a masked reset (CrossroadEnd2end.reset(mask=...)) costs what the
+ *   reset envs cost, not the batch. */
 int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx,
                int32_t path_id, int32_t m_cand, const float* cand, const uint8_t* cand_mode,
                const uint8_t* v_light, const uint8_t* virtual_flag, const uint8_t* exit_id,
-               float* obs_out, void* stream);
+               const uint8_t* row_mask, float* obs_out, void* stream);
 
 /* cal_ego_info_in_transform_coordination (UTL:184-196) for a batch: (x, y, phi) of ego [n,6] rotated into
  * (inverse = 0) or out of (inverse = 1: angle -a, multi_ego.py:118) the frame of each env's exit; the other

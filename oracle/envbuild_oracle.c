@@ -1014,7 +1014,7 @@ static void build_veh_row(const eb_handle h, int m_cand, const float* cand, cons
 /* a16: _get_obs, E2E:285-303 */
 int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx, int32_t path_id,
                int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* v_light,
-               const uint8_t* virtual_flag, const uint8_t* exit_id, float* obs_out, void* stream) {
+               const uint8_t* virtual_flag, const uint8_t* exit_id, const uint8_t* row_mask, float* obs_out, void* stream) {
     (void)stream;
     int rc = check_paths(h, "eb_get_obs: null handle");
     if (rc) return rc;
@@ -1030,6 +1030,7 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
     const int D = obs_dim(c), T = 3 * (c->n_future + 1);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n_env; ++i) {
+        if (row_mask && !row_mask[i]) continue;                        /* masked pass: the other rows keep their contents */
         const float* e = ego + 6 * (size_t)i;
         float* o = obs_out + (size_t)D * i;
         for (int k = 0; k < 6; ++k) o[k] = e[k];                       /* E2E:329-338 */
@@ -1273,7 +1274,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!rc) rc = eb_env_ego_step(h, n_env, ego, scaled_actions, ego, params, stream);           /* E2E:135 */
     free(own_scaled);
     if (!rc) rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                            /* TRF:220-238's role */
-    if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, NULL, obs_out, stream);   /* E2E:140 */
+    if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, NULL, NULL, obs_out, stream);   /* E2E:140 */
     if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, cand_lw, v_light, done_code, stream);   /* E2E:141 */
     if (!rc && respawn)   /* the pool's re-entry, after the observation saw this step's state */
         rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,

@@ -86,3 +86,17 @@ def composite_case(make, task, B, M, NV, nf, tile=None):
         if w is not None:
             assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w), k
     return got
+
+
+def masked_obs_case(make, task, B=150, M=10, seed=8):
+    """eb_get_obs with a row mask: the masked rows equal the unmasked call's, the others keep what the buffer held."""
+    native = VEHICLE_MODE_LIST[task]
+    ego, cand, cmode, _, light, _, ref = random_scene(task, B, M, seed)
+    m = make(task, mode='training')
+    full = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    rng = np.random.default_rng(seed)
+    for mask in (rng.random(B) < 0.2, np.zeros(B, bool), np.ones(B, bool), np.arange(B) == B - 1):
+        init = rng.normal(size=full.shape).astype(np.float32)
+        got = m.get_obs(ego, cand, cmode, light, ref_idx=ref, row_mask=mask.astype(np.uint8), obs_init=init)
+        assert np.array_equal(got[mask], full[mask]) and np.array_equal(got[~mask], init[~mask])
+    return full

@@ -303,13 +303,15 @@ class HostModel(object):
         self.api.env_ego_step(self.h, n, self._ptr(eg), self._ptr(ac), self._ptr(nxt), self._ptr(par), self.stream)
         return self._ret(nxt), self._ret(par)
 
-    def get_obs(self, ego, cand, cand_mode, v_light=None, ref_idx=None, path_id=0, virtual=None, exit_id=None):
+    def get_obs(self, ego, cand, cand_mode, v_light=None, ref_idx=None, path_id=0, virtual=None, exit_id=None, row_mask=None,
+                obs_init=None):
         eg, cd, ri = self._in(ego), self._in(cand), self._in(ref_idx, np.int32)
         cm, vl, vf, ex = self._in(cand_mode, np.uint8), self._in(v_light, np.uint8), self._in(virtual, np.uint8), self._in(exit_id, np.uint8)
         n, m = len(eg), cd.shape[1]
-        out = self._out((n, self.D))
+        out = self._out((n, self.D)) if obs_init is None else self._in(obs_init)
+        rm = self._in(row_mask, np.uint8)
         self.api.get_obs(self.h, n, self._ptr(eg), self._ptr(ri), int(path_id), m, self._ptr(cd), self._ptr(cm), self._ptr(vl),
-                         self._ptr(vf), self._ptr(ex), self._ptr(out), self.stream)
+                         self._ptr(vf), self._ptr(ex), self._ptr(rm), self._ptr(out), self.stream)
         return self._ret(out)
 
     def env_step(self, traffic, obs, raw, ego, cand, cand_mode, ref_idx=None, path_id=0, cand_lw=None, v_light=None,

@@ -434,6 +434,22 @@ def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf, tile):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('task', TASKS)
+@pytest.mark.parametrize('B,tile', [(150, -1), (1000, 0), (1000, 2)])
+def test_masked_observation_pass(task, B, tile):
+    """eb_get_obs(row_mask): the observation pass of a masked reset touches the masked rows only (both tile shapes of the
+    one-launch machinery; whole tiles without a masked row leave at once) and equals the oracle's."""
+    from tests._env_step_check import masked_obs_case
+
+    def make(t, **kw):
+        d = DeviceModel(t, **kw)
+        d.set_tile(tile)
+        return d
+    got = masked_obs_case(make, task, B=B)
+    want = masked_obs_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B=B)
+    assert np.array_equal(got, want)
+
+
 def test_env_step_separate_launches_equal_the_one_launch_kernel():
     """A candidate buffer that is not 16-byte aligned (or more than 64 candidates) takes eb_env_step's separate launches
     — same outputs, bit for bit, as the one-launch kernel on the same scene."""

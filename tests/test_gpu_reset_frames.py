@@ -73,6 +73,7 @@ def test_env_facade_batched_reset_is_one_kernel_state_and_keeps_the_old_flag_for
         mask = (np.random.default_rng(it).random(B) < 0.5)
         ego0, par0, ref0 = env._ego.cpu().numpy(), env._params.cpu().numpy(), env._ref_idx.cpu().numpy()
         virt0, cand0 = env._virtual.cpu().numpy(), env._cand.cpu().numpy()
+        obs_prev = env._obs.cpu().numpy()
         counter = env._reset_counter + 1
         obs = env.reset(mask=mask)
         want = host.env_reset(B, env._respawn_seed ^ env._RESET_SALT, counter, 1, ego0, par0, ref0, mask.astype(np.uint8))
@@ -84,7 +85,8 @@ def test_env_facade_batched_reset_is_one_kernel_state_and_keeps_the_old_flag_for
         assert np.array_equal(cand[~mask], cand0[~mask]) and not np.array_equal(cand[mask], cand0[mask])
         o_want = host.get_obs(want[0], cand, env._cand_mode.cpu().numpy(), env._v_light.cpu().numpy(), ref_idx=want[2],
                               virtual=virt0)                                   # the OLD flags
-        assert np.array_equal(obs.numpy(), o_want)
+        assert np.array_equal(obs.numpy()[mask], o_want[mask])                 # the reset envs' rows
+        assert np.array_equal(obs.numpy()[~mask], obs_prev[~mask])            # the others keep the observation they had (row_mask)
         assert (env.done_type.numpy()[mask] == 0).all()
         env.step(np.zeros((B, 2), np.float32))
 

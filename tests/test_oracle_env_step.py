@@ -2,10 +2,15 @@
 equals its own single calls — the same check the GPU suite runs on the one-launch kernel (tests/_env_step_check.py)."""
 import pytest
 
-from tests._env_step_check import CASES, composite_case
+from tests._env_step_check import CASES, composite_case, masked_obs_case
 from tests._helpers import HostModel
 
 
 @pytest.mark.parametrize('task,B,M,NV,nf', CASES[3:7])
 def test_oracle_env_step_composite(oracle, task, B, M, NV, nf):
     composite_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B, M, NV, nf)
+
+
+@pytest.mark.parametrize('task', ['left', 'straight', 'right'])
+def test_oracle_masked_observation_pass(oracle, task):
+    masked_obs_case(lambda t, **kw: HostModel(oracle, t, **kw), task)
