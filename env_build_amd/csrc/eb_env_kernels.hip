@@ -737,60 +737,83 @@ hipError_t launch_traffic_flow_reset(int n_env, int K, const uint8_t* mask, cons
     return hipGetLastError();
 }
 
-// ---- flow traffic source (eb_traffic_flow_step): one thread per (env, route) ----------------------
-__global__ void traffic_flow_step_kernel(int n_env, int K, float* __restrict__ cand, uint8_t* __restrict__ active,
+// ---- flow traffic source (eb_traffic_flow_step) ------------------------------------------------------
+// A block owns a tile of FS_ENVS envs (FS_ENVS * 12 * K <= 960 slot records).  The first version ran one thread per
+// (env, route) walking its K slots: 16-byte accesses 80 bytes apart across a wave, 47 us at 65 536 envs x 60 slots for
+// 144 MB of traffic.  Now: (1) one lane per slot record, coalesced — exit test / acceleration, the `on` flag to LDS;
+// (2) one lane per (env, route) — first vacant slot from the LDS flags, timer, emission; (3) one lane per slot — active
+// and mode bytes out.  Same arithmetic and the same per-slot order of decisions as before (and as the oracle's twin).
+constexpr int FS_ENVS = 16;
+__global__ __launch_bounds__(256) void traffic_flow_step_kernel(int n_env, int K, float* __restrict__ cand, uint8_t* __restrict__ active,
                                          float* __restrict__ timer, int* __restrict__ emitted, int* __restrict__ sim_step,
                                          const float* __restrict__ lane, const float* __restrict__ period,
                                          const float* __restrict__ v_max, float dt, float exit_range, float accel,
                                          float lane_len, int light_cycle, uint64_t seed, uint64_t counter,
-                                         uint8_t* __restrict__ cand_mode, uint8_t* __restrict__ v_light) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_env * 12) return;
-    const int e = idx / 12, r = idx - e * 12, M = 12 * K;
-    const size_t s0 = (size_t)e * M + (size_t)r * K;
-    int vacant = -1;
-    for (int k = 0; k < K; ++k) {
-        float4* c = reinterpret_cast<float4*>(cand) + s0 + k;
-        bool on = active[s0 + k] != 0;
+                                         uint8_t* __restrict__ cand_mode, uint8_t* __restrict__ v_light, unsigned m_magic) {
+    __shared__ uint8_t s_on[FS_ENVS * 64];
+    const int M = 12 * K, e0 = blockIdx.x * FS_ENVS;
+    const int nE = n_env - e0 < FS_ENVS ? n_env - e0 : FS_ENVS;
+    const int n_rec = nE * M;
+    float4* ctile = reinterpret_cast<float4*>(cand) + (size_t)e0 * M;
+    uint8_t* atile = active + (size_t)e0 * M;
+    for (int idx = threadIdx.x; idx < n_rec; idx += 256) {                 // (1) per slot record
+        bool on = atile[idx] != 0;
         if (on) {
-            float4 v = *c;
+            float4 v = ctile[idx];
+            const int e = m_magic ? (int)__umulhi((unsigned)idx, m_magic) : idx, j = idx - e * M;
             float sn, cs;
             sincos_det(deg2rad(v.w), sn, cs);
             const bool outward = v.x * cs + v.y * sn > 0.0f;
             if (__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)) > exit_range && outward) {
                 on = false;
             } else {
-                const float vn = v.z + accel * dt, vm = v_max[r * K + k];
+                const float vn = v.z + accel * dt, vm = v_max[j];
                 v.z = vn < vm ? vn : vm;
-                *c = v;
+                ctile[idx] = v;
             }
         }
-        active[s0 + k] = on ? 1 : 0;
-        if (!on && vacant < 0) vacant = k;
+        s_on[idx] = on ? 1 : 0;
     }
-    float t = timer[idx] + dt;
-    const float per = period[r];
-    if (t >= per && vacant >= 0) {
-        const int j = r * K + vacant;
-        const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)(r * K) * 2u;
-        const float u1 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
-        const float u2 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
-        const float* ln = lane + 5 * j;
-        const float along = u1 * lane_len;
-        reinterpret_cast<float4*>(cand)[s0 + vacant] = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * v_max[j], ln[2]);
-        active[s0 + vacant] = 1;
-        t = t - per;
-        emitted[idx] += 1;
-    }
-    timer[idx] = t;
-    for (int k = 0; k < K; ++k) cand_mode[s0 + k] = active[s0 + k] ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
-    if (r == 0) {
-        const int n = sim_step[e] + 1;
-        sim_step[e] = n;
-        if (light_cycle) {   // a.net.xml:145-150: 25 s phase 0, 5 s phase 1, 25 s phase 2, 5 s phase 3, in steps of dt
-            const float tt = (float)(n % (int)(60.0f / dt + 0.5f)) * dt;
-            v_light[e] = tt < 25.0f ? 0 : (tt < 30.0f ? 1 : (tt < 55.0f ? 2 : 3));
+    __syncthreads();
+    for (int q = threadIdx.x; q < nE * 12; q += 256) {                      // (2) per (env, route)
+        const int e = q / 12, r = q - e * 12;
+        const int ge = e0 + e;
+        uint8_t* on = s_on + e * M + r * K;
+        int vacant = -1;
+        for (int k = K - 1; k >= 0; --k)
+            if (!on[k]) vacant = k;
+        const size_t ti = (size_t)ge * 12 + r;
+        float t = timer[ti] + dt;
+        const float per = period[r];
+        if (t >= per && vacant >= 0) {
+            const int j = r * K + vacant;
+            const uint64_t base = (counter << 32) + (uint64_t)ge * 128u + (uint64_t)(r * K) * 2u;
+            const float u1 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * base) >> 40) * 5.9604644775390625e-8f;
+            const float u2 = (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * (base + 1)) >> 40) * 5.9604644775390625e-8f;
+            const float* ln = lane + 5 * j;
+            const float along = u1 * lane_len;
+            ctile[e * M + j] = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * v_max[j], ln[2]);
+            on[vacant] = 1;
+            t = t - per;
+            emitted[ti] += 1;
         }
+        timer[ti] = t;
+        if (r == 0) {
+            const int n = sim_step[ge] + 1;
+            sim_step[ge] = n;
+            if (light_cycle) {   // a.net.xml:145-150: 25 s phase 0, 5 s phase 1, 25 s phase 2, 5 s phase 3, in steps of dt
+                const float tt = (float)(n % (int)(60.0f / dt + 0.5f)) * dt;
+                v_light[ge] = tt < 25.0f ? 0 : (tt < 30.0f ? 1 : (tt < 55.0f ? 2 : 3));
+            }
+        }
+    }
+    __syncthreads();
+    uint8_t* mtile = cand_mode + (size_t)e0 * M;
+    for (int idx = threadIdx.x; idx < n_rec; idx += 256) {                 // (3) flags and mode bytes out
+        const int e = m_magic ? (int)__umulhi((unsigned)idx, m_magic) : idx, j = idx - e * M;
+        const bool on = s_on[idx] != 0;
+        atile[idx] = on ? 1 : 0;
+        mtile[idx] = on ? (uint8_t)(j / K) : (uint8_t)EB_VMODE_EMPTY;
     }
 }
 
@@ -798,11 +821,12 @@ hipError_t launch_traffic_flow_step(int n_env, int K, float* cand, uint8_t* acti
                                     int* sim_step, const float* lane, const float* period, const float* v_max, float dt,
                                     float exit_range, float accel, float lane_len, int light_cycle, uint64_t seed,
                                     uint64_t counter, uint8_t* cand_mode, uint8_t* v_light, hipStream_t s) {
-    const int n = n_env * 12;
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(traffic_flow_step_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n_env, K, cand, active, timer,
-                       emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len, light_cycle, seed, counter,
-                       cand_mode, v_light);
+    if (n_env <= 0) return hipSuccess;
+    const int M = 12 * K;
+    const unsigned m_magic = M <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)M - 1) / (unsigned)M);
+    hipLaunchKernelGGL(traffic_flow_step_kernel, dim3((n_env + FS_ENVS - 1) / FS_ENVS), dim3(256), 0, s, n_env, K, cand, active,
+                       timer, emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len, light_cycle, seed, counter,
+                       cand_mode, v_light, m_magic);
     return hipGetLastError();
 }
 
