@@ -1152,7 +1152,8 @@ int eb_mlp_set_layer(eb_mlp m, int32_t layer, const float* kernel, const float* 
     int kr, cr, kp, ct;
     mlp_layer_dims(m, layer, &kr, &cr, &kp, &ct);
     std::vector<float> wp((size_t)kp * ct * 32), bp((size_t)ct * 32, 0.0f);
-    eb::pack_weights(kernel, kr, cr, kp, ct, wp.data());
+    if (layer == m->cfg.n_hidden) eb::pack_weights16(kernel, kr, cr, kp, wp.data());   // (<= 2 tiles of 16: fits the 32-column buffer)
+    else eb::pack_weights(kernel, kr, cr, kp, ct, wp.data());
     std::copy(bias, bias + cr, bp.begin());
     EB_HIP(hipSetDevice(m->cfg.device));
     EB_HIP(hipMemcpy(m->d_w[layer], wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -184,6 +184,7 @@ struct MlpArgs {
 int mlp_padded_units(int n_units);
 size_t mlp_lds_bytes(const MlpArgs& A);
 void pack_weights(const float* kernel, int k_real, int cols_real, int k_pad, int col_tiles, float* out);
+void pack_weights16(const float* kernel, int k_real, int cols_real, int k_pad, float* out);   // the output layer's 16-column tiles
 hipError_t launch_mlp(const MlpArgs& A, hipStream_t s);
 hipError_t launch_shield_accumulate(int n, const float* pen, float* punish, uint8_t* safe, int first, int last,
                                     hipStream_t s);

@@ -15,8 +15,8 @@
 //     [k even | k odd] halves (m consecutive -> ds_read_b128 = 4 k-pairs); the host packs W the same way per
 //     32-column tile (eb_mlp_set_layer -> pack_weights), so a wave's global_load_dwordx4 is 1 KB contiguous.
 //   * a wave owns RT x CT tiles of 32 x 32 outputs (U = 256: 2 x 2; 512: 2 x 4; 128: 2 x 1; 64: 1 x 1), i.e.
-//     RT + CT fragment loads per 4 * RT * CT MFMAs; the output layer (<= 32 columns) is one column tile done
-//     by waves 0 and 1.
+//     RT + CT fragment loads per 4 * RT * CT MFMAs; the output layer (<= 32 columns) runs on 16 x 16 x 4 tiles, one row
+//     tile of 16 per wave (all four waves).
 //   * widths are padded with zero weights / zero bias to the next supported U; a padded unit outputs
 //     act(0) = 0 for all four activations and meets zero weights in the next layer — exact no-ops in the chain.
 #include "eb_kernels.h"
@@ -212,32 +212,50 @@ __global__ __launch_bounds__(MLP_THREADS, CT == 4 ? 1 : 2) void mlp_kernel(const
         __syncthreads();
     }
 
-    // ---- output layer: one 32-column tile, row tile = wave (waves 0 and 1) ----
-    if (wave < 2) {
-        f32x16 acc[1][1];
-        const float b = A.outl.b[i];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[0][0][v] = b;
-        layer_chain<1, 1>(lds + (wave * 32 + i) * RS + h * HS, 32 * RS, reinterpret_cast<const f32x4*>(A.outl.w),
-                          A.outl.k_pad >> 3, 0, lane, acc);
-        const int col = i;
-        if (A.head == MLP_HEAD_LOGITS) {
-            if (col < A.out_dim) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int row = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    if (row < rows_here) A.out[(size_t)(row0 + row) * A.out_dim + col] = activate_rt(A.out_act, acc[0][0][v]);
-                }
+    // ---- output layer: 16 x 16 x 4 tiles (v_mfma_f32_16x16x4_f32: same exact fp32, same k-ordered fma chain, half the
+    // issue time of a 32 x 32 x 2 per k), row tile = wave — all four waves, where the 32-column tile of rounds 1-2 kept two of
+    // them idle for 128 MFMAs of 64 cycles — and ceil(out_dim / 16) column tiles.  Lane l supplies A[i = l & 15][k = 4s + (l >> 4)]
+    // and B[k = 4s + (l >> 4)][j = l & 15]; it receives D[4 (l >> 4) + v][l & 15], v = 0..3.
+    {
+        const int i16 = lane & 15, kq = lane >> 4, hsel = kq >> 1;
+        const int steps4 = A.outl.k_pad >> 4;                               // groups of four MFMAs (16 inputs)
+        const float* a_ptr = lds + (wave * 16 + i16) * RS + (kq & 1) * HS;  // element (k >> 1) = m of this lane's parity at a_ptr[m]
+        const f32x4* w16 = reinterpret_cast<const f32x4*>(A.outl.w);
+        const int ct16 = (A.out_dim + 15) >> 4;
+        for (int ct = 0; ct < ct16; ++ct) {
+            const float b = A.outl.b[ct * 16 + i16];
+            f32x4 acc = {b, b, b, b};
+            const f32x4* wsrc = w16 + (size_t)ct * steps4 * 64 + lane;
+            f32x4 bq = wsrc[0];
+            for (int s4 = 0; s4 < steps4; ++s4) {
+                const f32x4 bn = wsrc[(size_t)(s4 + 1 < steps4 ? s4 + 1 : s4) * 64];      // the next group's weights under these MFMAs
+                const f32x4 a01 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * s4);
+                const f32x4 a23 = *reinterpret_cast<const f32x4*>(a_ptr + 8 * s4 + 4);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hsel ? a01[1] : a01[0], bq[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hsel ? a01[3] : a01[2], bq[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hsel ? a23[1] : a23[0], bq[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hsel ? a23[3] : a23[2], bq[3], acc, 0, 0, 0);
+                bq = bn;
             }
-        } else {   // deterministic action: action_range * tanh(mean), utils/policy.py:89-92
-            const int act_dim = A.out_dim >> 1;
-            if (col < act_dim) {
+            const int col = ct * 16 + i16;
+            if (A.head == MLP_HEAD_LOGITS) {
+                if (col < A.out_dim) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int row = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    const float mean = activate_rt(A.out_act, acc[0][0][v]);
-                    if (row < rows_here)
-                        A.out[(size_t)(row0 + row) * act_dim + col] = A.action_range > 0.0f ? A.action_range * tanh_det(mean) : mean;
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = wave * 16 + 4 * kq + v;
+                        if (row < rows_here) A.out[(size_t)(row0 + row) * A.out_dim + col] = activate_rt(A.out_act, acc[v]);
+                    }
+                }
+            } else {   // deterministic action: action_range * tanh(mean), utils/policy.py:89-92
+                const int act_dim = A.out_dim >> 1;
+                if (col < act_dim) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = wave * 16 + 4 * kq + v;
+                        const float mean = activate_rt(A.out_act, acc[v]);
+                        if (row < rows_here)
+                            A.out[(size_t)(row0 + row) * act_dim + col] = A.action_range > 0.0f ? A.action_range * tanh_det(mean) : mean;
+                    }
                 }
             }
         }
@@ -290,6 +308,19 @@ void pack_weights(const float* kernel, int k_real, int cols_real, int k_pad, int
                     const int k = 2 * (s * 4 + q) + (l >> 5), j = ct * 32 + (l & 31);
                     out[(((size_t)ct * steps + s) * 64 + l) * 4 + q] =
                         (k < k_real && j < cols_real) ? kernel[(size_t)k * cols_real + j] : 0.0f;
+                }
+}
+
+// Host side of eb_mlp_set_layer for the OUTPUT layer (16 x 16 x 4 tiles): per 16-column tile, per group of four MFMA steps
+// (16 inputs), per lane, the 4 values that lane feeds to those four MFMAs: W[4 (4 g + q) + (lane >> 4)][tile * 16 + (lane & 15)].
+void pack_weights16(const float* kernel, int k_real, int cols_real, int k_pad, float* out) {
+    const int groups = k_pad / 16, tiles = (cols_real + 15) / 16;
+    for (int ct = 0; ct < tiles; ++ct)
+        for (int g = 0; g < groups; ++g)
+            for (int l = 0; l < 64; ++l)
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 4 * (4 * g + q) + (l >> 4), j = ct * 16 + (l & 15);
+                    out[(((size_t)ct * groups + g) * 64 + l) * 4 + q] = (k < k_real && j < cols_real) ? kernel[(size_t)k * cols_real + j] : 0.0f;
                 }
 }
 
