@@ -62,10 +62,31 @@ EB_DEV float tanh_det(float x) {
     return ax > 44.0f ? sat : (ax >= 0.625f ? big : small);              // NaN: both compares false -> small = NaN
 }
 
+// ELU = x > 0 ? x : exp_det(x) - 1, written for the epilogue (64 values per lane and layer): only x <= 0 reaches the
+// exponential's result, so the upper clamp goes, the scaling by 2^n is one v_ldexp_f32 (exactly the multiplication by the
+// bit-built power of two, denormal results included) and a NaN needs no select — it travels through the fma chain by
+// itself (v_cvt_i32_f32 of NaN is 0).  Same bits as exp_det(x) - 1 for every x <= 0, so the oracle's eb_expf stays as it is.
+EB_DEV float elu_det(float x0) {
+    const float x = x0 < -87.0f ? -87.0f : x0;
+    const float fx = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(-fx, 0.693359375f, x);
+    r = __builtin_fmaf(-fx, -2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(p, z, r) + 1.0f;
+    const float v = __builtin_amdgcn_ldexpf(y, (int)fx);
+    return x0 > 0.0f ? x0 : v - 1.0f;
+}
+
 template <int ACT>
 EB_DEV float activate(float x) {
     if (ACT == MLP_ACT_RELU) return x > 0.0f ? x : 0.0f;
-    if (ACT == MLP_ACT_ELU) { const float e = exp_det(x) - 1.0f; return x > 0.0f ? x : e; }
+    if (ACT == MLP_ACT_ELU) return elu_det(x);
     if (ACT == MLP_ACT_TANH) return tanh_det(x);
     return x;
 }
