@@ -456,7 +456,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     scaled, out5, code = torch.empty((B, 2), **f32), torch.empty((5, B), **f32), torch.empty((B,), dtype=torch.uint8, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rule = _capi.EbRespawn(env._entry5.data_ptr(), 65.0, 60.0, 8.0, 12345, 0)
+    rule = _capi.EbRespawn(env._entry5.data_ptr(), 65.0, env.POOL_EDGE_SPAN, 8.0, 12345, 0)    # the facade's own re-entry rule
     fn = lib.eb_env_step
     h, ht = env._h, env._traffic.h
     argsets = []

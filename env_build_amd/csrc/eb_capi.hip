@@ -1059,13 +1059,13 @@ extern "C" {
 
 int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
                        float span, float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask,
-                       uint8_t* respawned, void* stream) {
+                       uint8_t* respawned, const float* ego, float edge_span, void* stream) {
     if (!h || n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!cand || !entry)))
         return fail(EB_EINVAL, "eb_traffic_respawn: bad argument");
     if (n_env == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
     EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, entry, limit, span, v_max, seed, counter, env_mask, respawned,
-                                      pick(h, stream)));
+                                      pick(h, stream), ego, edge_span));
     return EB_OK;
 }
 

@@ -601,9 +601,11 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
 }
 
 
+EB_DEV bool init_conflict(const float* ego6, float ego_l, float x, float y, float a, float veh_v, float veh_l);
 __global__ void traffic_respawn_kernel(int n_env, int m_cand, float* __restrict__ cand, const float* __restrict__ entry,
                                        float limit, float span, float v_max, uint64_t seed, uint64_t counter,
-                                       const uint8_t* __restrict__ env_mask, uint8_t* __restrict__ respawned) {
+                                       const uint8_t* __restrict__ env_mask, uint8_t* __restrict__ respawned,
+                                       const float* __restrict__ ego, float edge_span) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_env * m_cand) return;
     const int e = idx / m_cand, j = idx - e * m_cand;
@@ -615,19 +617,25 @@ __global__ void traffic_respawn_kernel(int n_env, int m_cand, float* __restrict_
         const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)j * 2u;
         const float u1 = u01(seed, base), u2 = u01(seed, base + 1);
         const float* en = entry + 5 * j;
-        const float along = u1 * span;
-        *c = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * v_max, en[2]);
+        float along = u1 * span;
+        float4 nv = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * v_max, en[2]);
+        if (ego && init_conflict(ego + 6 * (size_t)e, 4.8f, nv.x, nv.y, nv.w, nv.z, 4.8f)) {   // TRF:168-192: not on top of the ego
+            along = u1 * edge_span;
+            nv.x = en[0] + along * en[3];
+            nv.y = en[1] + along * en[4];
+        }
+        *c = nv;
     }
     if (respawned) respawned[idx] = gone ? 1 : 0;
 }
 
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
                                   float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask, uint8_t* respawned,
-                                  hipStream_t s) {
+                                  hipStream_t s, const float* ego, float edge_span) {
     const int n = n_env * m_cand;
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(traffic_respawn_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n_env, m_cand, cand, entry, limit,
-                       span, v_max, seed, counter, env_mask, respawned);
+                       span, v_max, seed, counter, env_mask, respawned, ego, edge_span);
     return hipGetLastError();
 }
 

@@ -150,7 +150,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s);
 
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,
                                   float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask, uint8_t* respawned,
-                                  hipStream_t s);
+                                  hipStream_t s, const float* ego = nullptr, float edge_span = 0.0f);
 
 hipError_t launch_traffic_flow_step(int n_env, int K, float* cand, uint8_t* active, float* timer, int* emitted,
                                     int* sim_step, const float* lane, const float* period, const float* v_max, float dt,

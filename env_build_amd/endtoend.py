@@ -259,7 +259,9 @@ class CrossroadEnd2end(object):
         self._injected = False
         self._flows = None
         self._bufs, self._buf_i = None, 0
-        self._respawn_rule = _capi.EbRespawn(self._entry5.data_ptr(), CROSSROAD_SIZE / 2 + 40., 60.0, EXPECTED_V, 0, 0)
+        # during an episode a vehicle that left the map re-enters at its lane's edge (within POOL_EDGE_SPAN m of the entry
+        # point, 60 m from the centre: where no ego is), not somewhere along the lane
+        self._respawn_rule = _capi.EbRespawn(self._entry5.data_ptr(), CROSSROAD_SIZE / 2 + 40., self.POOL_EDGE_SPAN, EXPECTED_V, 0, 0)
         if traffic == 'flows':
             from .traffic import FlowTraffic
             self._flows = FlowTraffic(B, dev, None, self.training_task, mode=self.mode, per_route=per_route,
@@ -303,6 +305,7 @@ class CrossroadEnd2end(object):
 
     # -- reset ----------------------------------------------------------------------------------
     _RESET_SALT, _POOL_SALT = 0x2545F4914F6CDD1D, 0x5DEECE66D
+    POOL_EDGE_SPAN = 5.0      # metres from the map edge within which the pool re-enters a vehicle during an episode / on a conflict
 
     def _reset_init_state(self, mask8=None):  # E2E:472-499, per env
         """n_env == 1: the reference's own host-side draws (np.random, E2E:474-482).  A batch: ONE kernel, eb_env_reset —
@@ -357,9 +360,10 @@ class CrossroadEnd2end(object):
             self._reset_counter += 1
             if not self._cand.is_contiguous():
                 self._cand = self._cand.contiguous()
+            # (init_traffic's conflict rule, TRF:168-192: a candidate that would start on top of the ego goes to its lane's edge)
             self.api.traffic_respawn(self._traffic.h, B, self.n_cand, _ptr(self._cand), _ptr(self._entry5), C.c_float(-1.0),
                                      C.c_float(60.0), C.c_float(EXPECTED_V), C.c_uint64(self._respawn_seed ^ self._POOL_SALT),
-                                     C.c_uint64(self._reset_counter), _ptr(mask8), None, sp)
+                                     C.c_uint64(self._reset_counter), _ptr(mask8), None, _ptr(self._ego), C.c_float(self.POOL_EDGE_SPAN), sp)
             if mask8 is None:                      # the pool has no light programme: a reset env starts at phase 0
                 self._v_light.zero_()              # (a value injected through the multi_display seam does not survive reset)
             else:
@@ -507,8 +511,9 @@ class CrossroadEnd2end(object):
         if self.respawn and self._flows is None:
             self._respawn_counter += 1
             self.api.traffic_respawn(self._traffic.h, self.n_env, self.n_cand, _ptr(self._cand), _ptr(self._entry5),
-                                     C.c_float(CROSSROAD_SIZE / 2 + 40.), C.c_float(60.0), C.c_float(EXPECTED_V),
-                                     C.c_uint64(self._respawn_seed), C.c_uint64(self._respawn_counter), None, None, self._sp())
+                                     C.c_float(CROSSROAD_SIZE / 2 + 40.), C.c_float(self.POOL_EDGE_SPAN), C.c_float(EXPECTED_V),
+                                     C.c_uint64(self._respawn_seed), C.c_uint64(self._respawn_counter), None, None, None,
+                                     C.c_float(0.0), self._sp())
 
     def _judge_done(self):  # E2E:200-256 -> (done_type, done)
         code = torch.empty((self.n_env,), dtype=torch.uint8, device=self.device)

@@ -377,10 +377,14 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
  * so the result depends on (seed, counter, env, slot) only and the two libraries agree bit for bit.
  * env_mask (nullable, uint8 [n_env]): only the envs with a non-zero byte are touched; limit < 0 re-enters every
  * candidate of those envs (the pool's part of reset).  `respawned` (nullable, uint8 [n_env, m_cand]) marks the
- * slots that were re-entered. */
+ * slots that were re-entered.
+ * ego (nullable, [n_env, 6]): Traffic.init_traffic's conflict rule for the pool (TRF:168-192 pushes conflicting cars away
+ * when an episode starts): a re-entered candidate whose new pose conflicts with its env's ego — the box test of
+ * TRF:183-184 in the ego's frame or in the vehicle's, both lengths 4.8 m — is put within `edge_span` metres of its lane's
+ * start instead, (entry.x + u1 * edge_span * entry.dx, ...), so that no episode starts inside a collision. */
 int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
                        float span, float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask,
-                       uint8_t* respawned, void* stream);
+                       uint8_t* respawned, const float* ego, float edge_span, void* stream);
 
 /* One step of the SUMO-free FLOW traffic source (env_build_amd/traffic.py states the rules and where each number
  * comes from in sumo_files/cross.rou.xml and a.net.xml) AFTER the slots have been advanced by eb_veh_predict:

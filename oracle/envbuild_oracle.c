@@ -1278,7 +1278,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, cand_lw, v_light, done_code, stream);   /* E2E:141 */
     if (!rc && respawn)   /* the pool's re-entry, after the observation saw this step's state */
         rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
-                                respawn->seed, respawn->counter, NULL, NULL, stream);
+                                respawn->seed, respawn->counter, NULL, NULL, NULL, 0.0f, stream);
     return rc;
 }
 
@@ -1356,9 +1356,10 @@ static inline float eb_u01(uint64_t seed, uint64_t idx) {   /* top 24 bits of sp
     return (float)(eb_splitmix64(seed + 0x9E3779B97F4A7C15ull * idx) >> 40) * 5.9604644775390625e-8f;
 }
 
+static int init_conflict(const float* ego6, float ego_l, float x, float y, float a, float veh_v, float veh_l);
 int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
                        float span, float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask,
-                       uint8_t* respawned, void* stream) {
+                       uint8_t* respawned, const float* ego, float edge_span, void* stream) {
     (void)stream;
     if (!h || n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!cand || !entry)))
         return fail(EB_EINVAL, "eb_traffic_respawn: bad argument");
@@ -1371,11 +1372,16 @@ int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, 
                 const uint64_t base = (counter << 32) + (uint64_t)e * 128u + (uint64_t)j * 2u;
                 const float u1 = eb_u01(seed, base), u2 = eb_u01(seed, base + 1);
                 const float* en = entry + 5 * j;
-                const float along = u1 * span;
-                c[0] = en[0] + along * en[3];
-                c[1] = en[1] + along * en[4];
+                float along = u1 * span;
                 c[2] = u2 * v_max;
                 c[3] = en[2];
+                c[0] = en[0] + along * en[3];
+                c[1] = en[1] + along * en[4];
+                if (ego && init_conflict(ego + 6 * (size_t)e, 4.8f, c[0], c[1], c[3], c[2], 4.8f)) {   /* TRF:168-192 */
+                    along = u1 * edge_span;
+                    c[0] = en[0] + along * en[3];
+                    c[1] = en[1] + along * en[4];
+                }
             }
             if (respawned) respawned[(size_t)e * m_cand + j] = gone ? 1 : 0;
         }

@@ -100,3 +100,29 @@ def masked_obs_case(make, task, B=150, M=10, seed=8):
         got = m.get_obs(ego, cand, cmode, light, ref_idx=ref, row_mask=mask.astype(np.uint8), obs_init=init)
         assert np.array_equal(got[mask], full[mask]) and np.array_equal(got[~mask], init[~mask])
     return full
+
+
+def respawn_conflict_case(make, B=300, M=16, seed=4):
+    """eb_traffic_respawn with the ego given (init_traffic's conflict rule for the pool, TRF:168-192): a forced re-entry
+    puts nobody inside the ego's box; the candidates that would have been are at their lane's edge; everybody else is
+    where the rule without the ego puts them."""
+    from env_build_amd.endtoend import _lane_entry
+    task = 'left'
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    entry = np.array([list(_lane_entry(m)[:3]) + list(_lane_entry(m)[3]) for m in modes], np.float32)
+    ego, cand, _, _, _, _, _ = random_scene(task, B, M, seed)
+    ego[:, 1:3] = 0
+    tr = make(task, n_veh=M, modes=modes)
+    plain, f0 = tr.traffic_respawn(cand, entry, -1.0, 60.0, 8.0, 99, 5)
+    safe, f1 = tr.traffic_respawn(cand, entry, -1.0, 60.0, 8.0, 99, 5, ego=ego, edge_span=5.0)
+    assert f0.all() and f1.all()
+    moved = np.any(plain != safe, axis=2)
+    assert 0.005 < moved.mean() < 0.3                                    # some candidates would have started on the ego
+    assert np.array_equal(plain[~moved], safe[~moved])
+    along = np.abs((safe[..., :2] - entry[None, :, :2]) @ np.array([1.0, 1.0], np.float32))   # lanes are axis-parallel
+    assert (along[moved] < 5.0 + 1e-3).all()
+    # nobody within 3 m laterally and [-5, v + 6.8] m longitudinally of an ego heading along its lane... checked loosely:
+    d = np.hypot(safe[..., 0] - ego[:, None, 3], safe[..., 1] - ego[:, None, 4])
+    assert d.min() > 2.0
+    return safe

@@ -338,13 +338,13 @@ class HostModel(object):
                           C.byref(rs) if rs is not None else None, self.stream)
         return [None if x is None else self._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code)]
 
-    def traffic_respawn(self, cand, entry, limit, span, v_max, seed, counter, mask=None):
+    def traffic_respawn(self, cand, entry, limit, span, v_max, seed, counter, mask=None, ego=None, edge_span=0.0):
         """eb_traffic_respawn on a copy of the candidates -> (cand, respawned)"""
-        cd, en, mk = self._in(np.array(cand, np.float32)), self._in(entry), self._in(mask, np.uint8)
+        cd, en, mk, eg = self._in(np.array(cand, np.float32)), self._in(entry), self._in(mask, np.uint8), self._in(ego)
         B, M = cd.shape[0], cd.shape[1]
         flags = self._out((B, M), np.uint8)
         self.api.traffic_respawn(self.h, B, M, self._ptr(cd), self._ptr(en), C.c_float(limit), C.c_float(span), C.c_float(v_max),
-                                 C.c_uint64(seed), C.c_uint64(counter), self._ptr(mk), self._ptr(flags), self.stream)
+                                 C.c_uint64(seed), C.c_uint64(counter), self._ptr(mk), self._ptr(flags), self._ptr(eg), C.c_float(edge_span), self.stream)
         return self._ret(cd), self._ret(flags)
 
     def judge_done(self, ego, params, obs, cand, cand_mode, cand_lw, v_light):

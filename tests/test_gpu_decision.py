@@ -53,6 +53,15 @@ def test_batched_decision_steps_match_oracle_composition(task):
     rows = np.arange(B)
     switches = shields = 0
     for t in range(8):
+        if t == 2:    # the pool no longer starts anybody on top of an ego (TRF:168-192): park a vehicle in front of every fourth
+            e = env._ego.cpu().numpy()           # one so that the shield has something to refuse
+            c = env._cand.cpu().numpy()
+            rad = np.deg2rad(e[::4, 5])
+            c[::4, 0, 0] = e[::4, 3] + 3.0 * np.cos(rad)
+            c[::4, 0, 1] = e[::4, 4] + 3.0 * np.sin(rad)
+            c[::4, 0, 2] = 0.0
+            env._cand.copy_(torch.from_numpy(c))
+            env._get_obs()
         ego, cand = env._ego.cpu().numpy(), env._cand.cpu().numpy()
         cmode = env._cand_mode.cpu().numpy()
         light = ((env._v_light != 0) | (env._virtual != 0)).to(torch.uint8).cpu().numpy()   # E2E:387-388, on the host

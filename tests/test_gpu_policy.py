@@ -205,14 +205,14 @@ def test_policy_and_traffic_entry_points_reject_bad_arguments():
         c = mdl._in(np.zeros((2, 4, 4), np.float32)); en = mdl._in(np.zeros((4, 5), np.float32))
         with pytest.raises(ValueError):
             api.traffic_respawn(mdl.h, 2, 0, mdl._ptr(c), mdl._ptr(en), C.c_float(65.), C.c_float(60.), C.c_float(8.),
-                                C.c_uint64(1), C.c_uint64(1), None, None, mdl.stream)  # m_cand < 1
+                                C.c_uint64(1), C.c_uint64(1), None, None, None, C.c_float(0.), mdl.stream)  # m_cand < 1
         with pytest.raises(ValueError):
             api.traffic_respawn(mdl.h, 2, 4, None, mdl._ptr(en), C.c_float(65.), C.c_float(60.), C.c_float(8.),
-                                C.c_uint64(1), C.c_uint64(1), None, None, mdl.stream)
+                                C.c_uint64(1), C.c_uint64(1), None, None, None, C.c_float(0.), mdl.stream)
         with pytest.raises(ValueError):
             api.traffic_flow_step(mdl.h, 2, 6, None, None, None, None, None, None, None, None, C.c_float(0.1), C.c_float(65.),
                                   C.c_float(2.6), C.c_float(75.), 1, C.c_uint64(1), C.c_uint64(1), None, None, mdl.stream)   # 72 slots
-        assert api.lib.eb_traffic_respawn(mdl.h, 0, 4, None, None, C.c_float(1), C.c_float(1), C.c_float(1), 1, 1, None, None, None) == 0
+        assert api.lib.eb_traffic_respawn(mdl.h, 0, 4, None, None, C.c_float(1), C.c_float(1), C.c_float(1), 1, 1, None, None, None, C.c_float(0.), None) == 0
 
 
 # ---- G13: fixtures from the reference's own MLPNet / Policy4Toyota / Preprocessor / LoadPolicy.run_batch ----

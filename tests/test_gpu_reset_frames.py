@@ -105,7 +105,7 @@ def test_traffic_respawn_mask_and_forced_reentry_equal_oracle():
             c, en, mk = mdl._in(cand.copy()), mdl._in(entry), mdl._in(mask, np.uint8)
             flag = mdl._out((B, M), np.uint8)
             mdl.api.traffic_respawn(mdl.h, B, M, mdl._ptr(c), mdl._ptr(en), C.c_float(limit), C.c_float(60.0), C.c_float(8.0),
-                                    C.c_uint64(987654321), C.c_uint64(5), mdl._ptr(mk), mdl._ptr(flag), mdl.stream)
+                                    C.c_uint64(987654321), C.c_uint64(5), mdl._ptr(mk), mdl._ptr(flag), None, C.c_float(0.0), mdl.stream)
             outs.append((mdl._ret(c), mdl._ret(flag)))
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
         got, flag = outs[1]

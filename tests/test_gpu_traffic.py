@@ -118,7 +118,7 @@ def test_traffic_respawn_equals_oracle_and_depends_on_its_key_only():
         c, en = mdl._in(cand.copy()), mdl._in(entry)
         flag = mdl._out((B, M), np.uint8)
         mdl.api.traffic_respawn(mdl.h, B, M, mdl._ptr(c), mdl._ptr(en), C.c_float(65.0), C.c_float(60.0), C.c_float(8.0),
-                                C.c_uint64(12345678901234567), C.c_uint64(77), None, mdl._ptr(flag), mdl.stream)
+                                C.c_uint64(12345678901234567), C.c_uint64(77), None, mdl._ptr(flag), None, C.c_float(0.), mdl.stream)
         outs.append((mdl._ret(c), mdl._ret(flag)))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     got, flag = outs[1]
@@ -130,7 +130,7 @@ def test_traffic_respawn_equals_oracle_and_depends_on_its_key_only():
     # the same (env, slot) rows inside a smaller batch draw the same values
     c2, en2 = dev._in(cand[:100].copy()), dev._in(entry)
     dev.api.traffic_respawn(dev.h, 100, M, dev._ptr(c2), dev._ptr(en2), C.c_float(65.0), C.c_float(60.0),
-                            C.c_float(8.0), C.c_uint64(12345678901234567), C.c_uint64(77), None, None, dev.stream)
+                            C.c_float(8.0), C.c_uint64(12345678901234567), C.c_uint64(77), None, None, None, C.c_float(0.), dev.stream)
     assert np.array_equal(dev._ret(c2), got[:100])
     u = got[gone][:, 2] / 8.0
     assert abs(u.mean() - 0.5) < 0.03                                   # roughly uniform draws
@@ -212,3 +212,12 @@ def test_single_env_predicates_agree_with_the_done_code():
             if done:
                 env.reset()
     assert len(seen) >= 3
+
+
+def test_pool_reset_keeps_clear_of_the_ego_and_equals_oracle():
+    """eb_traffic_respawn(ego=...): TRF:168-192's conflict rule for the pool, GPU == oracle bit for bit"""
+    from tests._env_step_check import respawn_conflict_case
+    from tests._helpers import DeviceModel, HostModel, oracle_lib
+    got = respawn_conflict_case(lambda t, **kw: DeviceModel(t, **kw))
+    want = respawn_conflict_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw))
+    assert np.array_equal(got, want)
