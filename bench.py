@@ -481,6 +481,8 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
                 api.check(rc)
         return k
 
+    import gc
+    gc.collect()              # handles and buffers of earlier measurements go now, not inside a timed segment
     k = 0
     for _ in range(3):
         restore(); k = segment(k)
@@ -493,13 +495,13 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
         lib.eb_event_record(ev[2 * r + 1], sp)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    ms, tot = C.c_float(), 0.0
+    ms, seg_us = C.c_float(), []
     for r in range(reps):
         api.event_elapsed_ms(ev[2 * r], ev[2 * r + 1], C.byref(ms))
-        tot += ms.value
+        seg_us.append(ms.value * 1e3 / seg)
     for e in ev:
         api.event_destroy(e)
-    us = tot * 1e3 / (reps * seg)
+    us = median(seg_us)       # per-step time of the median segment: one host hiccup (a collection, a free) does not move it
     alg = env_step_alg_bytes(D, M) * B
     achieved, frac = roofline_of(alg, us)
     done_frac = float((code != 0).float().mean().item())
@@ -511,7 +513,9 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     return {'workload': 'env_step: CrossroadEnd2end.step for N_env=%d single-ego envs x %d traffic candidates (task %s, D=%d): eb_env_step '
                         '= ONE launch (action scaling, reward, ego step, traffic step, observation, done code, pool re-entry)' % (B, M, TASK, D),
             'n_env_per_gpu': B, 'n_cand': M, 'obs_dim': D, 'dtype': 'f32', 'value': B / (us * 1e-6), 'unit': 'env-steps/s',
-            'avg_launch_us': us, 'launches_timed': reps * seg, 'wall_us_per_step_incl_state_restores': wall * 1e6 / (reps * seg),
+            'avg_launch_us': us, 'launches_timed': reps * seg, 'segments': {'n': reps, 'steps_each': seg, 'statistic': 'median',
+                                                                      'us_per_step_min': min(seg_us), 'us_per_step_max': max(seg_us)},
+            'wall_us_per_step_incl_state_restores': wall * 1e6 / (reps * seg),
             'alg_bytes_per_env_step': env_step_alg_bytes(D, M), 'alg_bytes_per_launch': alg, 'achieved_GBs': achieved, 'frac': frac,
             'traffic': traffic, 'traffic_source': 'profiles/r3_pmc_traffic.json (separate rocprofv3 --pmc passes, scripts/pmc_traffic.sh)' if traffic else None,
             'kernel': 'eb::env_step_kernel<0, %d>' % (16 if B <= 16384 else 64), 'done_fraction_after_segment': done_frac}
