@@ -34,7 +34,7 @@ class EbMlpConfig(C.Structure):
 
 class EbRespawn(C.Structure):     # struct eb_respawn: the pool's re-entry rule as the last stage of eb_env_step
     _fields_ = [('entry', C.c_void_p), ('limit', C.c_float), ('span', C.c_float), ('v_max', C.c_float),
-                ('seed', C.c_uint64), ('counter', C.c_uint64)]
+                ('seed', C.c_uint64), ('counter', C.c_uint64), ('edge_span', C.c_float)]
 
 
 ACT_ID = {'linear': 0, None: 0, 'relu': 1, 'elu': 2, 'tanh': 3}        # EB_ACT_*
@@ -85,6 +85,7 @@ PROTOTYPES = {
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P]),
+    'eb_env_reset_pool': (C.c_int, [_P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, _P, C.c_float, _P]),
     'eb_traffic_flow_reset': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I,
                                         C.c_uint64, C.c_uint64, _P, _P, _P]),

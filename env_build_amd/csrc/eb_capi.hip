@@ -57,6 +57,8 @@ struct eb_handle_s {
     hipStream_t gate_stream;  // producer stream of gated rollouts (high priority: a hardware queue of its own), made on first use
     hipEvent_t gate_event;    // orders eb_gate_feed behind the caller's stream (after_stream)
     float* d_scratch;         // eb_env_step's scaled actions when the caller passes none (separate-launch path only)
+    uint8_t* d_vnext;         // eb_env_reset_pool: the flags eb_env_reset drew, until they are swapped in
+    size_t vnext_bytes;
     size_t scratch_floats;
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
     int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
@@ -187,6 +189,7 @@ int eb_destroy(eb_handle h) {
     if (h->gate_stream) hipStreamDestroy(h->gate_stream);
     if (h->gate_event) hipEventDestroy(h->gate_event);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
+    if (h->d_vnext) (void)hipFree(h->d_vnext);
     delete h;
     return EB_OK;
 }
@@ -836,6 +839,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!scaled) {
         if (h->scratch_floats < (size_t)n_env * 2) {
             if (h->d_scratch) (void)hipFree(h->d_scratch);
+    if (h->d_vnext) (void)hipFree(h->d_vnext);
             h->d_scratch = nullptr; h->scratch_floats = 0;
             EB_HIP(hipMalloc(&h->d_scratch, (size_t)n_env * 2 * sizeof(float)));
             h->scratch_floats = (size_t)n_env * 2;
@@ -874,6 +878,38 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
     EB_HIP(hipSetDevice(h->cfg.device));
     EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx,
                                 virtual_next, done_code, pick(h, stream)));
+    return EB_OK;
+}
+
+int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
+                      int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
+                      uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
+                      float* obs, void* stream) {
+    if (!h || !traffic || !pool || !pool->entry) return fail(EB_EINVAL, "eb_env_reset_pool: null argument");
+    if (n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!ego || !params || !ref_idx || !virtual_flag || !cand || !cand_mode || !obs)))
+        return fail(EB_EINVAL, "eb_env_reset_pool: bad argument");
+    if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_reset_pool: the traffic handle must have n_veh == m_cand");
+    if (traffic->cfg.device != h->cfg.device) return fail(EB_EINVAL, "eb_env_reset_pool: the two handles live on different devices");
+    int rc = check_paths(h, "eb_env_reset_pool: null handle");
+    if (!rc) rc = check_modes(h);
+    if (rc) return rc;
+    if (n_env == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    if (h->vnext_bytes < (size_t)n_env) {
+        if (h->d_vnext) (void)hipFree(h->d_vnext);
+        h->d_vnext = nullptr; h->vnext_bytes = 0;
+        EB_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_vnext), (size_t)n_env));
+        h->vnext_bytes = (size_t)n_env;
+    }
+    hipStream_t s = pick(h, stream);
+    // four launches behind one call: state + flags, pool re-entry (clear of the ego), masked observation, flag swap
+    EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx, h->d_vnext,
+                                done_code, s, v_light));
+    EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, pool->entry, -1.0f, pool->span, pool->v_max, pool->seed, pool->counter, mask,
+                                      nullptr, s, ego, pool->edge_span));
+    EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ref_idx, 0,
+                              m_cand, cand, cand_mode, v_light, virtual_flag, obs, s, nullptr, nullptr, nullptr, nullptr, nullptr, mask));
+    EB_HIP(eb::launch_flag_swap(n_env, mask, h->d_vnext, virtual_flag, s));
     return EB_OK;
 }
 

@@ -642,7 +642,8 @@ hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const floa
 // ---- a18: CrossroadEnd2end.reset + _reset_init_state for the masked envs (E2E:99-127, 472-499), one thread per env ----
 __global__ void env_reset_kernel(int task, int n_env, PathTables pt, const uint8_t* __restrict__ mask, uint64_t seed,
                                  uint64_t counter, int training, float* __restrict__ ego, float* __restrict__ params,
-                                 int* __restrict__ ref_idx, uint8_t* __restrict__ virtual_next, uint8_t* __restrict__ done_code) {
+                                 int* __restrict__ ref_idx, uint8_t* __restrict__ virtual_next, uint8_t* __restrict__ done_code,
+                                 uint8_t* __restrict__ v_light) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_env) return;
     if (mask && !mask[e]) return;
@@ -661,14 +662,26 @@ __global__ void env_reset_kernel(int task, int n_env, PathTables pt, const uint8
     ref_idx[e] = p;
     if (virtual_next) virtual_next[e] = (training && u3 > 0.9f) ? 1 : 0;  // E2E:120-126
     if (done_code) done_code[e] = EB_DONE_NOT_YET;                         // E2E:119
+    if (v_light) v_light[e] = 0;                                           // (eb_env_reset_pool: an episode starts at phase 0)
+}
+
+// eb_env_reset_pool's last stage: the flags eb_env_reset drew replace the old ones AFTER the reset observation (E2E:120-126)
+__global__ void flag_swap_kernel(int n_env, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ next, uint8_t* __restrict__ flag) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_env && (!mask || mask[e])) flag[e] = next[e];
+}
+hipError_t launch_flag_swap(int n_env, const uint8_t* mask, const uint8_t* next, uint8_t* flag, hipStream_t s) {
+    if (n_env <= 0) return hipSuccess;
+    hipLaunchKernelGGL(flag_swap_kernel, dim3((n_env + 255) / 256), dim3(256), 0, s, n_env, mask, next, flag);
+    return hipGetLastError();
 }
 
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
                             int training, float* ego, float* params, int* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
-                            hipStream_t s) {
+                            hipStream_t s, uint8_t* v_light) {
     if (n_env <= 0) return hipSuccess;
     hipLaunchKernelGGL(env_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, s, task, n_env, pt, mask, seed, counter,
-                       training, ego, params, ref_idx, virtual_next, done_code);
+                       training, ego, params, ref_idx, virtual_next, done_code, v_light);
     return hipGetLastError();
 }
 

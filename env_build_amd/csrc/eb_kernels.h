@@ -101,7 +101,8 @@ hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const E
                              hipStream_t s);
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
                             int training, float* ego, float* params, int* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
-                            hipStream_t s);
+                            hipStream_t s, uint8_t* v_light = nullptr);
+hipError_t launch_flag_swap(int n_env, const uint8_t* mask, const uint8_t* next, uint8_t* flag, hipStream_t s);
 hipError_t launch_traffic_flow_reset(int n_env, int K, const uint8_t* mask, const float* ego, float* cand, uint8_t* active,
                                      float* timer, int* emitted, int* sim_step, uint8_t* phase0, const float* lane,
                                      const float* period, const float* v_max, const float* cand_len, float lane_len,

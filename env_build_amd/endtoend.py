@@ -262,6 +262,8 @@ class CrossroadEnd2end(object):
         # during an episode a vehicle that left the map re-enters at its lane's edge (within POOL_EDGE_SPAN m of the entry
         # point, 60 m from the centre: where no ego is), not somewhere along the lane
         self._respawn_rule = _capi.EbRespawn(self._entry5.data_ptr(), CROSSROAD_SIZE / 2 + 40., self.POOL_EDGE_SPAN, EXPECTED_V, 0, 0)
+        # a reset spreads the pool over the first 60 m of every lane, clear of the ego (eb_env_reset_pool)
+        self._reset_rule = _capi.EbRespawn(self._entry5.data_ptr(), 0.0, 60.0, EXPECTED_V, 0, 0, self.POOL_EDGE_SPAN)
         if traffic == 'flows':
             from .traffic import FlowTraffic
             self._flows = FlowTraffic(B, dev, None, self.training_task, mode=self.mode, per_route=per_route,
@@ -348,9 +350,35 @@ class CrossroadEnd2end(object):
             mt = mask.t if isinstance(mask, DevArray) else mask
             mt = mt if isinstance(mt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(mt)))
             mask8 = mt.to(device=dev).reshape(B).to(torch.uint8).contiguous()
-            mask_b = mask8 != 0
         if B > 1:
             self.done_code = self.done_code.clone()      # the array handed out by the last step stays as it was
+        sp = self._sp()
+        if B > 1 and self._flows is None and self._exit_id is None:
+            # the whole masked reset over the traffic pool as ONE C call (eb_env_reset_pool): state and flags (E2E:100-101,
+            # 119), the pool's re-entry clear of the ego (E2E:102-103), v_light cleared, the reset observation of those rows
+            # with the OLD flags (E2E:116), the drawn flags swapped in (E2E:120-126)
+            self._reset_counter += 2
+            if not self._cand.is_contiguous():
+                self._cand = self._cand.contiguous()
+            if self._obs.data_ptr() in (self._bufs[0]['obs'].data_ptr(), self._bufs[1]['obs'].data_ptr()) if self._bufs else False:
+                self._obs = self._obs.clone()        # the array handed out by the last step stays as it was
+            rule = self._reset_rule
+            rule.seed, rule.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
+            self.api.env_reset_pool(self._h, self._traffic.h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
+                                    C.c_uint64(self._reset_counter - 1), 1 if self.mode == 'training' else 0, _ptr(self._ego),
+                                    _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual), _ptr(self._v_light),
+                                    _ptr(self.done_code), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), C.byref(rule),
+                                    _ptr(self._obs), sp)
+            route = {'left': 'dl', 'straight': 'du', 'right': 'dr'}[self.training_task]
+            self.init_state = _LazyInitState(self._ego, self.ego_l, self.ego_w, route)
+            self._injected = False
+            self.ego_dynamics = self.all_vehicles = None
+            self.obs = DevArray(self._obs)
+            self.action = None
+            self.reward_info = None
+            self.virtual_red_light_vehicle = None
+            self.done_type = DevArray(self.done_code)
+            return self.obs
         self.init_state = self._reset_init_state(mask8)                                 # E2E:101
         sp = self._sp()
         if self._flows is not None:                                                      # E2E:102-103 (init_traffic)
@@ -367,7 +395,7 @@ class CrossroadEnd2end(object):
             if mask8 is None:                      # the pool has no light programme: a reset env starts at phase 0
                 self._v_light.zero_()              # (a value injected through the multi_display seam does not survive reset)
             else:
-                self._v_light.masked_fill_(mask_b, 0)
+                self._v_light.masked_fill_(mask8 != 0, 0)
         self._injected = False
         self._publish_state()                                                            # E2E:104-115
         self.obs = self._get_obs(row_mask=mask8)                                         # E2E:116 (with the OLD flag)
@@ -383,7 +411,7 @@ class CrossroadEnd2end(object):
             if mask8 is None:
                 self._virtual.copy_(self._virtual_next)
             else:
-                torch.where(mask_b, self._virtual_next, self._virtual, out=self._virtual)
+                torch.where(mask8 != 0, self._virtual_next, self._virtual, out=self._virtual)
             self.virtual_red_light_vehicle = None
             self.done_type = DevArray(self.done_code)
         return self.obs

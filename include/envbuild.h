@@ -348,6 +348,7 @@ typedef struct eb_respawn {
     float v_max;
     uint64_t seed;
     uint64_t counter;
+    float edge_span;    /* eb_env_reset_pool only: where a candidate goes that would start on top of the ego (eb_traffic_respawn) */
 } eb_respawn;
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
@@ -368,6 +369,20 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
  *   done_code = EB_DONE_NOT_YET. */
 int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter, int32_t training,
                  float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code, void* stream);
+
+/* CrossroadEnd2end.reset (E2E:99-127) over the traffic POOL for the envs of a batch whose mask byte is non-zero (NULL = all),
+ * as ONE call — what a vectorised driver issues after every step for the envs that finished:
+ *   eb_env_reset(h, n_env, mask, seed, counter, training, ego, params, ref_idx, <next flags>, done_code)        E2E:100-101, 119
+ *   eb_traffic_respawn(traffic, n_env, m_cand, cand, pool->entry, -1 (unconditional), pool->span, pool->v_max,
+ *                      pool->seed, pool->counter, mask, NULL, ego, pool->edge_span)      E2E:102-103 (init_traffic, TRF:151-195)
+ *   v_light[e] = 0 (nullable): the pool has no light programme, an episode starts at phase 0
+ *   eb_get_obs(h, ..., v_light, virtual_flag, NULL, mask, obs): the reset observation, built with the OLD flags    E2E:116
+ *   virtual_flag[e] = the flag eb_env_reset drew                                                       E2E:120-126
+ * each for the masked envs only; the rows of the other envs (state, candidates, flags, obs) are not touched. */
+int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
+                      int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
+                      uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
+                      float* obs, void* stream);
 
 /* The traffic pool's re-entry rule (the SUMO flows' role for the batched env, TRF:37-238 is out of scope): every
  * candidate of cand [n_env, m_cand, 4] that has left the square |x|, |y| <= limit is put back on its entry lane,

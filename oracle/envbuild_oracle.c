@@ -1416,6 +1416,38 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
     return EB_OK;
 }
 
+int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, const float* entry, float limit,
+                       float span, float v_max, uint64_t seed, uint64_t counter, const uint8_t* env_mask,
+                       uint8_t* respawned, const float* ego, float edge_span, void* stream);
+/* the masked reset over the pool as one call: the composition its header comment spells out */
+int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
+                      int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
+                      uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
+                      float* obs, void* stream) {
+    if (!h || !traffic || !pool || !pool->entry) return fail(EB_EINVAL, "eb_env_reset_pool: null argument");
+    if (n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!ego || !params || !ref_idx || !virtual_flag || !cand || !cand_mode || !obs)))
+        return fail(EB_EINVAL, "eb_env_reset_pool: bad argument");
+    if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_reset_pool: the traffic handle must have n_veh == m_cand");
+    int rc = check_paths(h, "eb_env_reset_pool: null handle");
+    if (!rc) rc = check_modes(h);
+    if (rc) return rc;
+    if (n_env == 0) return EB_OK;
+    uint8_t* vnext = (uint8_t*)malloc((size_t)n_env);
+    if (!vnext) return fail(EB_ENOMEM, "eb_env_reset_pool: out of memory");
+    rc = eb_env_reset(h, n_env, mask, seed, counter, training, ego, params, ref_idx, vnext, done_code, stream);
+    if (!rc) rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, pool->entry, -1.0f, pool->span, pool->v_max, pool->seed,
+                                     pool->counter, mask, NULL, ego, pool->edge_span, stream);
+    if (!rc && v_light)
+        for (int e = 0; e < n_env; ++e)
+            if (!mask || mask[e]) v_light[e] = 0;
+    if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, 0, m_cand, cand, cand_mode, v_light, virtual_flag, NULL, mask, obs, stream);
+    if (!rc)
+        for (int e = 0; e < n_env; ++e)
+            if (!mask || mask[e]) virtual_flag[e] = vnext[e];
+    free(vnext);
+    return rc;
+}
+
 /* Traffic.init_traffic's conflict test, TRF:168-192: the vehicle (x, y, a, speed v, length l) against the ego pose,
  * through shift_and_rotate_coordination (UTL:145-149), fp32 with the deterministic sin / cos */
 static void shift_rotate_f32(float x, float y, float d, float sx, float sy, float rd, float* ox, float* oy, float* od) {

@@ -126,3 +126,38 @@ def respawn_conflict_case(make, B=300, M=16, seed=4):
     d = np.hypot(safe[..., 0] - ego[:, None, 3], safe[..., 1] - ego[:, None, 4])
     assert d.min() > 2.0
     return safe
+
+
+def reset_pool_case(make, task, B=260, M=12, seed=21):
+    """eb_env_reset_pool == eb_env_reset, eb_traffic_respawn(forced, clear of the ego), v_light clear, eb_get_obs(row mask, OLD
+    flags), flag swap — for the masked envs only; the other envs' rows are untouched."""
+    from env_build_amd.endtoend import _lane_entry
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    entry = np.array([list(_lane_entry(m)[:3]) + list(_lane_entry(m)[3]) for m in modes], np.float32)
+    ego, cand, _, _, _, _, ref = random_scene(task, B, M, seed)
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    rng = np.random.default_rng(seed)
+    params = rng.normal(size=(B, 4)).astype(np.float32)
+    virtual = (rng.random(B) < 0.5).astype(np.uint8)
+    v_light = rng.integers(0, 4, B).astype(np.uint8)
+    obs = rng.normal(size=(B, 9 + 4 * len(native))).astype(np.float32)
+    m, tr = make(task, mode='training'), make(task, n_veh=M, modes=modes)
+    pool = dict(entry=entry, span=60.0, v_max=8.0, seed=4242, counter=17, edge_span=5.0)
+    outs = []
+    for mask in (rng.random(B) < 0.3, None):
+        mk = None if mask is None else mask.astype(np.uint8)
+        sel = np.ones(B, bool) if mask is None else mask
+        got = m.env_reset_pool(tr, 99, 5, 1, ego, params, ref, virtual, v_light, cand, cmode, obs, pool, mask=mk)
+        # the single calls
+        e1, p1, r1, vnext, dc = m.env_reset(B, 99, 5, 1, ego, params, ref, mask=mk)
+        c1, _ = tr.traffic_respawn(cand, entry, -1.0, 60.0, 8.0, 4242, 17, mask=mk, ego=e1, edge_span=5.0)
+        vl1 = np.where(sel, 0, v_light).astype(np.uint8)
+        o1 = m.get_obs(e1, c1, cmode, vl1, ref_idx=r1, virtual=virtual, row_mask=mk, obs_init=obs)
+        vf1 = np.where(sel, vnext, virtual).astype(np.uint8)
+        want = [e1, p1, r1, vf1, vl1, np.where(sel, 0, 7).astype(np.uint8), c1, o1]
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert np.array_equal(g, w), k
+        assert np.array_equal(got[0][~sel], ego[~sel]) and np.array_equal(got[7][~sel], obs[~sel]) and np.array_equal(got[6][~sel], cand[~sel])
+        outs.append(got)
+    return outs

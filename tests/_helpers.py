@@ -268,7 +268,7 @@ class HostModel(object):
 
     def env_reset(self, n_env, seed, counter, training, ego, params, ref_idx, mask=None):
         """-> (ego, params, ref_idx, virtual_next, done_code) after eb_env_reset on copies of the given state"""
-        eg, pr, ri = self._in(ego), self._in(params), self._in(ref_idx, np.int32)
+        eg, pr, ri = self._in(np.array(ego, np.float32)), self._in(np.array(params, np.float32)), self._in(np.array(ref_idx, np.int32), np.int32)
         mk = self._in(mask, np.uint8)
         vn, dc = self._out((n_env,), np.uint8), self._out((n_env,), np.uint8)
         for t in (vn, dc):
@@ -276,6 +276,24 @@ class HostModel(object):
         self.api.env_reset(self.h, n_env, self._ptr(mk), C.c_uint64(seed), C.c_uint64(counter), int(training), self._ptr(eg),
                            self._ptr(pr), self._ptr(ri), self._ptr(vn), self._ptr(dc), self.stream)
         return self._ret(eg), self._ret(pr), self._ret(ri), self._ret(vn), self._ret(dc)
+
+    def env_reset_pool(self, traffic, seed, counter, training, ego, params, ref_idx, virtual, v_light, cand, cand_mode, obs, pool,
+                       mask=None):
+        """eb_env_reset_pool on copies of the state -> (ego, params, ref_idx, virtual, v_light, done_code, cand, obs)"""
+        cp = lambda a, t: self._in(np.array(a, t))          # in/out arguments: explicit copies (the oracle writes in place)
+        eg, pr, ri = cp(ego, np.float32), cp(params, np.float32), self._in(np.array(ref_idx, np.int32), np.int32)
+        vf, vl, mk = self._in(np.array(virtual, np.uint8), np.uint8), self._in(np.array(v_light, np.uint8), np.uint8), self._in(mask, np.uint8)
+        cd, cm, ob = cp(cand, np.float32), self._in(cand_mode, np.uint8), cp(obs, np.float32)
+        n, m = len(eg), cd.shape[1]
+        dc = self._out((n,), np.uint8)
+        dc[...] = 7
+        en = self._in(pool['entry'])
+        rs = _capi.EbRespawn(self._ptr(en).value, 0.0, float(pool['span']), float(pool['v_max']), int(pool['seed']), int(pool['counter']),
+                             float(pool['edge_span']))
+        self.api.env_reset_pool(self.h, traffic.h, n, self._ptr(mk), C.c_uint64(seed), C.c_uint64(counter), int(training), self._ptr(eg),
+                                self._ptr(pr), self._ptr(ri), self._ptr(vf), self._ptr(vl), self._ptr(dc), m, self._ptr(cd), self._ptr(cm),
+                                C.byref(rs), self._ptr(ob), self.stream)
+        return [self._ret(x) for x in (eg, pr, ri, vf, vl, dc, cd, ob)]
 
     def tracking_error(self, xs, ys, phis, vs, n_future, ref_idx=None, path_id=0):
         x, y, ph, v, ri = self._in(xs), self._in(ys), self._in(phis), self._in(vs), self._in(ref_idx, np.int32)
@@ -308,7 +326,7 @@ class HostModel(object):
         eg, cd, ri = self._in(ego), self._in(cand), self._in(ref_idx, np.int32)
         cm, vl, vf, ex = self._in(cand_mode, np.uint8), self._in(v_light, np.uint8), self._in(virtual, np.uint8), self._in(exit_id, np.uint8)
         n, m = len(eg), cd.shape[1]
-        out = self._out((n, self.D)) if obs_init is None else self._in(obs_init)
+        out = self._out((n, self.D)) if obs_init is None else self._in(np.array(obs_init, np.float32))   # (a copy: the oracle writes in place)
         rm = self._in(row_mask, np.uint8)
         self.api.get_obs(self.h, n, self._ptr(eg), self._ptr(ri), int(path_id), m, self._ptr(cd), self._ptr(cm), self._ptr(vl),
                          self._ptr(vf), self._ptr(ex), self._ptr(rm), self._ptr(out), self.stream)

@@ -91,6 +91,18 @@ def test_env_facade_batched_reset_is_one_kernel_state_and_keeps_the_old_flag_for
         env.step(np.zeros((B, 2), np.float32))
 
 
+@pytest.mark.parametrize('task', TASKS)
+def test_reset_pool_composite_equals_the_single_calls_and_the_oracle(task):
+    """eb_env_reset_pool (the masked reset as one call) on both libraries"""
+    from tests._env_step_check import reset_pool_case
+    got = reset_pool_case(lambda t, **kw: DeviceModel(t, **kw), task)
+    want = reset_pool_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task)
+    names = ('ego', 'params', 'ref_idx', 'virtual', 'v_light', 'done_code', 'cand', 'obs')
+    for a, b in zip(got, want):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), (names[k], int((x != y).sum()))
+
+
 # ---- traffic: pool reset (masked, unconditional re-entry) and the flow source's reset ---------------------
 def test_traffic_respawn_mask_and_forced_reentry_equal_oracle():
     rng = np.random.default_rng(8)
@@ -268,6 +280,29 @@ def test_exit_frames_random_scenes_equal_oracle(task):
     plain = dev.get_obs(ego, cand2, cmode, vl, ref_idx=ref, virtual=virt)
     via_d = dev.get_obs(ego, cand2, cmode, vl, ref_idx=ref, virtual=virt, exit_id=d0)
     assert np.array_equal(plain, via_d)
+
+
+def test_exit_ids_above_three_are_refused_or_marked():
+    """An exit id that is not EB_EXIT_D .. EB_EXIT_L: the oracle (host arguments) returns EB_EINVAL; the HIP library cannot read
+    device memory on the host — it writes NaN into that env's row (eb_get_obs) / pose (eb_exit_frame) and leaves the others
+    alone, instead of a plausible-looking wrong frame."""
+    task, B, M = 'left', 70, 6
+    host, dev = _pair(task)
+    from tests._env_step_check import random_scene
+    ego, cand, cmode, _, light, _, ref = random_scene(task, B, M, 12)
+    ex = np.random.default_rng(1).integers(0, 4, B).astype(np.uint8)
+    good_obs, good_pose = dev.get_obs(ego, cand, cmode, light, ref_idx=ref, exit_id=ex), dev.exit_frame(ex, ego)
+    bad = ex.copy()
+    bad[[3, 40]] = (4, 255)
+    obs, pose = dev.get_obs(ego, cand, cmode, light, ref_idx=ref, exit_id=bad), dev.exit_frame(bad, ego)
+    ok = np.ones(B, bool)
+    ok[[3, 40]] = False
+    assert np.isnan(obs[~ok]).all() and np.array_equal(obs[ok], good_obs[ok])
+    assert np.isnan(pose[~ok][:, 3:]).all() and np.array_equal(pose[~ok][:, :3], ego[~ok][:, :3]) and np.array_equal(pose[ok], good_pose[ok])
+    with pytest.raises(ValueError):
+        host.get_obs(ego, cand, cmode, light, ref_idx=ref, exit_id=bad)
+    with pytest.raises(ValueError):
+        host.exit_frame(bad, ego)
 
 
 def test_env_facade_exit_frames_for_a_batch():
