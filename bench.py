@@ -518,7 +518,8 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
             'wall_us_per_step_incl_state_restores': wall * 1e6 / (reps * seg),
             'alg_bytes_per_env_step': env_step_alg_bytes(D, M), 'alg_bytes_per_launch': alg, 'achieved_GBs': achieved, 'frac': frac,
             'traffic': traffic, 'traffic_source': 'profiles/r3_pmc_traffic.json (separate rocprofv3 --pmc passes, scripts/pmc_traffic.sh)' if traffic else None,
-            'kernel': 'eb::env_step_kernel<0, %d>' % (16 if B <= 16384 else 64), 'done_fraction_after_segment': done_frac}
+            'kernel': 'eb::env_step_kernel<0, %d, false>' % (16 if B <= 6144 else 32 if B <= 24576 else 64),
+            'done_fraction_after_segment': done_frac}
 
 
 def shield_bench(args):

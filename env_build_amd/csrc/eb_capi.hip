@@ -826,7 +826,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         A.cand_lw = cand_lw; A.v_light = v_light; A.virtual_flag = virtual_flag; A.scaled = scaled_actions; A.out5 = out5;
         A.d16 = out_dict16; A.obs_out = obs_out; A.done_code = done_code;
         A.trace = h->trace;
-        A.tile_envs = h->tile_variant == 0 ? 64 : h->tile_variant == 2 ? 16 : 0;   // eb_debug_set_tile: every shape computes the same bits
+        A.tile_envs = h->tile_variant == 0 ? 64 : h->tile_variant == 1 ? 32 : h->tile_variant == 2 ? 16 : 0;   // eb_debug_set_tile: every shape computes the same bits
         if (respawn) {
             A.respawn_entry = respawn->entry; A.limit = respawn->limit; A.span = respawn->span; A.v_max = respawn->v_max;
             A.seed = respawn->seed; A.counter = respawn->counter;

@@ -30,6 +30,8 @@
 // Nothing but the tile's LDS is shared between waves: no cross-block traffic, no XCD consideration beyond "a tile's lines
 // belong to one workgroup".  The arithmetic is the same device functions the single-entry kernels run (eb_env_device.h,
 // eb_device.h): bit-identical to the six (seven) calls — tests/_env_step_check.py holds it to that.
+#include <cstdlib>
+
 #include "eb_env_device.h"
 
 #pragma clang fp contract(off)
@@ -57,12 +59,15 @@ size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs) {
     b += (size_t)4 * ES_QCAP * 2;                // s_queue
     return (b + 15) & ~(size_t)15;
 }
-// envs per block: 64 for throughput; small batches take 16-env tiles so that four times as many blocks (and a quarter of
-// the records per lane) stand behind the same step — a step of 4 096 envs is latency, not bandwidth
+// envs per block: 64 for throughput; small batches take 16- or 32-env tiles so that more blocks (and fewer records per lane)
+// stand behind the same step — a step of 4 096 envs is latency, not bandwidth
 // Many candidates per env (the flow source: 60) make a 64-env tile too big for four blocks per CU (> 40 KB of LDS): 16-env
 // tiles then, at any batch size (measured at 65 536 envs x 60 candidates: 119 us with one 85 KB block per CU).
+// Measured (16 candidates, us per step at tiles of 16 / 32 / 64 envs): 4 096 envs 10.8 / 11.4 / 13.2; 8 192: 11.8 / 11.7 / 13.4;
+// 16 384: 14.9 / 13.0 / 14.0; 32 768: 24.9 / 17.2 / 16.2; 65 536: 42.8 / 28.2 / 21.2; 131 072: 76.8 / 49.3 / 39.5.
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand) {
-    return (n_env <= 16384 || env_step_lds_bytes(D, NV, m_cand, 64) > 40 * 1024) ? 16 : 64;
+    if (env_step_lds_bytes(D, NV, m_cand, 64) > 40 * 1024) return 16;
+    return n_env <= 6144 ? 16 : n_env <= 24576 ? 32 : 64;
 }
 
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand) {
@@ -578,8 +583,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
 }
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
-    int ET = A.tile_envs == 16 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
-    if (ET == 64 && env_step_lds_bytes(A.D, A.NV, A.m_cand, 64) > 150 * 1024) ET = 16;     // a forced shape that does not fit
+    int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
+    static const int force = std::getenv("EB_ENV_TILE") ? std::atoi(std::getenv("EB_ENV_TILE")) : 0;   // tuning aid
+    if (force == 16 || force == 32 || force == 64) ET = force;
+    if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET) > 150 * 1024) ET = 16;     // a forced shape that does not fit
     const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -598,8 +605,8 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     } while (0)
 #define EB_ENV_STEP_T(T)                                                                                             \
     do {                                                                                                             \
-        if (A.obs_only) { if (ET == 16) EB_ENV_STEP(T, 16, true); else EB_ENV_STEP(T, 64, true); }                   \
-        else { if (ET == 16) EB_ENV_STEP(T, 16, false); else EB_ENV_STEP(T, 64, false); }                            \
+        if (A.obs_only) { if (ET == 16) EB_ENV_STEP(T, 16, true); else if (ET == 32) EB_ENV_STEP(T, 32, true); else EB_ENV_STEP(T, 64, true); } \
+        else { if (ET == 16) EB_ENV_STEP(T, 16, false); else if (ET == 32) EB_ENV_STEP(T, 32, false); else EB_ENV_STEP(T, 64, false); } \
     } while (0)
     switch (task) {
         case TASK_LEFT: EB_ENV_STEP_T(TASK_LEFT); break;

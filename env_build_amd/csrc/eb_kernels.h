@@ -142,7 +142,7 @@ struct EnvStepArgs {
     long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * 4][8] wall-clock marks, or NULL
     int obs_only;                          // 1: eb_get_obs — ego / cand are inputs, only obs_out is written
     const uint8_t* row_mask;               // obs_only: nullable [n_env]; rows with a zero byte are left alone
-    int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 64: forced (eb_debug_set_tile 2 / 0)
+    int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 32 / 64: forced (eb_debug_set_tile 2 / 1 / 0)
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand);

@@ -21,7 +21,7 @@ while time.time() < t_end:
     M = int(rng.choice([1, 2, 7, 16, 23, 40, 60, 64]))
     B = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 300, 1500]))
     nf = int(rng.choice([0, 0, 2]))
-    tile = int(rng.choice([-1, 0, 2]))
+    tile = int(rng.choice([-1, 0, 1, 2]))
     seed = int(rng.integers(1 << 30))
     kw = dict(mode='training', n_future=nf)
     if NV is not None:

@@ -16,7 +16,8 @@ lib = env.api.lib
 lib.eb_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
 for _ in range(3): env.step(act)
 torch.cuda.synchronize()
-nb = (B + 15) // 16 if B <= 16384 else (B + 63) // 64
+te = 16 if B <= 6144 else 32 if B <= 24576 else 64
+nb = (B + te - 1) // te
 trs = [torch.zeros((nb * 4, 8), dtype=torch.int64, device=env.device) for _ in range(3)]
 for k in range(3):
     lib.eb_debug_set_trace(env._h, C.c_void_p(trs[k].data_ptr())); env.step(act)

@@ -59,7 +59,7 @@ def composite_case(make, task, B, M, NV, nf, tile=None):
         kw.update(n_veh=NV)
     m, tr = make(task, **kw), make(task, n_veh=M, modes=modes)
     if tile is not None:
-        m.set_tile(tile)          # the one-launch step: 0 = 64-env tiles, 2 = 16-env tiles (eb_debug_set_tile)
+        m.set_tile(tile)          # the one-launch step: 0 / 1 / 2 = 64- / 32- / 16-env tiles (eb_debug_set_tile)
     obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
     # the six calls
     act = m.action_transform(raw)

@@ -415,11 +415,11 @@ def test_get_obs_candidate_and_slot_counts(task, M, NV):
 
 
 @pytest.mark.parametrize('task,B,M,NV,nf', __import__('tests._env_step_check', fromlist=['CASES']).CASES)
-@pytest.mark.parametrize('tile', [0, 2])
+@pytest.mark.parametrize('tile', [0, 1, 2])
 def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf, tile):
     """eb_env_step == action_transform, compute_rewards, env_ego_step, veh_predict, get_obs, judge_done (+ traffic_respawn
     when a re-entry rule is given) in that order, on both libraries (bit for bit against the oracle's composite too).
-    The HIP library runs the composite as ONE launch (csrc/eb_env_step.hip) with 64-env (tile 0) or 16-env (tile 2) tiles;
+    The HIP library runs the composite as ONE launch (csrc/eb_env_step.hip) with 64- / 32- / 16-env tiles (tile 0 / 1 / 2);
     the last case does not fit 64-env tiles and takes the small ones either way: partial tiles, 1..64 candidates,
     non-native slot counts and look-ahead columns go through the same check (tests/_env_step_check.py)."""
     from tests._env_step_check import composite_case
@@ -435,7 +435,7 @@ def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf, tile):
 
 
 @pytest.mark.parametrize('task', TASKS)
-@pytest.mark.parametrize('B,tile', [(150, -1), (1000, 0), (1000, 2)])
+@pytest.mark.parametrize('B,tile', [(150, -1), (1000, 0), (1000, 1), (1000, 2)])
 def test_masked_observation_pass(task, B, tile):
     """eb_get_obs(row_mask): the observation pass of a masked reset touches the masked rows only (both tile shapes of the
     one-launch machinery; whole tiles without a masked row leave at once) and equals the oracle's."""
