@@ -51,6 +51,10 @@ def _worker(rank, world, port, q):
         pend = [gather_summaries_async(torch.from_numpy(s8)), gather_summaries_async(torch.from_numpy(s8 * 2))]
         assert torch.equal(pend[0].result(), all8) and torch.equal(pend[1].result(), all8 * 2)
         total = combine_summaries(all8)
+        # bench.py's per-rank figures at N > 1 (launch durations for roofline.aggregate): every rank ends with all of them
+        import bench
+        per_rank = bench.gather_floats(torch, dist, [10.0 + rank, 400.0], torch.device('cpu'))
+        assert per_rank == [[10.0, 400.0], [11.0, 400.0]] and dist.get_world_size() == world and dist.get_backend() == 'gloo'
         q.put((rank, lo, hi, all8.numpy(), total.numpy(), out[:2].copy()))
     finally:
         dist.destroy_process_group()
