@@ -360,8 +360,8 @@ class CrossroadEnd2end(object):
             self._reset_counter += 2
             if not self._cand.is_contiguous():
                 self._cand = self._cand.contiguous()
-            if self._obs.data_ptr() in (self._bufs[0]['obs'].data_ptr(), self._bufs[1]['obs'].data_ptr()) if self._bufs else False:
-                self._obs = self._obs.clone()        # the array handed out by the last step stays as it was
+            if self._bufs is not None and any(self._obs.data_ptr() == b['obs'].data_ptr() for b in self._bufs):
+                self._obs = self._obs.clone()        # the obs array handed out by the last step stays as it was
             rule = self._reset_rule
             rule.seed, rule.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
             self.api.env_reset_pool(self._h, self._traffic.h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
