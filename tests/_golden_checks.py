@@ -115,3 +115,29 @@ def check_g12_exit_frames(make, tag=''):
     close(want_phi + d, want_phi, RTOL, 2e-5, tag + 'G12 exit frame: ego phi (UTL:184-196)')
     back = m.exit_frame(exit_id, out, inverse=True)
     close(back[:, 3:5], ego[:, 3:5], RTOL, ATOL['g12'], tag + 'G12 exit frame: there and back')
+
+
+def check_g7_through_env_step(make, tag=''):
+    """G7 = BASELINE.json configs[0]: one `left` env, 8 surrounding vehicles, 200 steps (SUMO-free composition generated from
+    the reference's own methods) — through eb_env_step, the composite entry CrossroadEnd2end.step uses (one launch on the
+    GPU), with the state carried from step to step by the library under test."""
+    from env_build_amd import _capi
+    from env_build_amd.endtoend_env_utils import VEHICLE_MODE_LIST
+    g = golden('g7_config1_left')
+    modes = [str(m) for m in g['modes']]
+    assert modes == VEHICLE_MODE_LIST['left']
+    m, tr = make('left', mode='selecting'), make('left', n_veh=len(modes), modes=modes)
+    H = g['actions'].shape[0]
+    ref = np.array([int(g['ref_index'])], np.int32)
+    ego, veh, obs = g['ego'][0:1].copy(), g['veh'][0][None].copy(), g['obs'][0:1].copy()
+    cmode = np.array([[_capi.VMODE_ID[x] for x in modes]], np.uint8)
+    n_done_mismatch = 0
+    for t in range(H):
+        _, out5, _, ego, _, veh, obs, done = m.env_step(tr, obs, g['actions'][t:t + 1], ego, veh, cmode, ref_idx=ref,
+                                                        v_light=np.zeros(1, np.uint8))
+        close(out5[0, 0], g['reward'][t], RTOL, ATOL['g7_reward'], tag + 'G7 through eb_env_step: reward')
+        close(ego[0], g['ego'][t + 1], RTOL, ATOL['g7_state'], tag + 'G7 through eb_env_step: ego')
+        close(veh[0], g['veh'][t + 1], RTOL, ATOL['g7_state'], tag + 'G7 through eb_env_step: vehicles')
+        close(obs[0], g['obs'][t + 1], RTOL, ATOL['g7_state'], tag + 'G7 through eb_env_step: obs')
+        n_done_mismatch += int(done[0] != g['done_code'][t])
+    assert n_done_mismatch == 0

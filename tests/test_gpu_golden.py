@@ -48,3 +48,9 @@ def test_g9_ss_on_gpu(task):
 
 def test_g12_exit_frames_on_gpu():
     CK.check_g12_exit_frames(_make, TAG)
+
+
+def test_g7_config1_through_the_one_launch_env_step():
+    """BASELINE.json configs[0] (single env, 8 vehicles, 200 steps) through the one-launch kernel, state carried on the device side
+    of the test from step to step"""
+    CK.check_g7_through_env_step(_make, TAG)

@@ -165,6 +165,10 @@ def test_g7_config1_single_env_200_steps(oracle):
     assert n_done_mismatch == 0
 
 
+def test_g7_config1_through_the_composite_entry(oracle):
+    CK.check_g7_through_env_step(lambda task, **kw: HostModel(oracle, task, **kw))
+
+
 # ---- G8: fp16 state storage (BASELINE configs[4]) -------------------------------------------------
 def _half_ulps(a_u16, b_u16):
     """distance in binary16 steps between two arrays of half bit patterns (monotone integer mapping)"""
