@@ -356,6 +356,10 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
            'launch_form': 'eager' if (tm.eager or shard.plan(HORIZON) is None) else 'hipGraph',
            'alg_bytes_per_launch': alg, 'avg_launch_us': r['launch_us'], 'launches_timed': r['launches_timed'],
            'achieved_GBs': achieved, 'frac': frac, 'footprint_MB': shard.footprint_bytes() / 1e6}
+    if f16 and (n_env, n_veh, lanes) == (N_ENV, 64, 1):      # configs[4]: HBM bytes from the PMC passes of scripts/pmc_traffic.sh
+        tpath = os.path.join(ROOT, 'profiles', 'r3_pmc_traffic.json')
+        if os.path.isfile(tpath):
+            out['traffic'] = (json.load(open(tpath)).get('fp16_x64') or {}).get('hbm_bytes_per_launch')
     tm.close()
     del shard, tm
     torch.cuda.empty_cache()

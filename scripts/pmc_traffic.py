@@ -18,7 +18,7 @@ def mean_counter(sub, counter, kernel_substr, grid=None):
     vals = []
     for f in glob.glob(os.path.join(out, sub, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            if kernel_substr in r['Kernel_Name'] and r['Counter_Name'] == counter and (grid is None or int(r['Grid_Size']) == grid):
+            if any(k in r['Kernel_Name'] for k in ([kernel_substr] if isinstance(kernel_substr, str) else kernel_substr)) and r['Counter_Name'] == counter and (grid is None or int(r['Grid_Size']) == grid):
                 vals.append(float(r['Counter_Value']))
     if not vals:
         raise SystemExit('no %s rows for %s in %s' % (counter, kernel_substr, sub))
@@ -55,8 +55,24 @@ try:
 except SystemExit as e:
     summary['env_step'] = None
     print('(no env-step passes: %s)' % e)
+# configs[4]: 65 536 envs x 64 slots, binary16 state (scripts/time_rollout.py --n-veh 64 --f16: 2048 tiles of 32 envs x 5 waves)
+try:
+    f16 = {}
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        k_kib, n_k = mean_counter('f16_' + c, c, ('rollout_fused_4x8<0, true, _Float16>', 'rollout_fused_4x8ILi0ELb1EDF16_'), 2048 * 320)
+        f16[c] = {'kib_per_launch': k_kib, 'launches': n_k, 'bytes_per_launch': k_kib * 1024.0 * res[c]['calibration_factor']}
+    f_alg = (68 + 16 * 64) * 65536
+    f_total = f16['FETCH_SIZE']['bytes_per_launch'] + f16['WRITE_SIZE']['bytes_per_launch']
+    summary['fp16_x64'] = {'hbm_bytes_per_launch': f_total, 'read_bytes_per_launch': f16['FETCH_SIZE']['bytes_per_launch'],
+                           'write_bytes_per_launch': f16['WRITE_SIZE']['bytes_per_launch'], 'algorithmic_bytes_per_launch': f_alg,
+                           'traffic_over_algorithmic': f_total / f_alg, 'kernel': 'eb::rollout_fused_4x8<0, true, _Float16>', 'counters': f16}
+except SystemExit as e:
+    summary['fp16_x64'] = None
+    print('(no fp16 passes: %s)' % e)
 json.dump(summary, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k not in ('counters', 'env_step')}, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k not in ('counters', 'env_step', 'fp16_x64')}, indent=1))
+if summary.get('fp16_x64'):
+    print('fp16 x 64:', json.dumps({k: v for k, v in summary['fp16_x64'].items() if k != 'counters'}))
 if summary.get('env_step'):
     print('env step:', json.dumps({k: v for k, v in summary['env_step'].items() if k != 'counters'}))
 for c, r in res.items():

@@ -12,5 +12,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -o p -- python bench.py --steps 50 --warmup 25 --no-cpu-baseline --no-side > $OUT/bench_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/copy_$c -o p -- scripts/micro/copybench calib > $OUT/copy_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/envstep_$c -o p -- python bench.py --env-step > $OUT/envstep_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/f16_$c -o p -- python scripts/time_rollout.py --n-veh 64 --f16 --iters 60 > $OUT/f16_$c.log 2>&1
 done
 python scripts/pmc_traffic.py $OUT | tee $OUT/pmc_traffic.txt
