@@ -173,21 +173,21 @@ int eb_create(const eb_config* cfg, eb_handle* out) {
     e = hipMalloc(reinterpret_cast<void**>(&h->d_partials), sizeof(double) * 6 * eb::SUMMARY_MAX_PARTS);
     if (e != hipSuccess) { delete h; return fail_hip("hipMalloc(summary partials)", e); }
     e = hipMalloc(reinterpret_cast<void**>(&h->d_pt), sizeof(eb::PathTables));
-    if (e != hipSuccess) { hipFree(h->d_partials); delete h; return fail_hip("hipMalloc(tables)", e); }
+    if (e != hipSuccess) { (void)hipFree(h->d_partials); delete h; return fail_hip("hipMalloc(tables)", e); }
     *out = h;
     return EB_OK;
 }
 
 int eb_destroy(eb_handle h) {
     if (!h) return EB_OK;
-    hipSetDevice(h->cfg.device);
-    hipDeviceSynchronize();
-    if (h->d_tables) hipFree(h->d_tables);
-    if (h->d_cells) hipFree(h->d_cells);
-    if (h->d_partials) hipFree(h->d_partials);
-    if (h->d_pt) hipFree(h->d_pt);
-    if (h->gate_stream) hipStreamDestroy(h->gate_stream);
-    if (h->gate_event) hipEventDestroy(h->gate_event);
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->d_cells) (void)hipFree(h->d_cells);
+    if (h->d_partials) (void)hipFree(h->d_partials);
+    if (h->d_pt) (void)hipFree(h->d_pt);
+    if (h->gate_stream) (void)hipStreamDestroy(h->gate_stream);
+    if (h->gate_event) (void)hipEventDestroy(h->gate_event);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
     if (h->d_vnext) (void)hipFree(h->d_vnext);
     delete h;
@@ -278,8 +278,8 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     if (e == hipSuccess) e = hipMemcpy(d_cells, grid.cells.data(), grid.cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipDeviceSynchronize();   // nothing in flight reads the old tables any more
     if (e != hipSuccess) {
-        if (d_tables) hipFree(d_tables);
-        if (d_cells) hipFree(d_cells);
+        if (d_tables) (void)hipFree(d_tables);
+        if (d_cells) (void)hipFree(d_cells);
         return fail_hip("eb_set_paths: device tables", e);
     }
     // ---- swap ----
@@ -311,8 +311,8 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     if (e != hipSuccess) {   // the device copy of the table descriptor still names the old tables: keep them
         h->pt = old_pt;
         for (int k = 0; k < 3; ++k) h->red_off[k] = old_off[k];
-        hipFree(d_tables);
-        hipFree(d_cells);
+        (void)hipFree(d_tables);
+        (void)hipFree(d_cells);
         return fail_hip("eb_set_paths: upload", e);
     }
     h->d_tables = d_tables;
@@ -321,8 +321,8 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     h->d_rad_all = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + rad_byte_off);
     h->d_phi10_all = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + phi10_byte_off);
     h->red_total = (int)red_total;
-    if (old_tables) hipFree(old_tables);
-    if (old_cells) hipFree(old_cells);
+    if (old_tables) (void)hipFree(old_tables);
+    if (old_cells) (void)hipFree(old_cells);
     return EB_OK;
 }
 
@@ -839,7 +839,6 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!scaled) {
         if (h->scratch_floats < (size_t)n_env * 2) {
             if (h->d_scratch) (void)hipFree(h->d_scratch);
-    if (h->d_vnext) (void)hipFree(h->d_vnext);
             h->d_scratch = nullptr; h->scratch_floats = 0;
             EB_HIP(hipMalloc(&h->d_scratch, (size_t)n_env * 2 * sizeof(float)));
             h->scratch_floats = (size_t)n_env * 2;
@@ -977,20 +976,20 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
     hipStream_t cs = nullptr;
     EB_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { hipStreamDestroy(cs); return fail_hip("hipStreamBeginCapture", e); }
+    if (e != hipSuccess) { (void)hipStreamDestroy(cs); return fail_hip("hipStreamBeginCapture", e); }
     // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph
     rc = rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs, 0);
     if (rc == EB_OK && summary8) rc = eb_episode_summary(h, n_env, horizon, out5_steps, obs_out, summary8, cs);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(cs, &graph);
-    hipStreamDestroy(cs);
-    if (rc != EB_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    (void)hipStreamDestroy(cs);
+    if (rc != EB_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) return fail_hip("hipStreamEndCapture", e);
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { hipGraphDestroy(graph); return fail_hip("hipGraphInstantiate", e); }
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); return fail_hip("hipGraphInstantiate", e); }
     eb_plan p = new (std::nothrow) eb_plan_s();
-    if (!p) { hipGraphExecDestroy(exec); hipGraphDestroy(graph); return fail(EB_ENOMEM, "eb_plan_create: out of memory"); }
+    if (!p) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); return fail(EB_ENOMEM, "eb_plan_create: out of memory"); }
     p->h = h; p->graph = graph; p->exec = exec;
     *out = p;
     return EB_OK;
@@ -1005,10 +1004,10 @@ int eb_plan_launch(eb_plan p, void* stream) {
 
 int eb_plan_destroy(eb_plan p) {
     if (!p) return EB_OK;
-    hipSetDevice(p->h->cfg.device);
-    hipDeviceSynchronize();
-    if (p->exec) hipGraphExecDestroy(p->exec);
-    if (p->graph) hipGraphDestroy(p->graph);
+    (void)hipSetDevice(p->h->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
     delete p;
     return EB_OK;
 }
@@ -1019,7 +1018,7 @@ int eb_event_create(eb_handle h, eb_event* out) {
     hipEvent_t ev;
     EB_HIP(hipEventCreate(&ev));
     eb_event e = new (std::nothrow) eb_event_s();
-    if (!e) { hipEventDestroy(ev); return fail(EB_ENOMEM, "eb_event_create: out of memory"); }
+    if (!e) { (void)hipEventDestroy(ev); return fail(EB_ENOMEM, "eb_event_create: out of memory"); }
     e->ev = ev; e->device = h->cfg.device;
     *out = e;
     return EB_OK;
@@ -1042,8 +1041,8 @@ int eb_event_elapsed_ms(eb_event start, eb_event stop, float* ms) {
 
 int eb_event_destroy(eb_event e) {
     if (!e) return EB_OK;
-    hipSetDevice(e->device);
-    hipEventDestroy(e->ev);
+    (void)hipSetDevice(e->device);
+    (void)hipEventDestroy(e->ev);
     delete e;
     return EB_OK;
 }
@@ -1175,10 +1174,10 @@ int eb_mlp_create(const eb_mlp_config* cfg, eb_mlp* out) {
 int eb_mlp_destroy(eb_mlp m) {
     if (!m) return EB_OK;
     for (int L = 0; L <= EB_MLP_MAX_HIDDEN; ++L) {
-        if (m->d_w[L]) hipFree(m->d_w[L]);
-        if (m->d_b[L]) hipFree(m->d_b[L]);
+        if (m->d_w[L]) (void)hipFree(m->d_w[L]);
+        if (m->d_b[L]) (void)hipFree(m->d_b[L]);
     }
-    if (m->d_scale) hipFree(m->d_scale);
+    if (m->d_scale) (void)hipFree(m->d_scale);
     delete m;
     return EB_OK;
 }
