@@ -85,7 +85,7 @@ PROTOTYPES = {
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P]),
-    'eb_env_reset_pool': (C.c_int, [_P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    'eb_env_reset_pool': (C.c_int, [_P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, _P, C.c_float, _P]),
     'eb_traffic_flow_reset': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I,
                                         C.c_uint64, C.c_uint64, _P, _P, _P]),

@@ -745,6 +745,9 @@ int eb_env_ego_step(eb_handle h, int32_t n, const float* ego, const float* actio
     return EB_OK;
 }
 
+// eb_debug_set_tile on the env-side kernels: 0 / 1 / 2 = 64- / 32- / 16-env tiles (every shape computes the same bits), else by batch size
+static int forced_env_tile(const eb_handle_s* h) { return h->tile_variant == 0 ? 64 : h->tile_variant == 1 ? 32 : h->tile_variant == 2 ? 16 : 0; }
+
 int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_idx, int32_t path_id,
                int32_t m_cand, const float* cand, const uint8_t* cand_mode, const uint8_t* v_light,
                const uint8_t* virtual_flag, const uint8_t* exit_id, const uint8_t* row_mask, float* obs_out, void* stream) {
@@ -760,7 +763,7 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
     // (exit ids live in device memory: the kernel masks them to 0..3 instead of a host-side range check)
     EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
                               ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, pick(h, stream),
-                              nullptr, nullptr, nullptr, exit_id, &h->xc, row_mask));
+                              nullptr, nullptr, nullptr, exit_id, &h->xc, row_mask, nullptr, forced_env_tile(h)));
     return EB_OK;
 }
 
@@ -826,7 +829,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         A.cand_lw = cand_lw; A.v_light = v_light; A.virtual_flag = virtual_flag; A.scaled = scaled_actions; A.out5 = out5;
         A.d16 = out_dict16; A.obs_out = obs_out; A.done_code = done_code;
         A.trace = h->trace;
-        A.tile_envs = h->tile_variant == 0 ? 64 : h->tile_variant == 1 ? 32 : h->tile_variant == 2 ? 16 : 0;   // eb_debug_set_tile: every shape computes the same bits
+        A.tile_envs = forced_env_tile(h);
         if (respawn) {
             A.respawn_entry = respawn->entry; A.limit = respawn->limit; A.span = respawn->span; A.v_max = respawn->v_max;
             A.seed = respawn->seed; A.counter = respawn->counter;
@@ -883,7 +886,7 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
 int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
                       int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
                       uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
-                      float* obs, void* stream) {
+                      float* obs, const float* obs_src, const uint8_t* done_src, void* stream) {
     if (!h || !traffic || !pool || !pool->entry) return fail(EB_EINVAL, "eb_env_reset_pool: null argument");
     if (n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!ego || !params || !ref_idx || !virtual_flag || !cand || !cand_mode || !obs)))
         return fail(EB_EINVAL, "eb_env_reset_pool: bad argument");
@@ -894,6 +897,18 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
     if (rc) return rc;
     if (n_env == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
+    if (eb::env_step_is_fused(obs_dim(h->cfg), h->cfg.n_veh, m_cand, cand)) {
+        // ONE launch (csrc/eb_env_step.hip, env_reset_pool_kernel): a tile's masked rows are drawn, their pool re-entered clear of
+        // the new ego, their observation built from the state still in LDS, their flag swapped — the same arithmetic, in the
+        // same order per row, as the four launches below
+        const eb::EnvResetArgs R{seed, counter, training ? 1 : 0, params, ref_idx, virtual_flag, v_light, done_code, pool->entry,
+                                 pool->span, pool->v_max, pool->edge_span, pool->seed, pool->counter,
+                                 mask && obs_src != obs ? obs_src : nullptr, mask && done_code && done_src != done_code ? done_src : nullptr};
+        EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ref_idx, 0,
+                                  m_cand, cand, cand_mode, nullptr, virtual_flag, obs, pick(h, stream), nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, mask, &R, forced_env_tile(h)));
+        return EB_OK;
+    }
     if (h->vnext_bytes < (size_t)n_env) {
         if (h->d_vnext) (void)hipFree(h->d_vnext);
         h->d_vnext = nullptr; h->vnext_bytes = 0;
@@ -901,7 +916,12 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
         h->vnext_bytes = (size_t)n_env;
     }
     hipStream_t s = pick(h, stream);
-    // four launches behind one call: state + flags, pool re-entry (clear of the ego), masked observation, flag swap
+    if (mask && obs_src && obs_src != obs)       // the rows outside the mask: carried over from the caller's previous arrays
+        EB_HIP(hipMemcpyAsync(obs, obs_src, (size_t)n_env * obs_dim(h->cfg) * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (mask && done_src && done_code && done_src != done_code)
+        EB_HIP(hipMemcpyAsync(done_code, done_src, (size_t)n_env, hipMemcpyDeviceToDevice, s));
+    // (an unaligned candidate buffer or a tile that does not fit the LDS) four launches behind one call: state + flags, pool
+    // re-entry (clear of the ego), masked observation, flag swap
     EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx, h->d_vnext,
                                 done_code, s, v_light));
     EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, pool->entry, -1.0f, pool->span, pool->v_max, pool->seed, pool->counter, mask,

@@ -388,7 +388,14 @@ EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, flo
     return bi;
 }
 
+// The reference wraps angles with `while` loops (UTL:134-139, 232-237).  On a GPU a loop that never ends takes the device with
+// it, and it never ends for +-inf (and takes > 10^4 turns beyond +-3.6e6 degrees, where a diverged state can land): such a
+// value is returned as it is — both backends, same rule (oracle: EB_WRAP_MAX_DEG).  NaN fails every loop test by itself.
+constexpr float WRAP_MAX_DEG = 3.6e6f;
+EB_DEV bool wrap_bounded(float d) { return __builtin_fabsf(d) <= WRAP_MAX_DEG; }
+EB_DEV bool wrap_bounded(double d) { return __builtin_fabs(d) <= (double)WRAP_MAX_DEG; }
 EB_DEV float wrap_deal_with_phi(float phi) {  // UTL:232-237
+    if (!wrap_bounded(phi)) return phi;
     while (phi > 180.0f) phi -= 360.0f;
     while (phi <= -180.0f) phi += 360.0f;
     return phi;

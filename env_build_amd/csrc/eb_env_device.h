@@ -222,4 +222,26 @@ EB_DEV float u01(uint64_t seed, uint64_t idx) {   // top 24 bits of splitmix64(s
     return (float)(splitmix64(seed + 0x9E3779B97F4A7C15ull * idx) >> 40) * 5.9604644775390625e-8f;
 }
 
+// ---- Traffic.init_traffic's conflict rule (TRF:168-192): is a vehicle at (x, y, a) on top of / right in front of the ego? ----
+EB_DEV void shift_rotate(float x, float y, float d, float sx, float sy, float rd, float& ox, float& oy, float& od) {   // UTL:145-149
+    const float hx = x - sx, hy = y - sy;
+    float sn, cs;
+    sincos_det(rd * PI_F / 180.0f, sn, cs);
+    ox = hx * cs + hy * sn;
+    oy = -hx * sn + hy * cs;
+    float t = d - rd;
+    if (!wrap_bounded(t)) {}
+    else if (t > 180.0f) { while (t > 180.0f) t = t - 360.0f; }
+    else if (t <= -180.0f) { while (t <= -180.0f) t = t + 360.0f; }
+    od = t;
+}
+EB_DEV bool init_conflict(const float* ego6, float ego_l, float x, float y, float a, float veh_v, float veh_l) {   // TRF:168-192
+    float xe, ye, ae, xv, yv, av;
+    shift_rotate(x, y, a, ego6[3], ego6[4], ego6[5], xe, ye, ae);
+    shift_rotate(0.0f, 0.0f, 0.0f, xe, ye, ae, xv, yv, av);
+    return (-5.0f < xe && xe < 1.0f * ego6[0] + ego_l / 2.0f + veh_l / 2.0f + 2.0f && __builtin_fabsf(ye) < 3.0f) ||
+           (-5.0f < xv && xv < 1.0f * veh_v + ego_l / 2.0f + veh_l / 2.0f + 2.0f && __builtin_fabsf(yv) < 3.0f);   // TRF:183-184
+}
+
+
 }  // namespace eb

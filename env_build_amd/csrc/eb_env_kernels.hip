@@ -402,7 +402,8 @@ EB_DEV bool fetch_candidate_exit(int m, int c, int m_cand, const float* cand, co
         v.y = -x * xc.s[k] + y * xc.c[k];                                            // UTL:132
         const int ang = k == 0 ? 0 : k == 1 ? 90 : k == 2 ? 180 : -90;
         double t = (double)cand[4 * c + 3] - ang;                                    // UTL:133-139
-        if (t > 180) { while (t > 180) t = t - 360; }
+        if (!wrap_bounded(t)) {}
+        else if (t > 180) { while (t > 180) t = t - 360; }
         else if (t <= -180) { while (t <= -180) t = t + 360; }
         v.phi = t;
         v.v = cand[4 * c + 2];
@@ -520,7 +521,8 @@ __global__ void exit_frame_kernel(int n, const uint8_t* __restrict__ exit_id, in
     const float tx = x * c + y * sn;                                        // UTL:131
     const float ty = -x * sn + y * c;                                       // UTL:132
     float d = e[5] - a;                                                     // UTL:133-139
-    if (d > 180.0f) { while (d > 180.0f) d = d - 360.0f; }
+    if (!wrap_bounded(d)) {}
+    else if (d > 180.0f) { while (d > 180.0f) d = d - 360.0f; }
     else if (d <= -180.0f) { while (d <= -180.0f) d = d + 360.0f; }
     o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = tx; o[4] = ty; o[5] = d;
 }
@@ -536,7 +538,9 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
                           const float* cand, const uint8_t* cand_mode, const uint8_t* v_light, const uint8_t* virtual_flag,
                           float* obs_out, hipStream_t s, const float* params, const float* cand_lw,
-                          uint8_t* done_code, const uint8_t* exit_id, const ExitConsts* xc, const uint8_t* row_mask) {
+                          uint8_t* done_code, const uint8_t* exit_id, const ExitConsts* xc, const uint8_t* row_mask,
+                          const EnvResetArgs* reset, int tile_envs) {
+    if (reset && (exit_id || done_code || !env_step_is_fused(D, NV, m_cand, cand))) return hipErrorInvalidValue;
     if (exit_id) {
         if (done_code || !xc) return hipErrorInvalidValue;
         const dim3 g((n_env + 63) / 64), b(64);
@@ -563,6 +567,15 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
         }
         A.ref_idx = ref_idx; A.ego = const_cast<float*>(ego); A.cand = const_cast<float*>(cand); A.cand_mode = cand_mode;
         A.v_light = v_light; A.virtual_flag = virtual_flag; A.obs_out = obs_out; A.obs_only = 1; A.row_mask = row_mask;
+        A.tile_envs = tile_envs;
+        if (reset) {   // eb_env_reset_pool: the masked rows' state is drawn in the same launch
+            A.reset = 1; A.training = reset->training; A.reset_seed = reset->seed; A.reset_counter = reset->counter;
+            A.params = reset->params; A.ref_idx_out = reset->ref_idx; A.virtual_flag = reset->virtual_flag; A.virtual_out = reset->virtual_flag;
+            A.v_light = nullptr; A.v_light_out = reset->v_light; A.done_code = reset->done_code;
+            A.respawn_entry = reset->entry; A.span = reset->span; A.v_max = reset->v_max; A.edge_span = reset->edge_span;
+            A.seed = reset->pool_seed; A.counter = reset->pool_counter; A.limit = -1.0f;
+            A.obs = reset->obs_src; A.done_src = reset->done_src;
+        }
         return launch_env_step(task, A, s);
     }
     const size_t lds = get_obs_lds_bytes(D, m_cand);
@@ -601,7 +614,6 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
 }
 
 
-EB_DEV bool init_conflict(const float* ego6, float ego_l, float x, float y, float a, float veh_v, float veh_l);
 __global__ void traffic_respawn_kernel(int n_env, int m_cand, float* __restrict__ cand, const float* __restrict__ entry,
                                        float limit, float span, float v_max, uint64_t seed, uint64_t counter,
                                        const uint8_t* __restrict__ env_mask, uint8_t* __restrict__ respawned,
@@ -686,25 +698,6 @@ hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uin
 }
 
 // ---- Traffic.init_traffic's role for the flow source (TRF:151-195), one thread per (env, route) ----
-EB_DEV void shift_rotate(float x, float y, float d, float sx, float sy, float rd, float& ox, float& oy, float& od) {   // UTL:145-149
-    const float hx = x - sx, hy = y - sy;
-    float sn, cs;
-    sincos_det(rd * PI_F / 180.0f, sn, cs);
-    ox = hx * cs + hy * sn;
-    oy = -hx * sn + hy * cs;
-    float t = d - rd;
-    if (t > 180.0f) { while (t > 180.0f) t = t - 360.0f; }
-    else if (t <= -180.0f) { while (t <= -180.0f) t = t + 360.0f; }
-    od = t;
-}
-EB_DEV bool init_conflict(const float* ego6, float ego_l, float x, float y, float a, float veh_v, float veh_l) {   // TRF:168-192
-    float xe, ye, ae, xv, yv, av;
-    shift_rotate(x, y, a, ego6[3], ego6[4], ego6[5], xe, ye, ae);
-    shift_rotate(0.0f, 0.0f, 0.0f, xe, ye, ae, xv, yv, av);
-    return (-5.0f < xe && xe < 1.0f * ego6[0] + ego_l / 2.0f + veh_l / 2.0f + 2.0f && __builtin_fabsf(ye) < 3.0f) ||
-           (-5.0f < xv && xv < 1.0f * veh_v + ego_l / 2.0f + veh_l / 2.0f + 2.0f && __builtin_fabsf(yv) < 3.0f);   // TRF:183-184
-}
-
 __global__ void traffic_flow_reset_kernel(int n_env, int K, const uint8_t* __restrict__ mask, const float* __restrict__ ego,
                                           float* __restrict__ cand, uint8_t* __restrict__ active, float* __restrict__ timer,
                                           int* __restrict__ emitted, int* __restrict__ sim_step, uint8_t* __restrict__ phase0,

@@ -112,8 +112,11 @@ struct WaveQueue {
 // ET: envs per tile (64 or 16); lanes >= ET of the per-env roles idle.  OBS: the observation alone (eb_get_obs on an ego and
 // candidates given as they are: no action, reward, ego step, traffic step, collision test or done code — phases 1-4 shrink to
 // staging, tracking, slots and the row store; the arithmetic of what remains is the same code).
-template <int TASK, int ET, bool OBS>
-__global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
+// RESET (with OBS): eb_env_reset_pool in one launch — the masked rows get eb_env_reset's draws (wave 0, lane = env), then a fresh
+// pool clear of that ego (the staging lanes, eb_traffic_respawn's arithmetic with init_traffic's conflict rule), then their
+// observation from the state just made; the drawn virtual-red-light flag replaces the old one at the end (E2E:116-126).
+template <int TASK, int ET, bool OBS, bool RESET>
+EB_DEV void env_step_body(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET];
     __shared__ float s_miu[ET];                                                  // miu_r of the step (the stability predicate's input)
@@ -122,7 +125,14 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     const int nE = n_env - e0 < ET ? n_env - e0 : ET;
     const int i = e0 + lane;
     const bool live = lane < nE && !(OBS && A.row_mask && A.row_mask[i] == 0);   // (a masked observation pass: the other rows are left alone)
-    if (OBS && A.row_mask && __builtin_amdgcn_ballot_w64(live) == 0ull) return;   // same lanes -> envs in every wave: the whole block leaves
+    if (OBS && A.row_mask && __builtin_amdgcn_ballot_w64(live) == 0ull) {         // same lanes -> envs in every wave: the whole block leaves
+        if (RESET) {                                                              // (its rows are carried over from the previous arrays)
+            if (A.obs)
+                for (int idx = tid; idx < nE * A.D; idx += 256) A.obs_out[(size_t)e0 * A.D + idx] = A.obs[(size_t)e0 * A.D + idx];
+            if (A.done_src && A.done_code && tid < nE) A.done_code[e0 + tid] = A.done_src[e0 + tid];
+        }
+        return;
+    }
     const int RS4 = obs_cand_stride4(m_cand), OS = es_obs_stride(D), TS4 = es_tag_stride4(m_cand), T = 3 * (n_future + 1);
     float4* s_cand = reinterpret_cast<float4*>(smem);                            // [64][RS4] candidates after the traffic step
     float* s_out = reinterpret_cast<float*>(s_cand + (size_t)ET * RS4);          // [64][OS]  next observation rows
@@ -178,18 +188,41 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
     };
     load_pairs(0);
     const int slot_mode = lane < NV ? A.modes.mode[lane] : 0xff;                        // lane = slot
-    const bool red_light = live && A.v_light && A.v_light[i] != 0;
+    const bool red_light = !RESET && live && A.v_light && A.v_light[i] != 0;   // (a reset clears v_light before its observation)
     const bool light = red_light || (live && A.virtual_flag && A.virtual_flag[i] != 0);   // E2E:387-388
     float nx[6] = {0, 0, 0, 0, 0, 0};                                        // wave 0
     float steer = 0.0f, a_x = 0.0f, o9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // wave 1
     float road_t = 0.0f, road_r = 0.0f;
+    int reset_path = 0;
+    bool virtual_next = false;
     if (OBS) {
-        if (wave == 0 && live) {                                                // the ego as given (eb_get_obs)
-            const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
-            const float2 g0 = eg[0], g1 = eg[1], g2 = eg[2];
-            nx[0] = g0.x; nx[1] = g0.y; nx[2] = g1.x; nx[3] = g1.y; nx[4] = g2.x; nx[5] = g2.y;
+        if (wave == 0 && live) {
+            if (RESET) {                                                        // eb_env_reset's draws (env_reset_kernel: same keys, same arithmetic)
+                const float span = TASK == TASK_LEFT ? 900 + 500 : TASK == TASK_STRAIGHT ? 1200 + 500 : 420 + 500;   // E2E:473-478
+                const uint64_t base = (A.reset_counter << 32) + (uint64_t)i * 128u;
+                const float u0 = u01(A.reset_seed, base), u1 = u01(A.reset_seed, base + 1), u2 = u01(A.reset_seed, base + 2),
+                            u3 = u01(A.reset_seed, base + 3);
+                int p = (int)(u0 * (float)A.pt.n_paths);                        // DAM:591
+                if (p > A.pt.n_paths - 1) p = A.pt.n_paths - 1;
+                const int ci = clamp_index((int)(u1 * span) + 700, A.pt.len[p]);   // E2E:474-478; indexs2points, DAM:727-728
+                nx[0] = 8.0f * u2; nx[1] = 0.0f; nx[2] = 0.0f;                  // E2E:482-486
+                nx[3] = A.pt.x[p][ci]; nx[4] = A.pt.y[p][ci]; nx[5] = A.pt.phi[p][ci];
+                reset_path = p;
+                virtual_next = A.training && u3 > 0.9f;                         // E2E:120-126
+                float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
+                ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
+                reinterpret_cast<float4*>(A.params)[i] = make_float4(0.0f, 0.0f, VehParams::miu, VehParams::miu);   // E2E:110-113
+                A.ref_idx_out[i] = p;
+                if (A.done_code) A.done_code[i] = EB_DONE_NOT_YET;              // E2E:119
+                if (A.v_light_out) A.v_light_out[i] = 0;
+            } else {                                                            // the ego as given (eb_get_obs)
+                const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
+                const float2 g0 = eg[0], g1 = eg[1], g2 = eg[2];
+                nx[0] = g0.x; nx[1] = g0.y; nx[2] = g1.x; nx[3] = g1.y; nx[4] = g2.x; nx[5] = g2.y;
+            }
             s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
         }
+        if (RESET) __syncthreads();   // the pool's re-entry below stays clear of the NEW ego
     } else if (wave < 2 && live) {
         const float2 r2 = reinterpret_cast<const float2*>(A.raw)[i];
         const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
@@ -232,7 +265,25 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
         auto stage = [&](int idx, const float4 v, unsigned mode) {
             const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
             float sn, cs;     // (the record loop of the rollout kernel: one code path for every turn class, eb_device.h)
-            if (OBS) s_cand[e * RS4 + c] = v;
+            if (RESET) {
+                float4 nv = v;
+                if (!s_col[e]) {                                               // a row of the mask: eb_traffic_respawn, unconditional
+                    const uint64_t ub = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
+                    const float u1 = u01(A.seed, ub), u2 = u01(A.seed, ub + 1);
+                    const float* en = A.respawn_entry + 5 * c;
+                    float along = u1 * A.span;
+                    nv = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
+                    const float4 eg = s_ego[e];
+                    const float ego6[6] = {eg.w, 0.0f, 0.0f, eg.x, eg.y, eg.z};
+                    if (init_conflict(ego6, 4.8f, nv.x, nv.y, nv.w, nv.z, 4.8f)) {   // TRF:168-192: not on top of the ego
+                        along = u1 * A.edge_span;
+                        nv.x = en[0] + along * en[3];
+                        nv.y = en[1] + along * en[4];
+                    }
+                    reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = nv;
+                }
+                s_cand[e * RS4 + c] = nv;
+            } else if (OBS) s_cand[e * RS4 + c] = v;
             else {
                 const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs);
                 s_cand[e * RS4 + c] = make_float4(r.x, r.y, r.z, r.w);
@@ -272,7 +323,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) orow[c] = nx[c];
             const PathTables& pt = A.pt;
-            const int p = row_path(pt, A.ref_idx, A.path_id, i);
+            const int p = RESET ? reset_path : row_path(pt, A.ref_idx, A.path_id, i);
             if (p < 0) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }
             else {
                 const float2* red = pt.red[p];
@@ -561,6 +612,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
 
     // ---- phase 4 ---------------------------------------------------------------------------------------------
     if (!OBS && wave == 0 && live) A.done_code[i] = judge_merge(jbits, s_col[lane] != 0, delta_y);                // E2E:200-221
+    if (RESET && wave == 0 && live) A.virtual_out[i] = virtual_next ? 1 : 0;   // every wave read the old flag before the barriers above
+    if (RESET && wave == 0 && !live && lane < nE && A.done_src && A.done_code) A.done_code[i] = A.done_src[i];
     {   // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane)
         float* dst = A.obs_out + (size_t)e0 * D;
         const int total = nE * D;
@@ -575,12 +628,19 @@ __global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = base + 256 * k;
-                if (idx < total && !(OBS && A.row_mask && s_col[fast_div(idx, A.d_magic)])) dst[idx] = v[k];
+                if (idx >= total) continue;
+                if (!(OBS && A.row_mask && s_col[fast_div(idx, A.d_magic)])) dst[idx] = v[k];
+                else if (RESET && A.obs) dst[idx] = A.obs[(size_t)e0 * D + idx];            // a row outside the mask: carried over
             }
         }
     }
     ES_MARK(4);
 }
+
+template <int TASK, int ET, bool OBS>
+__global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false>(A); }
+template <int TASK, int ET>
+__global__ __launch_bounds__(256) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true>(A); }
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
@@ -603,9 +663,20 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
         }                                                                                                            \
         if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O>), g, b, lds, s, A);                        \
     } while (0)
+#define EB_ENV_RESET(T, E)                                                                                            \
+    do {                                                                                                             \
+        static size_t granted[64];                                                                                   \
+        if (lds > 48 * 1024 && lds > granted[dev]) {                                                                 \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_reset_pool_kernel<T, E>),                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            if (e == hipSuccess) granted[dev] = lds;                                                                 \
+        }                                                                                                            \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_reset_pool_kernel<T, E>), g, b, lds, s, A);                     \
+    } while (0)
 #define EB_ENV_STEP_T(T)                                                                                             \
     do {                                                                                                             \
-        if (A.obs_only) { if (ET == 16) EB_ENV_STEP(T, 16, true); else if (ET == 32) EB_ENV_STEP(T, 32, true); else EB_ENV_STEP(T, 64, true); } \
+        if (A.reset) { if (ET == 16) EB_ENV_RESET(T, 16); else if (ET == 32) EB_ENV_RESET(T, 32); else EB_ENV_RESET(T, 64); } \
+        else if (A.obs_only) { if (ET == 16) EB_ENV_STEP(T, 16, true); else if (ET == 32) EB_ENV_STEP(T, 32, true); else EB_ENV_STEP(T, 64, true); } \
         else { if (ET == 16) EB_ENV_STEP(T, 16, false); else if (ET == 32) EB_ENV_STEP(T, 32, false); else EB_ENV_STEP(T, 64, false); } \
     } while (0)
     switch (task) {
@@ -614,6 +685,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
         default: EB_ENV_STEP_T(TASK_RIGHT); break;
     }
 #undef EB_ENV_STEP_T
+#undef EB_ENV_RESET
 #undef EB_ENV_STEP
     return e != hipSuccess ? e : hipGetLastError();
 }

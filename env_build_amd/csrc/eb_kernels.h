@@ -91,12 +91,14 @@ struct ExitConsts {
 };
 // done_code != NULL appends _judge_done to the observation kernel (only in its LDS-staged form: get_obs_is_staged).
 // exit_id != NULL: the 12-ego scene's frames (one thread per env, float64 vehicle coordinates); needs `xc`.
+struct EnvResetArgs;
 hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
                           const float* cand, const uint8_t* cand_mode, const uint8_t* v_light, const uint8_t* virtual_flag,
                           float* obs_out, hipStream_t s, const float* params = nullptr, const float* cand_lw = nullptr,
                           uint8_t* done_code = nullptr, const uint8_t* exit_id = nullptr, const ExitConsts* xc = nullptr,
-                          const uint8_t* row_mask = nullptr);
+                          const uint8_t* row_mask = nullptr, const EnvResetArgs* reset = nullptr,
+                          int tile_envs = 0);   // tile_envs: EnvStepArgs::tile_envs for the one-launch machinery
 hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const ExitConsts& xc, const float* ego, float* out,
                              hipStream_t s);
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
@@ -143,6 +145,30 @@ struct EnvStepArgs {
     int obs_only;                          // 1: eb_get_obs — ego / cand are inputs, only obs_out is written
     const uint8_t* row_mask;               // obs_only: nullable [n_env]; rows with a zero byte are left alone
     int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 32 / 64: forced (eb_debug_set_tile 2 / 1 / 0)
+    // reset (eb_env_reset_pool as one launch; obs_only = 1 too): the rows of row_mask get a fresh ego (eb_env_reset's draws), a
+    // fresh pool clear of that ego (respawn_entry / span / v_max / seed / counter / edge_span), their reset observation
+    int reset;
+    int training;
+    uint64_t reset_seed, reset_counter;
+    float edge_span;
+    int* ref_idx_out;                      // [n_env] the drawn path
+    uint8_t* virtual_out;                  // [n_env] == virtual_flag: the OLD flag feeds the observation, the drawn one replaces it after
+    uint8_t* v_light_out;                  // nullable: cleared
+    const uint8_t* done_src;               // nullable (obs: the observation source of the rows outside the mask, nullable)
+};
+struct EnvResetArgs {                      // launch_get_obs(..., reset): what eb_env_reset_pool adds to a masked observation pass
+    uint64_t seed, counter;                // eb_env_reset's
+    int training;
+    float* params;
+    int* ref_idx;
+    uint8_t* virtual_flag;
+    uint8_t* v_light;                      // nullable
+    uint8_t* done_code;                    // nullable
+    const float* entry;                    // the pool rule
+    float span, v_max, edge_span;
+    uint64_t pool_seed, pool_counter;
+    const float* obs_src;                  // nullable: the observation rows of the envs outside the mask
+    const uint8_t* done_src;               // nullable: their done codes
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand);

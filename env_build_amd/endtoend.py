@@ -259,6 +259,7 @@ class CrossroadEnd2end(object):
         self._injected = False
         self._flows = None
         self._bufs, self._buf_i = None, 0
+        self._rbufs, self._rbuf_i = None, 0      # reset(mask=...) over the pool: its observation / done-code sets
         # during an episode a vehicle that left the map re-enters at its lane's edge (within POOL_EDGE_SPAN m of the entry
         # point, 60 m from the centre: where no ego is), not somewhere along the lane
         self._respawn_rule = _capi.EbRespawn(self._entry5.data_ptr(), CROSSROAD_SIZE / 2 + 40., self.POOL_EDGE_SPAN, EXPECTED_V, 0, 0)
@@ -347,28 +348,38 @@ class CrossroadEnd2end(object):
         B, dev = self.n_env, self.device
         mask8 = None
         if mask is not None and B > 1:
-            mt = mask.t if isinstance(mask, DevArray) else mask
+            if isinstance(mask, _LazyDone) and mask._t is None:
+                mt = mask._code          # step()'s `done`, not read yet: its done codes serve as the mask (non-zero = reset)
+            else:
+                mt = mask.t if isinstance(mask, DevArray) else mask
             mt = mt if isinstance(mt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(mt)))
             mask8 = mt.to(device=dev).reshape(B).to(torch.uint8).contiguous()
-        if B > 1:
-            self.done_code = self.done_code.clone()      # the array handed out by the last step stays as it was
         sp = self._sp()
         if B > 1 and self._flows is None and self._exit_id is None:
-            # the whole masked reset over the traffic pool as ONE C call (eb_env_reset_pool): state and flags (E2E:100-101,
-            # 119), the pool's re-entry clear of the ego (E2E:102-103), v_light cleared, the reset observation of those rows
-            # with the OLD flags (E2E:116), the drawn flags swapped in (E2E:120-126)
+            # the whole masked reset over the traffic pool as ONE C call and one launch (eb_env_reset_pool): state and flags
+            # (E2E:100-101, 119), the pool's re-entry clear of the ego (E2E:102-103), v_light cleared, the reset observation of
+            # those rows with the OLD flags (E2E:116), the drawn flags swapped in (E2E:120-126).  The observation and the done
+            # codes go to one of two pre-allocated sets used in turn; the rows of the other envs are carried over inside the
+            # kernel (obs_src / done_src), so the arrays the last step handed out stay as they were and nothing is cloned.
             self._reset_counter += 2
             if not self._cand.is_contiguous():
                 self._cand = self._cand.contiguous()
-            if self._bufs is not None and any(self._obs.data_ptr() == b['obs'].data_ptr() for b in self._bufs):
-                self._obs = self._obs.clone()        # the obs array handed out by the last step stays as it was
+            if self._rbufs is None:
+                self._rbufs = [dict(obs=torch.empty((B, self.obs_dim), dtype=torch.float32, device=dev),
+                                    code=torch.empty((B,), dtype=torch.uint8, device=dev)) for _ in range(2)]
+            self._rbuf_i ^= 1
+            rb = self._rbufs[self._rbuf_i]
+            if rb['obs'].data_ptr() == self._obs.data_ptr():      # two resets in a row: the other set
+                self._rbuf_i ^= 1
+                rb = self._rbufs[self._rbuf_i]
             rule = self._reset_rule
             rule.seed, rule.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
             self.api.env_reset_pool(self._h, self._traffic.h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
                                     C.c_uint64(self._reset_counter - 1), 1 if self.mode == 'training' else 0, _ptr(self._ego),
                                     _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual), _ptr(self._v_light),
-                                    _ptr(self.done_code), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), C.byref(rule),
-                                    _ptr(self._obs), sp)
+                                    _ptr(rb['code']), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), C.byref(rule),
+                                    _ptr(rb['obs']), _ptr(self._obs), _ptr(self.done_code), sp)
+            self._obs, self.done_code = rb['obs'], rb['code']
             route = {'left': 'dl', 'straight': 'du', 'right': 'dr'}[self.training_task]
             self.init_state = _LazyInitState(self._ego, self.ego_l, self.ego_w, route)
             self._injected = False
@@ -379,8 +390,9 @@ class CrossroadEnd2end(object):
             self.virtual_red_light_vehicle = None
             self.done_type = DevArray(self.done_code)
             return self.obs
+        if B > 1:
+            self.done_code = self.done_code.clone()      # the array handed out by the last step stays as it was
         self.init_state = self._reset_init_state(mask8)                                 # E2E:101
-        sp = self._sp()
         if self._flows is not None:                                                      # E2E:102-103 (init_traffic)
             self._flows.reset(self.api, self._traffic.h, mask8, self._ego, sp)
             self._cand, self._cand_mode, self._v_light = self._flows.cand, self._flows.mode(), self._flows.v_light()

@@ -89,6 +89,13 @@ extern "C" {
 #define EB_MAX_PATHS 3
 #define EB_MAX_VEH 64
 
+/* Angle wrapping.  The reference wraps headings with `while` loops (UTL:134-139, 232-237: eb_env_ego_step / eb_env_step,
+ * eb_exit_frame, eb_get_obs(exit_id), the traffic reset's conflict test).  Such a loop never ends for +-inf and spins for more
+ * than 10^4 turns beyond +-3.6e6 degrees — on a GPU that is a hung device, not a slow env.  Both backends therefore return a
+ * value whose magnitude exceeds EB_WRAP_MAX_DEG (or is not a number) UNWRAPPED; every value the reference wraps in reasonable
+ * time is wrapped by the same subtractions, bit for bit. */
+#define EB_WRAP_MAX_DEG 3.6e6f
+
 typedef struct eb_handle_s* eb_handle;
 
 typedef struct eb_config {
@@ -378,11 +385,15 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
  *   v_light[e] = 0 (nullable): the pool has no light programme, an episode starts at phase 0
  *   eb_get_obs(h, ..., v_light, virtual_flag, NULL, mask, obs): the reset observation, built with the OLD flags    E2E:116
  *   virtual_flag[e] = the flag eb_env_reset drew                                                       E2E:120-126
- * each for the masked envs only; the rows of the other envs (state, candidates, flags, obs) are not touched. */
+ * each for the masked envs only; the rows of the other envs (state, candidates, flags) are not touched.
+ * obs_src / done_src (nullable): where the observation / done-code rows of the envs OUTSIDE the mask come from — a driver that
+ * must leave the arrays of the last step as they were passes them here and fresh arrays as obs / done_code, and gets the whole
+ * batch's current rows without a copy of its own.  NULL (or the same array): those rows of obs / done_code are left alone.
+ * The HIP library runs all of it as ONE launch (csrc/eb_env_step.hip, env_reset_pool_kernel) under the conditions of eb_env_step. */
 int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
                       int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
                       uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
-                      float* obs, void* stream);
+                      float* obs, const float* obs_src, const uint8_t* done_src, void* stream);
 
 /* The traffic pool's re-entry rule (the SUMO flows' role for the batched env, TRF:37-238 is out of scope): every
  * candidate of cand [n_env, m_cand, 4] that has left the square |x|, |y| <= limit is put back on its entry lane,

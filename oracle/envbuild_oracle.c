@@ -856,6 +856,7 @@ int eb_ss(eb_handle h, int32_t n_env, const float* obs, const float* actions, co
 /* margins).                                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 static inline float deal_with_phi(float phi) { /* UTL:232-237 */
+    if (!(fabsf(phi) <= EB_WRAP_MAX_DEG)) return phi;   /* +-inf would never leave the loops (include/envbuild.h, "angle wrapping") */
     while (phi > 180.0f) phi -= 360.0f;
     while (phi <= -180.0f) phi += 360.0f;
     return phi;
@@ -965,7 +966,8 @@ static void rotate_f64(double x, double y, double d, int rotate_d, double* ox, d
     *ox = x * cos(r) + y * sin(r);
     *oy = -x * sin(r) + y * cos(r);
     double t = d - rotate_d;
-    if (t > 180) { while (t > 180) t = t - 360; }
+    if (!(fabs(t) <= (double)EB_WRAP_MAX_DEG)) {}
+    else if (t > 180) { while (t > 180) t = t - 360; }
     else if (t <= -180) { while (t <= -180) t = t + 360; }
     *od = t;
 }
@@ -1065,7 +1067,8 @@ int eb_exit_frame(eb_handle h, int32_t n, const uint8_t* exit_id, int32_t invers
         const float tx = x * c + y * sn;                               /* UTL:131 */
         const float ty = -x * sn + y * c;                              /* UTL:132 */
         float d = e[5] - (float)a;                                     /* UTL:133 */
-        if (d > 180.0f) { while (d > 180.0f) d = d - 360.0f; }         /* UTL:134-139 */
+        if (!(fabsf(d) <= EB_WRAP_MAX_DEG)) {}
+        else if (d > 180.0f) { while (d > 180.0f) d = d - 360.0f; }    /* UTL:134-139 */
         else if (d <= -180.0f) { while (d <= -180.0f) d = d + 360.0f; }
         o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = tx; o[4] = ty; o[5] = d;
     }
@@ -1423,7 +1426,7 @@ int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, 
 int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
                       int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
                       uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
-                      float* obs, void* stream) {
+                      float* obs, const float* obs_src, const uint8_t* done_src, void* stream) {
     if (!h || !traffic || !pool || !pool->entry) return fail(EB_EINVAL, "eb_env_reset_pool: null argument");
     if (n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!ego || !params || !ref_idx || !virtual_flag || !cand || !cand_mode || !obs)))
         return fail(EB_EINVAL, "eb_env_reset_pool: bad argument");
@@ -1434,6 +1437,9 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
     if (n_env == 0) return EB_OK;
     uint8_t* vnext = (uint8_t*)malloc((size_t)n_env);
     if (!vnext) return fail(EB_ENOMEM, "eb_env_reset_pool: out of memory");
+    /* the rows outside the mask: carried over from the caller's previous arrays */
+    if (mask && obs_src && obs_src != obs) memcpy(obs, obs_src, (size_t)n_env * (size_t)obs_dim(&h->cfg) * sizeof(float));
+    if (mask && done_src && done_code && done_src != done_code) memcpy(done_code, done_src, (size_t)n_env);
     rc = eb_env_reset(h, n_env, mask, seed, counter, training, ego, params, ref_idx, vnext, done_code, stream);
     if (!rc) rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, pool->entry, -1.0f, pool->span, pool->v_max, pool->seed,
                                      pool->counter, mask, NULL, ego, pool->edge_span, stream);
@@ -1457,7 +1463,8 @@ static void shift_rotate_f32(float x, float y, float d, float sx, float sy, floa
     *ox = hx * cs + hy * sn;                                            /* UTL:131 */
     *oy = -hx * sn + hy * cs;                                           /* UTL:132 */
     float t = d - rd;                                                   /* UTL:133-139 */
-    if (t > 180.0f) { while (t > 180.0f) t = t - 360.0f; }
+    if (!(fabsf(t) <= EB_WRAP_MAX_DEG)) {}
+    else if (t > 180.0f) { while (t > 180.0f) t = t - 360.0f; }
     else if (t <= -180.0f) { while (t <= -180.0f) t = t + 360.0f; }
     *od = t;
 }

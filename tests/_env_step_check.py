@@ -128,7 +128,7 @@ def respawn_conflict_case(make, B=300, M=16, seed=4):
     return safe
 
 
-def reset_pool_case(make, task, B=260, M=12, seed=21):
+def reset_pool_case(make, task, B=260, M=12, seed=21, tile=None, NV=None):
     """eb_env_reset_pool == eb_env_reset, eb_traffic_respawn(forced, clear of the ego), v_light clear, eb_get_obs(row mask, OLD
     flags), flag swap — for the masked envs only; the other envs' rows are untouched."""
     from env_build_amd.endtoend import _lane_entry
@@ -141,8 +141,12 @@ def reset_pool_case(make, task, B=260, M=12, seed=21):
     params = rng.normal(size=(B, 4)).astype(np.float32)
     virtual = (rng.random(B) < 0.5).astype(np.uint8)
     v_light = rng.integers(0, 4, B).astype(np.uint8)
-    obs = rng.normal(size=(B, 9 + 4 * len(native))).astype(np.float32)
-    m, tr = make(task, mode='training'), make(task, n_veh=M, modes=modes)
+    nv = len(native) if NV is None else NV
+    obs = rng.normal(size=(B, 9 + 4 * nv)).astype(np.float32)
+    m = make(task, mode='training') if NV is None else make(task, n_veh=NV, mode='training')
+    tr = make(task, n_veh=M, modes=modes)
+    if tile is not None:
+        m.set_tile(tile)          # the one-launch reset: 0 / 1 / 2 = 64- / 32- / 16-env tiles (eb_debug_set_tile)
     pool = dict(entry=entry, span=60.0, v_max=8.0, seed=4242, counter=17, edge_span=5.0)
     outs = []
     for mask in (rng.random(B) < 0.3, None):
@@ -160,4 +164,30 @@ def reset_pool_case(make, task, B=260, M=12, seed=21):
             assert np.array_equal(g, w), k
         assert np.array_equal(got[0][~sel], ego[~sel]) and np.array_equal(got[7][~sel], obs[~sel]) and np.array_equal(got[6][~sel], cand[~sel])
         outs.append(got)
+        # obs_src / done_src: the rows outside the mask come from the previous arrays, those inside are the same as above
+        prev_obs = rng.normal(size=obs.shape).astype(np.float32)
+        prev_done = rng.integers(0, 7, B).astype(np.uint8)
+        g2 = m.env_reset_pool(tr, 99, 5, 1, ego, params, ref, virtual, v_light, cand, cmode, obs, pool, mask=mk, obs_src=prev_obs, done_src=prev_done)
+        for k in (0, 1, 2, 3, 4, 6):
+            assert np.array_equal(g2[k], got[k]), k
+        assert np.array_equal(g2[7][sel], got[7][sel]) and np.array_equal(g2[7][~sel], prev_obs[~sel])
+        assert (g2[5][sel] == 0).all() and np.array_equal(g2[5][~sel], prev_done[~sel])
+        outs.append(g2)
     return outs
+
+
+def wrap_guard_case(m):
+    """Headings the reference's `while` wraps (UTL:134-139, 232-237) would never finish on — +-inf, +-1e30, 4e6 degrees — come back
+    unwrapped (EB_WRAP_MAX_DEG) instead of hanging; ordinary and just-inside values wrap as always."""
+    phis = np.array([0.0, 179.0, 181.0, -540.0, 3.59e6, -3.59e6, 3.6e6, 4.0e6, -4.0e6, 1e30, -1e30, np.inf, -np.inf, np.nan], np.float32)
+    n = len(phis)
+    ego = np.zeros((n, 6), np.float32)
+    ego[:, 0], ego[:, 5] = 5.0, phis
+    out = [m.exit_frame(np.full(n, k, np.uint8), ego, inverse=inv)[:, 5] for k in range(4) for inv in (False, True)]
+    nxt, _ = m.env_ego_step(ego, np.zeros((n, 2), np.float32))
+    out.append(nxt[:, 5])
+    big = np.abs(phis) > 3.6e6
+    for o in out[:2]:                                   # exit D: the heading itself
+        assert np.array_equal(o[big], phis[big], equal_nan=True) and (np.abs(o[~big & np.isfinite(phis)]) <= 180.0).all()
+    assert (np.abs(out[-1][:6]) <= 180.0).all()         # the ego step wraps what it can
+    return out

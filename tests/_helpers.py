@@ -278,7 +278,7 @@ class HostModel(object):
         return self._ret(eg), self._ret(pr), self._ret(ri), self._ret(vn), self._ret(dc)
 
     def env_reset_pool(self, traffic, seed, counter, training, ego, params, ref_idx, virtual, v_light, cand, cand_mode, obs, pool,
-                       mask=None):
+                       mask=None, obs_src=None, done_src=None):
         """eb_env_reset_pool on copies of the state -> (ego, params, ref_idx, virtual, v_light, done_code, cand, obs)"""
         cp = lambda a, t: self._in(np.array(a, t))          # in/out arguments: explicit copies (the oracle writes in place)
         eg, pr, ri = cp(ego, np.float32), cp(params, np.float32), self._in(np.array(ref_idx, np.int32), np.int32)
@@ -288,11 +288,12 @@ class HostModel(object):
         dc = self._out((n,), np.uint8)
         dc[...] = 7
         en = self._in(pool['entry'])
+        osrc, dsrc = self._in(obs_src), self._in(done_src, np.uint8)
         rs = _capi.EbRespawn(self._ptr(en).value, 0.0, float(pool['span']), float(pool['v_max']), int(pool['seed']), int(pool['counter']),
                              float(pool['edge_span']))
         self.api.env_reset_pool(self.h, traffic.h, n, self._ptr(mk), C.c_uint64(seed), C.c_uint64(counter), int(training), self._ptr(eg),
                                 self._ptr(pr), self._ptr(ri), self._ptr(vf), self._ptr(vl), self._ptr(dc), m, self._ptr(cd), self._ptr(cm),
-                                C.byref(rs), self._ptr(ob), self.stream)
+                                C.byref(rs), self._ptr(ob), self._ptr(osrc), self._ptr(dsrc), self.stream)
         return [self._ret(x) for x in (eg, pr, ri, vf, vl, dc, cd, ob)]
 
     def tracking_error(self, xs, ys, phis, vs, n_future, ref_idx=None, path_id=0):

@@ -2,7 +2,7 @@
 equals its own single calls — the same check the GPU suite runs on the one-launch kernel (tests/_env_step_check.py)."""
 import pytest
 
-from tests._env_step_check import CASES, composite_case, masked_obs_case, reset_pool_case, respawn_conflict_case
+from tests._env_step_check import CASES, composite_case, masked_obs_case, reset_pool_case, respawn_conflict_case, wrap_guard_case
 from tests._helpers import HostModel
 
 
@@ -23,3 +23,8 @@ def test_oracle_pool_reset_keeps_clear_of_the_ego(oracle):
 @pytest.mark.parametrize('task', ['left', 'straight', 'right'])
 def test_oracle_reset_pool_composite(oracle, task):
     reset_pool_case(lambda t, **kw: HostModel(oracle, t, **kw), task)
+
+
+@pytest.mark.timeout(60)
+def test_angle_wrap_loops_are_bounded(oracle):
+    wrap_guard_case(HostModel(oracle, 'left'))
