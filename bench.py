@@ -503,6 +503,28 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     for r in range(reps):
         api.event_elapsed_ms(ev[2 * r], ev[2 * r + 1], C.byref(ms))
         seg_us.append(ms.value * 1e3 / seg)
+    # the masked reset a vectorised driver issues after every step (eb_env_reset_pool, one launch: draws, pool re-entry clear of
+    # the new ego, reset observation, flag swap, the other rows carried over into fresh arrays): 2 % of the envs, 100 calls
+    restore()
+    gmask = (torch.rand((B,), generator=g) < 0.02).to(torch.uint8).to(dev)
+    rrule = _capi.EbRespawn(env._entry5.data_ptr(), 0.0, 60.0, 8.0, 777, 0, env.POOL_EDGE_SPAN)
+    code2 = torch.empty_like(code)
+    n_reset = 100
+
+    def resets(k0):
+        for k in range(k0, k0 + n_reset):
+            rrule.counter = k
+            rc = lib.eb_env_reset_pool(h, ht, B, p(gmask), C.c_uint64(99), C.c_uint64(k), 1, p(ego), p(params), p(env._ref_idx), p(env._virtual),
+                                       p(env._v_light), p(code2), M, p(cand), p(env._cand_mode), C.byref(rrule), p(obs[1]), p(obs[0]), p(code), sp)
+            if rc != 0:
+                api.check(rc)
+    resets(1)
+    lib.eb_event_record(ev[0], sp)
+    resets(1 + n_reset)
+    lib.eb_event_record(ev[1], sp)
+    torch.cuda.synchronize()
+    api.event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+    reset_us = ms.value * 1e3 / n_reset
     for e in ev:
         api.event_destroy(e)
     us = median(seg_us)       # per-step time of the median segment: one host hiccup (a collection, a free) does not move it
@@ -523,7 +545,9 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
             'alg_bytes_per_env_step': env_step_alg_bytes(D, M), 'alg_bytes_per_launch': alg, 'achieved_GBs': achieved, 'frac': frac,
             'traffic': traffic, 'traffic_source': 'profiles/r3_pmc_traffic.json (separate rocprofv3 --pmc passes, scripts/pmc_traffic.sh)' if traffic else None,
             'kernel': 'eb::env_step_kernel<0, %d, false>' % (16 if B <= 6144 else 32 if B <= 24576 else 64),
-            'done_fraction_after_segment': done_frac}
+            'done_fraction_after_segment': done_frac,
+            'masked_reset': {'entry': 'eb_env_reset_pool (one launch: eb::env_reset_pool_kernel)', 'mask_fraction': 0.02, 'calls_timed': n_reset,
+                             'us_per_call': reset_us, 'carries_over': 'observation and done-code rows of the other envs (obs_src / done_src)'}}
 
 
 def shield_bench(args):

@@ -646,6 +646,8 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
     static const int force = std::getenv("EB_ENV_TILE") ? std::atoi(std::getenv("EB_ENV_TILE")) : 0;   // tuning aid
     if (force == 16 || force == 32 || force == 64) ET = force;
+    static const int rforce = std::getenv("EB_RESET_TILE") ? std::atoi(std::getenv("EB_RESET_TILE")) : 0;   // tuning aid (the masked reset only)
+    if (A.reset && (rforce == 16 || rforce == 32 || rforce == 64)) ET = rforce;
     if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET) > 150 * 1024) ET = 16;     // a forced shape that does not fit
     const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET);
     int dev = 0;
