@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (not part of the test suite): eb_env_step — the one-launch kernel, both tile shapes, random
 slot / candidate counts, arbitrary candidate modes, per-candidate sizes, re-entry rule — on the GPU against the CPU oracle's
-composite, and eb_get_obs with a row mask."""
+composite, eb_get_obs with a row mask, and eb_env_reset_pool (the one-launch masked reset, with and without carry-over)."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -50,8 +50,19 @@ while time.time() < t_end:
             mask = (np.random.default_rng(seed).random(B) < 0.3)
             init = np.full(obs0.shape, 7.0, np.float32)
             masked = m.get_obs(ego, cand, cmode, light, ref_idx=ref, row_mask=mask.astype(np.uint8), obs_init=init)
-            outs.append(got + [masked])
-        names = ['scaled', 'out5', 'd16', 'ego', 'params', 'cand', 'obs', 'done', 'masked obs']
+            # the masked reset as one launch (eb_env_reset_pool): random mask density, carry-over from other arrays or in place
+            rs = np.random.default_rng(seed + 1)
+            dens = float(rs.choice([0.02, 0.3, 1.0]))
+            rmask = None if dens == 1.0 and rs.integers(2) else (rs.random(B) < dens).astype(np.uint8)
+            pool = dict(entry=entry, span=60.0, v_max=8.0, seed=int(rs.integers(1 << 40)), counter=int(rs.integers(1 << 20)), edge_span=5.0)
+            carry = rs.integers(2) == 1
+            prev_obs = rs.normal(size=obs0.shape).astype(np.float32) if carry else None
+            prev_done = rs.integers(0, 7, B).astype(np.uint8) if carry else None
+            rst = m.env_reset_pool(tr, int(rs.integers(1 << 40)), int(rs.integers(1 << 20)), int(rs.integers(2)), ego, got[4], ref, virtual, v_light,
+                                   cand, cmode, obs0, pool, mask=rmask, obs_src=prev_obs, done_src=prev_done)
+            outs.append(got + [masked] + rst)
+        names = ['scaled', 'out5', 'd16', 'ego', 'params', 'cand', 'obs', 'done', 'masked obs', 'reset ego', 'reset params', 'reset ref', 'reset virtual',
+                 'reset v_light', 'reset done', 'reset cand', 'reset obs']
         for k, (h, d) in enumerate(zip(*outs)):
             if names[k] == 'out5':
                 assert np.array_equal(h[0], d[0]) and np.allclose(h[1:], d[1:], rtol=1e-6, atol=0), names[k]
