@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Profiling aid (GPU box only, on the scratch copy gpurun makes): where the one-launch env step spends its time.  Each variant
+patches ONE stage out of csrc/eb_env_step.hip in place (results are wrong, timings are what is wanted), rebuilds the library and
+runs `bench.py --env-step`; the source is restored at the end.  Usage: python scripts/ablate_env_step.py [variant ...]"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'env_build_amd', 'csrc', 'eb_env_step.hip')
+VARIANTS = {
+    'base': [],
+    'no_predict': [("            } else if (OBS) s_cand[e * RS4 + c] = v;", "            } else if (OBS || true) s_cand[e * RS4 + c] = v;")],
+    'no_reward_pairs': [("            for (int base = 0; base < n_pairs; base += 192 * 4) {", "            for (int base = 0; base < 0; base += 192 * 4) {")],
+    'no_collision': [("            for (int base = 0; base < n_rec; base += 192 * 3) {", "            for (int base = 0; base < 0; base += 192 * 3) {")],
+    'no_slots': [("        unsigned long long firsts = A.first_mask;", "        unsigned long long firsts = 0ull;")],
+    'no_tracking': [("            if (p < 0) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }", "            if (true) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }")],
+    'no_cand_store': [("        for (int base = lane; !OBS && base < n_rec; base += 256) {", "        for (int base = lane; !OBS && base < 0; base += 256) {")],
+    'no_row_store': [("        for (int base = tid; base < total; base += 1024) {", "        for (int base = tid; base < 0; base += 1024) {")],
+    'no_ego_roles': [("    } else if (wave < 2 && live) {", "    } else if (false) {")],
+    'no_reward_sums': [("    if (!OBS && wave == 1 && live) {\n        // E2E:134", "    if (false) {\n        // E2E:134")],
+}
+orig = open(SRC).read()
+names = sys.argv[1:] or list(VARIANTS)
+out = {}
+try:
+    for n in names:
+        s = orig
+        for a, b in VARIANTS[n]:
+            assert s.count(a) == 1, (n, a)
+            s = s.replace(a, b)
+        open(SRC, 'w').write(s)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--env-step'], capture_output=True, text=True)
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+        out[n] = {l['n_env_per_gpu']: l['avg_launch_us'] for l in lines}
+        print('%-16s %s' % (n, '  '.join('%6d envs: %6.2f us' % kv for kv in sorted(out[n].items()))) if lines else '%s FAILED: %s' % (n, r.stderr[-400:]), flush=True)
+finally:
+    open(SRC, 'w').write(orig)
+if 'base' in out:
+    for n, v in out.items():
+        if n != 'base' and v:
+            print('%-16s saves %s' % (n, '  '.join('%6d: %5.2f us' % (k, out['base'][k] - v[k]) for k in sorted(v))))
