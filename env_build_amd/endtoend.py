@@ -106,9 +106,14 @@ class _RewardInfo(dict):
     """info['reward_info'] of a batch (E2E:142-143): the 16 reward terms are rows of one [16, B] device array; a row is
     wrapped as a DevArray when it is first read, so a driver that never looks pays nothing per step."""
 
+    _ROWS = {}                               # keys tuple -> {key: row}; built once, shared by every step's dict
+
     def __init__(self, keys, d16, final_rew):
         dict.__init__(self)
-        self._rows = {k: i for i, k in enumerate(keys)}
+        rows = self._ROWS.get(keys)
+        if rows is None:
+            rows = self._ROWS[keys] = {k: i for i, k in enumerate(keys)}
+        self._rows = rows
         self._d16 = d16
         dict.__setitem__(self, 'final_rew', final_rew)
 
