@@ -890,6 +890,8 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
     if (!h || !traffic || !pool || !pool->entry) return fail(EB_EINVAL, "eb_env_reset_pool: null argument");
     if (n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!ego || !params || !ref_idx || !virtual_flag || !cand || !cand_mode || !obs)))
         return fail(EB_EINVAL, "eb_env_reset_pool: bad argument");
+    if (mask && (mask == done_code || mask == virtual_flag || mask == v_light))
+        return fail(EB_EINVAL, "eb_env_reset_pool: mask must not be one of the arrays the call writes (pass the done codes as mask and done_src, a fresh array as done_code)");
     if (traffic->cfg.n_veh != m_cand) return fail(EB_EINVAL, "eb_env_reset_pool: the traffic handle must have n_veh == m_cand");
     if (traffic->cfg.device != h->cfg.device) return fail(EB_EINVAL, "eb_env_reset_pool: the two handles live on different devices");
     int rc = check_paths(h, "eb_env_reset_pool: null handle");

@@ -389,6 +389,7 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
  * obs_src / done_src (nullable): where the observation / done-code rows of the envs OUTSIDE the mask come from — a driver that
  * must leave the arrays of the last step as they were passes them here and fresh arrays as obs / done_code, and gets the whole
  * batch's current rows without a copy of its own.  NULL (or the same array): those rows of obs / done_code are left alone.
+ * mask may be the previous done-code array itself (non-zero = reset) but must not be an array this call writes (EB_EINVAL).
  * The HIP library runs all of it as ONE launch (csrc/eb_env_step.hip, env_reset_pool_kernel) under the conditions of eb_env_step. */
 int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
                       int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,

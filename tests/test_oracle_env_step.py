@@ -28,3 +28,25 @@ def test_oracle_reset_pool_composite(oracle, task):
 @pytest.mark.timeout(60)
 def test_angle_wrap_loops_are_bounded(oracle):
     wrap_guard_case(HostModel(oracle, 'left'))
+
+
+def test_reset_pool_refuses_a_mask_that_is_an_output(oracle):
+    """include/envbuild.h: the mask may be the previous done codes, but not the array the new ones are written to"""
+    import ctypes as C
+    import numpy as np
+    from env_build_amd import _capi
+    B, M = 8, 4
+    m = HostModel(oracle, 'left', mode='training')
+    tr = HostModel(oracle, 'left', n_veh=M, modes=['dl', 'du', 'ud', 'ul'])
+    f32 = lambda *s: np.zeros(s, np.float32)
+    ego, params, ref, virt, vl, done = f32(B, 6), f32(B, 4), np.zeros(B, np.int32), np.zeros(B, np.uint8), np.zeros(B, np.uint8), np.ones(B, np.uint8)
+    cand, cmode, obs, entry = f32(B, M, 4), np.zeros((B, M), np.uint8), f32(B, m.D), f32(M, 5)
+    rule = _capi.EbRespawn(entry.ctypes.data, 0.0, 60.0, 8.0, 1, 1, 5.0)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    args = lambda mask, dc: (m.h, tr.h, B, p(mask), C.c_uint64(1), C.c_uint64(1), 1, p(ego), p(params), p(ref), p(virt), p(vl), p(dc), M, p(cand),
+                             p(cmode), C.byref(rule), p(obs), None, None, None)
+    with pytest.raises(ValueError, match='mask must not be'):          # EB_EINVAL surfaces as ValueError (_capi.check)
+        oracle.env_reset_pool(*args(done, done))
+    fresh = np.full(B, 7, np.uint8)
+    oracle.env_reset_pool(*args(done, fresh))                # the done codes as the mask, a fresh array for the new ones
+    assert (fresh == 0).all()
