@@ -9,7 +9,7 @@
 // dependent LDS reads and divergent branches):
 //
 //   phase 1   wave 0, lane = env: ego state + raw action -> action scaling (E2E:133), ego step (E2E:135: f_xu core, floor,
-//             wrap) -> new pose to LDS and to HBM.   wave 1, lane = env: old observation head -> ego circle centres
+//             wrap) -> new pose to LDS (to HBM after the barrier: wave 1 reads the old row).   wave 1, lane = env: old observation head -> ego circle centres
 //             (DAM:210-214) to LDS; tyre parameters (DAM:65-71, two atan) -> HBM; reward scalars and road walls (E2E:134).
 //             Whoever is free: the traffic step (TRF:220-238's role) — 16-byte candidate records in coalesced chunks,
 //             predict_for_a_mode, staged in LDS with their mode byte.                                       barrier
@@ -243,8 +243,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;                              // E2E:281
             nx[5] = wrap_deal_with_phi(nx[5]);                                 // E2E:282
             s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
-            float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
-            ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
+            // (the new state goes to HBM after barrier 1: wave 1 computes the tyre parameters from the OLD row of the same array,
+            // and nothing orders its load before a store issued here — seen once in a while as a `params` row of the new state)
             if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
         } else {
             float es, ec;
@@ -320,6 +320,10 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             // E2E:329-338 ego vector, E2E:293-297 tracking error on the env's path
             float* orow = s_out + lane * OS;
             const float ex = nx[3], ey = nx[4];
+            if (!OBS) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1)
+                float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
+                ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
+            }
 #pragma unroll
             for (int c = 0; c < 6; ++c) orow[c] = nx[c];
             const PathTables& pt = A.pt;
