@@ -244,8 +244,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             nx[5] = wrap_deal_with_phi(nx[5]);                                 // E2E:282
             s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
             // (the new state goes to HBM after barrier 1: wave 1 computes the tyre parameters from the OLD row of the same array,
-            // and nothing orders its load before a store issued here — seen once in a while as a `params` row of the new state)
-            if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
+            // and nothing orders its load before a store issued here — seen once in a while as a `params` row of the new state;
+            // the scaled action waits there too, so that a caller may scale its action array in place)
         } else {
             float es, ec;
             sincos_det(deg2rad(o9[5]), es, ec);                                // DAM:211
@@ -323,6 +323,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             if (!OBS) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1)
                 float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
                 ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
+                if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
             }
 #pragma unroll
             for (int c = 0; c < 6; ++c) orow[c] = nx[c];

@@ -341,7 +341,8 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
  * (its slot modes = their modes) and the candidates move by the model's own prediction step (eb_veh_predict).
  * In-place state: ego [n_env,6], cand [n_env, m_cand, 4]; params [n_env,4] is written.  obs [n_env,D] is the
  * current observation (input), obs_out the next one; they must differ.  cand_lw (nullable) as in eb_judge_done,
- * v_light / virtual_flag (nullable) as in eb_get_obs.  scaled_actions and out_dict16 are nullable.
+ * v_light / virtual_flag (nullable) as in eb_get_obs.  scaled_actions and out_dict16 are nullable; scaled_actions may be the
+ * actions array itself (scaling in place).
  * respawn (nullable): the traffic pool's re-entry rule applied AFTER the observation and the done code were taken (the
  * observation sees the pool as this step left it, the way the reference sees SUMO's state of the step) =
  * eb_traffic_respawn(traffic, n_env, m_cand, cand, entry, limit, span, v_max, seed, counter, NULL, NULL) as a seventh call.

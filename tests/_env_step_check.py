@@ -85,6 +85,10 @@ def composite_case(make, task, B, M, NV, nf, tile=None):
     for k, (g, w) in enumerate(zip(got7, [None, o5, None, ego1, par1, cand2, obs1, done1])):
         if w is not None:
             assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w), k
+    # the scaled actions may overwrite the raw ones (the kernel stores them after every wave has read the raw pair)
+    inpl = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, cand_lw=lw, v_light=v_light, virtual=virtual, scale_in_place=True)
+    for k, (g, w) in enumerate(zip(inpl, want)):
+        assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w), ('in place', k)
     return got
 
 

@@ -334,8 +334,9 @@ class HostModel(object):
         return self._ret(out)
 
     def env_step(self, traffic, obs, raw, ego, cand, cand_mode, ref_idx=None, path_id=0, cand_lw=None, v_light=None,
-                 virtual=None, respawn=None, want_scaled=True, want_dict=True):
+                 virtual=None, respawn=None, want_scaled=True, want_dict=True, scale_in_place=False):
         """eb_env_step on copies of the state -> (scaled, out5, d16, ego, params, cand, obs_out, done_code).
+        scale_in_place: the scaled actions overwrite the (copy of the) raw action array.
         respawn: dict(entry [M, 5], limit, span, v_max, seed, counter) — the pool's re-entry as the step's last stage."""
         B, M = len(ego), cand.shape[1]
         e_io, c_io = self._in(np.array(ego, np.float32)), self._in(np.array(cand, np.float32))
@@ -343,7 +344,7 @@ class HostModel(object):
         cm, lw = self._in(cand_mode, np.uint8), self._in(cand_lw)
         vl, vf = self._in(v_light, np.uint8), self._in(virtual, np.uint8)
         par, out5 = self._out((B, 4)), self._out((5, B))
-        sc = self._out((B, 2)) if want_scaled else None
+        sc = rw if scale_in_place else (self._out((B, 2)) if want_scaled else None)
         dd = self._out((16, B)) if want_dict else None
         obs_o, code = self._out(np.asarray(obs).shape), self._out((B,), np.uint8)
         rs, entry = None, None
