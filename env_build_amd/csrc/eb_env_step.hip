@@ -320,11 +320,6 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             // E2E:329-338 ego vector, E2E:293-297 tracking error on the env's path
             float* orow = s_out + lane * OS;
             const float ex = nx[3], ey = nx[4];
-            if (!OBS) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1)
-                float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
-                ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
-                if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
-            }
 #pragma unroll
             for (int c = 0; c < 6; ++c) orow[c] = nx[c];
             const PathTables& pt = A.pt;
@@ -367,6 +362,12 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     orow[11 + 3 * k] = deal_with_phi_diff(nx[5] - pt.phi[p][fi]);
                 }
             }
+        }
+        if (!OBS && live) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1), and
+            // behind the tracking's dependent table reads rather than in front of them
+            float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
+            ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
+            if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
         }
         // candidates out (they are final since the barrier), the pool's re-entry rule on the way (eb_traffic_respawn: it
         // applies after the observation and the done code saw this step's state — both read the LDS copy); this wave
