@@ -1,0 +1,17 @@
+#!/bin/bash
+# Copy the summaries of one scripts/r3_measure.sh pass from gpurun_out/<tag>/ (scratch) into profiles/ (tracked) as <tag>_*.
+# Usage: bash scripts/install_profiles.sh <tag>
+set -e
+T=$1; G=gpurun_out/$T
+cp $G/bench.json profiles/${T}_bench.json
+cp $G/env_step.json profiles/${T}_bench_env_step.json
+cp $G/bench_shield.json profiles/${T}_bench_shield.json
+cp $G/prof_bench.json profiles/${T}_bench_under_rocprof.json
+cp $G/prof/p_kernel_stats.csv profiles/${T}_kernel_stats.csv
+cp $G/prof_env/p_kernel_stats.csv profiles/${T}_env_step_kernel_stats.csv
+cp $G/prof_flows/p_kernel_stats.csv profiles/${T}_flows_kernel_stats.csv
+(grep n_env $G/facade_pool.txt; grep n_env $G/facade_flows.txt) > profiles/${T}_facade_env_step_timing.txt
+grep n_env $G/reset_pool.txt > profiles/${T}_reset_pool_timing.txt
+cp gpurun_out/${T}_pmc/pmc_traffic.json profiles/r3_pmc_traffic.json
+python scripts/pmc_traffic.py gpurun_out/${T}_pmc > profiles/${T}_pmc_traffic.txt
+ls profiles | grep "^${T}_"
