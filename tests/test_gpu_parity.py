@@ -739,3 +739,21 @@ def test_batched_safety_shield_matches_per_row_reference_logic():
     act, started = safe_shield(model, policy, obs0, path_index=1)
     assert np.array_equal(started.numpy(), ~safe.numpy())
     assert np.array_equal(act.numpy()[started.numpy()], np.tile(np.float32([0., -1.]), (int(started.numpy().sum()), 1)))
+
+
+def test_env_step_and_masked_reset_at_the_bench_size_equal_the_oracle():
+    """65 536 envs x 16 candidates — the size `bench.py`'s env_step entry times (1 024 blocks of 64-env tiles, all resident at
+    once): every row of the one-launch step and of the one-launch masked reset against the oracle's composites."""
+    from tests._env_step_check import composite_case, reset_pool_case
+    task, B, M = 'left', 65536, 16
+    on_cpu, on_gpu = (lambda t, **kw: HostModel(oracle_lib(), t, **kw)), (lambda t, **kw: DeviceModel(t, **kw))
+    for a, b in zip(composite_case(on_cpu, task, B, M, None, 0), composite_case(on_gpu, task, B, M, None, 0)):
+        if a.dtype == np.float32 and a.shape == (5, B):
+            _check_out5(b, a, 'composite 65536')
+        elif a.shape == (16, B):
+            np.testing.assert_allclose(b, a, rtol=PEN_RTOL, atol=0)
+        else:
+            assert np.array_equal(a, b)
+    for a, b in zip(reset_pool_case(on_cpu, task, B=B, M=M, seed=77), reset_pool_case(on_gpu, task, B=B, M=M, seed=77)):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), k
