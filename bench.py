@@ -26,7 +26,8 @@ a short untimed trial picks the faster form and `config.workload` names the one 
                 (two 36 MB obs buffers + outputs) fits the 256 MiB Infinity Cache, so
   roofline.hbm_resident   repeats the measurement where it cannot: (a) the same kernel and batch size cycling over 8
                 independent env sets (lane l steps, then lane l+1, ...: 518 MB of other traffic between a line's write
-                and its re-read, 0.9 GB footprint), (b) one batch of 524 288 envs (290 MB per obs buffer);
+                and its re-read, 0.9 GB footprint), (b) one batch of 524 288 envs (290 MB per obs buffer), (c) the env sets
+                of (a) dealt to four HIP streams, so that launches of different sets overlap (wall-clock timed);
   strong        BASELINE configs[3]: 262 144 envs in total, split 262 144 / N per rank (strong scaling; at N = 1 the
                 one-GPU reference point of that curve);
   extra         configs[1] (4 096 x 16, fp32; + `one_launch_forms`: the same 25 steps as ONE gated launch with open gates /
@@ -134,7 +135,7 @@ class Shard(object):
     `lanes` > 1: that many independent env sets of n_env rows each (same inputs, distinct buffers), stepped round-robin —
     lane 0 step t, lane 1 step t, ... — so that every launch streams from and to memory no other recent launch touched."""
 
-    def __init__(self, torch, model, n_env, n_veh, seed, f16=False, lanes=1, keep_host=False):
+    def __init__(self, torch, model, n_env, n_veh, seed, f16=False, lanes=1, keep_host=False, streams=1):
         from env_build_amd.synthetic import make_rollout_inputs
         self.torch, self.model, self.n_env, self.n_veh, self.f16, self.lanes = torch, model, n_env, n_veh, f16, lanes
         dev = model.device
@@ -156,6 +157,12 @@ class Shard(object):
         self.out5 = [torch.empty((HORIZON, 5, n_env), dtype=torch.float32, device=dev) for _ in range(lanes)]
         self.api, self.h, self.lib = model.api, model.handle, model.api.lib
         self.sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # streams > 1: the lanes (independent env sets) are dealt to that many HIP streams — lane l's steps stay ordered on its
+        # own stream, launches of different lanes may overlap (one set's write-back under the next set's reads)
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(max(0, min(streams, lanes) - 1))]
+        self.sps = [self.sp] + [C.c_void_p(st.cuda_stream) for st in self._streams]
+        if self._streams:
+            torch.cuda.synchronize()          # the buffers above were filled on the current stream
         self.step_fn = self.lib.eb_rollout_step_f16 if f16 else self.lib.eb_rollout_step
         self._eager, self._plans = {}, {}
 
@@ -172,7 +179,7 @@ class Shard(object):
                 dst = [self.final[l] if (h - 1 - t) % 2 == 0 else self.work[l] for t in range(h)]
                 src = [self.obs0[l]] + dst[:-1]
                 per_lane.append([(self.h, self.n_env, p(src[t]), p(self.tape[t]), p(self.ref_idx), 0, p(dst[t]),
-                                  p(self.out5[l][t]), None, self.sp) for t in range(h)])
+                                  p(self.out5[l][t]), None, self.sps[l % len(self.sps)]) for t in range(h)])
             self._eager[h] = [per_lane[l][t] for t in range(h) for l in range(self.lanes)]   # round-robin over the lanes
         return self._eager[h]
 
@@ -335,9 +342,9 @@ def roofline_of(alg_bytes, launch_us):
 
 
 def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, f16=False, lanes=1, use_dist=False,
-                forms=('graph', 'eager')):
+                forms=('graph', 'eager'), streams=1):
     """One more workload through the same protocol (no summary kernels): -> compact result dict."""
-    shard = Shard(torch, model, n_env, n_veh, seed, f16=f16, lanes=lanes)
+    shard = Shard(torch, model, n_env, n_veh, seed, f16=f16, lanes=lanes, streams=streams)
     tm = Timer(torch, dist, use_dist, shard, with_summary=False)
     tm.run(min(warmup, HORIZON), False)
     torch.cuda.synchronize()
@@ -349,6 +356,8 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
     world = dist.get_world_size() if use_dist else 1
     dt = median(r['dt'])
     alg = alg_bytes_per_env_step(n_veh, f16) * n_env
+    if len(shard.sps) > 1:      # event pairs sit on one stream only: the per-launch time of a multi-stream run is wall clock / launches
+        r['launch_us'] = dt * 1e6 / (steps * lanes)
     achieved, frac = roofline_of(alg, r['launch_us'])
     out = {'n_env_per_gpu': n_env, 'n_veh': n_veh, 'dtype': 'f16 state / f32 arithmetic' if f16 else 'f32', 'lanes': lanes,
            'value': n_env * lanes * world * steps / dt, 'unit': 'env-steps/s',
@@ -356,6 +365,8 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
            'launch_form': 'eager' if (tm.eager or shard.plan(HORIZON) is None) else 'hipGraph',
            'alg_bytes_per_launch': alg, 'avg_launch_us': r['launch_us'], 'launches_timed': r['launches_timed'],
            'achieved_GBs': achieved, 'frac': frac, 'footprint_MB': shard.footprint_bytes() / 1e6}
+    if len(shard.sps) > 1:
+        out.update(streams=len(shard.sps), timing='wall clock of the timed region / launches (the lanes run on %d HIP streams)' % len(shard.sps))
     if f16 and (n_env, n_veh, lanes) == (N_ENV, 64, 1):      # configs[4]: HBM bytes from the PMC passes of scripts/pmc_traffic.sh
         tpath = os.path.join(ROOT, 'profiles', 'r3_pmc_traffic.json')
         if os.path.isfile(tpath):
@@ -750,7 +761,11 @@ def main():
                                              'between a line\'s write and its re-read, footprint %.0f MB; (b) one batch of 524 288 envs '
                                              '— 290 MB per obs buffer, footprint %.0f MB; Infinity Cache = 268 MB'
                                              % (a['footprint_MB'], b['footprint_MB']),
-                   'lanes8_x_65536': a, 'single_524288': b}
+                   'lanes8_x_65536': a, 'single_524288': b,
+                   # the same 8 independent env sets dealt to four HIP streams: a set's launch may start while another set's
+                   # blocks drain (what one generation of co-resident blocks cannot do for itself; wall-clock timed)
+                   'lanes8_x_65536_four_streams': side_config(torch, dist, m32, N_ENV, N_VEH, 0, 100, HORIZON, min(args.repeats, 5),
+                                                              lanes=lanes, forms=('eager',), streams=4)}
             m16 = model_for(torch, EnvironmentModel, dev, 16)
             extra.append(dict(side_config(torch, dist, m16, 4096, 16, 11, side_steps, side_warm, side_rep),
                               workload='configs[1]: N_env=4096, N_veh=16, horizon=25, fp32 (value: one launch per step)',
