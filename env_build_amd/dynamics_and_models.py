@@ -422,7 +422,7 @@ class EnvironmentModel(object):  # DAM:90-427
         scaled = torch.empty((B, 2), dtype=torch.float32, device=self.device)
         rc = self._step_fn(self.handle, B, obs.data_ptr(), act.data_ptr(), ri.data_ptr() if ri is not None else None, pid,
                            obs_out.data_ptr(), out5.data_ptr(), scaled.data_ptr(),
-                           torch.cuda.current_stream(self.device).cuda_stream)
+                           _stream(self.device))
         if rc != 0:
             self.api.check(rc)
         self.actions = DevArray(scaled)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .dynamics_and_models import DevArray, _default_device, _dev
+from .dynamics_and_models import DevArray, _default_device, _dev, _stream
 
 __all__ = ['MLPNet', 'Policy4Toyota', 'LoadPolicy', 'orthogonal']
 
@@ -101,7 +101,7 @@ class MLPNet(object):
         return t
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _stream(self.device)
 
     def call(self, x, **kwargs):                       # utils/model.py:39-43
         t = self._in(x)

@@ -14,7 +14,7 @@ import ctypes as C
 import torch
 
 from . import _capi
-from .dynamics_and_models import DevArray, _unwrap
+from .dynamics_and_models import DevArray, _stream, _unwrap
 
 PENALTIES = {'veh2veh4real': 4, 'real_punish_term': 3}       # index into rollout_out's 6-tuple (DAM:126)
 SAFE_ACTION = (0., -1.)                                        # action_safe_set, hier_decision.py:100
@@ -64,7 +64,7 @@ def _is_safe_native(model, native, steps, penalty):
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     model.api.shield_is_safe(model.handle, net._handle, B, p(obs), p(ri), pid, steps, _capi.PENALTY_ID[penalty],
                              C.c_float(-1.0 if action_range is None else float(action_range)), p(obs_a), p(obs_b),
-                             p(actions), p(out5), p(punish), p(safe), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                             p(actions), p(out5), p(punish), p(safe), _stream(dev))
     model.obses = DevArray(obs_a if steps % 2 == 1 else obs_b)      # where the last step landed, as the loop leaves it
     model._after_tracking()
     return DevArray(safe.bool()), DevArray(punish)
