@@ -478,7 +478,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     for t in range(seg):
         src, dst = obs[t & 1], obs[(t + 1) & 1]
         argsets.append((h, ht, B, p(src), p(tape[t]), p(env._ref_idx), 0, p(ego), p(params), M, p(cand), p(env._cand_mode), None,
-                        p(env._v_light), p(env._virtual), p(scaled), p(out5), None, p(dst), p(code), C.byref(rule), sp))
+                        p(env._v_light), p(env._virtual), p(scaled), p(out5), None, p(dst), p(code), C.byref(rule), None, sp))
     ev = []
     for _ in range(2 * reps):
         e = C.c_void_p()

@@ -8,7 +8,7 @@ with the same class to compare the two libraries call-for-call.)
 import ctypes as C
 import os
 
-EB_ABI_VERSION = 3
+EB_ABI_VERSION = 4
 TASK_ID = {'left': 0, 'straight': 1, 'right': 2}
 MODE_TRAINING, MODE_SELECTING = 0, 1
 # vehicle mode ids (EB_VMODE_*), in the order of the twelve lists of E2E:354
@@ -35,6 +35,11 @@ class EbMlpConfig(C.Structure):
 class EbRespawn(C.Structure):     # struct eb_respawn: the pool's re-entry rule as the last stage of eb_env_step
     _fields_ = [('entry', C.c_void_p), ('limit', C.c_float), ('span', C.c_float), ('v_max', C.c_float),
                 ('seed', C.c_uint64), ('counter', C.c_uint64), ('edge_span', C.c_float)]
+
+
+class EbAutoReset(C.Structure):   # struct eb_auto_reset (ABI 4): eb_env_step resets the envs it has just finished, same call
+    _fields_ = [('seed', C.c_uint64), ('counter', C.c_uint64), ('training', C.c_int32), ('ref_idx', C.c_void_p),
+                ('virtual_flag', C.c_void_p), ('v_light', C.c_void_p), ('pool', EbRespawn), ('final_obs', C.c_void_p)]
 
 
 ACT_ID = {'linear': 0, None: 0, 'relu': 1, 'elu': 2, 'tanh': 3}        # EB_ACT_*
@@ -83,7 +88,7 @@ PROTOTYPES = {
     'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_exit_frame': (C.c_int, [_P, _I, _P, _I, _P, _P, _P]),
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
-    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P]),
     'eb_env_reset_pool': (C.c_int, [_P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, _P, C.c_float, _P]),

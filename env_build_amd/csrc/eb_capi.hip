@@ -56,10 +56,6 @@ struct eb_handle_s {
     eb::ExitConsts xc;        // cos / sin of the exit angles (eb_get_obs with exit ids, eb_exit_frame)
     hipStream_t gate_stream;  // producer stream of gated rollouts (high priority: a hardware queue of its own), made on first use
     hipEvent_t gate_event;    // orders eb_gate_feed behind the caller's stream (after_stream)
-    float* d_scratch;         // eb_env_step's scaled actions when the caller passes none (separate-launch path only)
-    uint8_t* d_vnext;         // eb_env_reset_pool: the flags eb_env_reset drew, until they are swapped in
-    size_t vnext_bytes;
-    size_t scratch_floats;
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
     int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
 };
@@ -188,8 +184,6 @@ int eb_destroy(eb_handle h) {
     if (h->d_pt) (void)hipFree(h->d_pt);
     if (h->gate_stream) (void)hipStreamDestroy(h->gate_stream);
     if (h->gate_event) (void)hipEventDestroy(h->gate_event);
-    if (h->d_scratch) (void)hipFree(h->d_scratch);
-    if (h->d_vnext) (void)hipFree(h->d_vnext);
     delete h;
     return EB_OK;
 }
@@ -792,7 +786,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, void* stream) {
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, void* stream) {
     // every check first: an error return leaves ego / params / cand untouched
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
     if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
@@ -807,11 +801,18 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!rc) rc = check_modes(traffic);
     if (rc) return rc;
     if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
+    if (const eb_auto_reset* ar = auto_reset) {
+        if (!ar->pool.entry || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
+            ar->virtual_flag != virtual_flag || ar->v_light != v_light)
+            return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
+        if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))
+            return fail(EB_EINVAL, "eb_env_step: final_obs must be an array of its own");
+    }
     if (n_env == 0) return EB_OK;
     hipStream_t s = pick(h, stream);
     EB_HIP(hipSetDevice(h->cfg.device));
     const int D = obs_dim(h->cfg);
-    if (eb::env_step_is_fused(D, h->cfg.n_veh, m_cand, cand)) {
+    if (eb::env_step_is_fused(D, h->cfg.n_veh, m_cand, cand, ego, actions, scaled_actions, params)) {
         // the whole step — the six calls and the pool's re-entry — as ONE launch (csrc/eb_env_step.hip)
         eb::EnvStepArgs A;
         std::memset(&A, 0, sizeof A);
@@ -834,20 +835,27 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             A.respawn_entry = respawn->entry; A.limit = respawn->limit; A.span = respawn->span; A.v_max = respawn->v_max;
             A.seed = respawn->seed; A.counter = respawn->counter;
         }
+        if (const eb_auto_reset* ar = auto_reset) {   // the rows this step finishes are reset by their own block, same launch
+            A.auto_reset = 1; A.training = ar->training ? 1 : 0; A.reset_seed = ar->seed; A.reset_counter = ar->counter;
+            A.ref_idx_out = ar->ref_idx; A.virtual_out = ar->virtual_flag; A.v_light_out = ar->v_light; A.final_obs = ar->final_obs;
+            A.pool_entry = ar->pool.entry; A.pool_span = ar->pool.span; A.pool_v_max = ar->pool.v_max; A.edge_span = ar->pool.edge_span;
+            A.pool_seed = ar->pool.seed; A.pool_counter = ar->pool.counter;
+        }
         EB_HIP(eb::launch_env_step(h->cfg.task, A, s));
         return EB_OK;
     }
     // separate launches (no candidates, a tile that does not fit the LDS, an unaligned candidate buffer)
+    // (scratch per call, allocated and released in stream order: two streams may drive one handle through this path)
     float* scaled = scaled_actions;
+    float* own_scaled = nullptr;
     if (!scaled) {
-        if (h->scratch_floats < (size_t)n_env * 2) {
-            if (h->d_scratch) (void)hipFree(h->d_scratch);
-            h->d_scratch = nullptr; h->scratch_floats = 0;
-            EB_HIP(hipMalloc(&h->d_scratch, (size_t)n_env * 2 * sizeof(float)));
-            h->scratch_floats = (size_t)n_env * 2;
-        }
-        scaled = h->d_scratch;
+        EB_HIP(hipMallocAsync(reinterpret_cast<void**>(&own_scaled), (size_t)n_env * 2 * sizeof(float), s));
+        scaled = own_scaled;
     }
+    struct Release {   // on every return path below, after the launches that read it
+        float* p; hipStream_t s;
+        ~Release() { if (p) (void)hipFreeAsync(p, s); }
+    } release{own_scaled, s};
     // E2E:133-135 in one launch: action scaling, reward on the current obs, ego step in place (the same device
     // functions eb_action_transform / eb_compute_rewards / eb_env_ego_step run)
     EB_HIP(eb::launch_env_pre(h->cfg.task, n_env, D, h->cfg.n_future, h->cfg.n_veh, obs, actions,
@@ -868,6 +876,11 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (respawn)
         EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
                                           respawn->seed, respawn->counter, nullptr, nullptr, s));
+    if (const eb_auto_reset* ar = auto_reset) {   // the same composition the header spells out, as launches of their own
+        if (ar->final_obs) EB_HIP(eb::launch_copy_rows_masked(n_env, D, done_code, obs_out, ar->final_obs, s));
+        return eb_env_reset_pool(h, traffic, n_env, done_code, ar->seed, ar->counter, ar->training, ego, params, ar->ref_idx,
+                                 ar->virtual_flag, ar->v_light, nullptr, m_cand, cand, cand_mode, &ar->pool, obs_out, nullptr, nullptr, stream);
+    }
     return EB_OK;
 }
 
@@ -899,7 +912,7 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
     if (rc) return rc;
     if (n_env == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
-    if (eb::env_step_is_fused(obs_dim(h->cfg), h->cfg.n_veh, m_cand, cand)) {
+    if (eb::env_step_is_fused(obs_dim(h->cfg), h->cfg.n_veh, m_cand, cand, ego, nullptr, nullptr, params)) {
         // ONE launch (csrc/eb_env_step.hip, env_reset_pool_kernel): a tile's masked rows are drawn, their pool re-entered clear of
         // the new ego, their observation built from the state still in LDS, their flag swapped — the same arithmetic, in the
         // same order per row, as the four launches below
@@ -911,26 +924,26 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
                                   nullptr, mask, &R, forced_env_tile(h)));
         return EB_OK;
     }
-    if (h->vnext_bytes < (size_t)n_env) {
-        if (h->d_vnext) (void)hipFree(h->d_vnext);
-        h->d_vnext = nullptr; h->vnext_bytes = 0;
-        EB_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_vnext), (size_t)n_env));
-        h->vnext_bytes = (size_t)n_env;
-    }
     hipStream_t s = pick(h, stream);
+    uint8_t* d_vnext = nullptr;   // the flags eb_env_reset draws, until they are swapped in: per call, in stream order
+    EB_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_vnext), (size_t)n_env, s));
+    struct Release {
+        uint8_t* p; hipStream_t s;
+        ~Release() { (void)hipFreeAsync(p, s); }
+    } release{d_vnext, s};
     if (mask && obs_src && obs_src != obs)       // the rows outside the mask: carried over from the caller's previous arrays
         EB_HIP(hipMemcpyAsync(obs, obs_src, (size_t)n_env * obs_dim(h->cfg) * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (mask && done_src && done_code && done_src != done_code)
         EB_HIP(hipMemcpyAsync(done_code, done_src, (size_t)n_env, hipMemcpyDeviceToDevice, s));
     // (an unaligned candidate buffer or a tile that does not fit the LDS) four launches behind one call: state + flags, pool
     // re-entry (clear of the ego), masked observation, flag swap
-    EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx, h->d_vnext,
+    EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx, d_vnext,
                                 done_code, s, v_light));
     EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, pool->entry, -1.0f, pool->span, pool->v_max, pool->seed, pool->counter, mask,
                                       nullptr, s, ego, pool->edge_span));
     EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ref_idx, 0,
                               m_cand, cand, cand_mode, v_light, virtual_flag, obs, s, nullptr, nullptr, nullptr, nullptr, nullptr, mask));
-    EB_HIP(eb::launch_flag_swap(n_env, mask, h->d_vnext, virtual_flag, s));
+    EB_HIP(eb::launch_flag_swap(n_env, mask, d_vnext, virtual_flag, s));
     return EB_OK;
 }
 

@@ -533,6 +533,19 @@ hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const E
     return hipGetLastError();
 }
 
+// dst[e, :] = src[e, :] for the rows with mask[e] != 0 (eb_env_step(auto_reset) on the separate-launch path: the terminal
+// observations of the finished envs -> final_obs)
+__global__ void copy_rows_masked_kernel(int n_env, int D, const uint8_t* mask, const float* src, float* dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_env * D) return;
+    if (mask[idx / D]) dst[idx] = src[idx];
+}
+hipError_t launch_copy_rows_masked(int n_env, int D, const uint8_t* mask, const float* src, float* dst, hipStream_t s) {
+    const size_t total = (size_t)n_env * D;
+    hipLaunchKernelGGL(copy_rows_masked_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n_env, D, mask, src, dst);
+    return hipGetLastError();
+}
+
 // done_code != NULL appends _judge_done (needs the staged form: check get_obs_is_staged first)
 hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, const PathTables& pt,
                           const VehModes& modes, const float* ego, const int* ref_idx, int path_id, int m_cand,
@@ -540,7 +553,7 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
                           float* obs_out, hipStream_t s, const float* params, const float* cand_lw,
                           uint8_t* done_code, const uint8_t* exit_id, const ExitConsts* xc, const uint8_t* row_mask,
                           const EnvResetArgs* reset, int tile_envs) {
-    if (reset && (exit_id || done_code || !env_step_is_fused(D, NV, m_cand, cand))) return hipErrorInvalidValue;
+    if (reset && (exit_id || done_code || !env_step_is_fused(D, NV, m_cand, cand, ego, nullptr, nullptr, reset->params))) return hipErrorInvalidValue;
     if (exit_id) {
         if (done_code || !xc) return hipErrorInvalidValue;
         const dim3 g((n_env + 63) / 64), b(64);
@@ -551,7 +564,7 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
         }
         return hipGetLastError();
     }
-    if (!done_code && env_step_is_fused(D, NV, m_cand, cand)) {
+    if (!done_code && env_step_is_fused(D, NV, m_cand, cand, ego, nullptr, nullptr, reset ? reset->params : nullptr)) {
         // the observation alone through the one-launch step's machinery (eb_env_step.hip, OBS variant): pair-parallel
         // staging and the bit-set slot selection instead of one lane per env walking its candidates
         EnvStepArgs A;
@@ -572,8 +585,8 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
             A.reset = 1; A.training = reset->training; A.reset_seed = reset->seed; A.reset_counter = reset->counter;
             A.params = reset->params; A.ref_idx_out = reset->ref_idx; A.virtual_flag = reset->virtual_flag; A.virtual_out = reset->virtual_flag;
             A.v_light = nullptr; A.v_light_out = reset->v_light; A.done_code = reset->done_code;
-            A.respawn_entry = reset->entry; A.span = reset->span; A.v_max = reset->v_max; A.edge_span = reset->edge_span;
-            A.seed = reset->pool_seed; A.counter = reset->pool_counter; A.limit = -1.0f;
+            A.pool_entry = reset->entry; A.pool_span = reset->span; A.pool_v_max = reset->v_max; A.edge_span = reset->edge_span;
+            A.pool_seed = reset->pool_seed; A.pool_counter = reset->pool_counter;
             A.obs = reset->obs_src; A.done_src = reset->done_src;
         }
         return launch_env_step(task, A, s);

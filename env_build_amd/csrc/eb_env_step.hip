@@ -70,9 +70,13 @@ int env_step_tile_envs(int n_env, int D, int NV, int m_cand) {
     return n_env <= 6144 ? 16 : n_env <= 24576 ? 32 : 64;
 }
 
-bool env_step_is_fused(int D, int NV, int m_cand, const float* cand) {
+// cand and params are accessed as float4, ego / actions / scaled actions as float2: a buffer that is not aligned to its vector
+// access (an offset view handed in through the C-ABI) takes the separate launches instead
+bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego, const float* actions,
+                       const float* scaled, const float* params) {
+    auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     return m_cand >= 1 && m_cand <= 64 && env_step_lds_bytes(D, NV, m_cand, 16) <= 150 * 1024 &&
-           (reinterpret_cast<uintptr_t>(cand) & 15) == 0;
+           al(cand, 16) && al(ego, 8) && al(actions, 8) && al(scaled, 8) && al(params, 16);
 }
 
 // profiling aid (eb_debug_set_trace on the model handle): slot k of this wave's row [8] <- the 100 MHz wall clock, lane 0 only
@@ -115,10 +119,13 @@ struct WaveQueue {
 // RESET (with OBS): eb_env_reset_pool in one launch — the masked rows get eb_env_reset's draws (wave 0, lane = env), then a fresh
 // pool clear of that ego (the staging lanes, eb_traffic_respawn's arithmetic with init_traffic's conflict rule), then their
 // observation from the state just made; the drawn virtual-red-light flag replaces the old one at the end (E2E:116-126).
-template <int TASK, int ET, bool OBS, bool RESET>
+// AUTO (step only): eb_env_step(auto_reset) — the rows whose done code came out non-zero take RESET's path in the same block after
+// the step's own phases: terminal observation -> final_obs, draws, pool re-entry clear of the new ego, reset observation (OLD
+// flag) -> obs_out, flag swap.  A tile without a finished row leaves after phase 4 as before.
+template <int TASK, int ET, bool OBS, bool RESET, bool AUTO = false>
 EB_DEV void env_step_body(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint8_t smode[64], sturn[64], s_col[ET];
+    __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_fin[ET];
     __shared__ float s_miu[ET];                                                  // miu_r of the step (the stability predicate's input)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * ET;
     const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
@@ -189,38 +196,62 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     load_pairs(0);
     const int slot_mode = lane < NV ? A.modes.mode[lane] : 0xff;                        // lane = slot
     const bool red_light = !RESET && live && A.v_light && A.v_light[i] != 0;   // (a reset clears v_light before its observation)
-    const bool light = red_light || (live && A.virtual_flag && A.virtual_flag[i] != 0);   // E2E:387-388
+    const bool vflag = live && A.virtual_flag && A.virtual_flag[i] != 0;
+    const bool light = red_light || vflag;                                      // E2E:387-388
     float nx[6] = {0, 0, 0, 0, 0, 0};                                        // wave 0
     float steer = 0.0f, a_x = 0.0f, o9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // wave 1
     float road_t = 0.0f, road_r = 0.0f;
     int reset_path = 0;
     bool virtual_next = false;
+    // eb_env_reset's draws for this lane's env (env_reset_kernel: same keys, same arithmetic) -> nx, reset_path, virtual_next, and
+    // the new state to HBM and s_ego
+    auto draw_reset = [&]() {
+        const float span = TASK == TASK_LEFT ? 900 + 500 : TASK == TASK_STRAIGHT ? 1200 + 500 : 420 + 500;   // E2E:473-478
+        const uint64_t base = (A.reset_counter << 32) + (uint64_t)i * 128u;
+        const float u0 = u01(A.reset_seed, base), u1 = u01(A.reset_seed, base + 1), u2 = u01(A.reset_seed, base + 2),
+                    u3 = u01(A.reset_seed, base + 3);
+        int p = (int)(u0 * (float)A.pt.n_paths);                        // DAM:591
+        if (p > A.pt.n_paths - 1) p = A.pt.n_paths - 1;
+        const int ci = clamp_index((int)(u1 * span) + 700, A.pt.len[p]);   // E2E:474-478; indexs2points, DAM:727-728
+        nx[0] = 8.0f * u2; nx[1] = 0.0f; nx[2] = 0.0f;                  // E2E:482-486
+        nx[3] = A.pt.x[p][ci]; nx[4] = A.pt.y[p][ci]; nx[5] = A.pt.phi[p][ci];
+        reset_path = p;
+        virtual_next = A.training && u3 > 0.9f;                         // E2E:120-126
+        float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
+        ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
+        reinterpret_cast<float4*>(A.params)[i] = make_float4(0.0f, 0.0f, VehParams::miu, VehParams::miu);   // E2E:110-113
+        A.ref_idx_out[i] = p;
+        if (RESET && A.done_code) A.done_code[i] = EB_DONE_NOT_YET;     // E2E:119 (AUTO: done_code keeps the step's codes)
+        if (A.v_light_out) A.v_light_out[i] = 0;
+        s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
+    };
+    // eb_traffic_respawn's unconditional re-entry of candidate c of tile row e, clear of the NEW ego in s_ego (init_traffic's
+    // conflict rule, TRF:168-192) -> HBM and s_cand
+    auto respawn_fresh = [&](int e, int c) {
+        const uint64_t ub = (A.pool_counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
+        const float u1 = u01(A.pool_seed, ub), u2 = u01(A.pool_seed, ub + 1);
+        const float* en = A.pool_entry + 5 * c;
+        float along = u1 * A.pool_span;
+        float4 nv = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.pool_v_max, en[2]);
+        const float4 eg = s_ego[e];
+        const float ego6[6] = {eg.w, 0.0f, 0.0f, eg.x, eg.y, eg.z};
+        if (init_conflict(ego6, 4.8f, nv.x, nv.y, nv.w, nv.z, 4.8f)) {   // TRF:168-192: not on top of the ego
+            along = u1 * A.edge_span;
+            nv.x = en[0] + along * en[3];
+            nv.y = en[1] + along * en[4];
+        }
+        reinterpret_cast<float4*>(A.cand)[((size_t)e0 + e) * m_cand + c] = nv;
+        s_cand[e * RS4 + c] = nv;
+    };
     if (OBS) {
         if (wave == 0 && live) {
-            if (RESET) {                                                        // eb_env_reset's draws (env_reset_kernel: same keys, same arithmetic)
-                const float span = TASK == TASK_LEFT ? 900 + 500 : TASK == TASK_STRAIGHT ? 1200 + 500 : 420 + 500;   // E2E:473-478
-                const uint64_t base = (A.reset_counter << 32) + (uint64_t)i * 128u;
-                const float u0 = u01(A.reset_seed, base), u1 = u01(A.reset_seed, base + 1), u2 = u01(A.reset_seed, base + 2),
-                            u3 = u01(A.reset_seed, base + 3);
-                int p = (int)(u0 * (float)A.pt.n_paths);                        // DAM:591
-                if (p > A.pt.n_paths - 1) p = A.pt.n_paths - 1;
-                const int ci = clamp_index((int)(u1 * span) + 700, A.pt.len[p]);   // E2E:474-478; indexs2points, DAM:727-728
-                nx[0] = 8.0f * u2; nx[1] = 0.0f; nx[2] = 0.0f;                  // E2E:482-486
-                nx[3] = A.pt.x[p][ci]; nx[4] = A.pt.y[p][ci]; nx[5] = A.pt.phi[p][ci];
-                reset_path = p;
-                virtual_next = A.training && u3 > 0.9f;                         // E2E:120-126
-                float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
-                ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
-                reinterpret_cast<float4*>(A.params)[i] = make_float4(0.0f, 0.0f, VehParams::miu, VehParams::miu);   // E2E:110-113
-                A.ref_idx_out[i] = p;
-                if (A.done_code) A.done_code[i] = EB_DONE_NOT_YET;              // E2E:119
-                if (A.v_light_out) A.v_light_out[i] = 0;
-            } else {                                                            // the ego as given (eb_get_obs)
+            if (RESET) draw_reset();
+            else {                                                              // the ego as given (eb_get_obs)
                 const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
                 const float2 g0 = eg[0], g1 = eg[1], g2 = eg[2];
                 nx[0] = g0.x; nx[1] = g0.y; nx[2] = g1.x; nx[3] = g1.y; nx[4] = g2.x; nx[5] = g2.y;
+                s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
             }
-            s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
         }
         if (RESET) __syncthreads();   // the pool's re-entry below stays clear of the NEW ego
     } else if (wave < 2 && live) {
@@ -266,23 +297,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
             float sn, cs;     // (the record loop of the rollout kernel: one code path for every turn class, eb_device.h)
             if (RESET) {
-                float4 nv = v;
-                if (!s_col[e]) {                                               // a row of the mask: eb_traffic_respawn, unconditional
-                    const uint64_t ub = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
-                    const float u1 = u01(A.seed, ub), u2 = u01(A.seed, ub + 1);
-                    const float* en = A.respawn_entry + 5 * c;
-                    float along = u1 * A.span;
-                    nv = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
-                    const float4 eg = s_ego[e];
-                    const float ego6[6] = {eg.w, 0.0f, 0.0f, eg.x, eg.y, eg.z};
-                    if (init_conflict(ego6, 4.8f, nv.x, nv.y, nv.w, nv.z, 4.8f)) {   // TRF:168-192: not on top of the ego
-                        along = u1 * A.edge_span;
-                        nv.x = en[0] + along * en[3];
-                        nv.y = en[1] + along * en[4];
-                    }
-                    reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = nv;
-                }
-                s_cand[e * RS4 + c] = nv;
+                if (!s_col[e]) respawn_fresh(e, c);                            // a row of the mask: eb_traffic_respawn, unconditional
+                else s_cand[e * RS4 + c] = v;
             } else if (OBS) s_cand[e * RS4 + c] = v;
             else {
                 const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs);
@@ -315,15 +331,14 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
 
     // ---- phase 2 ---------------------------------------------------------------------------------------------
     float delta_y = 0.0f;
-    if (wave == 0) {
-        if (live) {
-            // E2E:329-338 ego vector, E2E:293-297 tracking error on the env's path
+    // E2E:329-338 ego vector, E2E:293-297 tracking error on path p: the head of this lane's observation row (from nx) -> s_out
+    auto track_row = [&](int p) {
+        {
             float* orow = s_out + lane * OS;
             const float ex = nx[3], ey = nx[4];
 #pragma unroll
             for (int c = 0; c < 6; ++c) orow[c] = nx[c];
             const PathTables& pt = A.pt;
-            const int p = RESET ? reset_path : row_path(pt, A.ref_idx, A.path_id, i);
             if (p < 0) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }
             else {
                 const float2* red = pt.red[p];
@@ -363,6 +378,9 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 }
             }
         }
+    };
+    if (wave == 0) {
+        if (live) track_row(RESET ? reset_path : row_path(A.pt, A.ref_idx, A.path_id, i));
         if (!OBS && live) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1), and
             // behind the tracking's dependent table reads rather than in front of them
             float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
@@ -492,11 +510,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
         }
     }
-    unsigned jbits = 0u;
-    if (!OBS && wave == 0 && live)   // the done predicates that need only the new ego state (E2E:223-256)
-        jbits = judge_bits(TASK, nx[0], nx[2], nx[3], nx[4], nx[5], s_miu[lane], red_light);
+    if (!OBS && wave == 0) {   // E2E:200-221: the predicates that need only the new ego state (E2E:223-256), then the priority chain
+        uint8_t code = EB_DONE_NOT_YET;
+        if (live) {
+            code = judge_merge(judge_bits(TASK, nx[0], nx[2], nx[3], nx[4], nx[5], s_miu[lane], red_light), s_col[lane] != 0, delta_y);
+            A.done_code[i] = code;
+        }
+        if (AUTO && lane < ET) s_fin[lane] = code != EB_DONE_NOT_YET;
+    }
     ES_MARK(6);
-    {
+    // E2E:340-464 for the lanes with `on` (lane = env): the vehicle slots of this wave's modes -> s_out
+    auto fill_slots = [&](const bool on, const bool light_on) {
         // E2E:340-464.  The slot plan is scalar: lane s of `slot_mode` holds the mode of slot s, so the distinct modes (first
         // occurrences: A.first_mask), their owners (waves 2, 3, 1, 0 in turn) and a mode's slots (a ballot) cost no memory
         // access; per mode (wave-uniform) and env (lane) the tag row becomes a candidate set and the slots are filled by
@@ -505,7 +529,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         const float ex = eg.x, ey = eg.y;
         const float4* crow = s_cand + lane * RS4;
         const unsigned* trow = s_tag32 + lane * TS4;
-        const bool virt = TASK != TASK_RIGHT && light && ey < -HALF_CROSS;                                   // E2E:386-388
+        const bool virt = TASK != TASK_RIGHT && light_on && ey < -HALF_CROSS;                                // E2E:386-388
         float* ov = s_out + lane * OS + 6 + T;
         const int nw = (m_cand + 3) >> 2;
         unsigned long long firsts = A.first_mask;
@@ -515,7 +539,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             if (((0x1e >> (2 * (k & 3))) & 3) != wave) continue;               // owners in turn: waves 2, 3, 1, 0
             const int m = __builtin_amdgcn_readlane(slot_mode, s);
             unsigned long long slots = __builtin_amdgcn_ballot_w64(slot_mode == m);   // the mode's slots, ascending
-            if (!live) continue;
+            if (!on) continue;
             const KeySpec ks = key_spec(TASK, m);
             // the env's candidates of this mode as a bit set (mode byte == m), 4 bytes per dword; the range filter of
             // E2E:393-411 is applied in the walk below, where the mode is wave-uniform
@@ -612,15 +636,18 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 *reinterpret_cast<f4a4*>(ov + 4 * s2) = f4a4{r.x, r.y, r.z, r.w};
             }
         }
-    }
+    };
+    fill_slots(live, light);
     ES_MARK(3);
-    __syncthreads();   // barrier: s_out complete, s_jbits
+    __syncthreads();   // barrier: s_out complete, s_fin
 
     // ---- phase 4 ---------------------------------------------------------------------------------------------
-    if (!OBS && wave == 0 && live) A.done_code[i] = judge_merge(jbits, s_col[lane] != 0, delta_y);                // E2E:200-221
     if (RESET && wave == 0 && live) A.virtual_out[i] = virtual_next ? 1 : 0;   // every wave read the old flag before the barriers above
     if (RESET && wave == 0 && !live && lane < nE && A.done_src && A.done_code) A.done_code[i] = A.done_src[i];
-    {   // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane)
+    // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane).  which = 0: every row
+    // (OBS with a row mask: the masked rows; RESET: the others carried over); 1 (AUTO, phase 4): the finished rows go to final_obs
+    // instead; 2 (AUTO, after the reset): the finished rows alone
+    auto store_rows = [&](const int which) {
         float* dst = A.obs_out + (size_t)e0 * D;
         const int total = nE * D;
         for (int base = tid; base < total; base += 1024) {
@@ -635,16 +662,45 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             for (int k = 0; k < 4; ++k) {
                 const int idx = base + 256 * k;
                 if (idx >= total) continue;
+                if (AUTO && which) {
+                    const bool fin_row = s_fin[fast_div(idx, A.d_magic)] != 0;
+                    if (which == 2) { if (fin_row) dst[idx] = v[k]; }
+                    else if (!fin_row) dst[idx] = v[k];
+                    else if (A.final_obs) A.final_obs[(size_t)e0 * D + idx] = v[k];
+                    continue;
+                }
                 if (!(OBS && A.row_mask && s_col[fast_div(idx, A.d_magic)])) dst[idx] = v[k];
                 else if (RESET && A.obs) dst[idx] = A.obs[(size_t)e0 * D + idx];            // a row outside the mask: carried over
             }
         }
-    }
+    };
+    store_rows(AUTO ? 1 : 0);
     ES_MARK(4);
+    if (AUTO) {
+        // ---- the envs this step finished start their next episode (E2E:99-127) — eb_env_reset_pool's arithmetic on those rows ----
+        const bool fin = lane < nE && s_fin[lane] != 0;                          // the same in every wave (barrier 3)
+        if (__builtin_amdgcn_ballot_w64(fin) == 0ull) return;                    // nobody in this tile: the usual case per row, not per tile
+        // this thread's stores of the step (ego, params, candidates, rows) are complete before ANOTHER thread overwrites them below,
+        // and everybody's reads of s_out / s_ego / s_cand are over
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave == 0 && fin) draw_reset();                                      // E2E:100-101, 110-113
+        __syncthreads();   // the pool's re-entry stays clear of the NEW ego
+        for (int idx = tid; idx < n_rec; idx += 256) {                           // E2E:102-103 (init_traffic, TRF:151-195)
+            const int e = fast_div(idx, A.m_magic);
+            if (s_fin[e]) respawn_fresh(e, idx - e * m_cand);
+        }
+        __syncthreads();
+        if (wave == 0 && fin) track_row(reset_path);                             // E2E:116: the reset observation, OLD virtual flag,
+        fill_slots(fin, vflag);                                                  // v_light already cleared
+        __syncthreads();
+        store_rows(2);
+        if (wave == 0 && fin) A.virtual_out[i] = virtual_next ? 1 : 0;           // E2E:120-126
+    }
 }
 
-template <int TASK, int ET, bool OBS>
-__global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false>(A); }
+template <int TASK, int ET, bool OBS, bool AUTO = false>
+__global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO>(A); }
 template <int TASK, int ET>
 __global__ __launch_bounds__(256) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true>(A); }
 
@@ -661,15 +717,15 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     dev = dev < 0 || dev >= 64 ? 0 : dev;
     hipError_t e = hipSuccess;
     const dim3 g((A.n_env + ET - 1) / ET), b(256);
-#define EB_ENV_STEP(T, E, O)                                                                                          \
+#define EB_ENV_STEP(T, E, O, AU)                                                                                      \
     do {                                                                                                             \
         static size_t granted[64];   /* the > 48 KB opt-in is per kernel and device, and sticky */                   \
         if (lds > 48 * 1024 && lds > granted[dev]) {                                                                 \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T, E, O>),                        \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T, E, O, AU>),                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             if (e == hipSuccess) granted[dev] = lds;                                                                 \
         }                                                                                                            \
-        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O>), g, b, lds, s, A);                        \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O, AU>), g, b, lds, s, A);                    \
     } while (0)
 #define EB_ENV_RESET(T, E)                                                                                            \
     do {                                                                                                             \
@@ -684,8 +740,9 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
 #define EB_ENV_STEP_T(T)                                                                                             \
     do {                                                                                                             \
         if (A.reset) { if (ET == 16) EB_ENV_RESET(T, 16); else if (ET == 32) EB_ENV_RESET(T, 32); else EB_ENV_RESET(T, 64); } \
-        else if (A.obs_only) { if (ET == 16) EB_ENV_STEP(T, 16, true); else if (ET == 32) EB_ENV_STEP(T, 32, true); else EB_ENV_STEP(T, 64, true); } \
-        else { if (ET == 16) EB_ENV_STEP(T, 16, false); else if (ET == 32) EB_ENV_STEP(T, 32, false); else EB_ENV_STEP(T, 64, false); } \
+        else if (A.obs_only) { if (ET == 16) EB_ENV_STEP(T, 16, true, false); else if (ET == 32) EB_ENV_STEP(T, 32, true, false); else EB_ENV_STEP(T, 64, true, false); } \
+        else if (A.auto_reset) { if (ET == 16) EB_ENV_STEP(T, 16, false, true); else if (ET == 32) EB_ENV_STEP(T, 32, false, true); else EB_ENV_STEP(T, 64, false, true); } \
+        else { if (ET == 16) EB_ENV_STEP(T, 16, false, false); else if (ET == 32) EB_ENV_STEP(T, 32, false, false); else EB_ENV_STEP(T, 64, false, false); } \
     } while (0)
     switch (task) {
         case TASK_LEFT: EB_ENV_STEP_T(TASK_LEFT); break;

@@ -104,6 +104,7 @@ hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const E
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
                             int training, float* ego, float* params, int* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
                             hipStream_t s, uint8_t* v_light = nullptr);
+hipError_t launch_copy_rows_masked(int n_env, int D, const uint8_t* mask, const float* src, float* dst, hipStream_t s);
 hipError_t launch_flag_swap(int n_env, const uint8_t* mask, const uint8_t* next, uint8_t* flag, hipStream_t s);
 hipError_t launch_traffic_flow_reset(int n_env, int K, const uint8_t* mask, const float* ego, float* cand, uint8_t* active,
                                      float* timer, int* emitted, int* sim_step, uint8_t* phase0, const float* lane,
@@ -155,6 +156,14 @@ struct EnvStepArgs {
     uint8_t* virtual_out;                  // [n_env] == virtual_flag: the OLD flag feeds the observation, the drawn one replaces it after
     uint8_t* v_light_out;                  // nullable: cleared
     const uint8_t* done_src;               // nullable (obs: the observation source of the rows outside the mask, nullable)
+    // the pool's part of a reset (reset = 1, or auto_reset = 1 next to the step's own re-entry rule above)
+    const float* pool_entry;
+    float pool_span, pool_v_max;
+    uint64_t pool_seed, pool_counter;
+    // auto_reset (eb_env_step, ABI 4): the rows whose done code is non-zero are reset in the same launch — reset_seed / reset_counter /
+    // training / edge_span / ref_idx_out / virtual_out / v_light_out as for reset; final_obs (nullable) takes their terminal rows
+    int auto_reset;
+    float* final_obs;
 };
 struct EnvResetArgs {                      // launch_get_obs(..., reset): what eb_env_reset_pool adds to a masked observation pass
     uint64_t seed, counter;                // eb_env_reset's
@@ -172,7 +181,8 @@ struct EnvResetArgs {                      // launch_get_obs(..., reset): what e
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand);
-bool env_step_is_fused(int D, int NV, int m_cand, const float* cand);
+bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego = nullptr, const float* actions = nullptr,
+                       const float* scaled = nullptr, const float* params = nullptr);   // NULL: not an argument of the call at hand
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s);
 
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,

@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.environ.get('ENVBUILD_LIB', os.path.join(_HERE, '..', 'env_build_amd', 'lib', 'libenvbuild_hip.so'))
 VMODE = {m: i for i, m in enumerate(('dl', 'du', 'dr', 'rd', 'rl', 'ru', 'ur', 'ud', 'ul', 'lu', 'lr', 'ld'))}   # EB_VMODE_*
 TASK = {'left': 0, 'straight': 1, 'right': 2}                                                                 # EB_TASK_*
+BINDING_ABI = 4     # the EB_ABI_VERSION of the include/envbuild.h these prototypes were written against
 
 
 class _Cfg(C.Structure):       # struct eb_config
@@ -58,8 +59,9 @@ class HipEnvironmentModel(object):
 
     def __init__(self, task, num_future_data, mode, ref_path, veh_mode_list, device=0, lib=None):
         self.lib = lib if lib is not None else load()
-        cfg = _Cfg(self.lib.eb_abi_version(), TASK[task], len(veh_mode_list), num_future_data,
-                   0 if mode == 'training' else 1, device)                       # the library's own EB_ABI_VERSION
+        if self.lib.eb_abi_version() != BINDING_ABI:     # a library with other prototypes: refuse, do not call it with shifted arguments
+            raise RuntimeError('libenvbuild: ABI %d, this binding was written for %d' % (self.lib.eb_abi_version(), BINDING_ABI))
+        cfg = _Cfg(BINDING_ABI, TASK[task], len(veh_mode_list), num_future_data, 0 if mode == 'training' else 1, device)
         self.h = _P()
         self._ck(self.lib.eb_create(C.byref(cfg), C.byref(self.h)))
         xs, ys, ph = (np.ascontiguousarray(np.concatenate([np.asarray(p[k], np.float32) for p in ref_path.path_list]))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EB_ABI_VERSION 3
+#define EB_ABI_VERSION 4
 
 /* error codes */
 #define EB_OK 0
@@ -346,9 +346,22 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
  * respawn (nullable): the traffic pool's re-entry rule applied AFTER the observation and the done code were taken (the
  * observation sees the pool as this step left it, the way the reference sees SUMO's state of the step) =
  * eb_traffic_respawn(traffic, n_env, m_cand, cand, entry, limit, span, v_max, seed, counter, NULL, NULL) as a seventh call.
+ * auto_reset (nullable, ABI 4): "step, then reset the envs this step finished" — the loop of a vectorised driver
+ * (hier_decision.py:109-135 steps, tests done and calls reset, E2E:99-127) as ONE call.  After the steps above, with
+ * mask[e] = (done_code[e] != 0):
+ *   final_obs[e, :] = obs_out[e, :] for the masked envs (nullable; the other rows of final_obs are not touched) — the
+ *       terminal observation, Gym-vector's `final_observation`;
+ *   eb_env_reset_pool(h, traffic, n_env, mask, seed, counter, training, ego, params, ref_idx, virtual_flag, v_light,
+ *       NULL, m_cand, cand, cand_mode, &pool, obs_out, NULL, NULL): fresh state and flags, the pool re-entered clear of the
+ *       new ego, v_light cleared, the reset observation (built with the OLD flag, E2E:116) in place of the terminal one,
+ *       the drawn flag swapped in (E2E:120-126) — for the masked envs only.
+ * done_code keeps the step's codes (what the driver reads to know who finished and why).  ref_idx / virtual_flag /
+ * v_light inside the struct are the writable views of the arrays passed as the const arguments of the same name and must
+ * BE those arrays (EB_EINVAL otherwise; ref_idx and virtual_flag must not be NULL, v_light may be).
  * Every argument is validated before the first launch: an error return leaves the state untouched.  Equivalent to the
- * six (seven) calls in that order; the HIP library runs them as ONE launch (csrc/eb_env_step.hip) when the candidate
- * tile fits the LDS, m_cand <= 64 and cand is 16-byte aligned, and as separate launches otherwise. */
+ * six (seven) calls in that order (+ the reset above); the HIP library runs them as ONE launch (csrc/eb_env_step.hip)
+ * when the candidate tile fits the LDS, m_cand <= 64 and cand / ego / actions / scaled_actions / params are aligned to
+ * their vector accesses (16 / 8 / 8 / 8 / 16 bytes), and as separate launches otherwise. */
 typedef struct eb_respawn {
     const float* entry; /* [m_cand, 5] = (x, y, phi, dx, dy) per slot, as eb_traffic_respawn */
     float limit;        /* a candidate with |x| or |y| beyond it re-enters (>= 0) */
@@ -358,11 +371,20 @@ typedef struct eb_respawn {
     uint64_t counter;
     float edge_span;    /* eb_env_reset_pool only: where a candidate goes that would start on top of the ego (eb_traffic_respawn) */
 } eb_respawn;
+typedef struct eb_auto_reset {
+    uint64_t seed, counter;  /* eb_env_reset's draws for the finished envs */
+    int32_t training;        /* E2E:120-126: the virtual red-light flag is drawn in training mode only */
+    int32_t* ref_idx;        /* == the ref_idx argument: the finished envs get their drawn path */
+    uint8_t* virtual_flag;   /* == the virtual_flag argument */
+    uint8_t* v_light;        /* == the v_light argument (nullable): cleared for the finished envs */
+    eb_respawn pool;         /* the pool's part of reset: entry, span, v_max, seed, counter, edge_span (limit unused) */
+    float* final_obs;        /* nullable [n_env, D]: the terminal observation rows of the finished envs */
+} eb_auto_reset;
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, void* stream);
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, void* stream);
 
 /* CrossroadEnd2end.reset (E2E:99-127) with _reset_init_state (E2E:472-499) for the envs of a batch whose mask byte is
  * non-zero (mask NULL = every env); the other envs keep their state.  Per env, with u_k in [0, 1) the counter-based

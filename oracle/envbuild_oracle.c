@@ -1252,7 +1252,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, void* stream) {
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, void* stream) {
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
     if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
         m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)))
@@ -1265,6 +1265,14 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!rc) rc = check_modes(traffic);
     if (rc) return rc;
     if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
+    if (auto_reset) {   /* the same checks as the HIP library, before anything is written */
+        const eb_auto_reset* ar = auto_reset;
+        if (!ar->pool.entry || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
+            ar->virtual_flag != virtual_flag || ar->v_light != v_light)
+            return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
+        if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))
+            return fail(EB_EINVAL, "eb_env_step: final_obs must be an array of its own");
+    }
     if (n_env == 0) return EB_OK;
     float* own_scaled = NULL;
     if (!scaled_actions) {                                                                       /* nullable output */
@@ -1282,6 +1290,19 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!rc && respawn)   /* the pool's re-entry, after the observation saw this step's state */
         rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
                                 respawn->seed, respawn->counter, NULL, NULL, NULL, 0.0f, stream);
+    if (!rc && auto_reset) {   /* hier_decision.py:109-135 / E2E:99-127: the envs this step finished start their next episode */
+        const eb_auto_reset* ar = auto_reset;
+        const size_t D = (size_t)obs_dim(&h->cfg);
+        uint8_t* mask = (uint8_t*)malloc((size_t)n_env);
+        if (!mask) return fail(EB_ENOMEM, "eb_env_step: out of memory");
+        for (int e = 0; e < n_env; ++e) {
+            mask[e] = done_code[e] != 0;
+            if (mask[e] && ar->final_obs) memcpy(ar->final_obs + D * e, obs_out + D * e, D * sizeof(float));   /* the terminal observation */
+        }
+        rc = eb_env_reset_pool(h, traffic, n_env, mask, ar->seed, ar->counter, ar->training, ego, params, ar->ref_idx, ar->virtual_flag,
+                               ar->v_light, NULL, m_cand, cand, cand_mode, &ar->pool, obs_out, NULL, NULL, stream);
+        free(mask);
+    }
     return rc;
 }
 

@@ -92,6 +92,91 @@ def composite_case(make, task, B, M, NV, nf, tile=None):
     return got
 
 
+def auto_reset_case(make, task, B, M, NV=None, nf=0, tile=None, close_p=0.02, seed=5, v_light_none=False):
+    """eb_env_step(auto_reset) == eb_env_step, then the terminal rows -> final_obs, then eb_env_reset_pool(mask = done != 0) in place —
+    every output and every piece of state, bit for bit; done_code keeps the step's codes."""
+    from env_build_amd.endtoend import _lane_entry
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    entry = np.array([list(_lane_entry(m)[:3]) + list(_lane_entry(m)[3]) for m in modes], np.float32)
+    ego, cand, _, _, _, _, ref = random_scene(task, B, M, seed)
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    rng = np.random.default_rng(seed + 1)
+    cmode[rng.random((B, M)) < 0.05] = _capi.VMODE_EMPTY
+    raw = rng.uniform(-1.2, 1.2, (B, 2)).astype(np.float32)
+    close = rng.random((B, M)) < close_p                                # a few candidates on the ego: collisions
+    ang, dist = rng.uniform(-np.pi, np.pi, (B, M)), rng.uniform(1.5, 3.6, (B, M))
+    cand = cand.copy()
+    cand[:, :, 0] = np.where(close, ego[:, 3:4] + dist * np.cos(ang), cand[:, :, 0])
+    cand[:, :, 1] = np.where(close, ego[:, 4:5] + dist * np.sin(ang), cand[:, :, 1])
+    gone = rng.random((B, M)) < 0.1
+    cand[:, :, 0] = np.where(gone, rng.choice([-70.0, 66.0, 64.9], (B, M)), cand[:, :, 0]).astype(np.float32)
+    virtual = (rng.random(B) < 0.4).astype(np.uint8)
+    v_light = None if v_light_none else rng.integers(0, 3, B).astype(np.uint8)
+    rule = dict(entry=entry, limit=65.0, span=5.0, v_max=8.0, seed=0x1234567, counter=9)
+    pool = dict(entry=entry, span=60.0, v_max=8.0, seed=4242, counter=17, edge_span=5.0)
+    kw = dict(mode='training', n_future=nf)
+    if NV is not None:
+        kw.update(n_veh=NV)
+    m, tr = make(task, **kw), make(task, n_veh=M, modes=modes)
+    if tile is not None:
+        m.set_tile(tile)
+    obs0 = m.get_obs(ego, cand, cmode, v_light, ref_idx=ref, virtual=virtual)
+    # the two calls
+    sc, o5, d16, ego1, par1, cand1, obs1, done1 = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=v_light, virtual=virtual,
+                                                             respawn=rule)
+    fin = done1 != 0
+    assert 0.02 < fin.mean() < 0.9, fin.mean()
+    vl_in = np.zeros(B, np.uint8) if v_light is None else v_light
+    e2, p2, r2, vf2, vl2, _, c2, o2 = m.env_reset_pool(tr, 99, 5, 1, ego1, par1, ref, virtual, vl_in, cand1, cmode, obs1, pool,
+                                                       mask=fin.astype(np.uint8))
+    final = np.where(fin[:, None], obs1, np.float32(np.nan))
+    # the one call
+    got = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=v_light, virtual=virtual, respawn=rule,
+                     auto_reset=dict(seed=99, counter=5, training=1, pool=pool))
+    want = [sc, o5, d16, e2, p2, c2, o2, done1, r2, vf2, None if v_light is None else vl2, final]
+    names = ['scaled', 'out5', 'dict16', 'ego', 'params', 'cand', 'obs', 'done', 'ref_idx', 'virtual', 'v_light', 'final_obs']
+    for k, (g, w) in enumerate(zip(got, want)):
+        if w is None:
+            assert g is None, names[k]
+            continue
+        assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w, equal_nan=True), names[k]
+    # the rows that did not finish are the plain step's; those that did start from a drawn state
+    assert np.array_equal(got[6][~fin], obs1[~fin]) and np.array_equal(got[3][~fin], ego1[~fin])
+    assert (got[3][fin][:, 1:3] == 0).all() and not np.array_equal(got[6][fin], obs1[fin])
+    # final_obs left out; auto_reset without the step's own re-entry rule
+    g2 = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=v_light, virtual=virtual, respawn=rule,
+                    auto_reset=dict(seed=99, counter=5, training=1, pool=pool, final_obs=False))
+    assert g2[11] is None
+    for k in range(11):
+        if want[k] is not None:
+            assert np.array_equal(g2[k], got[k]), names[k]
+    return got
+
+
+def auto_reset_bad_args_case(make, task='left', B=40, M=8):
+    """auto_reset's pointers must be the call's own arrays, final_obs an array of its own: EB_EINVAL, state untouched."""
+    import pytest
+    from env_build_amd.endtoend import _lane_entry
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    entry = np.array([list(_lane_entry(m)[:3]) + list(_lane_entry(m)[3]) for m in modes], np.float32)
+    ego, cand, _, _, light, _, ref = random_scene(task, B, M, 3)
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    m, tr = make(task, mode='training'), make(task, n_veh=M, modes=modes)
+    obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    raw = np.zeros((B, 2), np.float32)
+    pool = dict(entry=entry, span=60.0, v_max=8.0, seed=1, counter=1, edge_span=5.0)
+    virtual = np.zeros(B, np.uint8)
+    for wrong in ('ref_idx', 'virtual', 'v_light'):
+        with pytest.raises(ValueError):
+            m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=light, virtual=virtual,
+                       auto_reset=dict(seed=1, counter=1, training=1, pool=pool, wrong=(wrong,)))
+    with pytest.raises(ValueError):      # no per-env path ids: a reset cannot record its drawn path
+        m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=None, v_light=light, virtual=virtual,
+                   auto_reset=dict(seed=1, counter=1, training=1, pool=pool))
+
+
 def masked_obs_case(make, task, B=150, M=10, seed=8):
     """eb_get_obs with a row mask: the masked rows equal the unmasked call's, the others keep what the buffer held."""
     native = VEHICLE_MODE_LIST[task]

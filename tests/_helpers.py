@@ -334,10 +334,13 @@ class HostModel(object):
         return self._ret(out)
 
     def env_step(self, traffic, obs, raw, ego, cand, cand_mode, ref_idx=None, path_id=0, cand_lw=None, v_light=None,
-                 virtual=None, respawn=None, want_scaled=True, want_dict=True, scale_in_place=False):
+                 virtual=None, respawn=None, want_scaled=True, want_dict=True, scale_in_place=False, auto_reset=None):
         """eb_env_step on copies of the state -> (scaled, out5, d16, ego, params, cand, obs_out, done_code).
         scale_in_place: the scaled actions overwrite the (copy of the) raw action array.
-        respawn: dict(entry [M, 5], limit, span, v_max, seed, counter) — the pool's re-entry as the step's last stage."""
+        respawn: dict(entry [M, 5], limit, span, v_max, seed, counter) — the pool's re-entry as the step's last stage.
+        auto_reset: dict(seed, counter, training, pool=dict(entry, span, v_max, seed, counter, edge_span), final_obs=bool) — the
+        envs the step finishes are reset in the same call (ABI 4); the result gains (ref_idx, virtual, v_light, final_obs),
+        final_obs pre-filled with NaN."""
         B, M = len(ego), cand.shape[1]
         e_io, c_io = self._in(np.array(ego, np.float32)), self._in(np.array(cand, np.float32))
         ob, rw, ri = self._in(obs), self._in(raw), self._in(ref_idx, np.int32)
@@ -352,11 +355,28 @@ class HostModel(object):
             entry = self._in(respawn['entry'])
             rs = _capi.EbRespawn(self._ptr(entry).value, float(respawn['limit']),
                                  float(respawn['span']), float(respawn['v_max']), int(respawn['seed']), int(respawn['counter']))
+        ar, extra = None, ()
+        if auto_reset is not None:
+            pool = auto_reset['pool']
+            pentry = self._in(pool['entry'])
+            ri = None if ref_idx is None else self._in(np.array(ref_idx, np.int32), np.int32)   # (copies: the call writes them)
+            vf = self._in(np.array(virtual, np.uint8), np.uint8)
+            vl = None if v_light is None else self._in(np.array(v_light, np.uint8), np.uint8)
+            fo = self._in(np.full(np.asarray(obs).shape, np.nan, np.float32)) if auto_reset.get('final_obs', True) else None
+            pr = _capi.EbRespawn(self._ptr(pentry).value, 0.0, float(pool['span']), float(pool['v_max']), int(pool['seed']),
+                                 int(pool['counter']), float(pool['edge_span']))
+            vp = lambda t: None if t is None else self._ptr(t).value
+            ar = _capi.EbAutoReset(int(auto_reset['seed']), int(auto_reset['counter']), int(auto_reset['training']), vp(ri), vp(vf),
+                                   vp(vl), pr, vp(fo))
+            for k in ('ref_idx', 'virtual', 'v_light'):                  # test hook: a pointer that is NOT the call's argument
+                if k in auto_reset.get('wrong', ()):
+                    setattr(ar, {'virtual': 'virtual_flag'}.get(k, k), vp(self._out((B,), np.int32 if k == 'ref_idx' else np.uint8)))
+            extra = (ri, vf, vl, fo)
         self.api.env_step(self.h, traffic.h, B, self._ptr(ob), self._ptr(rw), self._ptr(ri), int(path_id), self._ptr(e_io),
                           self._ptr(par), M, self._ptr(c_io), self._ptr(cm), self._ptr(lw), self._ptr(vl), self._ptr(vf),
                           self._ptr(sc), self._ptr(out5), self._ptr(dd), self._ptr(obs_o), self._ptr(code),
-                          C.byref(rs) if rs is not None else None, self.stream)
-        return [None if x is None else self._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code)]
+                          C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None, self.stream)
+        return [None if x is None else self._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code) + extra]
 
     def traffic_respawn(self, cand, entry, limit, span, v_max, seed, counter, mask=None, ego=None, edge_span=0.0):
         """eb_traffic_respawn on a copy of the candidates -> (cand, respawned)"""

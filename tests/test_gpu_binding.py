@@ -73,3 +73,15 @@ def test_vector_env_loop_example_runs():
     assert out['episodes'] > 0 and np.isfinite(out['mean_return']) and out['steps_per_s'] > 0
     again = mod.run(n_env=512, steps=120, task='left', seed=3)
     assert again['episodes'] == out['episodes'] and again['mean_return'] == out['mean_return']      # counter-based draws: reproducible
+
+
+def test_binding_refuses_a_library_of_another_abi(monkeypatch):
+    """The stub carries the ABI version its prototypes were written for: a library that answers another one is never called."""
+    from env_build_amd import _capi
+    _capi.hip_api()
+    eb = _binding()
+    assert eb.BINDING_ABI == _capi.EB_ABI_VERSION
+    monkeypatch.setattr(eb, 'BINDING_ABI', eb.BINDING_ABI - 1)
+    paths, _, _ = build_ref_paths('left')
+    with pytest.raises(RuntimeError, match='ABI'):
+        eb.HipEnvironmentModel('left', 0, 'training', SimpleNamespace(path_list=paths), VEHICLE_MODE_LIST['left'])

@@ -434,6 +434,79 @@ def test_env_step_composite_equals_the_six_calls(task, B, M, NV, nf, tile):
             assert np.array_equal(a, b)
 
 
+def _compare_auto_reset(a, b, B, what):
+    for k, (x, y) in enumerate(zip(a, b)):
+        if x is None:
+            assert y is None
+        elif x.dtype == np.float32 and x.shape == (5, B):
+            _check_out5(y, x, what)
+        elif x.shape == (16, B):
+            np.testing.assert_allclose(y, x, rtol=PEN_RTOL, atol=0)
+        else:
+            assert np.array_equal(x, y, equal_nan=True), (what, k)
+
+
+@pytest.mark.parametrize('task,B,M,NV,nf,vln', [('left', 700, 16, None, 0, False), ('straight', 333, 10, None, 1, False),
+                                                 ('right', 130, 20, 7, 0, True), ('left', 260, 64, 16, 0, False),
+                                                 ('left', 100, 64, 64, 0, False)])
+@pytest.mark.parametrize('tile', [0, 1, 2])
+def test_env_step_with_auto_reset(task, B, M, NV, nf, vln, tile):
+    """ABI 4 — "step, then reset the envs it has just finished" as ONE launch (env_step_kernel<.., AUTO>): equal to eb_env_step ->
+    terminal rows -> eb_env_reset_pool(mask = done != 0) on the HIP library (asserted inside the case), and to the oracle's
+    composite bit for bit; every tile shape, a nullable v_light, look-ahead columns, non-native slot counts, 64 candidates."""
+    from tests._env_step_check import auto_reset_case
+    want = auto_reset_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B, M, NV=NV, nf=nf, v_light_none=vln)
+    got = auto_reset_case(lambda t, **kw: DeviceModel(t, **kw), task, B, M, NV=NV, nf=nf, tile=tile, v_light_none=vln)
+    _compare_auto_reset(want, got, B, 'auto reset')
+
+
+def test_auto_reset_argument_checks_on_the_gpu():
+    from tests._env_step_check import auto_reset_bad_args_case
+    auto_reset_bad_args_case(lambda t, **kw: DeviceModel(t, **kw))
+
+
+def test_auto_reset_on_the_separate_launch_path():
+    """Candidates that are not 16-byte aligned: eb_env_step(auto_reset) runs the step's separate launches, the masked row copy
+    and eb_env_reset_pool's four launches — the same bits as the one-launch kernel."""
+    import ctypes as C
+    import torch
+    from env_build_amd.endtoend import _lane_entry
+    task, B, M = 'left', 400, 12
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    entry = np.array([list(_lane_entry(m)[:3]) + list(_lane_entry(m)[3]) for m in modes], np.float32)
+    ego, cand, _, _, light, _, ref = _random_scene(task, B, M, 17)
+    ego[::5, 3] += 9.0                                                   # a fifth of the egos off the road: they finish
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    rng = np.random.default_rng(6)
+    raw = rng.uniform(-1.1, 1.1, (B, 2)).astype(np.float32)
+    virtual = (rng.random(B) < 0.5).astype(np.uint8)
+    m, tr = DeviceModel(task, mode='training'), DeviceModel(task, n_veh=M, modes=modes)
+    obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref, virtual=virtual)
+    pool = dict(entry=entry, span=60.0, v_max=8.0, seed=4242, counter=17, edge_span=5.0)
+    ar = dict(seed=99, counter=5, training=1, pool=pool)
+    want = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=light, virtual=virtual, auto_reset=ar)
+    assert 0.05 < (want[7] != 0).mean() < 0.9
+    t, dev = torch, m.dev
+    p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+    big = t.zeros(B * M * 4 + 1, dtype=t.float32, device=dev)
+    c_io = big[1:].view(B, M, 4)                                         # 4-byte aligned only
+    c_io.copy_(t.from_numpy(cand))
+    e_io, ob, rw, ri = m._in(ego.copy()), m._in(obs0), m._in(raw), m._in(ref, np.int32)
+    cm, vl, vf, en = m._in(cmode, np.uint8), m._in(light, np.uint8), m._in(virtual, np.uint8), m._in(entry)
+    par, sc, out5, dd = m._out((B, 4)), m._out((B, 2)), m._out((5, B)), m._out((16, B))
+    obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
+    fo = m._in(np.full(obs0.shape, np.nan, np.float32))
+    rs = _capi.EbRespawn(en.data_ptr(), 0.0, 60.0, 8.0, 4242, 17, 5.0)
+    a = _capi.EbAutoReset(99, 5, 1, ri.data_ptr(), vf.data_ptr(), vl.data_ptr(), rs, fo.data_ptr())
+    m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), p(vf), p(sc), p(out5), p(dd),
+                   p(obs_o), p(code), None, C.byref(a), m.stream)
+    t.cuda.synchronize()
+    got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code, ri, vf, vl, fo)]
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w, equal_nan=True), k
+
+
 @pytest.mark.parametrize('task', TASKS)
 @pytest.mark.parametrize('B,tile', [(150, -1), (1000, 0), (1000, 1), (1000, 2)])
 def test_masked_observation_pass(task, B, tile):
@@ -481,7 +554,7 @@ def test_env_step_separate_launches_equal_the_one_launch_kernel():
     obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
     rs = _capi.EbRespawn(en.data_ptr(), 65.0, 60.0, 8.0, 77, 3)
     m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), None, p(sc), p(out5), p(dd),
-                   p(obs_o), p(code), C.byref(rs), m.stream)
+                   p(obs_o), p(code), C.byref(rs), None, m.stream)
     t.cuda.synchronize()
     got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code)]
     for k, (g, w) in enumerate(zip(got, want)):
@@ -757,3 +830,6 @@ def test_env_step_and_masked_reset_at_the_bench_size_equal_the_oracle():
     for a, b in zip(reset_pool_case(on_cpu, task, B=B, M=M, seed=77), reset_pool_case(on_gpu, task, B=B, M=M, seed=77)):
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x, y), k
+    # the step with the reset of the envs it finishes in the same launch (ABI 4), every row
+    from tests._env_step_check import auto_reset_case
+    _compare_auto_reset(auto_reset_case(on_cpu, task, B, M), auto_reset_case(on_gpu, task, B, M), B, 'auto reset 65536')

@@ -1,8 +1,9 @@
-"""CPU (-m "not gpu"): the oracle's eb_env_step composite (incl. the re-entry rule and the nullable outputs of ABI 3)
+"""CPU (-m "not gpu"): the oracle's eb_env_step composite (incl. the re-entry rule, the nullable outputs and ABI 4's auto_reset)
 equals its own single calls — the same check the GPU suite runs on the one-launch kernel (tests/_env_step_check.py)."""
 import pytest
 
-from tests._env_step_check import CASES, composite_case, masked_obs_case, reset_pool_case, respawn_conflict_case, wrap_guard_case
+from tests._env_step_check import (CASES, auto_reset_bad_args_case, auto_reset_case, composite_case, masked_obs_case, reset_pool_case,
+                                   respawn_conflict_case, wrap_guard_case)
 from tests._helpers import HostModel
 
 
@@ -23,6 +24,17 @@ def test_oracle_pool_reset_keeps_clear_of_the_ego(oracle):
 @pytest.mark.parametrize('task', ['left', 'straight', 'right'])
 def test_oracle_reset_pool_composite(oracle, task):
     reset_pool_case(lambda t, **kw: HostModel(oracle, t, **kw), task)
+
+
+@pytest.mark.parametrize('task,B,M,NV,nf,vln', [('left', 300, 16, None, 0, False), ('straight', 200, 10, None, 1, False),
+                                                 ('right', 130, 20, 7, 0, True)])
+def test_oracle_step_with_auto_reset(oracle, task, B, M, NV, nf, vln):
+    """ABI 4: eb_env_step(auto_reset) == eb_env_step + terminal rows + eb_env_reset_pool(mask = done != 0)"""
+    auto_reset_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B, M, NV=NV, nf=nf, v_light_none=vln)
+
+
+def test_oracle_auto_reset_argument_checks(oracle):
+    auto_reset_bad_args_case(lambda t, **kw: HostModel(oracle, t, **kw))
 
 
 @pytest.mark.timeout(60)
