@@ -104,21 +104,28 @@ def _unwrap_action(action, B, dev):
 
 class _RewardInfo(dict):
     """info['reward_info'] of a batch (E2E:142-143): the 16 reward terms are rows of one [16, B] device array; a row is
-    wrapped as a DevArray when it is first read, so a driver that never looks pays nothing per step."""
+    wrapped as a DevArray when it is first read, so a driver that never looks pays nothing per step.  The array itself is
+    optional: until somebody has read a term once, step() does not ask the kernel for it (64 B per env-step) and `compute`
+    makes it on demand from the observation and action the step consumed (eb_compute_rewards: the same bits)."""
 
     _ROWS = {}                               # keys tuple -> {key: row}; built once, shared by every step's dict
 
-    def __init__(self, keys, d16, final_rew):
+    def __init__(self, keys, d16, final_rew, compute=None):
         dict.__init__(self)
         rows = self._ROWS.get(keys)
         if rows is None:
             rows = self._ROWS[keys] = {k: i for i, k in enumerate(keys)}
         self._rows = rows
         self._d16 = d16
+        self._compute = compute
         dict.__setitem__(self, 'final_rew', final_rew)
 
     def __missing__(self, k):
-        v = DevArray(self._d16[self._rows[k]])
+        row = self._rows[k]                  # KeyError for a name that is not a reward term
+        if self._d16 is None:
+            self._d16 = self._compute()
+            self._compute = None
+        v = DevArray(self._d16[row])
         dict.__setitem__(self, k, v)
         return v
 
@@ -134,6 +141,18 @@ class _RewardInfo(dict):
 
     def values(self):
         self._fill(); return dict.values(self)
+
+    def get(self, k, default=None):          # (dict.get bypasses __missing__)
+        try:
+            return self[k]
+        except KeyError:
+            return default
+
+    def copy(self):
+        self._fill(); return dict(dict.items(self))
+
+    def __reduce__(self):                    # pickles / deep-copies as the plain dict it stands for
+        self._fill(); return (dict, (dict(dict.items(self)),))
 
     def __iter__(self):
         self._fill(); return dict.__iter__(self)
@@ -165,6 +184,30 @@ class _LazyInitState(dict):
     def __contains__(self, k):
         return k == 'ego'
 
+    def get(self, k, default=None):
+        return self[k] if k == 'ego' else default
+
+    def keys(self):
+        self['ego']; return dict.keys(self)
+
+    def items(self):
+        self['ego']; return dict.items(self)
+
+    def values(self):
+        self['ego']; return dict.values(self)
+
+    def __iter__(self):
+        self['ego']; return dict.__iter__(self)
+
+    def __len__(self):
+        return 1
+
+    def copy(self):
+        self['ego']; return dict(dict.items(self))
+
+    def __reduce__(self):
+        self['ego']; return (dict, (dict(dict.items(self)),))
+
 
 class _LazyDone(DevArray):
     """done of a batch: uint8 0 / 1 per env = (done code != 0) — the one small kernel that makes it runs when the value
@@ -187,7 +230,15 @@ class _LazyDone(DevArray):
 
 class CrossroadEnd2end(object):
     def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
-                 device=None, respawn=True, traffic='pool', per_route=5, **kwargs):
+                 device=None, respawn=True, traffic='pool', per_route=5, auto_reset=False, copy_outputs=True, **kwargs):
+        """n_env > 1 makes a batch of independent single-ego envs (the reference is one env: every argument before n_env is its).
+        auto_reset (a batch over the traffic pool): step() also resets the envs it has just finished, in the same kernel launch —
+            the observation it returns holds their reset observation, info['final_observation'] their terminal one (rows of the
+            other envs unspecified), `done` says which.  The vectorised-env convention; hier_decision.py:109-135's loop in one call.
+        copy_outputs: True (default) — what step() / reset() hand out are arrays of their own, as in the reference: they can be
+            kept in a rollout list or a replay buffer.  False — the outputs live in two pre-allocated buffer sets used in turn
+            (zero allocations per step): a value handed out stays valid until the step AFTER the next one and must be consumed or
+            copied by then; `done` and info['reward_info'] are materialised on first read and must be read in that window too."""
         if training_task not in ('left', 'straight', 'right'):
             raise ValueError("training_task must be 'left', 'straight' or 'right'")
         self.device = device if device is not None else _default_device()
@@ -225,6 +276,9 @@ class CrossroadEnd2end(object):
         self.mode = mode
         self.multi_display = multi_display
         self.respawn = respawn
+        self.copy_outputs = bool(copy_outputs)
+        self.auto_reset = bool(auto_reset)
+        self._want_d16 = False     # the 16-term reward dict is requested from the kernel once somebody has read a term
         self.obs_dim = 6 + 3 * (num_future_data + 1) + 4 * self.veh_num
         self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)
 
@@ -263,13 +317,19 @@ class CrossroadEnd2end(object):
         self.done_code = torch.zeros((B,), dtype=torch.uint8, device=dev)
         self._injected = False
         self._flows = None
-        self._bufs, self._buf_i = None, 0
+        self._bufs, self._buf_i, self._ri1 = None, 0, None
         self._rbufs, self._rbuf_i = None, 0      # reset(mask=...) over the pool: its observation / done-code sets
         # during an episode a vehicle that left the map re-enters at its lane's edge (within POOL_EDGE_SPAN m of the entry
         # point, 60 m from the centre: where no ego is), not somewhere along the lane
         self._respawn_rule = _capi.EbRespawn(self._entry5.data_ptr(), CROSSROAD_SIZE / 2 + 40., self.POOL_EDGE_SPAN, EXPECTED_V, 0, 0)
         # a reset spreads the pool over the first 60 m of every lane, clear of the ego (eb_env_reset_pool)
         self._reset_rule = _capi.EbRespawn(self._entry5.data_ptr(), 0.0, 60.0, EXPECTED_V, 0, 0, self.POOL_EDGE_SPAN)
+        if self.auto_reset and (B == 1 or traffic != 'pool'):
+            raise ValueError('auto_reset needs a batch (n_env > 1) over the traffic pool')
+        self._auto_rule = None
+        if self.auto_reset:       # eb_auto_reset: the state arrays are fixed, the counters and final_obs are set per step
+            self._auto_rule = _capi.EbAutoReset(0, 0, 1 if self.mode == 'training' else 0, self._ref_idx.data_ptr(),
+                                                self._virtual.data_ptr(), self._v_light.data_ptr(), self._reset_rule, None)
         if traffic == 'flows':
             from .traffic import FlowTraffic
             self._flows = FlowTraffic(B, dev, None, self.training_task, mode=self.mode, per_route=per_route,
@@ -369,16 +429,23 @@ class CrossroadEnd2end(object):
             self._reset_counter += 2
             if not self._cand.is_contiguous():
                 self._cand = self._cand.contiguous()
-            if self._rbufs is None:
-                self._rbufs = [dict(obs=torch.empty((B, self.obs_dim), dtype=torch.float32, device=dev),
-                                    code=torch.empty((B,), dtype=torch.uint8, device=dev)) for _ in range(2)]
-            self._rbuf_i ^= 1
-            rb = self._rbufs[self._rbuf_i]
-            if rb['obs'].data_ptr() == self._obs.data_ptr():      # two resets in a row: the other set
+            if self.copy_outputs:                                     # arrays of their own, every call
+                rb = dict(obs=torch.empty((B, self.obs_dim), dtype=torch.float32, device=dev),
+                          code=torch.empty((B,), dtype=torch.uint8, device=dev))
+            else:
+                if self._rbufs is None:
+                    self._rbufs = [dict(obs=torch.empty((B, self.obs_dim), dtype=torch.float32, device=dev),
+                                        code=torch.empty((B,), dtype=torch.uint8, device=dev)) for _ in range(2)]
                 self._rbuf_i ^= 1
                 rb = self._rbufs[self._rbuf_i]
+                if rb['obs'].data_ptr() == self._obs.data_ptr():      # two resets in a row: the other set
+                    self._rbuf_i ^= 1
+                    rb = self._rbufs[self._rbuf_i]
             rule = self._reset_rule
             rule.seed, rule.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
+            if self._auto_rule is not None:
+                rule = self._auto_rule.pool                           # (the struct holds its own copy of the pool rule)
+                rule.seed, rule.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
             self.api.env_reset_pool(self._h, self._traffic.h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
                                     C.c_uint64(self._reset_counter - 1), 1 if self.mode == 'training' else 0, _ptr(self._ego),
                                     _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual), _ptr(self._v_light),
@@ -600,18 +667,30 @@ class CrossroadEnd2end(object):
         """done_type strings of the last step for every env of a batch (E2E:208-221)."""
         return [_capi.DONE_NAMES[int(c)] for c in self.done_code.cpu().numpy()]
 
+    def _new_step_set(self):
+        B, dev = self.n_env, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        bufs = dict(act=torch.empty((B, 2), **f32), out5=torch.empty((5, B), **f32),
+                    obs=torch.empty((B, self.obs_dim), **f32), code=torch.empty((B,), dtype=torch.uint8, device=dev))
+        bufs['d16'] = torch.empty((16, B), **f32) if (self._want_d16 or B == 1) else None
+        bufs['final'] = torch.empty((B, self.obs_dim), **f32) if self.auto_reset else None
+        return bufs
+
     def _step_buffers(self):
-        """Two pre-allocated sets of step outputs used in turn: what step() hands out stays valid until the step after
-        the next one, and the step loop itself allocates nothing on the device."""
+        """copy_outputs: a fresh set of output arrays per step (the caching allocator hands the blocks back in microseconds; nothing
+        that was handed out is ever written again).  Otherwise two pre-allocated sets used in turn: what step() hands out stays
+        valid until the step after the next one, and the step loop itself allocates nothing on the device."""
+        if self._ri1 is None:
+            self._ri1 = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        if self.copy_outputs:
+            return self._new_step_set()
         if self._bufs is None:
-            B, dev = self.n_env, self.device
-            f32 = dict(dtype=torch.float32, device=dev)
-            self._bufs = [dict(act=torch.empty((B, 2), **f32), out5=torch.empty((5, B), **f32), d16=torch.empty((16, B), **f32),
-                               obs=torch.empty((B, self.obs_dim), **f32), code=torch.empty((B,), dtype=torch.uint8, device=dev))
-                          for _ in range(2)]
-            self._ri1 = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self._bufs = [self._new_step_set() for _ in range(2)]
         self._buf_i ^= 1
-        return self._bufs[self._buf_i]
+        bufs = self._bufs[self._buf_i]
+        if bufs['d16'] is None and self._want_d16:
+            bufs['d16'] = torch.empty((16, self.n_env), dtype=torch.float32, device=self.device)
+        return bufs
 
     def step(self, action):
         """E2E:132-144 through ONE C-ABI call and — when the candidate tile fits the LDS — ONE kernel launch (eb_env_step,
@@ -622,9 +701,10 @@ class CrossroadEnd2end(object):
         B, dev = self.n_env, self.device
         raw = _unwrap_action(action, B, dev)
         bufs = self._step_buffers()
-        act, out5, d16, obs_out, code = bufs['act'], bufs['out5'], bufs['d16'], bufs['obs'], bufs['code']
+        act, out5, d16, obs_out, code, final = bufs['act'], bufs['out5'], bufs['d16'], bufs['obs'], bufs['code'], bufs['final']
         if obs_out.data_ptr() == self._obs.data_ptr():          # (after a reset wrote into the same buffer)
             self._obs = self._obs.clone()
+        obs_in = self._obs
         ri = self._ref_idx
         if B == 1:
             self._ri1.fill_(int(self.ref_path.ref_index))
@@ -638,10 +718,16 @@ class CrossroadEnd2end(object):
             self._respawn_counter += 1
             rs = self._respawn_rule
             rs.seed, rs.counter = self._respawn_seed, self._respawn_counter
-        self.api.env_step(self._h, self._traffic.h, B, _ptr(self._obs), _ptr(raw), _ptr(ri), 0, _ptr(self._ego),
+        ar = self._auto_rule
+        if ar is not None:     # the envs this step finishes start their next episode in the same launch: the draws reset(mask=done) would make
+            self._reset_counter += 2
+            ar.seed, ar.counter = self._respawn_seed ^ self._RESET_SALT, self._reset_counter - 1
+            ar.pool.seed, ar.pool.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
+            ar.final_obs = final.data_ptr()
+        self.api.env_step(self._h, self._traffic.h, B, _ptr(obs_in), _ptr(raw), _ptr(ri), 0, _ptr(self._ego),
                           _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(lw),
                           _ptr(self._v_light), _ptr(self._virtual), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out),
-                          _ptr(code), C.byref(rs) if rs is not None else None, sp)
+                          _ptr(code), C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None, sp)
         self._obs, self.done_code = obs_out, code
         if self._flows is not None:       # exits, emissions and the light for the NEXT step (the obs saw this step's state)
             self._flows.cand = self._cand
@@ -660,9 +746,24 @@ class CrossroadEnd2end(object):
             self.done_type, done = _capi.DONE_NAMES[c], int(c != 0)                     # E2E:141
         else:
             self.action, self.obs, reward = DevArray(act), DevArray(obs_out), DevArray(out5[0])
-            self.reward_info = _RewardInfo(keys, d16, reward)                           # rows of d16, wrapped on access
+            self.reward_info = _RewardInfo(keys, d16, reward, None if d16 is not None else
+                                           (lambda: self._reward_terms(obs_in, act)))   # rows of d16, wrapped on access
             self.done_type, done = DevArray(code), _LazyDone(code)                      # 0 / 1 per env, computed when read
         all_info = dict(all_vehicles=self.all_vehicles, ego_dynamics=self.ego_dynamics, v_light=self.v_light)
         all_info.update({'reward_info': self.reward_info,
-                         'ref_index': self.ref_path.ref_index if B == 1 else DevArray(self._ref_idx)})   # E2E:143
+                         'ref_index': self.ref_path.ref_index if B == 1 else
+                         DevArray(self._ref_idx.clone() if self.copy_outputs and ar is not None else self._ref_idx)})   # E2E:143
+        if ar is not None:
+            all_info['final_observation'] = DevArray(final)      # the terminal rows of the envs with done != 0
+            self._injected = False
         return self.obs, reward, done, all_info
+
+    def _reward_terms(self, obs_in, act):
+        """The 16 reward terms of a step whose dict was not requested from the kernel (first read): eb_compute_rewards on the
+        observation and the scaled action that step consumed — the same bits; from now on step() asks for them directly."""
+        self._want_d16 = True
+        B = self.n_env
+        out5 = torch.empty((5, B), dtype=torch.float32, device=self.device)
+        d16 = torch.empty((16, B), dtype=torch.float32, device=self.device)
+        self.api.compute_rewards(self._h, B, _ptr(obs_in), _ptr(act), _ptr(out5), _ptr(d16), self._sp())
+        return d16

@@ -73,6 +73,8 @@ def test_vector_env_loop_example_runs():
     assert out['episodes'] > 0 and np.isfinite(out['mean_return']) and out['steps_per_s'] > 0
     again = mod.run(n_env=512, steps=120, task='left', seed=3)
     assert again['episodes'] == out['episodes'] and again['mean_return'] == out['mean_return']      # counter-based draws: reproducible
+    manual = mod.run(n_env=512, steps=120, task='left', seed=3, auto_reset=False, copy_outputs=True)  # step + reset(mask=done): two launches,
+    assert manual['episodes'] == out['episodes'] and manual['mean_return'] == out['mean_return']      # the same episodes
 
 
 def test_binding_refuses_a_library_of_another_abi(monkeypatch):

@@ -603,6 +603,76 @@ def test_crossroad_env_facade_matches_oracle_composition(task, n_env):
             assert np.array_equal(env.done_code.cpu().numpy(), done1)
 
 
+@pytest.mark.parametrize('copy_outputs', [True, False])
+def test_facade_auto_reset_equals_step_then_masked_reset(copy_outputs):
+    """CrossroadEnd2end(auto_reset=True).step == step() followed by reset(mask=done) of an env with the same seed, step for step:
+    observation, reward, done, state; info['final_observation'] holds the terminal rows."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    B, task = 1500, 'left'
+    a = CrossroadEnd2end(task, n_env=B, mode='training', auto_reset=True, copy_outputs=copy_outputs)
+    b = CrossroadEnd2end(task, n_env=B, mode='training', copy_outputs=copy_outputs)
+    for env in (a, b):
+        env.seed(5)
+        env.reset()
+    assert np.array_equal(a.obs.numpy(), b.obs.numpy())
+    rng = np.random.default_rng(1)
+    finished = 0
+    for t in range(40):
+        act = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+        oa, ra, da, ia = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        fin = db.numpy() != 0
+        term = ob.numpy().copy()
+        ob = b.reset(mask=db)
+        assert np.array_equal(da.numpy(), fin.astype(np.uint8)) and np.array_equal(ra.numpy(), rb.numpy())
+        assert np.array_equal(oa.numpy(), ob.numpy()), t
+        assert np.array_equal(ia['final_observation'].numpy()[fin], term[fin])
+        for k in ('_ego', '_params', '_cand', '_ref_idx', '_virtual', '_v_light'):
+            assert np.array_equal(getattr(a, k).cpu().numpy(), getattr(b, k).cpu().numpy()), (t, k)
+        finished += int(fin.sum())
+    assert finished > 20                                                  # episodes did end (and restart) on the way
+    with pytest.raises(ValueError):
+        CrossroadEnd2end(task, n_env=1, auto_reset=True)
+
+
+def test_facade_outputs_are_arrays_of_their_own_by_default():
+    """what step() hands out can be kept (a rollout list, a replay buffer) — three steps later every stored value still
+    holds its own step, `done` and reward_info included when they are first read late; copy_outputs=False is the opt-in
+    two-set scheme whose values live until the step after next."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    B = 300
+    env = CrossroadEnd2end('left', n_env=B, mode='training', auto_reset=True)
+    ref = CrossroadEnd2end('left', n_env=B, mode='training', auto_reset=True)
+    for e in (env, ref):
+        e.seed(9)
+        e.reset()
+    rng = np.random.default_rng(2)
+    kept, want = [], []
+    for t in range(5):
+        act = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+        kept.append(env.step(act))                                        # nothing read yet
+        o, r, d, info = ref.step(act)
+        want.append((o.numpy().copy(), r.numpy().copy(), d.numpy().copy(), info['reward_info']['punish_steer'].numpy().copy(),
+                     info['ref_index'].numpy().copy(), info['final_observation'].numpy().copy()))
+    for (o, r, d, info), w in zip(kept, want):
+        fin = w[2] != 0
+        assert np.array_equal(o.numpy(), w[0]) and np.array_equal(r.numpy(), w[1]) and np.array_equal(d.numpy(), w[2])
+        assert np.array_equal(info['reward_info'].get('punish_steer').numpy(), w[3])      # computed now, from that step's inputs
+        assert np.array_equal(info['ref_index'].numpy(), w[4])
+        assert np.array_equal(info['final_observation'].numpy()[fin], w[5][fin])
+    # the dict behaves like the dict it stands for
+    ri = kept[-1][3]['reward_info']
+    assert ri.get('no_such_term') is None and set(ri.copy()) == set(ri.keys()) and len(ri.copy()) == 17
+    import pickle
+    assert set(pickle.loads(pickle.dumps({k: v.numpy() for k, v in ri.items()}))) == set(ri)
+    assert env._want_d16                                                  # from now on the kernel writes the 16 terms itself
+    o, r, d, info = env.step(np.zeros((B, 2), np.float32))
+    o2, r2, d2, info2 = ref.step(np.zeros((B, 2), np.float32))
+    assert np.array_equal(info['reward_info']['veh2road4real'].numpy(), info2['reward_info']['veh2road4real'].numpy())
+    st = env.init_state
+    assert st.get('ego') is not None and st.get('nothing') is None and list(st.copy()) == ['ego']
+
+
 # ---- fp16 state storage (BASELINE configs[4]) -------------------------------------------------------------
 @pytest.mark.parametrize('tile', [-1, 0, 1, 2])
 @pytest.mark.parametrize('task,N,nf', [('left', 64, 0), ('straight', 9, 0), ('right', 64, 2), ('left', 32, 0)])
