@@ -536,6 +536,37 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     torch.cuda.synchronize()
     api.event_elapsed_ms(ev[0], ev[1], C.byref(ms))
     reset_us = ms.value * 1e3 / n_reset
+    # step AND the reset of the envs it finishes as ONE launch (ABI 4, eb_env_step(auto_reset); env_step_kernel<.., AUTO>): the
+    # self-sustaining loop of a vectorised driver — no state restore between segments, finished envs restart inside the launch
+    restore()
+    final = torch.empty_like(obs[0])
+    ar = _capi.EbAutoReset(4242, 0, 1, env._ref_idx.data_ptr(), env._virtual.data_ptr(), env._v_light.data_ptr(), rrule, final.data_ptr())
+    auto_sets = [a[:-2] + (C.byref(ar), sp) for a in argsets]
+
+    def auto_segment(k):
+        for a in auto_sets:
+            rule.counter = ar.counter = ar.pool.counter = k = k + 1
+            rc = fn(*a)
+            if rc != 0:
+                api.check(rc)
+        return k
+    k = 10000
+    fin_count = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(3):                   # untimed: the loop settles into its steady done rate, which is counted here
+        for a in auto_sets:
+            rule.counter = ar.counter = ar.pool.counter = k = k + 1
+            fn(*a)
+            fin_count += (code != 0).sum()
+    auto_done_rate = float(fin_count.item()) / (3 * seg * B)
+    auto_us = []
+    for r in range(reps):
+        lib.eb_event_record(ev[2 * r], sp)
+        k = auto_segment(k)
+        lib.eb_event_record(ev[2 * r + 1], sp)
+    torch.cuda.synchronize()
+    for r in range(reps):
+        api.event_elapsed_ms(ev[2 * r], ev[2 * r + 1], C.byref(ms))
+        auto_us.append(ms.value * 1e3 / seg)
     for e in ev:
         api.event_destroy(e)
     us = median(seg_us)       # per-step time of the median segment: one host hiccup (a collection, a free) does not move it
@@ -558,7 +589,14 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
             'kernel': 'eb::env_step_kernel<0, %d, false>' % (16 if B <= 6144 else 32 if B <= 24576 else 64),
             'done_fraction_after_segment': done_frac,
             'masked_reset': {'entry': 'eb_env_reset_pool (one launch: eb::env_reset_pool_kernel)', 'mask_fraction': 0.02, 'calls_timed': n_reset,
-                             'us_per_call': reset_us, 'carries_over': 'observation and done-code rows of the other envs (obs_src / done_src)'}}
+                             'us_per_call': reset_us, 'carries_over': 'observation and done-code rows of the other envs (obs_src / done_src)'},
+            'step_with_auto_reset': {'entry': 'eb_env_step(auto_reset) — ONE launch (eb::env_step_kernel<.., AUTO>): the step, the terminal rows '
+                                              'to final_obs and the reset of the envs it finished (draws, pool re-entry, reset observation, flag swap)',
+                                     'us_per_step': median(auto_us), 'us_per_step_min': min(auto_us), 'us_per_step_max': max(auto_us),
+                                     'launches_timed': reps * seg, 'finished_per_step_fraction': auto_done_rate,
+                                     'two_launch_equivalent_us': us + reset_us,
+                                     'value': B / (median(auto_us) * 1e-6), 'unit': 'env-steps/s',
+                                     'frac': roofline_of(alg, median(auto_us))[1]}}
 
 
 def shield_bench(args):
