@@ -342,10 +342,13 @@ def roofline_of(alg_bytes, launch_us):
 
 
 def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, f16=False, lanes=1, use_dist=False,
-                forms=('graph', 'eager'), streams=1):
-    """One more workload through the same protocol (no summary kernels): -> compact result dict."""
+                forms=('graph', 'eager'), streams=1, with_summary=False, tile=None):
+    """One more workload through the same protocol (with_summary: incl. the episodic summary kernels and their gather per
+    horizon, as the headline; tile: eb_debug_set_tile variant for this measurement only): -> compact result dict."""
+    if tile is not None:
+        model.api.debug_set_tile(model.handle, tile)
     shard = Shard(torch, model, n_env, n_veh, seed, f16=f16, lanes=lanes, streams=streams)
-    tm = Timer(torch, dist, use_dist, shard, with_summary=False)
+    tm = Timer(torch, dist, use_dist, shard, with_summary=with_summary)
     tm.run(min(warmup, HORIZON), False)
     torch.cuda.synchronize()
     if 'graph' in forms and 'eager' in forms:
@@ -371,6 +374,11 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
         tpath = os.path.join(ROOT, 'profiles', 'r3_pmc_traffic.json')
         if os.path.isfile(tpath):
             out['traffic'] = (json.load(open(tpath)).get('fp16_x64') or {}).get('hbm_bytes_per_launch')
+    if with_summary:
+        out['protocol'] = 'episodic summary kernels + their gather once per horizon inside the timed region, as the headline'
+    if tile is not None:
+        out['tile_variant'] = tile
+        model.api.debug_set_tile(model.handle, -1)
     tm.close()
     del shard, tm
     torch.cuda.empty_cache()
@@ -789,6 +797,24 @@ def main():
         if rank == 0:
             strong = dict(s, workload='configs[3]: N_env=%d in total, %d per GPU, N_veh=%d, horizon=%d (strong scaling: the total '
                                       'is fixed as N grows)' % (STRONG_TOTAL, per, N_VEH, HORIZON), n_gpus=world, scaling='strong')
+        if world == 1:
+            # north_star's ">= 6x at 8 GPUs" seen from ONE GPU: the per-rank shards of configs[3] at N = 2 / 4 / 8 through the
+            # headline's protocol (summary kernels + gather per horizon included).  Ranks share nothing on the data path, so the
+            # N-GPU time of a step is the time of its slowest shard: t(262144) / t(262144 / N) is what N GPUs give before RCCL's
+            # 32-byte all-gather per horizon (asynchronous, off the launch stream) and rank-to-rank jitter.
+            proj = {}
+            t1 = side_config(torch, dist, m32, STRONG_TOTAL, N_VEH, 1000, side_steps, side_warm, side_rep, with_summary=True)
+            for n in (2, 4, 8):
+                sh = side_config(torch, dist, m32, STRONG_TOTAL // n, N_VEH, 1000, side_steps, side_warm, side_rep, with_summary=True)
+                proj[str(n)] = {'n_env_per_gpu': STRONG_TOTAL // n, 'ms_per_step': sh['ms_per_step'], 'avg_launch_us': sh['avg_launch_us'],
+                                'frac': sh['frac'], 'launch_form': sh['launch_form'],
+                                'projected_speedup': t1['ms_per_step'] / sh['ms_per_step']}
+            strong['projection'] = {'what': 'per-rank shard of configs[3] at N GPUs timed on this one GPU, same protocol as the headline '
+                                            '(episodic summary + gather per horizon inside the timed region)',
+                                    'one_gpu_ms_per_step': t1['ms_per_step'], 'one_gpu_frac': t1['frac'], 'by_n_gpus': proj,
+                                    'projected_speedup_at_8': proj['8']['projected_speedup'], 'target': 6.0,
+                                    'not_included': 'RCCL all-gather of 8 floats per rank and horizon (asynchronous, on RCCL\'s own stream), '
+                                                    'rank-to-rank jitter'}
         if world == 1:
             lanes = 8
             a = side_config(torch, dist, m32, N_ENV, N_VEH, 0, 100, HORIZON, min(args.repeats, 5), lanes=lanes, forms=('eager',))

@@ -286,6 +286,7 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
         pt.y[k] = d_tables + total + off;
         pt.phi[k] = d_tables + 2 * total + off;
         pt.red[k] = d_red_all + red_off[k];
+        pt.phi10[k] = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + phi10_byte_off) + red_off[k];
         pt.len[k] = lens[k];
         pt.red_len[k] = red_len[k];
         off += (size_t)lens[k];

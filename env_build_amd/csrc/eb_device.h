@@ -306,6 +306,7 @@ struct PathTables {
     const float* y[3];
     const float* phi[3];
     const float2* red[3];   // stride-10 (x, y) pairs, red_len[k] entries (DAM:704-706)
+    const float* phi10[3];  // stride-10 headings, indexed like red: the heading of the point the search returns
     int len[3];
     int red_len[3];
     int n_paths;

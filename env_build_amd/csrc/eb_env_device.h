@@ -41,6 +41,33 @@ EB_DEV bool veh_in_range(int task, int m, const V4& v, float ego_x, float ego_y)
     }
 }
 
+// The same filter as data, for a wave-uniform mode: up to four strict bounds on (v.x, v.y) — which ones exist depends on the
+// mode alone (uniform), their values on the ego (per lane).  box_in_range(range_box(task, m, ex, ey), x, y) ==
+// veh_in_range(task, m, {x, y, ..}, ex, ey) for every input, NaN and infinities included: an absent bound is a flag, not an infinity.
+struct RangeBox { bool has_lox, has_hix, has_loy, has_hiy; float lox, hix, loy, hiy; };
+EB_DEV RangeBox range_box(int task, int m, float ego_x, float ego_y) {
+    const float C2 = HALF_CROSS;
+    RangeBox b = {false, false, false, false, 0.0f, 0.0f, 0.0f, 0.0f};
+    switch (m) {
+        case EB_VMODE_DL: b.has_lox = true; b.lox = -C2 - 10.0f; b.has_loy = true; b.loy = ego_y - 2.0f; break;
+        case EB_VMODE_DU: b.has_loy = true; b.loy = ego_y - 2.0f; b.has_hiy = true; b.hiy = C2 + 10.0f; b.has_hix = true; b.hix = ego_x + 5.0f; break;
+        case EB_VMODE_DR: b.has_hix = true; b.hix = C2 + 10.0f; b.has_loy = true; b.loy = ego_y; break;
+        case EB_VMODE_RU: b.has_hix = true; b.hix = C2 + 10.0f; b.has_hiy = true; b.hiy = C2 + 10.0f; break;
+        case EB_VMODE_UR:
+            if (task == TASK_STRAIGHT) { b.has_hix = true; b.hix = ego_x + 7.0f; b.has_loy = true; b.loy = ego_y; b.has_hiy = true; b.hiy = C2 + 10.0f; }
+            else if (task == TASK_RIGHT) { b.has_hix = true; b.hix = C2 + 10.0f; b.has_hiy = true; b.hiy = C2; }
+            break;
+        case EB_VMODE_UD: b.has_loy = true; b.loy = __builtin_fmaxf(ego_y - 2.0f, -C2); b.has_hiy = true; b.hiy = C2; b.has_hix = true; b.hix = ego_x; break;
+        case EB_VMODE_UL: b.has_lox = true; b.lox = -C2 - 10.0f; b.has_hix = true; b.hix = ego_x; b.has_hiy = true; b.hiy = C2; break;
+        case EB_VMODE_LR: b.has_lox = true; b.lox = -C2 - 10.0f; b.has_hix = true; b.hix = C2 + 10.0f; break;
+        default: break;
+    }
+    return b;
+}
+EB_DEV bool box_in_range(const RangeBox& b, float x, float y) {   // (bitwise: no short-circuit branches)
+    return ((!b.has_lox) | (x > b.lox)) & ((!b.has_hix) | (x < b.hix)) & ((!b.has_loy) | (y > b.loy)) & ((!b.has_hiy) | (y < b.hiy));
+}
+
 // sort key of each mode (E2E:414-428): <0 when a sorts before b, 0 when the keys tie
 EB_DEV int veh_cmp(int task, int m, const V4& a, const V4& b) {
 #define EB_ASC(f) do { if (a.f < b.f) return -1; if (a.f > b.f) return 1; } while (0)
@@ -87,7 +114,7 @@ EB_DEV float2 key_of(const KeySpec& k, float x, float y) {
     const float a = k.f1 == 1 ? x : k.f1 == 2 ? y : 0.0f, b = k.f2 == 1 ? x : k.f2 == 2 ? y : 0.0f;
     return make_float2(k.s1 < 0.0f ? -a : a, k.s2 < 0.0f ? -b : b);
 }
-EB_DEV bool key_less(const float2 a, const float2 b) { return a.x < b.x || (!(a.x > b.x) && a.y < b.y); }
+EB_DEV bool key_less(const float2 a, const float2 b) { return (a.x < b.x) | (!(a.x > b.x) & (a.y < b.y)); }
 EB_DEV bool key_before(const float2 a, int ia, const float2 b, int ib) {
     const bool lt1 = a.x < b.x, gt1 = a.x > b.x, lt2 = a.y < b.y, gt2 = a.y > b.y;
     return lt1 || (!gt1 && (lt2 || (!gt2 && ia < ib)));

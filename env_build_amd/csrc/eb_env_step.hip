@@ -79,8 +79,8 @@ bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float
            al(cand, 16) && al(ego, 8) && al(actions, 8) && al(scaled, 8) && al(params, 16);
 }
 
-// profiling aid (eb_debug_set_trace on the model handle): slot k of this wave's row [8] <- the 100 MHz wall clock, lane 0 only
-#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)
+// profiling aid (eb_debug_set_trace on the model handle): slot k of this wave's row [16] <- the 100 MHz wall clock, lane 0 only
+#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
 
 // A per-wave queue of 16-bit item ids: `hit` lanes append (ballot / mbcnt), and whenever 64 are waiting the wave runs
 // `body(item)` on a full set of lanes; flush() runs the rest.
@@ -113,6 +113,50 @@ struct WaveQueue {
     EB_DEV void flush() { if (n > 0) run(n); }
 };
 
+// The first two of a candidate set under (key, insertion index) for ONE mode known at compile time (E2E:393-437): the mode's range
+// filter and sort key fold to the two or three comparisons they are (veh_in_range / key_of with constant arguments), the running
+// pair is kept as (key, index) and updated by selects — straight-line code, one round per set bit of the wave's largest set; only
+// (x, y) of a candidate is read in the loop, the winners' records at the end.  The first version re-ran the mode switch and a nest
+// of divergent branches per candidate (~850 cycles each); a data-driven straight-line version still spent ~75 instructions on
+// flags and selects per candidate.  `crow`: this lane's candidate row in LDS; virt: the stop-line car exists for this env.
+template <int TASK, int MODE>
+EB_DEV void slot_pair_walk(const float4* crow, unsigned long long elig, float ex, float ey, bool virt, int m_cand, float* ov, int sa, int sb) {
+    const KeySpec ks = key_spec(TASK, MODE);
+    const V4 fill = veh_fill_value(MODE);
+    float2 k1 = make_float2(0.0f, 0.0f), k2 = k1;
+    int i1 = -1, i2 = -1;
+    // candidates arrive in ascending index: c sorts before an earlier one only with a strictly smaller key
+    auto offer = [&](const bool valid, const float2 kk, const int c) {
+        const bool first = valid & ((i1 < 0) | key_less(kk, k1));
+        const bool second = valid & !first & ((i2 < 0) | key_less(kk, k2));
+        k2.x = first ? k1.x : (second ? kk.x : k2.x); k2.y = first ? k1.y : (second ? kk.y : k2.y);
+        i2 = first ? i1 : (second ? c : i2);
+        k1.x = first ? kk.x : k1.x; k1.y = first ? kk.y : k1.y;
+        i1 = first ? c : i1;
+    };
+    const float2* cxy = reinterpret_cast<const float2*>(crow);           // (x, y) of candidate c at cxy[2 * c]
+    bool has = elig != 0ull;
+    int c = has ? __builtin_ctzll(elig) : 0;
+    elig &= elig - 1ull;
+    while (__builtin_amdgcn_ballot_w64(has)) {
+        const float2 q = cxy[2 * c];
+        const bool hq = has;
+        const int cq = c;
+        has = elig != 0ull;
+        c = has ? __builtin_ctzll(elig) : 0;
+        elig &= elig - 1ull;
+        offer(hq & veh_in_range(TASK, MODE, V4{q.x, q.y, 0.0f, 0.0f}, ex, ey), key_of(ks, q.x, q.y), cq);
+    }
+    const float4 vv4 = make_float4(MODE == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f);
+    if (MODE == EB_VMODE_DL || MODE == EB_VMODE_DU)                      // the stop-line car (E2E:386-390), index m_cand: after every real one
+        offer(virt & veh_in_range(TASK, MODE, V4{vv4.x, vv4.y, 0.0f, 90.0f}, ex, ey), key_of(ks, vv4.x, vv4.y), m_cand);
+    const float4 fill4 = make_float4(fill.x, fill.y, fill.v, fill.phi);   // slice_or_fill, E2E:431-437
+    const float4 q1 = crow[i1 < 0 || i1 >= m_cand ? 0 : i1], q2 = crow[i2 < 0 || i2 >= m_cand ? 0 : i2];
+    const float4 r1 = i1 < 0 ? fill4 : (i1 >= m_cand ? vv4 : q1), r2 = i2 < 0 ? fill4 : (i2 >= m_cand ? vv4 : q2);
+    *reinterpret_cast<f4a4*>(ov + 4 * sa) = f4a4{r1.x, r1.y, r1.z, r1.w};
+    if (sb >= 0) *reinterpret_cast<f4a4*>(ov + 4 * sb) = f4a4{r2.x, r2.y, r2.z, r2.w};
+}
+
 // ET: envs per tile (64 or 16); lanes >= ET of the per-env roles idle.  OBS: the observation alone (eb_get_obs on an ego and
 // candidates given as they are: no action, reward, ego step, traffic step, collision test or done code — phases 1-4 shrink to
 // staging, tracking, slots and the row store; the arithmetic of what remains is the same code).
@@ -125,7 +169,7 @@ struct WaveQueue {
 template <int TASK, int ET, bool OBS, bool RESET, bool AUTO = false>
 EB_DEV void env_step_body(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_fin[ET];
+    __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_jb[ET];
     __shared__ float s_miu[ET];                                                  // miu_r of the step (the stability predicate's input)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * ET;
     const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
@@ -178,15 +222,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             cv[g][k] = make_float4(0, 0, 0, 0); cm[g][k] = EB_VMODE_EMPTY;
             if (idx >= 0 && idx < n_rec) { cv[g][k] = csrc[idx]; cm[g][k] = msrc[idx]; }
         }
-    // (waves 1-3) the first batch of compute_rewards' (env, old slot) pairs: their (x, y) are needed in phase 2 only
-    const int n_pairs = nE * NV, pt_ = tid - 64;
+    // (wave 1) the first batch of compute_rewards' (env, old slot) pairs: their (x, y) are needed in phase 2 only.  Phase 2's two
+    // pair-parallel passes have one owner each — wave 1 the reward pairs, waves 2 and 3 the collision test — so that a wave pays
+    // for ONE queue flush (a serial chain of ~250 instructions behind a sin / cos), not two
+    const int n_pairs = nE * NV, pt_ = lane, ct_ = tid - 128;
     float2 pxy[4];
     auto load_pairs = [&](int base) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int p = base + pt_ + 192 * k;
+            const int p = base + pt_ + 64 * k;
             pxy[k] = make_float2(1e30f, 1e30f);                                  // (past the end: never near)
-            if (!OBS && wave > 0 && p < n_pairs) {
+            if (!OBS && wave == 1 && p < n_pairs) {
                 const int e = fast_div(p, A.nv_magic), j = p - e * NV;
                 const f2a4 q = *reinterpret_cast<const f2a4*>(A.obs + (size_t)D * (e0 + e) + 6 + T + 4 * j);
                 pxy[k] = make_float2(q.x, q.y);
@@ -196,6 +242,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     load_pairs(0);
     const int slot_mode = lane < NV ? A.modes.mode[lane] : 0xff;                        // lane = slot
     const bool red_light = !RESET && live && A.v_light && A.v_light[i] != 0;   // (a reset clears v_light before its observation)
+    // (wave 0) the env's path id now: the tracking chain of phase 2 starts with it
+    const int path_pre = (!RESET && wave == 0 && live) ? row_path(A.pt, A.ref_idx, A.path_id, i) : -1;
     const bool vflag = live && A.virtual_flag && A.virtual_flag[i] != 0;
     const bool light = red_light || vflag;                                      // E2E:387-388
     float nx[6] = {0, 0, 0, 0, 0, 0};                                        // wave 0
@@ -302,7 +350,19 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             } else if (OBS) s_cand[e * RS4 + c] = v;
             else {
                 const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs);
-                s_cand[e * RS4 + c] = make_float4(r.x, r.y, r.z, r.w);
+                float4 o = make_float4(r.x, r.y, r.z, r.w);
+                s_cand[e * RS4 + c] = o;
+                // the record goes back to HBM right here, from the lane that loaded it, with the pool's re-entry rule on the way
+                // (eb_traffic_respawn: it applies AFTER the observation and the done code saw this step's state — both read the LDS
+                // copy above).  It used to leave from LDS in phase 2, 16 KB through one wave that had the tracking chain to do.
+                if (A.respawn_entry && (__builtin_fabsf(o.x) > A.limit || __builtin_fabsf(o.y) > A.limit)) {
+                    const uint64_t ub = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
+                    const float u1 = u01(A.seed, ub), u2 = u01(A.seed, ub + 1);
+                    const float* en = A.respawn_entry + 5 * c;
+                    const float along = u1 * A.span;
+                    o = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
+                }
+                reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;
             }
             s_tag[e * TS4 * 4 + c] = (uint8_t)mode;
         };
@@ -328,6 +388,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     }
     ES_MARK(1);
     __syncthreads();   // barrier: s_ego, s_pts, s_oldc, s_cand, mode bytes
+    ES_MARK(8);
 
     // ---- phase 2 ---------------------------------------------------------------------------------------------
     float delta_y = 0.0f;
@@ -342,30 +403,36 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             if (p < 0) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }
             else {
                 const float2* red = pt.red[p];
+                const float* ph10 = pt.phi10[p];
                 const float fx = (ex - pt.gx0) * CELL_INV, fy = (ey - pt.gy0) * CELL_INV;
                 int bi = 0;
+                // the table point itself comes out of the scan — stride-10 entry bi IS path point 10 * bi (x, y, heading): no
+                // third dependent round trip to the full-resolution tables (the rollout kernel's closest_cell_index does the same)
+                float rx, ry, rphi;
                 if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) {
                     const unsigned cw = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
                     const int lo = (int)(cw & 0xffffu), hi = (int)(cw >> 16);
                     float best = __builtin_inff();
+                    rx = red[0].x; ry = red[0].y; rphi = ph10[0];   // index 0 unless a distance compares below +inf, as in the full scan
                     for (int r = lo; r <= hi; r += 4) {        // same order, same strict '<' as the full scan: same index
                         typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
                         const f4a8 q01 = *reinterpret_cast<const f4a8*>(red + r), q23 = *reinterpret_cast<const f4a8*>(red + r + 2);
+                        const f4a4 h = *reinterpret_cast<const f4a4*>(ph10 + r);
                         const float d0 = sq(ex - q01.x) + sq(ey - q01.y), d1 = sq(ex - q01.z) + sq(ey - q01.w);
                         const float d2 = sq(ex - q23.x) + sq(ey - q23.y), d3 = sq(ex - q23.z) + sq(ey - q23.w);
-                        if (d0 < best) { best = d0; bi = r; }
-                        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; }
-                        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; }
-                        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; }
+                        if (d0 < best) { best = d0; bi = r; rx = q01.x; ry = q01.y; rphi = h.x; }
+                        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; rx = q01.z; ry = q01.w; rphi = h.y; }
+                        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; rx = q23.x; ry = q23.y; rphi = h.z; }
+                        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; rx = q23.z; ry = q23.w; rphi = h.w; }
                     }
                 } else {
                     bi = closest_reduced_index(red, pt.rad + 32 * p, pt.red_len[p], ex, ey);
+                    rx = red[bi].x; ry = red[bi].y; rphi = ph10[bi];
                 }
                 const int idx = bi * 10, len = pt.len[p];
-                const int ci = clamp_index(idx, len);
-                delta_y = two2one<TASK>(ex, ey, pt.x[p][ci], pt.y[p][ci]);
+                delta_y = two2one<TASK>(ex, ey, rx, ry);
                 orow[6] = delta_y;
-                orow[7] = deal_with_phi_diff(nx[5] - pt.phi[p][ci]);
+                orow[7] = deal_with_phi_diff(nx[5] - rphi);
                 orow[8] = nx[0] - EXP_V;
                 int cur = idx;
                 for (int k = 0; k < n_future; ++k) {
@@ -380,43 +447,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         }
     };
     if (wave == 0) {
-        if (live) track_row(RESET ? reset_path : row_path(A.pt, A.ref_idx, A.path_id, i));
+        if (live) track_row(RESET ? reset_path : path_pre);
+        ES_MARK(9);
         if (!OBS && live) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1), and
             // behind the tracking's dependent table reads rather than in front of them
             float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
             ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
             if (A.scaled) reinterpret_cast<float2*>(A.scaled)[i] = make_float2(steer, a_x);
         }
-        // candidates out (they are final since the barrier), the pool's re-entry rule on the way (eb_traffic_respawn: it
-        // applies after the observation and the done code saw this step's state — both read the LDS copy); this wave
-        // would otherwise idle here while the others test pairs
-        float4* cdst = reinterpret_cast<float4*>(A.cand) + (size_t)e0 * m_cand;
-        for (int base = lane; !OBS && base < n_rec; base += 256) {
-            float4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = base + 64 * k < n_rec ? base + 64 * k : 0;
-                const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
-                v[k] = s_cand[e * RS4 + c];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = base + 64 * k;
-                if (idx >= n_rec) continue;
-                if (A.respawn_entry && (__builtin_fabsf(v[k].x) > A.limit || __builtin_fabsf(v[k].y) > A.limit)) {
-                    const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
-                    const uint64_t ub = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
-                    const float u1 = u01(A.seed, ub), u2 = u01(A.seed, ub + 1);
-                    const float* en = A.respawn_entry + 5 * c;
-                    const float along = u1 * A.span;
-                    v[k] = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
-                }
-                cdst[idx] = v[k];
-            }
-        }
     } else if (!OBS) {
         unsigned short* myq = s_queue + wave * ES_QCAP;
-        {   // compute_rewards' vehicle loop on the CURRENT observation (DAM:218-229), one lane per (env, slot).  A circle pair
+        if (wave == 1) {   // compute_rewards' vehicle loop on the CURRENT observation (DAM:218-229), one lane per (env, slot).  A circle pair
             // can only be closer than 3.5 m when the two centres are within 3.5 + 2 * 1.4 = 6.3 m: pairs inside 6.364 m
             // (slack >> fp32 rounding; the rollout kernel's test) are queued, every other pair contributes exact zeros.
             auto body = [&](int item) {
@@ -428,11 +469,11 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 s_part[e * NV + j] = make_float2(((t35[0] + t35[1]) + t35[2]) + t35[3], ((t25[0] + t25[1]) + t25[2]) + t25[3]);
             };
             WaveQueue<decltype(body)> Q{myq, 0, body};
-            for (int base = 0; base < n_pairs; base += 192 * 4) {              // four pairs per lane per batch
+            for (int base = 0; base < n_pairs; base += 64 * 4) {               // four pairs per lane per batch
                 if (base > 0) load_pairs(base);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int p = base + pt_ + 192 * k;
+                    const int p = base + pt_ + 64 * k;
                     const bool valid = p < n_pairs;
                     const int e = valid ? fast_div(p, A.nv_magic) : 0, j = valid ? p - e * NV : 0;
                     const float2 c = s_oldc[e];
@@ -445,7 +486,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             Q.flush();
         }
         ES_MARK(5);
-        {   // one lane per (env, candidate): the collision test (TRF:263-295), its 10 m box first
+        if (wave >= 2) {   // one lane per (env, candidate): the collision test (TRF:263-295), its 10 m box first
             auto body = [&](int item) {
                 const int e = item >> 6, c = item & 63;
                 const float4 eg = s_ego[e];
@@ -456,12 +497,12 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     s_col[e] = 1;
             };
             WaveQueue<decltype(body)> Q{myq, 0, body};
-            for (int base = 0; base < n_rec; base += 192 * 3) {                // three records per lane in flight
-                float2 v3[3], eg3[3];
-                int m3[3], e3[3], c3[3];
+            for (int base = 0; base < n_rec; base += 128 * 4) {                // four records per lane in flight
+                float2 v3[4], eg3[4];
+                int m3[4], e3[4], c3[4];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int idx = base + pt_ + 192 * k;
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = base + ct_ + 128 * k;
                     e3[k] = 0; c3[k] = 0;
                     if (idx < n_rec) { e3[k] = fast_div(idx, A.m_magic); c3[k] = idx - e3[k] * m_cand; }
                     v3[k] = *reinterpret_cast<const float2*>(s_cand + e3[k] * RS4 + c3[k]);
@@ -469,8 +510,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     m3[k] = s_tag[e3[k] * TS4 * 4 + c3[k]];
                 }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const bool box = base + pt_ + 192 * k < n_rec && m3[k] != EB_VMODE_EMPTY &&
+                for (int k = 0; k < 4; ++k) {
+                    const bool box = base + ct_ + 128 * k < n_rec && m3[k] != EB_VMODE_EMPTY &&
                                      __builtin_fabsf(v3[k].x - eg3[k].x) < 10.0f && __builtin_fabsf(v3[k].y - eg3[k].y) < 10.0f;
                     Q.push(box, e3[k] * 64 + c3[k]);
                 }
@@ -479,45 +520,11 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         }
     }
     ES_MARK(2);
-    __syncthreads();   // barrier: s_part, tags, s_col, the row heads
-
-    // ---- phase 3 ---------------------------------------------------------------------------------------------
-    if (!OBS && wave == 1 && live) {
-        // E2E:134: the reward of the step taken from the CURRENT observation; penalty partials in vehicle order
-        float v2v_train = 0.0f, v2v_real = 0.0f;
-        for (int j = 0; j < NV; ++j) {
-            const float2 q = s_part[lane * NV + j];
-            v2v_train += q.x;
-            v2v_real += q.y;
-        }
-        const float punish_steer = -sq(steer), punish_a_x = -sq(a_x), punish_yaw_rate = -sq(o9[2]);
-        const float devi_y = -sq(o9[6]), devi_phi = -sq(deg2rad(o9[7])), devi_v = -sq(o9[8]);
-        const float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
-                              5.0f * punish_steer + 0.05f * punish_a_x;
-        const size_t n = (size_t)n_env;
-        float* out5 = A.out5;
-        out5[i] = rewards;
-        out5[n + i] = v2v_train + road_t;
-        out5[2 * n + i] = v2v_real + road_r;
-        out5[3 * n + i] = v2v_real;
-        out5[4 * n + i] = road_r;
-        if (float* d16 = A.d16) {   // DAM:302-318
-            d16[i] = punish_steer; d16[n + i] = punish_a_x; d16[2 * n + i] = punish_yaw_rate;
-            d16[3 * n + i] = devi_v; d16[4 * n + i] = devi_y; d16[5 * n + i] = devi_phi;
-            d16[6 * n + i] = 5.0f * punish_steer; d16[7 * n + i] = 0.05f * punish_a_x;
-            d16[8 * n + i] = 0.02f * punish_yaw_rate; d16[9 * n + i] = 0.05f * devi_v;
-            d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
-            d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
-        }
-    }
-    if (!OBS && wave == 0) {   // E2E:200-221: the predicates that need only the new ego state (E2E:223-256), then the priority chain
-        uint8_t code = EB_DONE_NOT_YET;
-        if (live) {
-            code = judge_merge(judge_bits(TASK, nx[0], nx[2], nx[3], nx[4], nx[5], s_miu[lane], red_light), s_col[lane] != 0, delta_y);
-            A.done_code[i] = code;
-        }
-        if (AUTO && lane < ET) s_fin[lane] = code != EB_DONE_NOT_YET;
-    }
+    // (no barrier here any more: the slots below need the ego, the candidates and the mode bytes — final since barrier 1 — so a wave
+    // walks its modes as soon as its own pair / collision / tracking work is done; what DOES depend on the other waves' phase-2
+    // results — the penalty sums, the done code — runs behind the one barrier that also completes the rows)
+    if (!OBS && wave == 0 && lane < ET)   // the done predicates that need only the new ego state (E2E:223-256): a byte for the merge below
+        s_jb[lane] = live ? (uint8_t)judge_bits(TASK, nx[0], nx[2], nx[3], nx[4], nx[5], s_miu[lane], red_light) : (uint8_t)0xff;
     ES_MARK(6);
     // E2E:340-464 for the lanes with `on` (lane = env): the vehicle slots of this wave's modes -> s_out
     auto fill_slots = [&](const bool on, const bool light_on) {
@@ -540,7 +547,6 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             const int m = __builtin_amdgcn_readlane(slot_mode, s);
             unsigned long long slots = __builtin_amdgcn_ballot_w64(slot_mode == m);   // the mode's slots, ascending
             if (!on) continue;
-            const KeySpec ks = key_spec(TASK, m);
             // the env's candidates of this mode as a bit set (mode byte == m), 4 bytes per dword; the range filter of
             // E2E:393-411 is applied in the walk below, where the mode is wave-uniform
             unsigned long long elig = 0ull;
@@ -551,6 +557,23 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 const unsigned nib = (((z >> 7) * 0x01020408u) >> 24) & 0xfu;
                 elig |= (unsigned long long)nib << (4 * w);
             }
+            ES_MARK(7);
+            if (__popcll(slots) <= 2) {
+                // the usual case (the native lists have at most two slots per mode, VEHICLE_MODE_DICT UTL:21-23)
+                const int sa = __builtin_ctzll(slots);
+                slots &= slots - 1ull;
+                const int sb = slots ? __builtin_ctzll(slots) : -1;
+                switch (m) {   // (wave-uniform: one scalar jump per mode, not per candidate)
+#define EB_SLOT_CASE(M) case M: slot_pair_walk<TASK, M>(crow, elig, ex, ey, virt, m_cand, ov, sa, sb); break
+                    EB_SLOT_CASE(EB_VMODE_DL); EB_SLOT_CASE(EB_VMODE_DU); EB_SLOT_CASE(EB_VMODE_DR); EB_SLOT_CASE(EB_VMODE_RU);
+                    EB_SLOT_CASE(EB_VMODE_UR); EB_SLOT_CASE(EB_VMODE_UD); EB_SLOT_CASE(EB_VMODE_UL); EB_SLOT_CASE(EB_VMODE_LR);
+#undef EB_SLOT_CASE
+                    default: slot_pair_walk<TASK, EB_VMODE_RD>(crow, elig, ex, ey, virt, m_cand, ov, sa, sb); break;   // rd rl lu ld: no filter, no key, zero fill
+                }
+                ES_MARK(12);
+                continue;
+            }
+            const KeySpec ks = key_spec(TASK, m);
             // the virtual red-light car of the mode (E2E:386-390), candidate index m_cand
             const V4 vv = {m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f};
             const bool has_virt = virt && (m == EB_VMODE_DL || m == EB_VMODE_DU) && veh_in_range(TASK, m, vv, ex, ey);
@@ -558,40 +581,6 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             const V4 fill = veh_fill_value(m);
             const float4 fill4 = make_float4(fill.x, fill.y, fill.v, fill.phi);   // slice_or_fill, E2E:431-437
             const float4 vv4 = make_float4(vv.x, vv.y, vv.v, vv.phi);
-            if (__popcll(slots) <= 2) {
-                // the usual case (the native lists have at most two slots per mode, VEHICLE_MODE_DICT UTL:21-23): the first
-                // two of the candidate set under (key, insertion index) in ONE walk, each record read once
-                float2 k1 = make_float2(0.0f, 0.0f), k2 = k1;
-                float4 r1 = fill4, r2 = fill4;
-                int i1 = -1, i2 = -1;
-                unsigned long long rest = elig;
-                float4 nxt = make_float4(0, 0, 0, 0);
-                int nc = -1;
-                if (rest) { nc = __builtin_ctzll(rest); rest &= rest - 1ull; nxt = crow[nc]; }
-                while (nc >= 0) {
-                    const float4 q = nxt;
-                    const int c = nc;
-                    nc = -1;
-                    if (rest) { nc = __builtin_ctzll(rest); rest &= rest - 1ull; nxt = crow[nc]; }   // the next read under this compare
-                    if (!veh_in_range(TASK, m, V4{q.x, q.y, q.z, q.w}, ex, ey)) continue;
-                    const float2 kk = key_of(ks, q.x, q.y);
-                    // candidates arrive in ascending index: c sorts before an earlier one only with a strictly smaller key
-                    if (i1 < 0 || key_less(kk, k1)) { k2 = k1; r2 = r1; i2 = i1; k1 = kk; r1 = q; i1 = c; }
-                    else if (i2 < 0 || key_less(kk, k2)) { k2 = kk; r2 = q; i2 = c; }
-                }
-                if (has_virt) {                                                    // index m_cand: after every real candidate
-                    if (i1 < 0 || key_less(vk, k1)) { k2 = k1; r2 = r1; i2 = i1; k1 = vk; r1 = vv4; i1 = m_cand; }
-                    else if (i2 < 0 || key_less(vk, k2)) { k2 = vk; r2 = vv4; i2 = m_cand; }
-                }
-                const int sa = __builtin_ctzll(slots);
-                *reinterpret_cast<f4a4*>(ov + 4 * sa) = f4a4{r1.x, r1.y, r1.z, r1.w};
-                slots &= slots - 1ull;
-                if (slots) {
-                    const int sb = __builtin_ctzll(slots);
-                    *reinterpret_cast<f4a4*>(ov + 4 * sb) = f4a4{r2.x, r2.y, r2.z, r2.w};
-                }
-                continue;
-            }
             {   // more than two slots of one mode: the range filter first, then one selection pass per slot
                 unsigned long long in = 0ull, rest = elig;
                 while (rest) {
@@ -639,7 +628,45 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     };
     fill_slots(live, light);
     ES_MARK(3);
-    __syncthreads();   // barrier: s_out complete, s_fin
+    __syncthreads();   // barrier: s_out complete; s_part, s_col, s_jb
+    ES_MARK(10);
+    if (!OBS && wave == 1 && live) {
+        // E2E:134: the reward of the step taken from the CURRENT observation; penalty partials in vehicle order
+        float v2v_train = 0.0f, v2v_real = 0.0f;
+        for (int j = 0; j < NV; ++j) {
+            const float2 q = s_part[lane * NV + j];
+            v2v_train += q.x;
+            v2v_real += q.y;
+        }
+        const float punish_steer = -sq(steer), punish_a_x = -sq(a_x), punish_yaw_rate = -sq(o9[2]);
+        const float devi_y = -sq(o9[6]), devi_phi = -sq(deg2rad(o9[7])), devi_v = -sq(o9[8]);
+        const float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                              5.0f * punish_steer + 0.05f * punish_a_x;
+        const size_t n = (size_t)n_env;
+        float* out5 = A.out5;
+        out5[i] = rewards;
+        out5[n + i] = v2v_train + road_t;
+        out5[2 * n + i] = v2v_real + road_r;
+        out5[3 * n + i] = v2v_real;
+        out5[4 * n + i] = road_r;
+        if (float* d16 = A.d16) {   // DAM:302-318
+            d16[i] = punish_steer; d16[n + i] = punish_a_x; d16[2 * n + i] = punish_yaw_rate;
+            d16[3 * n + i] = devi_v; d16[4 * n + i] = devi_y; d16[5 * n + i] = devi_phi;
+            d16[6 * n + i] = 5.0f * punish_steer; d16[7 * n + i] = 0.05f * punish_a_x;
+            d16[8 * n + i] = 0.02f * punish_yaw_rate; d16[9 * n + i] = 0.05f * devi_v;
+            d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
+            d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
+        }
+    }
+    // E2E:200-221, the priority chain: every wave merges the tile's done codes for itself (lane = env: a byte, a flag and delta_y
+    // from LDS, a dozen instructions) — the finished rows as a wave-uniform bit mask, no further barrier before the rows leave
+    unsigned long long finmask = 0ull;
+    if (!OBS) {
+        uint8_t code = EB_DONE_NOT_YET;
+        if (lane < ET && s_jb[lane] != 0xff) code = judge_merge(s_jb[lane], s_col[lane] != 0, s_out[lane * OS + 6]);
+        if (wave == 0 && live) A.done_code[i] = code;
+        finmask = __builtin_amdgcn_ballot_w64(code != EB_DONE_NOT_YET);
+    }
 
     // ---- phase 4 ---------------------------------------------------------------------------------------------
     if (RESET && wave == 0 && live) A.virtual_out[i] = virtual_next ? 1 : 0;   // every wave read the old flag before the barriers above
@@ -663,7 +690,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 const int idx = base + 256 * k;
                 if (idx >= total) continue;
                 if (AUTO && which) {
-                    const bool fin_row = s_fin[fast_div(idx, A.d_magic)] != 0;
+                    const bool fin_row = (finmask >> fast_div(idx, A.d_magic)) & 1ull;
                     if (which == 2) { if (fin_row) dst[idx] = v[k]; }
                     else if (!fin_row) dst[idx] = v[k];
                     else if (A.final_obs) A.final_obs[(size_t)e0 * D + idx] = v[k];
@@ -678,24 +705,29 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     ES_MARK(4);
     if (AUTO) {
         // ---- the envs this step finished start their next episode (E2E:99-127) — eb_env_reset_pool's arithmetic on those rows ----
-        const bool fin = lane < nE && s_fin[lane] != 0;                          // the same in every wave (barrier 3)
-        if (__builtin_amdgcn_ballot_w64(fin) == 0ull) return;                    // nobody in this tile: the usual case per row, not per tile
+        const bool fin = (finmask >> lane) & 1ull;                               // the same in every wave
+        if (finmask == 0ull) return;                                             // nobody in this tile: the usual case per row, not per tile
         // this thread's stores of the step (ego, params, candidates, rows) are complete before ANOTHER thread overwrites them below,
         // and everybody's reads of s_out / s_ego / s_cand are over
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        ES_MARK(11);
         if (wave == 0 && fin) draw_reset();                                      // E2E:100-101, 110-113
         __syncthreads();   // the pool's re-entry stays clear of the NEW ego
+        ES_MARK(12);
         for (int idx = tid; idx < n_rec; idx += 256) {                           // E2E:102-103 (init_traffic, TRF:151-195)
             const int e = fast_div(idx, A.m_magic);
-            if (s_fin[e]) respawn_fresh(e, idx - e * m_cand);
+            if ((finmask >> e) & 1ull) respawn_fresh(e, idx - e * m_cand);
         }
+        ES_MARK(13);
         __syncthreads();
         if (wave == 0 && fin) track_row(reset_path);                             // E2E:116: the reset observation, OLD virtual flag,
         fill_slots(fin, vflag);                                                  // v_light already cleared
+        ES_MARK(14);
         __syncthreads();
         store_rows(2);
         if (wave == 0 && fin) A.virtual_out[i] = virtual_next ? 1 : 0;           // E2E:120-126
+        ES_MARK(15);
     }
 }
 

@@ -475,7 +475,7 @@ int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const u
  * eb_debug_set_tile: force the rollout kernel's tile shape — 0: 2048-record tiles, 1: 1024, 2: 256; -1: by batch size
  * (every shape computes the same bits); the one-launch eb_env_step takes 64- / 32- / 16-env tiles for 0 / 1 / 2 and
  * picks by batch size otherwise.  eb_debug_set_tape_stepwise: 1 = eb_rollout_tape[_f16] as `horizon` per-step
- * launches, 0 = the one-launch tape kernel.  eb_debug_set_trace: device buffer [n_waves][8] int64 the rollout kernel
+ * launches, 0 = the one-launch tape kernel.  eb_debug_set_trace: device buffer [n_waves][8] int64 the rollout kernel ([n_blocks * 4][16] for the one-launch env step)
  * fills with wall-clock marks (NULL = off).  The oracle accepts and ignores all three. */
 int eb_debug_set_tile(eb_handle h, int32_t variant);
 int eb_debug_set_tape_stepwise(eb_handle h, int32_t on);

@@ -6,10 +6,10 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from env_build_amd import _capi
 from env_build_amd.endtoend import CrossroadEnd2end
-ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16)
+ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16); ap.add_argument('--auto', action='store_true')
 a = ap.parse_args()
 B = a.n_env
-env = CrossroadEnd2end('left', n_env=B, multi_display=True, traffic='pool', n_cand=a.n_cand)
+env = CrossroadEnd2end('left', n_env=B, multi_display=True, traffic='pool', n_cand=a.n_cand, auto_reset=a.auto, copy_outputs=False)
 env.seed(0); env.reset()
 act = (torch.rand((B, 2), device=env.device) * 0.6 - 0.3).contiguous()
 lib = env.api.lib
@@ -18,24 +18,29 @@ for _ in range(3): env.step(act)
 torch.cuda.synchronize()
 te = 16 if B <= 6144 else 32 if B <= 24576 else 64
 nb = (B + te - 1) // te
-trs = [torch.zeros((nb * 4, 8), dtype=torch.int64, device=env.device) for _ in range(3)]
+trs = [torch.zeros((nb * 4, 16), dtype=torch.int64, device=env.device) for _ in range(3)]
 for k in range(3):
     lib.eb_debug_set_trace(env._h, C.c_void_p(trs[k].data_ptr())); env.step(act)
 torch.cuda.synchronize(); lib.eb_debug_set_trace(env._h, None)
 sp = []
 for x in trs:
-    x = x.cpu().numpy(); sp.append((x[:, 0].min(), x[:, 4].max()))
+    x = x.cpu().numpy(); sp.append((x[:, 0].min(), max(x[:, 4].max(), x[:, 15].max())))
 for k in (1, 2):
     print('launch %d: first wave start .. last wave end %.2f us; dead time since the previous launch %.2f us' % (k, (sp[k][1] - sp[k][0]) / 100., (sp[k][0] - sp[k - 1][1]) / 100.))
 t = trs[1].cpu().numpy().astype(np.float64); t = (t - t[:, 0].min()) / 100.0
-# marks: 0 start | 1 phase 1 done | 5 (waves 1-3) reward pairs done | 2 phase 2 done | 6 (after the barrier; wave 1: sums + done predicates) | 3 phase 3 done | 4 end
-order = [(0, 'start'), (1, 'phase 1 done: ego step / tyre params / traffic step (before barrier 1)'), (5, 'phase 2a: reward pairs done (waves 1-3)'),
-         (2, 'phase 2 done: tracking | tags + collision (before barrier 2)'), (6, 'after barrier 2 (wave 1: + penalty sums, done predicates)'),
-         (7, 'phase 3: candidate set of the (last) owned mode built'), (3, 'phase 3 done: slots built (before barrier 3)'), (4, 'end: done code, rows and candidates stored')]
-def q(x): return ' '.join('%6.2f' % v for v in np.percentile(x, [0, 10, 50, 90, 100]))
+# marks (this wave's lane 0): see `order`
+order = [(0, 'start'), (1, 'phase 1 done: ego step / tyre params / traffic step (before barrier 1)'), (8, 'after barrier 1'),
+         (9, 'wave 0: closest point + tracking done (before the candidate store)'), (5, 'phase 2a: reward pairs done (waves 1-3)'),
+         (2, 'phase 2 done: tracking + cand store | pairs + collision (before barrier 2)'), (6, 'after barrier 2 + sums (wave 1) / done code (wave 0)'),
+         (7, 'phase 3: candidate set built (last owned mode)'), (11, 'phase 3: walk done (no --auto)'), (12, 'phase 3: slots written (no --auto)'), (3, 'phase 3 done: slots built (before barrier 3)'), (10, 'after barrier 3'), (4, 'rows stored (end of the step proper)'),
+         (11, 'auto: after the drain + barrier'), (12, 'auto: draws done, after the barrier'), (13, 'auto: pool re-entry done (before the barrier)'),
+         (14, 'auto: tracking + slots done (before the barrier)'), (15, 'auto: rows stored, flags swapped (end)')]
+def q(x): return ' '.join('%6.2f' % v for v in np.percentile(x, [0, 10, 50, 90, 100])) + '   n=%d' % len(x)
 print('%d blocks; us since the first wave started; percentiles 0 10 50 90 100' % nb)
+raw = trs[1].cpu().numpy()
 for w in range(4):
     print('wave %d' % w)
     for k, n in order:
-        if k == 5 and w == 0: continue
-        print('  %-86s %s' % (n, q(t[w::4, k])))
+        sel = raw[w::4, k] != 0
+        if not sel.any(): continue
+        print('  %-86s %s' % (n, q(t[w::4, k][sel])))
