@@ -822,11 +822,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         A.d_magic = magic(D); A.m_magic = magic(m_cand); A.nv_magic = magic(h->cfg.n_veh);
         A.pt = h->pt; A.modes = h->modes;
         std::memcpy(A.tturn.t, traffic->modes.turn, sizeof A.tturn.t);
-        for (int sl = 0; sl < h->cfg.n_veh; ++sl) {
-            bool first = true;
-            for (int t = 0; t < sl; ++t) first = first && h->modes.mode[t] != h->modes.mode[sl];
-            if (first) A.first_mask |= 1ull << sl;
-        }
+        eb::env_step_slot_plan(h->modes, h->cfg.n_veh, A);
         A.obs = obs; A.raw = actions; A.ref_idx = ref_idx; A.ego = ego; A.params = params; A.cand = cand; A.cand_mode = cand_mode;
         A.cand_lw = cand_lw; A.v_light = v_light; A.virtual_flag = virtual_flag; A.scaled = scaled_actions; A.out5 = out5;
         A.d16 = out_dict16; A.obs_out = obs_out; A.done_code = done_code;

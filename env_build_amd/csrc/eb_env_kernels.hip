@@ -573,11 +573,7 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
         A.n_env = n_env; A.D = D; A.n_future = n_future; A.NV = NV; A.m_cand = m_cand; A.path_id = path_id;
         A.d_magic = magic(D); A.m_magic = magic(m_cand); A.nv_magic = magic(NV);
         A.pt = pt; A.modes = modes;
-        for (int sl = 0; sl < NV; ++sl) {
-            bool first = true;
-            for (int t = 0; t < sl; ++t) first = first && modes.mode[t] != modes.mode[sl];
-            if (first) A.first_mask |= 1ull << sl;
-        }
+        env_step_slot_plan(modes, NV, A);
         A.ref_idx = ref_idx; A.ego = const_cast<float*>(ego); A.cand = const_cast<float*>(cand); A.cand_mode = cand_mode;
         A.v_light = v_light; A.virtual_flag = virtual_flag; A.obs_out = obs_out; A.obs_only = 1; A.row_mask = row_mask;
         A.tile_envs = tile_envs;

@@ -72,6 +72,25 @@ int env_step_tile_envs(int n_env, int D, int NV, int m_cand) {
 
 // cand and params are accessed as float4, ego / actions / scaled actions as float2: a buffer that is not aligned to its vector
 // access (an offset view handed in through the C-ABI) takes the separate launches instead
+void env_step_slot_plan(const VehModes& modes, int NV, EnvStepArgs& A) {
+    A.first_mask = 0; A.n_dm = 0; A.dm_ok = 1;
+    for (int sl = 0; sl < NV; ++sl) {
+        int first = -1, rank = 0;
+        for (int t = 0; t < sl; ++t)
+            if (modes.mode[t] == modes.mode[sl]) { if (first < 0) first = t; ++rank; }
+        if (first < 0) {
+            A.first_mask |= 1ull << sl;
+            if (A.n_dm < EB_VMODE_COUNT) A.dm[A.n_dm] = (unsigned)modes.mode[sl] | (unsigned)sl << 8 | 0xffu << 16;
+            ++A.n_dm;
+        } else if (rank == 1) {
+            for (int j = 0; j < A.n_dm && j < EB_VMODE_COUNT; ++j)
+                if ((A.dm[j] & 0xffu) == modes.mode[sl]) A.dm[j] = (A.dm[j] & 0xffffu) | (unsigned)sl << 16;
+        } else A.dm_ok = 0;              // a third slot of one mode
+    }
+    if (A.n_dm > EB_VMODE_COUNT) A.dm_ok = 0;   // (cannot happen: twelve mode ids)
+    A.dm_magic = A.n_dm <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)A.n_dm - 1) / (unsigned)A.n_dm);
+}
+
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego, const float* actions,
                        const float* scaled, const float* params) {
     auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
@@ -171,6 +190,12 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_jb[ET];
     __shared__ float s_miu[ET];                                                  // miu_r of the step (the stability predicate's input)
+    // AUTO: the start state a reset would give every env of the tile (drawn at kernel start, under the latency of the first loads),
+    // the tile's finished envs as a list, the slot plan as a table
+    __shared__ float4 s_rst[AUTO ? ET : 1];                                      // (x, y, phi, v_x)
+    __shared__ unsigned s_rflag[AUTO ? ET : 1];                                  // path | drawn virtual-red-light flag << 2
+    __shared__ uint8_t s_finlist[AUTO ? ET : 1];
+    __shared__ unsigned s_dm[AUTO ? EB_VMODE_COUNT : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * ET;
     const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
     const int nE = n_env - e0 < ET ? n_env - e0 : ET;
@@ -196,6 +221,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_tag32 + (size_t)ET * TS4);   // [4][ES_QCAP]
     ES_MARK(0);
     if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
+    if (AUTO && tid < EB_VMODE_COUNT) s_dm[tid] = A.dm[tid];
     if (tid < ET) s_col[tid] = (OBS && A.row_mask && !(tid < nE && A.row_mask[e0 + tid] != 0)) ? 1 : 0;   // OBS: 1 = row not to be written
     for (int w = tid; w < ET * TS4; w += 256) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
     __syncthreads();   // (kernel-argument tables only: nobody waits for memory here)
@@ -253,7 +279,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     bool virtual_next = false;
     // eb_env_reset's draws for this lane's env (env_reset_kernel: same keys, same arithmetic) -> nx, reset_path, virtual_next, and
     // the new state to HBM and s_ego
-    auto draw_reset = [&]() {
+    auto draw_values = [&](float (&st)[6], int& path, bool& vnext) {
         const float span = TASK == TASK_LEFT ? 900 + 500 : TASK == TASK_STRAIGHT ? 1200 + 500 : 420 + 500;   // E2E:473-478
         const uint64_t base = (A.reset_counter << 32) + (uint64_t)i * 128u;
         const float u0 = u01(A.reset_seed, base), u1 = u01(A.reset_seed, base + 1), u2 = u01(A.reset_seed, base + 2),
@@ -261,27 +287,34 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         int p = (int)(u0 * (float)A.pt.n_paths);                        // DAM:591
         if (p > A.pt.n_paths - 1) p = A.pt.n_paths - 1;
         const int ci = clamp_index((int)(u1 * span) + 700, A.pt.len[p]);   // E2E:474-478; indexs2points, DAM:727-728
-        nx[0] = 8.0f * u2; nx[1] = 0.0f; nx[2] = 0.0f;                  // E2E:482-486
-        nx[3] = A.pt.x[p][ci]; nx[4] = A.pt.y[p][ci]; nx[5] = A.pt.phi[p][ci];
-        reset_path = p;
-        virtual_next = A.training && u3 > 0.9f;                         // E2E:120-126
+        st[0] = 8.0f * u2; st[1] = 0.0f; st[2] = 0.0f;                  // E2E:482-486
+        st[3] = A.pt.x[p][ci]; st[4] = A.pt.y[p][ci]; st[5] = A.pt.phi[p][ci];
+        path = p;
+        vnext = A.training && u3 > 0.9f;                                // E2E:120-126
+    };
+    // what a reset writes besides the observation and the candidates (this lane's env; nx holds the drawn state), and the new pose
+    auto store_reset_state = [&]() {
         float2* ego_out = reinterpret_cast<float2*>(A.ego + 6 * (size_t)i);
         ego_out[0] = make_float2(nx[0], nx[1]); ego_out[1] = make_float2(nx[2], nx[3]); ego_out[2] = make_float2(nx[4], nx[5]);
         reinterpret_cast<float4*>(A.params)[i] = make_float4(0.0f, 0.0f, VehParams::miu, VehParams::miu);   // E2E:110-113
-        A.ref_idx_out[i] = p;
+        A.ref_idx_out[i] = reset_path;
         if (RESET && A.done_code) A.done_code[i] = EB_DONE_NOT_YET;     // E2E:119 (AUTO: done_code keeps the step's codes)
         if (A.v_light_out) A.v_light_out[i] = 0;
         s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
     };
+    auto draw_reset = [&]() {
+        draw_values(nx, reset_path, virtual_next);
+        store_reset_state();
+    };
     // eb_traffic_respawn's unconditional re-entry of candidate c of tile row e, clear of the NEW ego in s_ego (init_traffic's
     // conflict rule, TRF:168-192) -> HBM and s_cand
-    auto respawn_fresh = [&](int e, int c) {
+    auto respawn_fresh = [&](int e, int c, const float4* pose) {
         const uint64_t ub = (A.pool_counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)c * 2u;
         const float u1 = u01(A.pool_seed, ub), u2 = u01(A.pool_seed, ub + 1);
         const float* en = A.pool_entry + 5 * c;
         float along = u1 * A.pool_span;
         float4 nv = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.pool_v_max, en[2]);
-        const float4 eg = s_ego[e];
+        const float4 eg = pose[e];
         const float ego6[6] = {eg.w, 0.0f, 0.0f, eg.x, eg.y, eg.z};
         if (init_conflict(ego6, 4.8f, nv.x, nv.y, nv.w, nv.z, 4.8f)) {   // TRF:168-192: not on top of the ego
             along = u1 * A.edge_span;
@@ -291,6 +324,24 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         reinterpret_cast<float4*>(A.cand)[((size_t)e0 + e) * m_cand + c] = nv;
         s_cand[e * RS4 + c] = nv;
     };
+    // (waves 0, 1) the step's per-env inputs: issued here, ahead of what follows
+    float2 in_r2 = make_float2(0.0f, 0.0f), in_g0 = in_r2, in_g1 = in_r2, in_g2 = in_r2;
+    if (!OBS && wave < 2 && live) {
+        in_r2 = reinterpret_cast<const float2*>(A.raw)[i];
+        const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
+        in_g0 = eg[0]; in_g1 = eg[1]; in_g2 = eg[2];
+    }
+    if (AUTO && wave == 0 && live) {
+        // Ahead of time, under the latency of the loads just issued: the start state a reset would give this env — the draws depend
+        // on (seed, counter, env) alone.  If the step finishes the env, the tail finds its pose here instead of running eight 64-bit
+        // multiplies and a dependent table read per draw behind the step.
+        float rs[6];
+        int rpath;
+        bool rvn;
+        draw_values(rs, rpath, rvn);
+        s_rst[lane] = make_float4(rs[3], rs[4], rs[5], rs[0]);
+        s_rflag[lane] = (unsigned)rpath | (rvn ? 4u : 0u);
+    }
     if (OBS) {
         if (wave == 0 && live) {
             if (RESET) draw_reset();
@@ -303,9 +354,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         }
         if (RESET) __syncthreads();   // the pool's re-entry below stays clear of the NEW ego
     } else if (wave < 2 && live) {
-        const float2 r2 = reinterpret_cast<const float2*>(A.raw)[i];
-        const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
-        const float2 g0 = eg[0], g1 = eg[1], g2 = eg[2];
+        const float2 r2 = in_r2, g0 = in_g0, g1 = in_g1, g2 = in_g2;
         const float st[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
         if (wave == 1) {
             const float* o = A.obs + (size_t)D * i;
@@ -345,7 +394,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
             float sn, cs;     // (the record loop of the rollout kernel: one code path for every turn class, eb_device.h)
             if (RESET) {
-                if (!s_col[e]) respawn_fresh(e, c);                            // a row of the mask: eb_traffic_respawn, unconditional
+                if (!s_col[e]) respawn_fresh(e, c, s_ego);                            // a row of the mask: eb_traffic_respawn, unconditional
                 else s_cand[e * RS4 + c] = v;
             } else if (OBS) s_cand[e * RS4 + c] = v;
             else {
@@ -712,17 +761,96 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         ES_MARK(11);
-        if (wave == 0 && fin) draw_reset();                                      // E2E:100-101, 110-113
-        __syncthreads();   // the pool's re-entry stays clear of the NEW ego
-        ES_MARK(12);
-        for (int idx = tid; idx < n_rec; idx += 256) {                           // E2E:102-103 (init_traffic, TRF:151-195)
-            const int e = fast_div(idx, A.m_magic);
-            if ((finmask >> e) & 1ull) respawn_fresh(e, idx - e * m_cand);
+        if (wave == 0 && fin) {                                                  // E2E:100-101, 110-113: the state drawn at kernel start
+            const float4 q = s_rst[lane];
+            const unsigned fl = s_rflag[lane];
+            nx[0] = q.w; nx[1] = 0.0f; nx[2] = 0.0f; nx[3] = q.x; nx[4] = q.y; nx[5] = q.z;
+            reset_path = (int)(fl & 3u);
+            virtual_next = (fl & 4u) != 0u;
+            store_reset_state();
+        }
+        if (wave == 1 && fin)                                                    // the finished envs as a list, for the compact slot pass
+            s_finlist[__popcll(finmask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        for (int idx = tid; idx < n_rec; idx += 256) {                           // E2E:102-103 (init_traffic, TRF:151-195): the pool of the
+            const int e = fast_div(idx, A.m_magic);                              // finished envs re-enters clear of the NEW ego (s_rst:
+            if ((finmask >> e) & 1ull) respawn_fresh(e, idx - e * m_cand, s_rst);   // written before barrier 1)
         }
         ES_MARK(13);
-        __syncthreads();
-        if (wave == 0 && fin) track_row(reset_path);                             // E2E:116: the reset observation, OLD virtual flag,
-        fill_slots(fin, vflag);                                                  // v_light already cleared
+        __syncthreads();   // barrier: the re-entered candidates, s_ego, the list
+        ES_MARK(12);
+        // E2E:116: the reset observation, built with the OLD virtual flag (v_light already cleared).  The step's own slot phase spends
+        // four instruction streams (one mode per wave) on 64 lanes; here one or two lanes of a tile would be alive in each of them — at
+        // 65 536 envs more than half of the tiles have a finished env, and the tail was issue-bound on masked-off lanes (8.5 us).  So:
+        // wave 0 does the tracking of the new poses, wave 1 ALL (finished env, mode) pairs of the tile as lanes — one stream, the mode
+        // per lane (range box, key spec and fill value by data) — and waves 2, 3 wait at the barrier.
+        if (A.dm_ok) {
+            if (wave == 0) {
+                if (fin) track_row(reset_path);
+            } else if (wave == 1) {
+                const unsigned long long vmask = __builtin_amdgcn_ballot_w64(vflag);      // lane = env: the OLD flags of the tile
+                const int n_pairs_f = __popcll(finmask) * A.n_dm, nw = (m_cand + 3) >> 2;
+                for (int q0 = 0; q0 < n_pairs_f; q0 += 64) {
+                    const int q = q0 + lane;
+                    const bool act = q < n_pairs_f;
+                    const int ford = act ? fast_div(q, A.dm_magic) : 0, j = act ? q - ford * A.n_dm : 0;
+                    const int e = s_finlist[ford];
+                    const unsigned dm = s_dm[j];
+                    const int m = (int)(dm & 0xffu), sa = (int)((dm >> 8) & 0xffu), sb = (int)((dm >> 16) & 0xffu);
+                    const float4 eg = s_rst[e];
+                    const float ex = eg.x, ey = eg.y;
+                    const bool virt = TASK != TASK_RIGHT && ((vmask >> e) & 1ull) && ey < -HALF_CROSS;      // E2E:386-388
+                    const float4* crow = s_cand + e * RS4;
+                    const unsigned* trow = s_tag32 + e * TS4;
+                    float* ov = s_out + e * OS + 6 + T;
+                    unsigned long long elig = 0ull;
+                    const unsigned mm = (unsigned)m * 0x01010101u;
+                    for (int w = 0; w < nw; ++w) {
+                        const unsigned x = trow[w] ^ mm;
+                        const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
+                        elig |= (unsigned long long)((((z >> 7) * 0x01020408u) >> 24) & 0xfu) << (4 * w);
+                    }
+                    if (!act) elig = 0ull;
+                    const RangeBox rb = range_box(TASK, m, ex, ey);
+                    const KeySpec ks = key_spec(TASK, m);
+                    const V4 fill = veh_fill_value(m);
+                    float2 k1 = make_float2(0.0f, 0.0f), k2 = k1;
+                    int i1 = -1, i2 = -1;
+                    auto offer = [&](const bool valid, const float2 kk, const int c) {        // slot_pair_walk's, the mode per lane
+                        const bool first = valid & ((i1 < 0) | key_less(kk, k1));
+                        const bool second = valid & !first & ((i2 < 0) | key_less(kk, k2));
+                        k2.x = first ? k1.x : (second ? kk.x : k2.x); k2.y = first ? k1.y : (second ? kk.y : k2.y);
+                        i2 = first ? i1 : (second ? c : i2);
+                        k1.x = first ? kk.x : k1.x; k1.y = first ? kk.y : k1.y;
+                        i1 = first ? c : i1;
+                    };
+                    const float2* cxy = reinterpret_cast<const float2*>(crow);
+                    bool has = elig != 0ull;
+                    int c = has ? __builtin_ctzll(elig) : 0;
+                    elig &= elig - 1ull;
+                    while (__builtin_amdgcn_ballot_w64(has)) {
+                        const float2 xy = cxy[2 * c];
+                        const bool hq = has;
+                        const int cq = c;
+                        has = elig != 0ull;
+                        c = has ? __builtin_ctzll(elig) : 0;
+                        elig &= elig - 1ull;
+                        offer(hq & box_in_range(rb, xy.x, xy.y), key_of(ks, xy.x, xy.y), cq);
+                    }
+                    const float4 vv4 = make_float4(m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f);
+                    offer(act & virt & ((m == EB_VMODE_DL) | (m == EB_VMODE_DU)) & box_in_range(rb, vv4.x, vv4.y), key_of(ks, vv4.x, vv4.y), m_cand);
+                    const float4 fill4 = make_float4(fill.x, fill.y, fill.v, fill.phi);   // slice_or_fill, E2E:431-437
+                    const float4 q1 = crow[i1 < 0 || i1 >= m_cand ? 0 : i1], q2 = crow[i2 < 0 || i2 >= m_cand ? 0 : i2];
+                    const float4 r1 = i1 < 0 ? fill4 : (i1 >= m_cand ? vv4 : q1), r2 = i2 < 0 ? fill4 : (i2 >= m_cand ? vv4 : q2);
+                    if (act) {
+                        *reinterpret_cast<f4a4*>(ov + 4 * sa) = f4a4{r1.x, r1.y, r1.z, r1.w};
+                        if (sb != 0xff) *reinterpret_cast<f4a4*>(ov + 4 * sb) = f4a4{r2.x, r2.y, r2.z, r2.w};
+                    }
+                }
+            }
+        } else {                                                                 // a mode with more than two slots: the step's own slot code
+            if (wave == 0 && fin) track_row(reset_path);
+            fill_slots(fin, vflag);
+        }
         ES_MARK(14);
         __syncthreads();
         store_rows(2);

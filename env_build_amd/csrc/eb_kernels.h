@@ -124,6 +124,11 @@ struct EnvStepArgs {
     VehModes modes;                        // the observation's slot modes (handle h)
     SlotTurns tturn;                       // turn class of every candidate slot (the traffic handle's modes)
     unsigned long long first_mask;         // bit s: slot s is the first slot of its mode
+    // the slot plan as a table (env_step_slot_plan): entry j = mode | first slot << 8 | second slot << 16 (0xff: none) of the j-th
+    // distinct slot mode; dm_ok: no mode has more than two slots (the native lists, UTL:21-23) — what the compact reset tail needs
+    unsigned dm[12];                       // (EB_VMODE_COUNT entries)
+    int n_dm, dm_ok;
+    unsigned dm_magic;                     // item / n_dm == umulhi(item, dm_magic) (0: n_dm == 1)
     const float* obs;                      // [n_env, D] current observation
     const float* raw;                      // [n_env, 2] raw actions
     const int* ref_idx;
@@ -183,6 +188,7 @@ size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand);
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego = nullptr, const float* actions = nullptr,
                        const float* scaled = nullptr, const float* params = nullptr);   // NULL: not an argument of the call at hand
+void env_step_slot_plan(const VehModes& modes, int NV, EnvStepArgs& A);   // first_mask, dm, n_dm, dm_ok, dm_magic
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s);
 
 hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const float* entry, float limit, float span,

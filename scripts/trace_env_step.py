@@ -6,15 +6,15 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from env_build_amd import _capi
 from env_build_amd.endtoend import CrossroadEnd2end
-ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16); ap.add_argument('--auto', action='store_true')
+ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16); ap.add_argument('--auto', action='store_true'); ap.add_argument('--wild', action='store_true', help='full-range random actions: many envs finish per step (the reset tail runs in most tiles)')
 a = ap.parse_args()
 B = a.n_env
 env = CrossroadEnd2end('left', n_env=B, multi_display=True, traffic='pool', n_cand=a.n_cand, auto_reset=a.auto, copy_outputs=False)
 env.seed(0); env.reset()
-act = (torch.rand((B, 2), device=env.device) * 0.6 - 0.3).contiguous()
+act = (torch.rand((B, 2), device=env.device) * (2.0 if a.wild else 0.6) - (1.0 if a.wild else 0.3)).contiguous()
 lib = env.api.lib
 lib.eb_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
-for _ in range(3): env.step(act)
+for _ in range(40 if a.wild else 3): env.step(act)
 torch.cuda.synchronize()
 te = 16 if B <= 6144 else 32 if B <= 24576 else 64
 nb = (B + te - 1) // te
