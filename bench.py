@@ -336,6 +336,30 @@ class Timer(object):
         self.s.close()
 
 
+def pmc_traffic(which, *path):
+    """HBM bytes per launch from the newest profiles/r*_pmc_traffic.json WHOSE KERNEL SOURCES ARE THE ONES THIS RUN EXECUTES (the
+    file records build.kernel_hash() of the code it measured): -> (bytes or None, source note).  A file measured on other code is
+    refused, not silently reused — the counters of a changed kernel are unknown until scripts/pmc_traffic.sh has run again."""
+    import glob
+    from env_build_amd import build as _build
+    want = _build.kernel_hash(which)
+    stale = []
+    for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        d = json.load(open(tpath))
+        name = os.path.basename(tpath)
+        if (d.get('kernel_source_hash') or {}).get(which) != want:
+            stale.append(name)
+            continue
+        v = d
+        for k in path:
+            v = (v or {}).get(k)
+        if v is not None:
+            return v, ('profiles/%s: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes of this kernel (same sources: '
+                       'hash %s...), not measured in this run' % (name, want[:12]))
+    return None, ('no PMC traffic file for the kernel sources of this run (hash %s...; measured on other code: %s) — run '
+                  'scripts/pmc_traffic.sh' % (want[:12], ', '.join(stale) or 'none'))
+
+
 def roofline_of(alg_bytes, launch_us):
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
     return achieved, achieved / HBM_PEAK_GBS
@@ -371,9 +395,7 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
     if len(shard.sps) > 1:
         out.update(streams=len(shard.sps), timing='wall clock of the timed region / launches (the lanes run on %d HIP streams)' % len(shard.sps))
     if f16 and (n_env, n_veh, lanes) == (N_ENV, 64, 1):      # configs[4]: HBM bytes from the PMC passes of scripts/pmc_traffic.sh
-        tpath = os.path.join(ROOT, 'profiles', 'r3_pmc_traffic.json')
-        if os.path.isfile(tpath):
-            out['traffic'] = (json.load(open(tpath)).get('fp16_x64') or {}).get('hbm_bytes_per_launch')
+        out['traffic'], out['traffic_source'] = pmc_traffic('rollout', 'fp16_x64', 'hbm_bytes_per_launch')
     if with_summary:
         out['protocol'] = 'episodic summary kernels + their gather once per horizon inside the timed region, as the headline'
     if tile is not None:
@@ -581,11 +603,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     alg = env_step_alg_bytes(D, M) * B
     achieved, frac = roofline_of(alg, us)
     done_frac = float((code != 0).float().mean().item())
-    traffic = None
-    for name in ('r3_pmc_traffic.json',):
-        tpath = os.path.join(ROOT, 'profiles', name)
-        if os.path.isfile(tpath) and (B, M) == (N_ENV, 16):
-            traffic = (json.load(open(tpath)).get('env_step') or {}).get('hbm_bytes_per_launch')
+    traffic, traffic_src = (pmc_traffic('env_step', 'env_step', 'hbm_bytes_per_launch') if (B, M) == (N_ENV, 16) else (None, None))
     return {'workload': 'env_step: CrossroadEnd2end.step for N_env=%d single-ego envs x %d traffic candidates (task %s, D=%d): eb_env_step '
                         '= ONE launch (action scaling, reward, ego step, traffic step, observation, done code, pool re-entry)' % (B, M, TASK, D),
             'n_env_per_gpu': B, 'n_cand': M, 'obs_dim': D, 'dtype': 'f32', 'value': B / (us * 1e-6), 'unit': 'env-steps/s',
@@ -593,8 +611,8 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
                                                                       'us_per_step_min': min(seg_us), 'us_per_step_max': max(seg_us)},
             'wall_us_per_step_incl_state_restores': wall * 1e6 / (reps * seg),
             'alg_bytes_per_env_step': env_step_alg_bytes(D, M), 'alg_bytes_per_launch': alg, 'achieved_GBs': achieved, 'frac': frac,
-            'traffic': traffic, 'traffic_source': 'profiles/r3_pmc_traffic.json (separate rocprofv3 --pmc passes, scripts/pmc_traffic.sh)' if traffic else None,
-            'kernel': 'eb::env_step_kernel<0, %d, false>' % (16 if B <= 6144 else 32 if B <= 24576 else 64),
+            'traffic': traffic, 'traffic_source': traffic_src,
+            'kernel': 'eb::env_step_kernel<0, %d, false, false>' % (16 if B <= 6144 else 32 if B <= 24576 else 64),
             'done_fraction_after_segment': done_frac,
             'masked_reset': {'entry': 'eb_env_reset_pool (one launch: eb::env_reset_pool_kernel)', 'mask_fraction': 0.02, 'calls_timed': n_reset,
                              'us_per_call': reset_us, 'carries_over': 'observation and done-code rows of the other envs (obs_src / done_src)'},
@@ -844,12 +862,8 @@ def main():
         alg = alg_bytes_per_env_step(n_veh) * n_env
         launch_us = r['launch_us']
         traffic, traffic_src = None, None
-        for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):      # separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
-            tpath = os.path.join(ROOT, 'profiles', name)
-            if os.path.isfile(tpath) and n_env == N_ENV and n_veh == N_VEH and not args.open_loop:
-                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-                traffic_src = 'profiles/%s: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes of this kernel, not measured in this run' % name
-                break
+        if n_env == N_ENV and n_veh == N_VEH and not args.open_loop:      # separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
+            traffic, traffic_src = pmc_traffic('rollout', 'hbm_bytes_per_launch')
         cfg = 'configs[2]' if (n_env, n_veh) == (N_ENV, N_VEH) else 'custom'
         kernel = 'eb::rollout_fused_4x8<0, true, float>'
         form = 'closed-loop rollout_out (one kernel launch per step, %s)' % headline_form

@@ -35,6 +35,23 @@ def source_hash():
     return h.hexdigest()
 
 
+KERNEL_SOURCES = {   # what a kernel's machine code depends on (its translation unit and the headers it includes) — pmc_traffic.py
+    'rollout': ['eb_rollout.hip', 'eb_device.h', 'eb_kernels.h'],             # records these next to the HBM bytes it measures,
+    'env_step': ['eb_env_step.hip', 'eb_env_device.h', 'eb_device.h', 'eb_kernels.h'],   # bench.py refuses the bytes of other code
+}
+
+
+def kernel_hash(which):
+    """SHA-256 over the compiler flags and the sources of one kernel family ('rollout' / 'env_step')."""
+    h = hashlib.sha256()
+    h.update('\0'.join(FLAGS).encode())
+    for f in KERNEL_SOURCES[which]:
+        h.update(b'\0' + f.encode() + b'\0')
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def built_hash():
     try:
         with open(HASH_FILE) as fh:

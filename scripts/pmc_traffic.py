@@ -6,6 +6,8 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  Calibration: the copy
 known / counted gives one factor per counter in this access pattern (16 bytes per lane, coalesced) — on
 gfx950 the read factor comes out at 2 (MI355X_MICROARCH.md §HBM), the write factor near 1."""
 import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from env_build_amd import build as _build
 
 out = sys.argv[1]
 COPY_BYTES = 65536 * 137 * 4
@@ -35,7 +37,8 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
               'rollout_bytes_per_launch': k_kib * 1024.0 * factor}
 read_b, write_b = res['FETCH_SIZE']['rollout_bytes_per_launch'], res['WRITE_SIZE']['rollout_bytes_per_launch']
 alg = (104 + 32 * 32) * 65536
-summary = {'hbm_bytes_per_launch': read_b + write_b, 'read_bytes_per_launch': read_b, 'write_bytes_per_launch': write_b,
+summary = {'kernel_source_hash': {k: _build.kernel_hash(k) for k in _build.KERNEL_SOURCES},   # bench.py checks these against the sources it runs
+           'hbm_bytes_per_launch': read_b + write_b, 'read_bytes_per_launch': read_b, 'write_bytes_per_launch': write_b,
            'algorithmic_bytes_per_launch': alg, 'traffic_over_algorithmic': (read_b + write_b) / alg,
            'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace; KiB per dispatch x 1024 x '
                      'calibration factor measured on a float4 copy of a known 35.9 MB buffer in the same run '
@@ -45,13 +48,13 @@ summary = {'hbm_bytes_per_launch': read_b + write_b, 'read_bytes_per_launch': re
 try:
     es = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        k_kib, n_k = mean_counter('envstep_' + c, c, 'env_step_kernel<0, 64, false>', 1024 * 256)
+        k_kib, n_k = mean_counter('envstep_' + c, c, 'env_step_kernel<0, 64, false, false>', 1024 * 256)
         es[c] = {'kib_per_launch': k_kib, 'launches': n_k, 'bytes_per_launch': k_kib * 1024.0 * res[c]['calibration_factor']}
     es_alg = (8 * 41 + 33 * 16 + 105) * 65536
     es_total = es['FETCH_SIZE']['bytes_per_launch'] + es['WRITE_SIZE']['bytes_per_launch']
     summary['env_step'] = {'hbm_bytes_per_launch': es_total, 'read_bytes_per_launch': es['FETCH_SIZE']['bytes_per_launch'],
                            'write_bytes_per_launch': es['WRITE_SIZE']['bytes_per_launch'], 'algorithmic_bytes_per_launch': es_alg,
-                           'traffic_over_algorithmic': es_total / es_alg, 'kernel': 'eb::env_step_kernel<0, 64, false>', 'counters': es}
+                           'traffic_over_algorithmic': es_total / es_alg, 'kernel': 'eb::env_step_kernel<0, 64, false, false>', 'counters': es}
 except SystemExit as e:
     summary['env_step'] = None
     print('(no env-step passes: %s)' % e)
@@ -70,7 +73,7 @@ except SystemExit as e:
     summary['fp16_x64'] = None
     print('(no fp16 passes: %s)' % e)
 json.dump(summary, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k not in ('counters', 'env_step', 'fp16_x64')}, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k not in ('counters', 'env_step', 'fp16_x64', 'kernel_source_hash')}, indent=1))
 if summary.get('fp16_x64'):
     print('fp16 x 64:', json.dumps({k: v for k, v in summary['fp16_x64'].items() if k != 'counters'}))
 if summary.get('env_step'):
