@@ -508,7 +508,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     for t in range(seg):
         src, dst = obs[t & 1], obs[(t + 1) & 1]
         argsets.append((h, ht, B, p(src), p(tape[t]), p(env._ref_idx), 0, p(ego), p(params), M, p(cand), p(env._cand_mode), None,
-                        p(env._v_light), p(env._virtual), p(scaled), p(out5), None, p(dst), p(code), C.byref(rule), None, sp))
+                        p(env._v_light), p(env._virtual), p(scaled), p(out5), None, p(dst), p(code), C.byref(rule), None, None, sp))
     ev = []
     for _ in range(2 * reps):
         e = C.c_void_p()
@@ -571,7 +571,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     restore()
     final = torch.empty_like(obs[0])
     ar = _capi.EbAutoReset(4242, 0, 1, env._ref_idx.data_ptr(), env._virtual.data_ptr(), env._v_light.data_ptr(), rrule, final.data_ptr())
-    auto_sets = [a[:-2] + (C.byref(ar), sp) for a in argsets]
+    auto_sets = [a[:-3] + (C.byref(ar), None, sp) for a in argsets]
 
     def auto_segment(k):
         for a in auto_sets:

@@ -42,6 +42,14 @@ class EbAutoReset(C.Structure):   # struct eb_auto_reset (ABI 4): eb_env_step re
                 ('virtual_flag', C.c_void_p), ('v_light', C.c_void_p), ('pool', EbRespawn), ('final_obs', C.c_void_p)]
 
 
+class EbFlowRule(C.Structure):    # struct eb_flow_rule (ABI 4): the flow source's step as the last stage of eb_env_step
+    _fields_ = [('per_route', C.c_int32), ('active', C.c_void_p), ('timer', C.c_void_p), ('emitted', C.c_void_p),
+                ('sim_step', C.c_void_p), ('lane', C.c_void_p), ('period', C.c_void_p), ('v_max', C.c_void_p),
+                ('dt', C.c_float), ('exit_range', C.c_float), ('accel', C.c_float), ('lane_len', C.c_float),
+                ('light_cycle', C.c_int32), ('seed', C.c_uint64), ('counter', C.c_uint64), ('cand_mode', C.c_void_p),
+                ('v_light', C.c_void_p)]
+
+
 ACT_ID = {'linear': 0, None: 0, 'relu': 1, 'elu': 2, 'tanh': 3}        # EB_ACT_*
 PENALTY_ID = {'veh2veh4real': 0, 'real_punish_term': 1}                # EB_PENALTY_*
 
@@ -88,7 +96,7 @@ PROTOTYPES = {
     'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_exit_frame': (C.c_int, [_P, _I, _P, _I, _P, _P, _P]),
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
-    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P]),
     'eb_env_reset_pool': (C.c_int, [_P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, _P, C.c_float, _P]),

@@ -787,7 +787,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, const eb_auto_reset* auto_reset, void* stream) {
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow, void* stream) {
     // every check first: an error return leaves ego / params / cand untouched
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
     if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
@@ -808,6 +808,12 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
         if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))
             return fail(EB_EINVAL, "eb_env_step: final_obs must be an array of its own");
+    }
+    if (flow) {
+        if (respawn || auto_reset) return fail(EB_EINVAL, "eb_env_step: the flow rule excludes respawn / auto_reset (the pool's rules)");
+        if (flow->per_route < 1 || 12 * flow->per_route != m_cand || m_cand > 64 || !flow->active || !flow->timer || !flow->emitted ||
+            !flow->sim_step || !flow->lane || !flow->period || !flow->v_max || !v_light || flow->v_light != v_light || flow->cand_mode != cand_mode)
+            return fail(EB_EINVAL, "eb_env_step: bad flow rule (m_cand == 12 * per_route <= 64, every array given, cand_mode / v_light the call's own)");
     }
     if (n_env == 0) return EB_OK;
     hipStream_t s = pick(h, stream);
@@ -837,6 +843,14 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             A.ref_idx_out = ar->ref_idx; A.virtual_out = ar->virtual_flag; A.v_light_out = ar->v_light; A.final_obs = ar->final_obs;
             A.pool_entry = ar->pool.entry; A.pool_span = ar->pool.span; A.pool_v_max = ar->pool.v_max; A.edge_span = ar->pool.edge_span;
             A.pool_seed = ar->pool.seed; A.pool_counter = ar->pool.counter;
+        }
+        if (flow) {   // the flow source's step rides on the way out of the same launch
+            A.flow_on = 1; A.flow_K = flow->per_route; A.flow_active = flow->active; A.flow_timer = flow->timer; A.flow_emitted = flow->emitted;
+            A.flow_sim_step = flow->sim_step; A.flow_lane = flow->lane; A.flow_period = flow->period; A.flow_v_max = flow->v_max;
+            A.flow_dt = flow->dt; A.flow_exit_range = flow->exit_range; A.flow_accel = flow->accel; A.flow_lane_len = flow->lane_len;
+            A.flow_light_cycle = flow->light_cycle; A.seed = flow->seed; A.counter = flow->counter;
+            A.flow_mode_out = flow->cand_mode; A.v_light_out = flow->v_light;
+            A.k_magic = magic(flow->per_route);
         }
         EB_HIP(eb::launch_env_step(h->cfg.task, A, s));
         return EB_OK;
@@ -878,6 +892,10 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         return eb_env_reset_pool(h, traffic, n_env, done_code, ar->seed, ar->counter, ar->training, ego, params, ar->ref_idx,
                                  ar->virtual_flag, ar->v_light, nullptr, m_cand, cand, cand_mode, &ar->pool, obs_out, nullptr, nullptr, stream);
     }
+    if (flow)
+        EB_HIP(eb::launch_traffic_flow_step(n_env, flow->per_route, cand, flow->active, flow->timer, flow->emitted, flow->sim_step, flow->lane,
+                                            flow->period, flow->v_max, flow->dt, flow->exit_range, flow->accel, flow->lane_len,
+                                            flow->light_cycle, flow->seed, flow->counter, flow->cand_mode, flow->v_light, s));
     return EB_OK;
 }
 

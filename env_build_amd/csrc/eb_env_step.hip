@@ -47,7 +47,7 @@ EB_DEV int es_tag_stride4(int m_cand) { return ((m_cand + 3) >> 2) | 1; }   // d
 EB_DEV int fast_div(int item, unsigned magic) { return magic ? (int)__umulhi((unsigned)item, magic) : item; }   // magic 0: / 1
 constexpr int ES_QCAP = 128;   // per-wave queue: flushed whenever 64 entries are waiting, so 64 + 64 suffice
 
-size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs) {
+size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow) {
     const int rs4 = m_cand + ((m_cand & 1) ? 2 : 1), os = D | 1, ts4 = ((m_cand + 3) >> 2) | 1;
     const size_t E = (size_t)tile_envs;
     size_t b = E * rs4 * 16;                     // s_cand
@@ -57,6 +57,7 @@ size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs) {
     b += E * 8;                                  // s_oldc
     b += E * ts4 * 4;                            // s_tag
     b += (size_t)4 * ES_QCAP * 2;                // s_queue
+    if (flow) b += E * 12 * 16 + E * 12 * 4 + E * m_cand;   // s_new, s_emit, s_on (eb_flow_rule)
     return (b + 15) & ~(size_t)15;
 }
 // envs per block: 64 for throughput; small batches take 16- or 32-env tiles so that more blocks (and fewer records per lane)
@@ -219,6 +220,11 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     unsigned* s_tag32 = reinterpret_cast<unsigned*>(s_oldc + ET);                // [64][TS4] mode bytes, then range tags
     uint8_t* s_tag = reinterpret_cast<uint8_t*>(s_tag32);
     unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_tag32 + (size_t)ET * TS4);   // [4][ES_QCAP]
+    // eb_flow_rule (flow_on): per (env, route) the vehicle an emission puts into the route's first vacant slot and that slot (or
+    // -1), per slot "a vehicle is here after the exit test"
+    float4* s_new = reinterpret_cast<float4*>(s_queue + 4 * ES_QCAP);           // [64][12]
+    int* s_emit = reinterpret_cast<int*>(s_new + (size_t)ET * 12);               // [64][12]
+    uint8_t* s_on = reinterpret_cast<uint8_t*>(s_emit + (size_t)ET * 12);        // [64][m_cand]
     ES_MARK(0);
     if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
     if (AUTO && tid < EB_VMODE_COUNT) s_dm[tid] = A.dm[tid];
@@ -246,7 +252,10 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         for (int k = 0; k < 3; ++k) {
             const int idx = rec_index(g, k);
             cv[g][k] = make_float4(0, 0, 0, 0); cm[g][k] = EB_VMODE_EMPTY;
-            if (idx >= 0 && idx < n_rec) { cv[g][k] = csrc[idx]; cm[g][k] = msrc[idx]; }
+            if (idx >= 0 && idx < n_rec) {
+                cv[g][k] = csrc[idx]; cm[g][k] = msrc[idx];
+                if (!OBS && A.flow_on) cm[g][k] |= (unsigned)A.flow_active[(size_t)e0 * m_cand + idx] << 8;   // (the flow rule's flag: bits 8..)
+            }
         }
     // (wave 1) the first batch of compute_rewards' (env, old slot) pairs: their (x, y) are needed in phase 2 only.  Phase 2's two
     // pair-parallel passes have one owner each — wave 1 the reward pairs, waves 2 and 3 the collision test — so that a wave pays
@@ -411,7 +420,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     const float along = u1 * A.span;
                     o = make_float4(en[0] + along * en[3], en[1] + along * en[4], u2 * A.v_max, en[2]);
                 }
-                reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;
+                if (A.flow_on) s_on[idx] = (uint8_t)(mode >> 8);            // (the flow rule stores the record in its own pass below)
+                else reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;
             }
             s_tag[e * TS4 * 4 + c] = (uint8_t)mode;
         };
@@ -426,7 +436,10 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int idx = rec_index(g, k);
-                if (idx >= 0 && idx < n_rec) { cv[0][k] = csrc[idx]; cm[0][k] = msrc[idx]; }
+                if (idx >= 0 && idx < n_rec) {
+                    cv[0][k] = csrc[idx]; cm[0][k] = msrc[idx];
+                    if (!OBS && A.flow_on) cm[0][k] |= (unsigned)A.flow_active[(size_t)e0 * m_cand + idx] << 8;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -434,6 +447,32 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 if (idx >= 0 && idx < n_rec) stage(idx, cv[0][k], cm[0][k]);
             }
         }
+    }
+    if (!OBS && A.flow_on) {
+        // eb_traffic_flow_step, per slot (one copy of the code, a pass of its own over this lane's records): a vehicle far out and
+        // heading away leaves (its record stays where the prediction put it), the others accelerate towards their vType's speed —
+        // what the NEXT step sees goes to HBM; the LDS copy stays this step's state
+        for (int g = 0; g * 512 < n_rec; ++g)
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                const int idx = rec_index(g, k);
+                if (idx < 0 || idx >= n_rec) continue;
+                const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
+                float4 o = s_cand[e * RS4 + c];
+                bool on = s_on[idx] != 0;
+                if (on) {
+                    float fs, fc;
+                    sincos_det(deg2rad(o.w), fs, fc);
+                    const bool outward = o.x * fc + o.y * fs > 0.0f;
+                    if (__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)) > A.flow_exit_range && outward) on = false;
+                    else {
+                        const float vn = o.z + A.flow_accel * A.flow_dt, vm = A.flow_v_max[c];
+                        o.z = vn < vm ? vn : vm;
+                    }
+                }
+                s_on[idx] = on ? 1 : 0;
+                reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;
+            }
     }
     ES_MARK(1);
     __syncthreads();   // barrier: s_ego, s_pts, s_oldc, s_cand, mode bytes
@@ -533,6 +572,35 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 }
             }
             Q.flush();
+            if (A.flow_on) {
+                // eb_traffic_flow_step, per (env, route): the route's timer, and — when it is due and a slot of the route is vacant —
+                // the vehicle that enters: into LDS; the slot's own staging lane stores it behind the observation (phase 4)
+                const int K = A.flow_K;
+                for (int q = lane; q < nE * 12; q += 64) {
+                    const int e = q / 12, r = q - e * 12, ge = e0 + e;
+                    const uint8_t* on = s_on + e * m_cand + r * K;
+                    int vacant = -1;
+                    for (int k = K - 1; k >= 0; --k)
+                        if (!on[k]) vacant = k;
+                    const size_t ti = (size_t)ge * 12 + r;
+                    float t = A.flow_timer[ti] + A.flow_dt;
+                    const float per = A.flow_period[r];
+                    int em = -1;
+                    if (t >= per && vacant >= 0) {
+                        const int j = r * K + vacant;
+                        const uint64_t base = (A.counter << 32) + (uint64_t)ge * 128u + (uint64_t)(r * K) * 2u;
+                        const float u1 = u01(A.seed, base), u2 = u01(A.seed, base + 1);
+                        const float* ln = A.flow_lane + 5 * j;
+                        const float along = u1 * A.flow_lane_len;
+                        s_new[q] = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
+                        em = vacant;
+                        t = t - per;
+                        A.flow_emitted[ti] += 1;
+                    }
+                    s_emit[q] = em;
+                    A.flow_timer[ti] = t;
+                }
+            }
         }
         ES_MARK(5);
         if (wave >= 2) {   // one lane per (env, candidate): the collision test (TRF:263-295), its 10 m box first
@@ -751,6 +819,35 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         }
     };
     store_rows(AUTO ? 1 : 0);
+    if (!OBS && A.flow_on) {
+        // eb_traffic_flow_step, the rest: a slot's flag and mode byte for the next step, the entering vehicle into its slot — by the
+        // lane that staged the slot (it stored the slot's record in phase 1 and read its mode byte: program order settles both) —
+        // and the env's clock and light (every wave has used the old light: barrier 3)
+        const int K = A.flow_K;
+        for (int g = 0; g * 512 < n_rec; ++g)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = rec_index(g, k);
+                if (idx < 0 || idx >= n_rec) continue;
+                const int e = fast_div(idx, A.m_magic), c = idx - e * m_cand;
+                const int r = fast_div(c, A.k_magic), kk = c - r * K, q = e * 12 + r;
+                bool on = s_on[idx] != 0;
+                if (s_emit[q] == kk) {
+                    reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = s_new[q];
+                    on = true;
+                }
+                A.flow_active[(size_t)e0 * m_cand + idx] = on ? 1 : 0;
+                A.flow_mode_out[(size_t)e0 * m_cand + idx] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+            }
+        if (wave == 0 && live) {
+            const int n = A.flow_sim_step[i] + 1;
+            A.flow_sim_step[i] = n;
+            if (A.flow_light_cycle) {   // a.net.xml:145-150: 25 s phase 0, 5 s phase 1, 25 s phase 2, 5 s phase 3, in steps of dt
+                const float tt = (float)(n % (int)(60.0f / A.flow_dt + 0.5f)) * A.flow_dt;
+                A.v_light_out[i] = tt < 25.0f ? 0 : (tt < 30.0f ? 1 : (tt < 55.0f ? 2 : 3));
+            }
+        }
+    }
     ES_MARK(4);
     if (AUTO) {
         // ---- the envs this step finished start their next episode (E2E:99-127) — eb_env_reset_pool's arithmetic on those rows ----
@@ -870,8 +967,8 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     if (force == 16 || force == 32 || force == 64) ET = force;
     static const int rforce = std::getenv("EB_RESET_TILE") ? std::atoi(std::getenv("EB_RESET_TILE")) : 0;   // tuning aid (the masked reset only)
     if (A.reset && (rforce == 16 || rforce == 32 || rforce == 64)) ET = rforce;
-    if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET) > 150 * 1024) ET = 16;     // a forced shape that does not fit
-    const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET);
+    if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0) > 150 * 1024) ET = 16;     // a forced shape that does not fit
+    const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0);
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;

@@ -169,6 +169,19 @@ struct EnvStepArgs {
     // training / edge_span / ref_idx_out / virtual_out / v_light_out as for reset; final_obs (nullable) takes their terminal rows
     int auto_reset;
     float* final_obs;
+    // flow (eb_env_step, ABI 4): eb_traffic_flow_step's rule applied on the way out (seed / counter above are its draws' keys;
+    // v_light_out = the light it writes; flow_mode_out = cand_mode, rewritten)
+    int flow_on, flow_K, flow_light_cycle;
+    unsigned k_magic;                      // item / flow_K
+    uint8_t* flow_active;
+    float* flow_timer;
+    int* flow_emitted;
+    int* flow_sim_step;
+    const float* flow_lane;
+    const float* flow_period;
+    const float* flow_v_max;
+    float flow_dt, flow_exit_range, flow_accel, flow_lane_len;
+    uint8_t* flow_mode_out;
 };
 struct EnvResetArgs {                      // launch_get_obs(..., reset): what eb_env_reset_pool adds to a masked observation pass
     uint64_t seed, counter;                // eb_env_reset's
@@ -184,7 +197,7 @@ struct EnvResetArgs {                      // launch_get_obs(..., reset): what e
     const float* obs_src;                  // nullable: the observation rows of the envs outside the mask
     const uint8_t* done_src;               // nullable: their done codes
 };
-size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs);
+size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow = false);
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand);
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego = nullptr, const float* actions = nullptr,
                        const float* scaled = nullptr, const float* params = nullptr);   // NULL: not an argument of the call at hand

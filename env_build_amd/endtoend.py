@@ -230,7 +230,8 @@ class _LazyDone(DevArray):
 
 class CrossroadEnd2end(object):
     def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
-                 device=None, respawn=True, traffic='pool', per_route=5, auto_reset=False, copy_outputs=True, **kwargs):
+                 device=None, respawn=True, traffic='pool', per_route=5, auto_reset=False, copy_outputs=True, flow_in_step=True,
+                 **kwargs):
         """n_env > 1 makes a batch of independent single-ego envs (the reference is one env: every argument before n_env is its).
         auto_reset (a batch over the traffic pool): step() also resets the envs it has just finished, in the same kernel launch —
             the observation it returns holds their reset observation, info['final_observation'] their terminal one (rows of the
@@ -277,6 +278,7 @@ class CrossroadEnd2end(object):
         self.multi_display = multi_display
         self.respawn = respawn
         self.copy_outputs = bool(copy_outputs)
+        self.flow_in_step = bool(flow_in_step)   # traffic='flows': the source's step inside the env step's launch (eb_flow_rule), or a launch of its own
         self.auto_reset = bool(auto_reset)
         self._want_d16 = False     # the 16-term reward dict is requested from the kernel once somebody has read a term
         self.obs_dim = 6 + 3 * (num_future_data + 1) + 4 * self.veh_num
@@ -724,14 +726,20 @@ class CrossroadEnd2end(object):
             ar.seed, ar.counter = self._respawn_seed ^ self._RESET_SALT, self._reset_counter - 1
             ar.pool.seed, ar.pool.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
             ar.final_obs = final.data_ptr()
+        fr = None
+        if self._flows is not None:    # exits, emissions, the new mode bytes and the light for the NEXT step ride on the way out of the
+            self._flows.cand = self._cand      # same launch (eb_flow_rule: the observation saw this step's state)
+            if self.flow_in_step:
+                fr = self._flows.step_rule()
         self.api.env_step(self._h, self._traffic.h, B, _ptr(obs_in), _ptr(raw), _ptr(ri), 0, _ptr(self._ego),
                           _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(lw),
                           _ptr(self._v_light), _ptr(self._virtual), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out),
-                          _ptr(code), C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None, sp)
+                          _ptr(code), C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None,
+                          C.byref(fr) if fr is not None else None, sp)
         self._obs, self.done_code = obs_out, code
-        if self._flows is not None:       # exits, emissions and the light for the NEXT step (the obs saw this step's state)
-            self._flows.cand = self._cand
-            self._flows.after_step(self.api, self._traffic.h, sp)
+        if self._flows is not None:
+            if not self.flow_in_step:          # (the same rule as a launch of its own: eb_traffic_flow_step)
+                self._flows.after_step(self.api, self._traffic.h, sp)
             self._cand, self._cand_mode, self._v_light = self._flows.cand, self._flows.mode(), self._flows.v_light()
         self._publish_state()                                                           # E2E:136, 139
         keys = EnvironmentModel.REWARD_KEYS

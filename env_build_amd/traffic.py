@@ -102,6 +102,7 @@ class FlowTraffic(object):
         self.veh_len = self.lw[:, 0].contiguous()                                                   # [M]
         self._lw_b = None
         self.seed, self.counter, self.reset_counter = 0x5EED, 0, 0
+        self._rule = None
 
     # -- views the env hands to the kernels -----------------------------------------------------------
     def mode(self):
@@ -132,6 +133,18 @@ class FlowTraffic(object):
                                p(self.veh_len), C.c_float(LANE_START - CROSSROAD_SIZE / 2), 1 if self.task == 'right' else 0,
                                1 if self.env_mode == 'training' else 0, C.c_uint64(self.seed ^ RESET_SALT),
                                C.c_uint64(self.reset_counter), p(self._mode), p(self._vlight), stream)
+
+    def step_rule(self):
+        """The same bookkeeping as the last stage of the env's own step launch: struct eb_flow_rule for eb_env_step (ABI 4) — the
+        arrays are this object's, the counter advances per step."""
+        self.counter += 1
+        if self._rule is None:
+            p = lambda t: t.data_ptr()
+            self._rule = _capi.EbFlowRule(self.K, p(self.active), p(self.timer), p(self.emitted), p(self.sim_step), p(self.lane5),
+                                          p(self.period), p(self.vmax), self.dt, EXIT_RANGE, ACCEL, LANE_START - CROSSROAD_SIZE / 2,
+                                          0 if self.env_mode == 'training' else 1, 0, 0, p(self._mode), p(self._vlight))
+        self._rule.seed, self._rule.counter = self.seed, self.counter
+        return self._rule
 
     def after_step(self, api, handle, stream):
         """Bookkeeping after the env has advanced every slot by one prediction step — exits, free-flow acceleration,

@@ -371,6 +371,27 @@ typedef struct eb_respawn {
     uint64_t counter;
     float edge_span;    /* eb_env_reset_pool only: where a candidate goes that would start on top of the ego (eb_traffic_respawn) */
 } eb_respawn;
+/* flow (nullable, ABI 4; not together with respawn / auto_reset): the step of the SUMO-free FLOW traffic source as the last stage
+ * of the call — eb_traffic_flow_step(traffic, n_env, per_route, cand, active, timer, emitted, sim_step, lane, period, v_max, dt,
+ * exit_range, accel, lane_len, light_cycle, seed, counter, cand_mode, v_light) AFTER the observation and the done code were taken
+ * (they see the slots as this step's prediction left them and the modes / light the call was given; the exits, accelerations,
+ * emissions, the new mode bytes and the new light are what the NEXT step sees).  m_cand must be 12 * per_route; cand_mode / v_light
+ * inside the struct are the writable views of the call's arguments of the same name and must BE those arrays (v_light not NULL). */
+typedef struct eb_flow_rule {
+    int32_t per_route;
+    uint8_t* active;         /* [n_env, m_cand] */
+    float* timer;            /* [n_env, 12] */
+    int32_t* emitted;        /* [n_env, 12] */
+    int32_t* sim_step;       /* [n_env] */
+    const float* lane;       /* [m_cand, 5] */
+    const float* period;     /* [12] */
+    const float* v_max;      /* [m_cand] */
+    float dt, exit_range, accel, lane_len;
+    int32_t light_cycle;
+    uint64_t seed, counter;
+    uint8_t* cand_mode;      /* == the cand_mode argument */
+    uint8_t* v_light;        /* == the v_light argument */
+} eb_flow_rule;
 typedef struct eb_auto_reset {
     uint64_t seed, counter;  /* eb_env_reset's draws for the finished envs */
     int32_t training;        /* E2E:120-126: the virtual red-light flag is drawn in training mode only */
@@ -384,7 +405,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, const eb_auto_reset* auto_reset, void* stream);
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow, void* stream);
 
 /* CrossroadEnd2end.reset (E2E:99-127) with _reset_init_state (E2E:472-499) for the envs of a batch whose mask byte is
  * non-zero (mask NULL = every env); the other envs keep their state.  Per env, with u_k in [0, 1) the counter-based

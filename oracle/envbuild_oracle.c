@@ -1252,7 +1252,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, const eb_auto_reset* auto_reset, void* stream) {
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow, void* stream) {
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
     if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
         m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)))
@@ -1272,6 +1272,12 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
         if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))
             return fail(EB_EINVAL, "eb_env_step: final_obs must be an array of its own");
+    }
+    if (flow) {   /* the same checks as the HIP library, before anything is written */
+        if (respawn || auto_reset) return fail(EB_EINVAL, "eb_env_step: the flow rule excludes respawn / auto_reset (the pool's rules)");
+        if (flow->per_route < 1 || 12 * flow->per_route != m_cand || m_cand > 64 || !flow->active || !flow->timer || !flow->emitted ||
+            !flow->sim_step || !flow->lane || !flow->period || !flow->v_max || !v_light || flow->v_light != v_light || flow->cand_mode != cand_mode)
+            return fail(EB_EINVAL, "eb_env_step: bad flow rule (m_cand == 12 * per_route <= 64, every array given, cand_mode / v_light the call's own)");
     }
     if (n_env == 0) return EB_OK;
     float* own_scaled = NULL;
@@ -1303,6 +1309,10 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                                ar->v_light, NULL, m_cand, cand, cand_mode, &ar->pool, obs_out, NULL, NULL, stream);
         free(mask);
     }
+    if (!rc && flow)   /* TRF:220-238's role for the flow source: exits, accelerations, emissions, clock and light, after the observation */
+        rc = eb_traffic_flow_step(traffic, n_env, flow->per_route, cand, flow->active, flow->timer, flow->emitted, flow->sim_step, flow->lane,
+                                  flow->period, flow->v_max, flow->dt, flow->exit_range, flow->accel, flow->lane_len, flow->light_cycle,
+                                  flow->seed, flow->counter, flow->cand_mode, flow->v_light, stream);
     return rc;
 }
 

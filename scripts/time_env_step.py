@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from env_build_amd.endtoend import CrossroadEnd2end
 ap = argparse.ArgumentParser()
-ap.add_argument('--sizes', default='1,4096,65536'); ap.add_argument('--traffic', default='pool'); ap.add_argument('--steps', type=int, default=50); ap.add_argument('--n-cand', type=int, default=None)
+ap.add_argument('--sizes', default='1,4096,65536'); ap.add_argument('--traffic', default='pool'); ap.add_argument('--steps', type=int, default=50); ap.add_argument('--n-cand', type=int, default=None); ap.add_argument('--separate-flow', action='store_true', help="traffic='flows': eb_traffic_flow_step as a launch of its own (A/B against the flow rule inside the step launch)")
 a = ap.parse_args()
 for B in [int(x) for x in a.sizes.split(',')]:
     # regimes: (a) auto_reset — the step's own launch resets the envs it finishes (ABI 4); (b) masked reset after every step
@@ -19,7 +19,7 @@ for B in [int(x) for x in a.sizes.split(',')]:
             if how == 'auto' and a.traffic != 'pool':
                 continue
             env = CrossroadEnd2end('left', n_env=B, multi_display=True, traffic=a.traffic, n_cand=a.n_cand, auto_reset=how == 'auto',
-                                   copy_outputs=copy)
+                                   copy_outputs=copy, flow_in_step=not a.separate_flow)
             env.reset()
             act = torch.rand((B, 2), device=env.device) * 2 - 1
             a1 = act[0].cpu().numpy() if B == 1 else act

@@ -177,6 +177,83 @@ def auto_reset_bad_args_case(make, task='left', B=40, M=8):
                    auto_reset=dict(seed=1, counter=1, training=1, pool=pool))
 
 
+def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, seed=3):
+    """eb_env_step(flow) == eb_env_step, then eb_traffic_flow_step on what it left — every output and every piece of the flow
+    source's state, bit for bit, over a closed loop that starts from an empty junction (emissions, exits, accelerations, the
+    light programme all occur on the way); -> the trace of the fused path (for cross-library comparison)."""
+    from env_build_amd.traffic import ACCEL, EXIT_RANGE, FLOWS, LANE_START, ROUTES, VTYPES, approach_lane
+    M = 12 * K
+    slot_modes = [r for r in ROUTES for _ in range(K)]
+    lane = np.array([list(approach_lane(m)[0]) + list(approach_lane(m)[1]) for m in slot_modes], np.float32)
+    period = (np.array([3600.0 / FLOWS[r][0] for r in ROUTES], np.float32) / 8).astype(np.float32)       # (dense traffic: things happen within 40 steps)
+    vmax = np.array([VTYPES[FLOWS[m][1]][2] for m in slot_modes], np.float32)
+    lw = np.tile(np.array([[VTYPES[FLOWS[m][1]][0], VTYPES[FLOWS[m][1]][1]] for m in slot_modes], np.float32), (B, 1, 1))
+    rng = np.random.default_rng(seed)
+    inp = make_rollout_inputs(task, B, 8, 1, seed=seed)
+    ego, ref = inp['ego'].copy(), inp['ref_idx']
+    m, tr = make(task, mode='training'), make(task, n_veh=M, modes=slot_modes)
+    if tile is not None:
+        m.set_tile(tile)
+    # a junction in mid-traffic: some slots occupied along their lanes (a few of them far out and heading away: they leave)
+    active = (rng.random((B, M)) < 0.4).astype(np.uint8)
+    along = rng.uniform(0, 95, (B, M)).astype(np.float32)
+    along = np.where(rng.random((B, M)) < 0.15, rng.uniform(150, 175, (B, M)), along).astype(np.float32)   # through the junction and 50-75 m beyond: leaving
+    cand = np.stack([lane[None, :, 0] + along * lane[None, :, 3], lane[None, :, 1] + along * lane[None, :, 4],
+                     rng.uniform(0, 9, (B, M)).astype(np.float32), np.broadcast_to(lane[None, :, 2], (B, M))], 2).astype(np.float32)
+    mode = np.where(active != 0, np.array([_capi.VMODE_ID[x] for x in slot_modes], np.uint8)[None, :], _capi.VMODE_EMPTY).astype(np.uint8)
+    timer = (rng.random((B, 12)) * period).astype(np.float32)
+    emitted, sim_step = np.zeros((B, 12), np.int32), rng.integers(0, 600, B).astype(np.int32)
+    light = rng.integers(0, 4, B).astype(np.uint8)
+    virtual = (rng.random(B) < 0.3).astype(np.uint8)
+    obs = m.get_obs(ego, cand, mode, light, ref_idx=ref, virtual=virtual)
+    const = dict(per_route=K, lane=lane, period=period, v_max=vmax, dt=0.1, exit_range=EXIT_RANGE, accel=ACCEL, lane_len=LANE_START - 25.0,
+                 light_cycle=light_cycle, seed=99)
+    trace, events = [], dict(emit=0, exit=0)
+    for t in range(steps):
+        raw = rng.uniform(-0.4, 0.4, (B, 2)).astype(np.float32)
+        flow = dict(const, active=active, timer=timer, emitted=emitted, sim_step=sim_step, counter=t + 1)
+        # the two calls
+        a = m.env_step(tr, obs, raw, ego, cand, mode, ref_idx=ref, cand_lw=lw, v_light=light, virtual=virtual)
+        f = tr.traffic_flow_step(K, a[5], active, timer, emitted, sim_step, lane, period, vmax, 0.1, EXIT_RANGE, ACCEL, LANE_START - 25.0,
+                                 light_cycle, 99, t + 1, light)
+        # the one call
+        g = m.env_step(tr, obs, raw, ego, cand, mode, ref_idx=ref, cand_lw=lw, v_light=light, virtual=virtual, flow=flow)
+        want = [a[0], a[1], a[2], a[3], a[4], f[0], a[6], a[7], f[1], f[2], f[3], f[4], f[5], f[6]]
+        names = ['scaled', 'out5', 'dict16', 'ego', 'params', 'cand', 'obs', 'done', 'active', 'timer', 'emitted', 'sim_step', 'cand_mode', 'v_light']
+        for k, (x, y) in enumerate(zip(g, want)):
+            assert np.array_equal(np.asarray(x).reshape(np.asarray(y).shape), y), (t, names[k])
+        events['emit'] += int((f[3] != emitted).sum())
+        events['exit'] += int(((active != 0) & (f[1] == 0)).sum())
+        ego, cand, obs = g[3], g[5], g[6]
+        active, timer, emitted, sim_step, mode, light = g[8], g[9], g[10], g[11], g[12], g[13]
+        trace.append([np.asarray(x) for x in g])
+    assert events['emit'] > B and events['exit'] > 0, events
+    return trace
+
+
+def flow_rule_bad_args_case(make, task='left', B=20, K=2):
+    """the flow rule excludes the pool's rules; its cand_mode / v_light must be the call's own arrays: EB_EINVAL, nothing written"""
+    import pytest
+    from env_build_amd.traffic import ROUTES
+    M = 12 * K
+    slot_modes = [r for r in ROUTES for _ in range(K)]
+    m, tr = make(task, mode='training'), make(task, n_veh=M, modes=slot_modes)
+    ego, cand, _, _, light, _, ref = random_scene(task, B, M, 3)
+    mode = np.tile(np.array([_capi.VMODE_ID[x] for x in slot_modes], np.uint8), (B, 1))
+    obs = m.get_obs(ego, cand, mode, light, ref_idx=ref)
+    raw = np.zeros((B, 2), np.float32)
+    z = lambda *s: np.zeros(s, np.float32)
+    flow = dict(per_route=K, active=np.ones((B, M), np.uint8), timer=z(B, 12), emitted=np.zeros((B, 12), np.int32), sim_step=np.zeros(B, np.int32),
+                lane=z(M, 5), period=np.ones(12, np.float32), v_max=np.ones(M, np.float32), dt=0.1, exit_range=40.0, accel=1.0, lane_len=60.0,
+                light_cycle=1, seed=1, counter=1)
+    for bad in (dict(flow, wrong=('mode',)), dict(flow, wrong=('v_light',)), dict(flow, per_route=K + 1)):
+        with pytest.raises(ValueError):
+            m.env_step(tr, obs, raw, ego, cand, mode, ref_idx=ref, v_light=light, flow=bad)
+    rule = dict(entry=z(M, 5), limit=65.0, span=5.0, v_max=8.0, seed=1, counter=1)
+    with pytest.raises(ValueError):
+        m.env_step(tr, obs, raw, ego, cand, mode, ref_idx=ref, v_light=light, flow=flow, respawn=rule)
+
+
 def masked_obs_case(make, task, B=150, M=10, seed=8):
     """eb_get_obs with a row mask: the masked rows equal the unmasked call's, the others keep what the buffer held."""
     native = VEHICLE_MODE_LIST[task]

@@ -334,7 +334,7 @@ class HostModel(object):
         return self._ret(out)
 
     def env_step(self, traffic, obs, raw, ego, cand, cand_mode, ref_idx=None, path_id=0, cand_lw=None, v_light=None,
-                 virtual=None, respawn=None, want_scaled=True, want_dict=True, scale_in_place=False, auto_reset=None):
+                 virtual=None, respawn=None, want_scaled=True, want_dict=True, scale_in_place=False, auto_reset=None, flow=None):
         """eb_env_step on copies of the state -> (scaled, out5, d16, ego, params, cand, obs_out, done_code).
         scale_in_place: the scaled actions overwrite the (copy of the) raw action array.
         respawn: dict(entry [M, 5], limit, span, v_max, seed, counter) — the pool's re-entry as the step's last stage.
@@ -372,10 +372,28 @@ class HostModel(object):
                 if k in auto_reset.get('wrong', ()):
                     setattr(ar, {'virtual': 'virtual_flag'}.get(k, k), vp(self._out((B,), np.int32 if k == 'ref_idx' else np.uint8)))
             extra = (ri, vf, vl, fo)
+        fl = None
+        if flow is not None:
+            # flow: dict(per_route, active, timer, emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len, light_cycle,
+            # seed, counter) — eb_traffic_flow_step as the call's last stage; the result gains (active, timer, emitted, sim_step,
+            # cand_mode, v_light) after it
+            vp = lambda t: None if t is None else self._ptr(t).value
+            cm = self._in(np.array(cand_mode, np.uint8), np.uint8)          # (copies: the call rewrites them)
+            vl = self._in(np.array(v_light, np.uint8), np.uint8)
+            f_act, f_tim = self._in(np.array(flow['active'], np.uint8), np.uint8), self._in(np.array(flow['timer'], np.float32))
+            f_emi, f_sim = self._in(np.array(flow['emitted'], np.int32), np.int32), self._in(np.array(flow['sim_step'], np.int32), np.int32)
+            f_lane, f_per, f_vm = self._in(flow['lane']), self._in(flow['period']), self._in(flow['v_max'])
+            fl = _capi.EbFlowRule(int(flow['per_route']), vp(f_act), vp(f_tim), vp(f_emi), vp(f_sim), vp(f_lane), vp(f_per), vp(f_vm),
+                                  float(flow['dt']), float(flow['exit_range']), float(flow['accel']), float(flow['lane_len']),
+                                  int(flow['light_cycle']), int(flow['seed']), int(flow['counter']),
+                                  vp(self._out((B, M), np.uint8)) if 'mode' in flow.get('wrong', ()) else vp(cm),
+                                  vp(self._out((B,), np.uint8)) if 'v_light' in flow.get('wrong', ()) else vp(vl))
+            extra = extra + (f_act, f_tim, f_emi, f_sim, cm, vl)
         self.api.env_step(self.h, traffic.h, B, self._ptr(ob), self._ptr(rw), self._ptr(ri), int(path_id), self._ptr(e_io),
                           self._ptr(par), M, self._ptr(c_io), self._ptr(cm), self._ptr(lw), self._ptr(vl), self._ptr(vf),
                           self._ptr(sc), self._ptr(out5), self._ptr(dd), self._ptr(obs_o), self._ptr(code),
-                          C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None, self.stream)
+                          C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None,
+                          C.byref(fl) if fl is not None else None, self.stream)
         return [None if x is None else self._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code) + extra]
 
     def traffic_respawn(self, cand, entry, limit, span, v_max, seed, counter, mask=None, ego=None, edge_span=0.0):
@@ -386,6 +404,20 @@ class HostModel(object):
         self.api.traffic_respawn(self.h, B, M, self._ptr(cd), self._ptr(en), C.c_float(limit), C.c_float(span), C.c_float(v_max),
                                  C.c_uint64(seed), C.c_uint64(counter), self._ptr(mk), self._ptr(flags), self._ptr(eg), C.c_float(edge_span), self.stream)
         return self._ret(cd), self._ret(flags)
+
+    def traffic_flow_step(self, K, cand, active, timer, emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len,
+                          light_cycle, seed, counter, v_light):
+        """eb_traffic_flow_step on copies of the state -> (cand, active, timer, emitted, sim_step, cand_mode, v_light)"""
+        cd, ac = self._in(np.array(cand, np.float32)), self._in(np.array(active, np.uint8), np.uint8)
+        tm, em = self._in(np.array(timer, np.float32)), self._in(np.array(emitted, np.int32), np.int32)
+        ss, vl = self._in(np.array(sim_step, np.int32), np.int32), self._in(np.array(v_light, np.uint8), np.uint8)
+        ln, pe, vm = self._in(lane), self._in(period), self._in(v_max)
+        B, M = cd.shape[0], cd.shape[1]
+        md = self._out((B, M), np.uint8)
+        self.api.traffic_flow_step(self.h, B, int(K), self._ptr(cd), self._ptr(ac), self._ptr(tm), self._ptr(em), self._ptr(ss), self._ptr(ln),
+                                   self._ptr(pe), self._ptr(vm), C.c_float(dt), C.c_float(exit_range), C.c_float(accel), C.c_float(lane_len),
+                                   int(light_cycle), C.c_uint64(seed), C.c_uint64(counter), self._ptr(md), self._ptr(vl), self.stream)
+        return [self._ret(x) for x in (cd, ac, tm, em, ss, md, vl)]
 
     def judge_done(self, ego, params, obs, cand, cand_mode, cand_lw, v_light):
         eg, pr, ob, cd = self._in(ego), self._in(params), self._in(obs), self._in(cand)

@@ -500,11 +500,28 @@ def test_auto_reset_on_the_separate_launch_path():
     rs = _capi.EbRespawn(en.data_ptr(), 0.0, 60.0, 8.0, 4242, 17, 5.0)
     a = _capi.EbAutoReset(99, 5, 1, ri.data_ptr(), vf.data_ptr(), vl.data_ptr(), rs, fo.data_ptr())
     m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), p(vf), p(sc), p(out5), p(dd),
-                   p(obs_o), p(code), None, C.byref(a), m.stream)
+                   p(obs_o), p(code), None, C.byref(a), None, m.stream)
     t.cuda.synchronize()
     got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code, ri, vf, vl, fo)]
     for k, (g, w) in enumerate(zip(got, want)):
         assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w, equal_nan=True), k
+
+
+@pytest.mark.parametrize('task,K,tile', [('left', 5, -1), ('left', 5, 1), ('straight', 5, 2), ('right', 2, 0), ('left', 1, -1), ('straight', 3, 1)])
+def test_env_step_with_the_flow_rule(task, K, tile):
+    """ABI 4 — the flow source's step (exits, accelerations, emissions, mode bytes, clock and light) as the last stage of the step's
+    own launch: equal to eb_env_step -> eb_traffic_flow_step on the HIP library over a 40-step closed loop (asserted inside the
+    case), and to the oracle's composite bit for bit at every step; 12 .. 60 slots, every tile shape that fits."""
+    from tests._env_step_check import flow_rule_case
+    want = flow_rule_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B=300, K=K)
+    got = flow_rule_case(lambda t, **kw: DeviceModel(t, **kw), task, B=300, K=K, tile=tile)
+    for t, (a, b) in enumerate(zip(want, got)):
+        _compare_auto_reset(a, b, 300, 'flow rule, step %d' % t)
+
+
+def test_flow_rule_argument_checks_on_the_gpu():
+    from tests._env_step_check import flow_rule_bad_args_case
+    flow_rule_bad_args_case(lambda t, **kw: DeviceModel(t, **kw))
 
 
 @pytest.mark.parametrize('task', TASKS)
@@ -554,7 +571,7 @@ def test_env_step_separate_launches_equal_the_one_launch_kernel():
     obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
     rs = _capi.EbRespawn(en.data_ptr(), 65.0, 60.0, 8.0, 77, 3)
     m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), None, p(sc), p(out5), p(dd),
-                   p(obs_o), p(code), C.byref(rs), None, m.stream)
+                   p(obs_o), p(code), C.byref(rs), None, None, m.stream)
     t.cuda.synchronize()
     got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code)]
     for k, (g, w) in enumerate(zip(got, want)):

@@ -474,7 +474,7 @@ def test_env_step_validates_before_it_launches_and_set_paths_failure_keeps_the_o
         with pytest.raises(ValueError):
             dev.api.env_step(dev.h, tr.h, B, p(dev._in(obs0)), p(dev._in(raw)), p(dev._in(bad['ref'], np.int32)), bad['path_id'],
                              p(e_io), p(par), M, p(c_io), p(dev._in(cmode, np.uint8)) if 'cmode' not in bad else None, None, None,
-                             None, p(sc), p(out5), None, p(obs_o), p(code), None, None, dev.stream)
+                             None, p(sc), p(out5), None, p(obs_o), p(code), None, None, None, dev.stream)
         assert np.array_equal(dev._ret(e_io), ego) and np.array_equal(dev._ret(c_io), cand) and (dev._ret(par) == 5.0).all()
     unset = DeviceModel.__new__(DeviceModel)               # a traffic handle without slot modes: EB_ESTATE before any launch
     import torch
@@ -482,7 +482,7 @@ def test_env_step_validates_before_it_launches_and_set_paths_failure_keeps_the_o
     unset.h = dev.api.create(task, M, 0, _capi.MODE_SELECTING)
     with pytest.raises(_capi.EbError):
         dev.api.env_step(dev.h, unset.h, B, p(dev._in(obs0)), p(dev._in(raw)), p(dev._in(ref, np.int32)), 0, p(e_io), p(par), M,
-                         p(c_io), p(dev._in(cmode, np.uint8)), None, None, None, p(sc), p(out5), None, p(obs_o), p(code), None, None, dev.stream)
+                         p(c_io), p(dev._in(cmode, np.uint8)), None, None, None, p(sc), p(out5), None, p(obs_o), p(code), None, None, None, dev.stream)
     assert np.array_equal(dev._ret(e_io), ego) and np.array_equal(dev._ret(c_io), cand)
     dev.api.destroy(unset.h)
     unset.h = None                                        # (its __del__ then destroys NULL: a no-op)

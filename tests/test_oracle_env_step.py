@@ -2,8 +2,8 @@
 equals its own single calls — the same check the GPU suite runs on the one-launch kernel (tests/_env_step_check.py)."""
 import pytest
 
-from tests._env_step_check import (CASES, auto_reset_bad_args_case, auto_reset_case, composite_case, masked_obs_case, reset_pool_case,
-                                   respawn_conflict_case, wrap_guard_case)
+from tests._env_step_check import (CASES, auto_reset_bad_args_case, auto_reset_case, composite_case, flow_rule_bad_args_case,
+                                   flow_rule_case, masked_obs_case, reset_pool_case, respawn_conflict_case, wrap_guard_case)
 from tests._helpers import HostModel
 
 
@@ -35,6 +35,16 @@ def test_oracle_step_with_auto_reset(oracle, task, B, M, NV, nf, vln):
 
 def test_oracle_auto_reset_argument_checks(oracle):
     auto_reset_bad_args_case(lambda t, **kw: HostModel(oracle, t, **kw))
+
+
+@pytest.mark.parametrize('task,K', [('left', 5), ('right', 2)])
+def test_oracle_step_with_the_flow_rule(oracle, task, K):
+    """ABI 4: eb_env_step(flow) == eb_env_step + eb_traffic_flow_step over a closed loop"""
+    flow_rule_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B=120, K=K, steps=30)
+
+
+def test_oracle_flow_rule_argument_checks(oracle):
+    flow_rule_bad_args_case(lambda t, **kw: HostModel(oracle, t, **kw))
 
 
 @pytest.mark.timeout(60)
