@@ -432,10 +432,8 @@ def one_launch_forms(torch, model, n_env, n_veh, seed, reps=100):
     nb = nb.value
     if nb == 0:
         return None
-    R = reps + 3
     i32 = dict(dtype=torch.int32, device=dev)
     open_gates, status = torch.ones(H, **i32), torch.zeros(2, **i32)
-    ready, done = torch.zeros((R, H), **i32), torch.zeros((R, H, nb, 16), **i32)   # one set of flags per repetition
     p = lambda t: C.c_void_p(t.data_ptr())
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     spin = 1 << 20
@@ -445,27 +443,43 @@ def one_launch_forms(torch, model, n_env, n_veh, seed, reps=100):
         api.rollout_gated(h, n_env, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), p(steps), p(open_gates), p(done[0]),
                           nb, p(status), spin, sp)
 
-    def gated_fed():
-        i = k[0] % R
-        k[0] += 1
-        api.gate_feed(h, n_env, H, nb, p(tape), p(live), p(ready[i]), p(done[i]), p(status), spin, sp, 1, None)
-        api.rollout_gated(h, n_env, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready[i]), p(done[i]),
-                          nb, p(status), spin, sp)
+    def fed(wait_after):
+        def run():
+            i = k[0] % R
+            k[0] += 1
+            api.gate_feed(h, n_env, H, nb, p(tape), p(live), p(ready[i]), p(done[i]), p(status), spin, sp, wait_after, None)
+            api.rollout_gated(h, n_env, H, p(obs0), p(live), p(ref), 0, p(work), p(out), p(out5), p(steps), p(ready[i]), p(done[i]),
+                              nb, p(status), spin, sp)
+        return run
 
     def tape_kernel():
         api.rollout_tape(h, n_env, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), sp)
 
-    res = {'horizon': H, 'gated_blocks': nb, 'rollouts_timed': reps}
-    for name, fn in (('gated_open_gates', gated_open), ('gated_fed_by_second_stream', gated_fed), ('open_loop_tape', tape_kernel)):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        res[name] = {'us_per_step': dt * 1e6 / H, 'value': n_env * H / dt, 'unit': 'env-steps/s'}
+    runs = 5
+    R = reps + 8             # one set of flags per fed repetition; zeroed again before every run
+    ready, done = torch.zeros((R, H), **i32), torch.zeros((R, H, nb, 16), **i32)
+    res = {'horizon': H, 'gated_blocks': nb, 'rollouts_timed': reps, 'runs': runs, 'statistic': 'us_per_step = median of the runs (us_per_step_min: the fastest)'}
+    # fed by a second stream, two orderings of the producer: (a) wait_after = 0 — the staged tape and the zeroed flags were ready long
+    # ago, so the feed of rollout k+1 may start while rollout k is still running; (b) wait_after = 1 — eb_gate_feed orders the feed
+    # behind everything the caller has enqueued on its stream (an event record + a stream wait per feed), which includes the previous
+    # gated rollout: the rollouts serialise.  Round 3 reported 6.7 us (before the ordering existed) and 10.1 us (after) under one name.
+    for name, fn in (('gated_open_gates', gated_open), ('gated_fed_by_second_stream', fed(0)),
+                     ('gated_fed_ordered_behind_the_caller_stream', fed(1)), ('open_loop_tape', tape_kernel)):
+        us = []
+        for _ in range(runs):
+            if name.startswith('gated_fed'):
+                k[0] = 0
+                ready.zero_(); done.zero_()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            us.append((time.perf_counter() - t0) / reps * 1e6 / H)
+        res[name] = {'us_per_step': median(us), 'us_per_step_min': min(us), 'us_per_step_max': max(us),
+                     'value': n_env / (median(us) * 1e-6), 'unit': 'env-steps/s'}
     if status.cpu().tolist() != [0, 0]:
         raise RuntimeError('gated rollout gave up at a gate: status %s' % status.cpu().tolist())
     return res

@@ -60,7 +60,7 @@ def test_one_launch_forms_of_configs1_run_and_report():
     model = EnvironmentModel(bench.TASK, num_future_data=0, mode='training', n_veh=16, device=torch.device('cuda', 0))
     r = bench.one_launch_forms(torch, model, 4096, 16, 11, reps=3)
     assert r['horizon'] == bench.HORIZON and r['gated_blocks'] >= 1
-    for k in ('gated_open_gates', 'gated_fed_by_second_stream', 'open_loop_tape'):
+    for k in ('gated_open_gates', 'gated_fed_by_second_stream', 'gated_fed_ordered_behind_the_caller_stream', 'open_loop_tape'):
         assert r[k]['value'] > 0 and r[k]['us_per_step'] > 0 and r[k]['unit'] == 'env-steps/s'
 
 
