@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy the summaries of one scripts/r3_measure.sh pass from gpurun_out/<tag>/ (scratch) into profiles/ (tracked) as <tag>_*.
+# Copy the summaries of one scripts/r3_measure.sh / r4_measure.sh pass from gpurun_out/<tag>/ (scratch) into profiles/ (tracked) as <tag>_*.
 # Usage: bash scripts/install_profiles.sh <tag>
 set -e
 T=$1; G=gpurun_out/$T
@@ -12,6 +12,10 @@ cp $G/prof_env/p_kernel_stats.csv profiles/${T}_env_step_kernel_stats.csv
 cp $G/prof_flows/p_kernel_stats.csv profiles/${T}_flows_kernel_stats.csv
 (grep n_env $G/facade_pool.txt; grep n_env $G/facade_flows.txt) > profiles/${T}_facade_env_step_timing.txt
 grep n_env $G/reset_pool.txt > profiles/${T}_reset_pool_timing.txt
-cp gpurun_out/${T}_pmc/pmc_traffic.json profiles/r3_pmc_traffic.json
+R=${T:0:2}                                        # r3 / r4: the round's traffic file (bench.py takes the newest whose kernel hash matches)
+cp gpurun_out/${T}_pmc/pmc_traffic.json profiles/${R}_pmc_traffic.json
+[ -f $G/prof_f16/p_kernel_stats.csv ] && cp $G/prof_f16/p_kernel_stats.csv profiles/${T}_f16x64_kernel_stats.csv
+[ -f $G/trace_env_step_4096_auto.txt ] && cp $G/trace_env_step_4096_auto.txt $G/trace_env_step_65536_auto.txt profiles/ && for f in trace_env_step_4096_auto trace_env_step_65536_auto; do mv profiles/$f.txt profiles/${T}_$f.txt; done
+[ -f $G/pmc_env_step.log ] && cp $G/pmc_env_step.log profiles/${T}_env_step_pmc.txt
 python scripts/pmc_traffic.py gpurun_out/${T}_pmc > profiles/${T}_pmc_traffic.txt
 ls profiles | grep "^${T}_"
