@@ -155,6 +155,24 @@ EB_DEV void slot_pair_walk(const float4* crow, unsigned long long elig, float ex
         i1 = first ? c : i1;
     };
     const float2* cxy = reinterpret_cast<const float2*>(crow);           // (x, y) of candidate c at cxy[2 * c]
+    {   // the first four members of the set without a loop: their indices first, then their (x, y) all in flight together, then the
+        // four offers — no branch, no LDS round trip per candidate (a mode rarely has more: the loop below takes the rest)
+        constexpr int UNR = 4;
+        int cs[UNR];
+        bool hs[UNR];
+        float2 q[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            hs[u] = elig != 0ull;
+            cs[u] = hs[u] ? __builtin_ctzll(elig) : 0;
+            elig &= elig - 1ull;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) q[u] = cxy[2 * cs[u]];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            offer(hs[u] & veh_in_range(TASK, MODE, V4{q[u].x, q[u].y, 0.0f, 0.0f}, ex, ey), key_of(ks, q[u].x, q[u].y), cs[u]);
+    }
     bool has = elig != 0ull;
     int c = has ? __builtin_ctzll(elig) : 0;
     elig &= elig - 1ull;
@@ -190,7 +208,7 @@ template <int TASK, int ET, bool OBS, bool RESET, bool AUTO = false>
 EB_DEV void env_step_body(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_jb[ET];
-    __shared__ float s_miu[ET];                                                  // miu_r of the step (the stability predicate's input)
+    __shared__ float s_miu[ET], s_r[ET];                                         // miu_r / yaw rate of the step (the stability predicate's inputs)
     // AUTO: the start state a reset would give every env of the tile (drawn at kernel start, under the latency of the first loads),
     // the tile's finished envs as a list, the slot plan as a table
     __shared__ float4 s_rst[AUTO ? ET : 1];                                      // (x, y, phi, v_x)
@@ -380,6 +398,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             nx[0] = nx[0] >= 0.0f ? nx[0] : 0.0f;                              // E2E:281
             nx[5] = wrap_deal_with_phi(nx[5]);                                 // E2E:282
             s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
+            s_r[lane] = nx[2];
             // (the new state goes to HBM after barrier 1: wave 1 computes the tyre parameters from the OLD row of the same array,
             // and nothing orders its load before a store issued here — seen once in a while as a `params` row of the new state;
             // the scaled action waits there too, so that a caller may scale its action array in place)
@@ -640,8 +659,40 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     // (no barrier here any more: the slots below need the ego, the candidates and the mode bytes — final since barrier 1 — so a wave
     // walks its modes as soon as its own pair / collision / tracking work is done; what DOES depend on the other waves' phase-2
     // results — the penalty sums, the done code — runs behind the one barrier that also completes the rows)
-    if (!OBS && wave == 0 && lane < ET)   // the done predicates that need only the new ego state (E2E:223-256): a byte for the merge below
-        s_jb[lane] = live ? (uint8_t)judge_bits(TASK, nx[0], nx[2], nx[3], nx[4], nx[5], s_miu[lane], red_light) : (uint8_t)0xff;
+    // (the penalty sums are wave 1's own business since every reward pair of the tile is: no barrier between its pair pass and them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!OBS && wave == 1 && live) {
+        // E2E:134: the reward of the step taken from the CURRENT observation; penalty partials in vehicle order
+        float v2v_train = 0.0f, v2v_real = 0.0f;
+        for (int j = 0; j < NV; ++j) {
+            const float2 q = s_part[lane * NV + j];
+            v2v_train += q.x;
+            v2v_real += q.y;
+        }
+        const float punish_steer = -sq(steer), punish_a_x = -sq(a_x), punish_yaw_rate = -sq(o9[2]);
+        const float devi_y = -sq(o9[6]), devi_phi = -sq(deg2rad(o9[7])), devi_v = -sq(o9[8]);
+        const float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+                              5.0f * punish_steer + 0.05f * punish_a_x;
+        const size_t n = (size_t)n_env;
+        float* out5 = A.out5;
+        out5[i] = rewards;
+        out5[n + i] = v2v_train + road_t;
+        out5[2 * n + i] = v2v_real + road_r;
+        out5[3 * n + i] = v2v_real;
+        out5[4 * n + i] = road_r;
+        if (float* d16 = A.d16) {   // DAM:302-318
+            d16[i] = punish_steer; d16[n + i] = punish_a_x; d16[2 * n + i] = punish_yaw_rate;
+            d16[3 * n + i] = devi_v; d16[4 * n + i] = devi_y; d16[5 * n + i] = devi_phi;
+            d16[6 * n + i] = 5.0f * punish_steer; d16[7 * n + i] = 0.05f * punish_a_x;
+            d16[8 * n + i] = 0.02f * punish_yaw_rate; d16[9 * n + i] = 0.05f * devi_v;
+            d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
+            d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
+        }
+    }
+    if (!OBS && wave == 3 && lane < ET) {   // the done predicates that need only the new ego state (E2E:223-256): a byte for the merge
+        const float4 eg = s_ego[lane];      // behind barrier 3 (wave 3, after its share of the collision pass: wave 0 has the tracking chain)
+        s_jb[lane] = live ? (uint8_t)judge_bits(TASK, eg.w, s_r[lane], eg.x, eg.y, eg.z, s_miu[lane], red_light) : (uint8_t)0xff;
+    }
     ES_MARK(6);
     // E2E:340-464 for the lanes with `on` (lane = env): the vehicle slots of this wave's modes -> s_out
     auto fill_slots = [&](const bool on, const bool light_on) {
@@ -747,34 +798,6 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     ES_MARK(3);
     __syncthreads();   // barrier: s_out complete; s_part, s_col, s_jb
     ES_MARK(10);
-    if (!OBS && wave == 1 && live) {
-        // E2E:134: the reward of the step taken from the CURRENT observation; penalty partials in vehicle order
-        float v2v_train = 0.0f, v2v_real = 0.0f;
-        for (int j = 0; j < NV; ++j) {
-            const float2 q = s_part[lane * NV + j];
-            v2v_train += q.x;
-            v2v_real += q.y;
-        }
-        const float punish_steer = -sq(steer), punish_a_x = -sq(a_x), punish_yaw_rate = -sq(o9[2]);
-        const float devi_y = -sq(o9[6]), devi_phi = -sq(deg2rad(o9[7])), devi_v = -sq(o9[8]);
-        const float rewards = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
-                              5.0f * punish_steer + 0.05f * punish_a_x;
-        const size_t n = (size_t)n_env;
-        float* out5 = A.out5;
-        out5[i] = rewards;
-        out5[n + i] = v2v_train + road_t;
-        out5[2 * n + i] = v2v_real + road_r;
-        out5[3 * n + i] = v2v_real;
-        out5[4 * n + i] = road_r;
-        if (float* d16 = A.d16) {   // DAM:302-318
-            d16[i] = punish_steer; d16[n + i] = punish_a_x; d16[2 * n + i] = punish_yaw_rate;
-            d16[3 * n + i] = devi_v; d16[4 * n + i] = devi_y; d16[5 * n + i] = devi_phi;
-            d16[6 * n + i] = 5.0f * punish_steer; d16[7 * n + i] = 0.05f * punish_a_x;
-            d16[8 * n + i] = 0.02f * punish_yaw_rate; d16[9 * n + i] = 0.05f * devi_v;
-            d16[10 * n + i] = 0.8f * devi_y; d16[11 * n + i] = 30.0f * devi_phi;
-            d16[12 * n + i] = v2v_train; d16[13 * n + i] = road_t; d16[14 * n + i] = v2v_real; d16[15 * n + i] = road_r;
-        }
-    }
     // E2E:200-221, the priority chain: every wave merges the tile's done codes for itself (lane = env: a byte, a flag and delta_y
     // from LDS, a dozen instructions) — the finished rows as a wave-uniform bit mask, no further barrier before the rows leave
     unsigned long long finmask = 0ull;

@@ -7,15 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'env_build_amd', 'csrc', 'eb_env_step.hip')
 VARIANTS = {
     'base': [],
-    'no_predict': [("            } else if (OBS) s_cand[e * RS4 + c] = v;", "            } else if (OBS || true) s_cand[e * RS4 + c] = v;")],
-    'no_reward_pairs': [("            for (int base = 0; base < n_pairs; base += 192 * 4) {", "            for (int base = 0; base < 0; base += 192 * 4) {")],
-    'no_collision': [("            for (int base = 0; base < n_rec; base += 192 * 3) {", "            for (int base = 0; base < 0; base += 192 * 3) {")],
+    'no_predict': [("            } else if (OBS) s_cand[e * RS4 + c] = v;", "            } else if (OBS || true) s_cand[e * RS4 + c] = v;")],     # (and no candidate store)
+    'no_reward_pairs': [("            for (int base = 0; base < n_pairs; base += 64 * 4) {", "            for (int base = 0; base < 0; base += 64 * 4) {")],
+    'no_collision': [("            for (int base = 0; base < n_rec; base += 128 * 4) {", "            for (int base = 0; base < 0; base += 128 * 4) {")],
     'no_slots': [("        unsigned long long firsts = A.first_mask;", "        unsigned long long firsts = 0ull;")],
     'no_tracking': [("            if (p < 0) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }", "            if (true) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }")],
-    'no_cand_store': [("        for (int base = lane; !OBS && base < n_rec; base += 256) {", "        for (int base = lane; !OBS && base < 0; base += 256) {")],
+    'no_cand_store': [("                else reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;", "                else if (e0 < 0) reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;")],
     'no_row_store': [("        for (int base = tid; base < total; base += 1024) {", "        for (int base = tid; base < 0; base += 1024) {")],
     'no_ego_roles': [("    } else if (wave < 2 && live) {", "    } else if (false) {")],
     'no_reward_sums': [("    if (!OBS && wave == 1 && live) {\n        // E2E:134", "    if (false) {\n        // E2E:134")],
+    'no_judge_bits': [("        s_jb[lane] = live ? (uint8_t)judge_bits(TASK, eg.w, s_r[lane], eg.x, eg.y, eg.z, s_miu[lane], red_light) : (uint8_t)0xff;",
+                       "        s_jb[lane] = live ? (uint8_t)15 : (uint8_t)0xff;")],
 }
 orig = open(SRC).read()
 names = sys.argv[1:] or list(VARIANTS)
