@@ -100,7 +100,7 @@ bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float
 }
 
 // profiling aid (eb_debug_set_trace on the model handle): slot k of this wave's row [16] <- the 100 MHz wall clock, lane 0 only
-#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
+#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
 
 // A per-wave queue of 16-bit item ids: `hit` lanes append (ballot / mbcnt), and whenever 64 are waiting the wave runs
 // `body(item)` on a full set of lanes; flush() runs the rest.
@@ -204,8 +204,15 @@ EB_DEV void slot_pair_walk(const float4* crow, unsigned long long elig, float ex
 // AUTO (step only): eb_env_step(auto_reset) — the rows whose done code came out non-zero take RESET's path in the same block after
 // the step's own phases: terminal observation -> final_obs, draws, pool re-entry clear of the new ego, reset observation (OLD
 // flag) -> obs_out, flag swap.  A tile without a finished row leaves after phase 4 as before.
-template <int TASK, int ET, bool OBS, bool RESET, bool AUTO = false>
+// NW: waves per block.  4: the roles share four waves (a wave walks a slot mode after its phase-2 work).  8 (small and medium
+// batches, where a block has its CU nearly to itself and a wave's instruction stream IS the step's duration): waves 4-7 own the
+// slot modes and walk them right after barrier 1, beside the tracking (wave 0), the reward pairs (wave 1) and the collision pass
+// (waves 2, 3); the staging is spread over six waves.
+template <int TASK, int ET, bool OBS, bool RESET, bool AUTO = false, int NW = 4>
 EB_DEV void env_step_body(const EnvStepArgs A) {
+    constexpr int NT = NW * 64;                                                  // threads per block
+    constexpr int KS = NW == 4 ? 3 : 2;                                          // chunks of a group per staging wave
+    constexpr int GCH = (NW - 2) * KS + 2, GREC = GCH * 64;                      // chunks / records per staging group (8 / 512, 14 / 896)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_jb[ET];
     __shared__ float s_miu[ET], s_r[ET];                                         // miu_r / yaw rate of the step (the stability predicate's inputs)
@@ -223,7 +230,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     if (OBS && A.row_mask && __builtin_amdgcn_ballot_w64(live) == 0ull) {         // same lanes -> envs in every wave: the whole block leaves
         if (RESET) {                                                              // (its rows are carried over from the previous arrays)
             if (A.obs)
-                for (int idx = tid; idx < nE * A.D; idx += 256) A.obs_out[(size_t)e0 * A.D + idx] = A.obs[(size_t)e0 * A.D + idx];
+                for (int idx = tid; idx < nE * A.D; idx += NT) A.obs_out[(size_t)e0 * A.D + idx] = A.obs[(size_t)e0 * A.D + idx];
             if (A.done_src && A.done_code && tid < nE) A.done_code[e0 + tid] = A.done_src[e0 + tid];
         }
         return;
@@ -247,7 +254,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
     if (AUTO && tid < EB_VMODE_COUNT) s_dm[tid] = A.dm[tid];
     if (tid < ET) s_col[tid] = (OBS && A.row_mask && !(tid < nE && A.row_mask[e0 + tid] != 0)) ? 1 : 0;   // OBS: 1 = row not to be written
-    for (int w = tid; w < ET * TS4; w += 256) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
+    for (int w = tid; w < ET * TS4; w += NT) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
     __syncthreads();   // (kernel-argument tables only: nobody waits for memory here)
 
     // ---- phase 1 ---------------------------------------------------------------------------------------------
@@ -259,8 +266,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     // chunks of 64 records in groups of eight: waves 2 and 3 take three chunks of a group each, waves 0 and 1 — which
     // have the ego step and the tyre parameters to do — one each
     auto rec_index = [&](int group, int k) -> int {
-        const int chunk = wave == 2 ? 2 * k : wave == 3 ? 2 * k + 1 : (k == 0 ? 6 + wave : -1);
-        return chunk < 0 ? -1 : (group * 8 + chunk) * 64 + lane;
+        const int chunk = wave >= 2 ? (wave - 2) + (NW - 2) * k : (k == 0 ? (NW - 2) * KS + wave : -1);   // (NW = 4: 0 2 4 / 1 3 5 / 6 / 7)
+        return chunk < 0 || k >= KS ? -1 : (group * GCH + chunk) * 64 + lane;
     };
     float4 cv[2][3];
     unsigned cm[2][3];
@@ -451,7 +458,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 const int idx = rec_index(g, k);
                 if (idx >= 0 && idx < n_rec) stage(idx, cv[g][k], cm[g][k]);
             }
-        for (int g = 2; g * 512 < n_rec; ++g) {                                // more than 16 candidates per env: one group at a time
+        for (int g = 2; g * GREC < n_rec; ++g) {                                // more than 16 candidates per env: one group at a time
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int idx = rec_index(g, k);
@@ -471,7 +478,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         // eb_traffic_flow_step, per slot (one copy of the code, a pass of its own over this lane's records): a vehicle far out and
         // heading away leaves (its record stays where the prediction put it), the others accelerate towards their vType's speed —
         // what the NEXT step sees goes to HBM; the LDS copy stays this step's state
-        for (int g = 0; g * 512 < n_rec; ++g)
+        for (int g = 0; g * GREC < n_rec; ++g)
 #pragma unroll 1
             for (int k = 0; k < 3; ++k) {
                 const int idx = rec_index(g, k);
@@ -622,7 +629,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         }
         ES_MARK(5);
-        if (wave >= 2) {   // one lane per (env, candidate): the collision test (TRF:263-295), its 10 m box first
+        if (wave == 2 || wave == 3) {   // one lane per (env, candidate): the collision test (TRF:263-295), its 10 m box first
             auto body = [&](int item) {
                 const int e = item >> 6, c = item & 63;
                 const float4 eg = s_ego[e];
@@ -711,7 +718,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         for (int k = 0; firsts; ++k) {
             const int s = __builtin_ctzll(firsts);
             firsts &= firsts - 1ull;
-            if (((0x1e >> (2 * (k & 3))) & 3) != wave) continue;               // owners in turn: waves 2, 3, 1, 0
+            if ((NW == 4 ? ((0x1e >> (2 * (k & 3))) & 3) : 4 + (k & 3)) != wave) continue;   // owners in turn: waves 2, 3, 1, 0 (NW = 8: 4, 5, 6, 7)
             const int m = __builtin_amdgcn_readlane(slot_mode, s);
             unsigned long long slots = __builtin_amdgcn_ballot_w64(slot_mode == m);   // the mode's slots, ascending
             if (!on) continue;
@@ -817,17 +824,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     auto store_rows = [&](const int which) {
         float* dst = A.obs_out + (size_t)e0 * D;
         const int total = nE * D;
-        for (int base = tid; base < total; base += 1024) {
+        for (int base = tid; base < total; base += 4 * NT) {
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int idx = base + 256 * k < total ? base + 256 * k : 0;
+                const int idx = base + NT * k < total ? base + NT * k : 0;
                 const int e = fast_div(idx, A.d_magic), c = idx - e * D;
                 v[k] = s_out[e * OS + c];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int idx = base + 256 * k;
+                const int idx = base + NT * k;
                 if (idx >= total) continue;
                 if (AUTO && which) {
                     const bool fin_row = (finmask >> fast_div(idx, A.d_magic)) & 1ull;
@@ -847,7 +854,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         // lane that staged the slot (it stored the slot's record in phase 1 and read its mode byte: program order settles both) —
         // and the env's clock and light (every wave has used the old light: barrier 3)
         const int K = A.flow_K;
-        for (int g = 0; g * 512 < n_rec; ++g)
+        for (int g = 0; g * GREC < n_rec; ++g)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int idx = rec_index(g, k);
@@ -891,7 +898,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         }
         if (wave == 1 && fin)                                                    // the finished envs as a list, for the compact slot pass
             s_finlist[__popcll(finmask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-        for (int idx = tid; idx < n_rec; idx += 256) {                           // E2E:102-103 (init_traffic, TRF:151-195): the pool of the
+        for (int idx = tid; idx < n_rec; idx += NT) {                            // E2E:102-103 (init_traffic, TRF:151-195): the pool of the
             const int e = fast_div(idx, A.m_magic);                              // finished envs re-enters clear of the NEW ego (s_rst:
             if ((finmask >> e) & 1ull) respawn_fresh(e, idx - e * m_cand, s_rst);   // written before barrier 1)
         }
@@ -979,8 +986,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     }
 }
 
-template <int TASK, int ET, bool OBS, bool AUTO = false>
-__global__ __launch_bounds__(256) void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO>(A); }
+template <int TASK, int ET, bool OBS, bool AUTO = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(A); }
 template <int TASK, int ET>
 __global__ __launch_bounds__(256) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true>(A); }
 
@@ -996,17 +1003,22 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;
     hipError_t e = hipSuccess;
-    const dim3 g((A.n_env + ET - 1) / ET), b(256);
-#define EB_ENV_STEP(T, E, O, AU)                                                                                      \
+    // eight waves per block for the step proper at small and medium batches (16- / 32-env tiles: few blocks per CU, the step is a
+    // wave's instruction stream), four otherwise; EB_ENV_WAVES=4 switches it off (tuning aid)
+    static const int wforce = std::getenv("EB_ENV_WAVES") ? std::atoi(std::getenv("EB_ENV_WAVES")) : 0;
+    const bool w8 = !A.reset && !A.obs_only && wforce != 4 && ET <= 32;
+    const dim3 g((A.n_env + ET - 1) / ET), b(w8 ? 512 : 256);
+#define EB_ENV_STEP_W(T, E, O, AU, W)                                                                                 \
     do {                                                                                                             \
         static size_t granted[64];   /* the > 48 KB opt-in is per kernel and device, and sticky */                   \
         if (lds > 48 * 1024 && lds > granted[dev]) {                                                                 \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T, E, O, AU>),                    \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<T, E, O, AU, W>),                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             if (e == hipSuccess) granted[dev] = lds;                                                                 \
         }                                                                                                            \
-        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O, AU>), g, b, lds, s, A);                    \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O, AU, W>), g, b, lds, s, A);                 \
     } while (0)
+#define EB_ENV_STEP(T, E, O, AU) do { if (!(O) && (E) <= 32 && w8) EB_ENV_STEP_W(T, (E) <= 32 ? (E) : 32, false, AU, 8); else EB_ENV_STEP_W(T, E, O, AU, 4); } while (0)
 #define EB_ENV_RESET(T, E)                                                                                            \
     do {                                                                                                             \
         static size_t granted[64];                                                                                   \
@@ -1032,6 +1044,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
 #undef EB_ENV_STEP_T
 #undef EB_ENV_RESET
 #undef EB_ENV_STEP
+#undef EB_ENV_STEP_W
     return e != hipSuccess ? e : hipGetLastError();
 }
 

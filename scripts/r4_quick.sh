@@ -9,7 +9,7 @@ fi
 python scripts/trace_env_step.py --n-env 4096 > gpurun_out/${tag}_trace_4096.txt 2>&1
 python scripts/trace_env_step.py --n-env 65536 > gpurun_out/${tag}_trace_65536.txt 2>&1
 grep -A13 "^wave 0" gpurun_out/${tag}_trace_4096.txt | cut -c1-135
-grep -A13 "^wave 2" gpurun_out/${tag}_trace_4096.txt | cut -c1-135
+grep -A13 "^wave 4" gpurun_out/${tag}_trace_4096.txt | cut -c1-135
 grep -A11 "^wave 2" gpurun_out/${tag}_trace_65536.txt | cut -c1-135
 python bench.py --env-step > gpurun_out/${tag}_bench_env_step.json 2>/dev/null
 python - <<PY

@@ -18,7 +18,8 @@ for _ in range(40 if a.wild else 3): env.step(act)
 torch.cuda.synchronize()
 te = 16 if B <= 6144 else 32 if B <= 24576 else 64
 nb = (B + te - 1) // te
-trs = [torch.zeros((nb * 4, 16), dtype=torch.int64, device=env.device) for _ in range(3)]
+nw = 8 if (te <= 32 and os.environ.get('EB_ENV_WAVES') != '4') else 4      # waves per block of the step kernel (csrc/eb_env_step.hip: launch_env_step)
+trs = [torch.zeros((nb * nw, 16), dtype=torch.int64, device=env.device) for _ in range(3)]
 for k in range(3):
     lib.eb_debug_set_trace(env._h, C.c_void_p(trs[k].data_ptr())); env.step(act)
 torch.cuda.synchronize(); lib.eb_debug_set_trace(env._h, None)
@@ -38,9 +39,9 @@ order = [(0, 'start'), (1, 'phase 1 done: ego step / tyre params / traffic step 
 def q(x): return ' '.join('%6.2f' % v for v in np.percentile(x, [0, 10, 50, 90, 100])) + '   n=%d' % len(x)
 print('%d blocks; us since the first wave started; percentiles 0 10 50 90 100' % nb)
 raw = trs[1].cpu().numpy()
-for w in range(4):
+for w in range(nw):
     print('wave %d' % w)
     for k, n in order:
-        sel = raw[w::4, k] != 0
+        sel = raw[w::nw, k] != 0
         if not sel.any(): continue
-        print('  %-86s %s' % (n, q(t[w::4, k][sel])))
+        print('  %-86s %s' % (n, q(t[w::nw, k][sel])))
