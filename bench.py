@@ -626,7 +626,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
             'wall_us_per_step_incl_state_restores': wall * 1e6 / (reps * seg),
             'alg_bytes_per_env_step': env_step_alg_bytes(D, M), 'alg_bytes_per_launch': alg, 'achieved_GBs': achieved, 'frac': frac,
             'traffic': traffic, 'traffic_source': traffic_src,
-            'kernel': 'eb::env_step_kernel<0, %d, false, false>' % (16 if B <= 6144 else 32 if B <= 24576 else 64),
+            'kernel': 'eb::env_step_kernel<0, %d, false, false, %d>' % ((16, 8) if B <= 1024 else (32, 8) if B <= 20480 else (64, 4)),
             'done_fraction_after_segment': done_frac,
             'masked_reset': {'entry': 'eb_env_reset_pool (one launch: eb::env_reset_pool_kernel)', 'mask_fraction': 0.02, 'calls_timed': n_reset,
                              'us_per_call': reset_us, 'carries_over': 'observation and done-code rows of the other envs (obs_src / done_src)'},

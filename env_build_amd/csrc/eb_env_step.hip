@@ -60,19 +60,18 @@ size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow) {
     if (flow) b += E * 12 * 16 + E * 12 * 4 + E * m_cand;   // s_new, s_emit, s_on (eb_flow_rule)
     return (b + 15) & ~(size_t)15;
 }
-// envs per block: 64 for throughput; small batches take 16- or 32-env tiles so that more blocks (and fewer records per lane)
-// stand behind the same step — a step of 4 096 envs is latency, not bandwidth
+// envs per block: 64 for throughput; small and medium batches take 32-env tiles (16 below 1 024 envs) with EIGHT waves per block
+// (launch_env_step) — a step of a few thousand envs is latency, i.e. the length of a wave's instruction stream, not bandwidth.
 // Many candidates per env (the flow source: 60) make a 64-env tile too big for four blocks per CU (> 40 KB of LDS): 16-env
 // tiles then, at any batch size (measured at 65 536 envs x 60 candidates: 119 us with one 85 KB block per CU).
-// Measured (16 candidates, us per step at tiles of 16 / 32 / 64 envs): 4 096 envs 10.8 / 11.4 / 13.2; 8 192: 11.8 / 11.7 / 13.4;
-// 16 384: 14.9 / 13.0 / 14.0; 32 768: 24.9 / 17.2 / 16.2; 65 536: 42.8 / 28.2 / 21.2; 131 072: 76.8 / 49.3 / 39.5.
+// Measured (16 candidates, us per step at tiles of 16 / 32 / 64 envs, round 4 — profiles/r4_env_tile_sweep.txt): 2 048 envs
+// 7.3 / 7.2 / 11.0; 4 096: 7.5 / 7.3 / 11.1; 8 192: 8.5 / 7.6 / 11.4; 16 384: 14.9 / 9.2 / 11.9; 24 576: 21.4 / 14.3 / 13.2;
+// 32 768: 27.4 / 16.4 / 13.6; 65 536: 51.7 / 29.4 / 18.2.  (Round 3, four waves everywhere: 4 096: 10.8 / 11.4 / 13.2.)
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand) {
     if (env_step_lds_bytes(D, NV, m_cand, 64) > 40 * 1024) return 16;
-    return n_env <= 6144 ? 16 : n_env <= 24576 ? 32 : 64;
+    return n_env <= 1024 ? 16 : n_env <= 20480 ? 32 : 64;
 }
 
-// cand and params are accessed as float4, ego / actions / scaled actions as float2: a buffer that is not aligned to its vector
-// access (an offset view handed in through the C-ABI) takes the separate launches instead
 void env_step_slot_plan(const VehModes& modes, int NV, EnvStepArgs& A) {
     A.first_mask = 0; A.n_dm = 0; A.dm_ok = 1;
     for (int sl = 0; sl < NV; ++sl) {
@@ -92,6 +91,8 @@ void env_step_slot_plan(const VehModes& modes, int NV, EnvStepArgs& A) {
     A.dm_magic = A.n_dm <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)A.n_dm - 1) / (unsigned)A.n_dm);
 }
 
+// cand and params are accessed as float4, ego / actions / scaled actions as float2: a buffer that is not aligned to its vector
+// access (an offset view handed in through the C-ABI) takes the separate launches instead
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego, const float* actions,
                        const float* scaled, const float* params) {
     auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };

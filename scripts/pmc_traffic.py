@@ -48,13 +48,13 @@ summary = {'kernel_source_hash': {k: _build.kernel_hash(k) for k in _build.KERNE
 try:
     es = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        k_kib, n_k = mean_counter('envstep_' + c, c, 'env_step_kernel<0, 64, false, false>', 1024 * 256)
+        k_kib, n_k = mean_counter('envstep_' + c, c, 'env_step_kernel<0, 64, false, false, 4>', 1024 * 256)
         es[c] = {'kib_per_launch': k_kib, 'launches': n_k, 'bytes_per_launch': k_kib * 1024.0 * res[c]['calibration_factor']}
     es_alg = (8 * 41 + 33 * 16 + 105) * 65536
     es_total = es['FETCH_SIZE']['bytes_per_launch'] + es['WRITE_SIZE']['bytes_per_launch']
     summary['env_step'] = {'hbm_bytes_per_launch': es_total, 'read_bytes_per_launch': es['FETCH_SIZE']['bytes_per_launch'],
                            'write_bytes_per_launch': es['WRITE_SIZE']['bytes_per_launch'], 'algorithmic_bytes_per_launch': es_alg,
-                           'traffic_over_algorithmic': es_total / es_alg, 'kernel': 'eb::env_step_kernel<0, 64, false, false>', 'counters': es}
+                           'traffic_over_algorithmic': es_total / es_alg, 'kernel': 'eb::env_step_kernel<0, 64, false, false, 4>', 'counters': es}
 except SystemExit as e:
     summary['env_step'] = None
     print('(no env-step passes: %s)' % e)

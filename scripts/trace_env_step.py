@@ -16,7 +16,7 @@ lib = env.api.lib
 lib.eb_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
 for _ in range(40 if a.wild else 3): env.step(act)
 torch.cuda.synchronize()
-te = 16 if B <= 6144 else 32 if B <= 24576 else 64
+te = 16 if B <= 1024 else 32 if B <= 20480 else 64
 nb = (B + te - 1) // te
 nw = 8 if (te <= 32 and os.environ.get('EB_ENV_WAVES') != '4') else 4      # waves per block of the step kernel (csrc/eb_env_step.hip: launch_env_step)
 trs = [torch.zeros((nb * nw, 16), dtype=torch.int64, device=env.device) for _ in range(3)]
