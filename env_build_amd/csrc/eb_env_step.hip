@@ -899,9 +899,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         }
         if (wave == 1 && fin)                                                    // the finished envs as a list, for the compact slot pass
             s_finlist[__popcll(finmask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-        for (int idx = tid; idx < n_rec; idx += NT) {                            // E2E:102-103 (init_traffic, TRF:151-195): the pool of the
-            const int e = fast_div(idx, A.m_magic);                              // finished envs re-enters clear of the NEW ego (s_rst:
-            if ((finmask >> e) & 1ull) respawn_fresh(e, idx - e * m_cand, s_rst);   // written before barrier 1)
+        // E2E:102-103 (init_traffic, TRF:151-195): the pool of the finished envs re-enters clear of the NEW ego (s_rst: written before
+        // barrier 1) — one lane per (finished env, candidate), not a sweep over the tile's records
+        const int n_fin = __popcll(finmask);
+        auto nth_fin = [&](int k) -> int {                                       // the k-th finished env of the tile (k is small)
+            unsigned long long mbits = finmask;
+            for (int t = 0; t < k; ++t) mbits &= mbits - 1ull;
+            return __builtin_ctzll(mbits);
+        };
+        for (int q = tid; q < n_fin * m_cand; q += NT) {
+            const int k = fast_div(q, A.m_magic);
+            respawn_fresh(nth_fin(k), q - k * m_cand, s_rst);
         }
         ES_MARK(13);
         __syncthreads();   // barrier: the re-entered candidates, s_ego, the list
@@ -981,7 +989,10 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         }
         ES_MARK(14);
         __syncthreads();
-        store_rows(2);
+        for (int k = wave; k < n_fin; k += NW) {                                 // the reset rows: a wave per finished env, a lane per column
+            const int e = nth_fin(k);
+            for (int c = lane; c < D; c += 64) A.obs_out[((size_t)e0 + e) * D + c] = s_out[e * OS + c];
+        }
         if (wave == 0 && fin) A.virtual_out[i] = virtual_next ? 1 : 0;           // E2E:120-126
         ES_MARK(15);
     }
