@@ -366,7 +366,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
         in_g0 = eg[0]; in_g1 = eg[1]; in_g2 = eg[2];
     }
-    if (AUTO && wave == 0 && live) {
+    if (AUTO && wave == (NW == 8 ? NW - 1 : 0) && live) {   // (eight waves: the last one stages the fewest records)
         // Ahead of time, under the latency of the loads just issued: the start state a reset would give this env — the draws depend
         // on (seed, counter, env) alone.  If the step finishes the env, the tail finds its pose here instead of running eight 64-bit
         // multiplies and a dependent table read per draw behind the step.
@@ -819,10 +819,10 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     // ---- phase 4 ---------------------------------------------------------------------------------------------
     if (RESET && wave == 0 && live) A.virtual_out[i] = virtual_next ? 1 : 0;   // every wave read the old flag before the barriers above
     if (RESET && wave == 0 && !live && lane < nE && A.done_src && A.done_code) A.done_code[i] = A.done_src[i];
-    // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane).  which = 0: every row
-    // (OBS with a row mask: the masked rows; RESET: the others carried over); 1 (AUTO, phase 4): the finished rows go to final_obs
-    // instead; 2 (AUTO, after the reset): the finished rows alone
-    auto store_rows = [&](const int which) {
+    // observation rows out: the tile's rows are contiguous in memory (four LDS reads in flight per lane) — every row (OBS with a row
+    // mask: the masked rows; RESET: the others carried over).  AUTO: the finished envs' rows go out here too, as everybody's; their
+    // copy for final_obs and, later, the reset rows that replace them are a wave per row (below)
+    auto store_rows = [&](const int) {
         float* dst = A.obs_out + (size_t)e0 * D;
         const int total = nE * D;
         for (int base = tid; base < total; base += 4 * NT) {
@@ -837,19 +837,12 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             for (int k = 0; k < 4; ++k) {
                 const int idx = base + NT * k;
                 if (idx >= total) continue;
-                if (AUTO && which) {
-                    const bool fin_row = (finmask >> fast_div(idx, A.d_magic)) & 1ull;
-                    if (which == 2) { if (fin_row) dst[idx] = v[k]; }
-                    else if (!fin_row) dst[idx] = v[k];
-                    else if (A.final_obs) A.final_obs[(size_t)e0 * D + idx] = v[k];
-                    continue;
-                }
                 if (!(OBS && A.row_mask && s_col[fast_div(idx, A.d_magic)])) dst[idx] = v[k];
                 else if (RESET && A.obs) dst[idx] = A.obs[(size_t)e0 * D + idx];            // a row outside the mask: carried over
             }
         }
     };
-    store_rows(AUTO ? 1 : 0);
+    store_rows(0);
     if (!OBS && A.flow_on) {
         // eb_traffic_flow_step, the rest: a slot's flag and mode byte for the next step, the entering vehicle into its slot — by the
         // lane that staged the slot (it stored the slot's record in phase 1 and read its mode byte: program order settles both) —
@@ -884,6 +877,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         // ---- the envs this step finished start their next episode (E2E:99-127) — eb_env_reset_pool's arithmetic on those rows ----
         const bool fin = (finmask >> lane) & 1ull;                               // the same in every wave
         if (finmask == 0ull) return;                                             // nobody in this tile: the usual case per row, not per tile
+        const int n_fin = __popcll(finmask);
+        auto nth_fin = [&](int k) -> int {                                       // the k-th finished env of the tile (k is small)
+            unsigned long long mbits = finmask;
+            for (int t = 0; t < k; ++t) mbits &= mbits - 1ull;
+            return __builtin_ctzll(mbits);
+        };
+        if (A.final_obs)                                                         // the terminal observations: a wave per finished env
+            for (int k = wave; k < n_fin; k += NW) {
+                const int e = nth_fin(k);
+                for (int c = lane; c < D; c += 64) A.final_obs[((size_t)e0 + e) * D + c] = s_out[e * OS + c];
+            }
         // this thread's stores of the step (ego, params, candidates, rows) are complete before ANOTHER thread overwrites them below,
         // and everybody's reads of s_out / s_ego / s_cand are over
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -901,12 +905,6 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             s_finlist[__popcll(finmask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
         // E2E:102-103 (init_traffic, TRF:151-195): the pool of the finished envs re-enters clear of the NEW ego (s_rst: written before
         // barrier 1) — one lane per (finished env, candidate), not a sweep over the tile's records
-        const int n_fin = __popcll(finmask);
-        auto nth_fin = [&](int k) -> int {                                       // the k-th finished env of the tile (k is small)
-            unsigned long long mbits = finmask;
-            for (int t = 0; t < k; ++t) mbits &= mbits - 1ull;
-            return __builtin_ctzll(mbits);
-        };
         for (int q = tid; q < n_fin * m_cand; q += NT) {
             const int k = fast_div(q, A.m_magic);
             respawn_fresh(nth_fin(k), q - k * m_cand, s_rst);
@@ -922,13 +920,21 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         if (A.dm_ok) {
             if (wave == 0) {
                 if (fin) track_row(reset_path);
-            } else if (wave == 1) {
+            } else if (NW == 8 || wave == 1) {
+                // (eight waves: the block has its CU nearly to itself and the stream's LENGTH is what counts — waves 1-7 take one distinct
+                // mode each, lanes = the finished envs, the mode wave-uniform again: no divergence in the per-mode switches)
                 const unsigned long long vmask = __builtin_amdgcn_ballot_w64(vflag);      // lane = env: the OLD flags of the tile
-                const int n_pairs_f = __popcll(finmask) * A.n_dm, nw = (m_cand + 3) >> 2;
-                for (int q0 = 0; q0 < n_pairs_f; q0 += 64) {
-                    const int q = q0 + lane;
-                    const bool act = q < n_pairs_f;
-                    const int ford = act ? fast_div(q, A.dm_magic) : 0, j = act ? q - ford * A.n_dm : 0;
+                const int n_pairs_f = n_fin * A.n_dm, nw = (m_cand + 3) >> 2;
+                const int rounds = NW == 8 ? (A.n_dm - (wave - 1) + (NW - 2)) / (NW - 1) : (n_pairs_f + 63) >> 6;
+                for (int rd = 0; rd < rounds; ++rd) {
+                    int ford, j;
+                    bool act;
+                    if (NW == 8) { j = wave - 1 + rd * (NW - 1); ford = lane; act = lane < n_fin; if (!act) ford = 0; }
+                    else {
+                        const int q = rd * 64 + lane;
+                        act = q < n_pairs_f;
+                        ford = act ? fast_div(q, A.dm_magic) : 0; j = act ? q - ford * A.n_dm : 0;
+                    }
                     const int e = s_finlist[ford];
                     const unsigned dm = s_dm[j];
                     const int m = (int)(dm & 0xffu), sa = (int)((dm >> 8) & 0xffu), sb = (int)((dm >> 16) & 0xffu);
