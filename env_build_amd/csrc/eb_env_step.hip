@@ -1024,8 +1024,16 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     // eight waves per block for the step proper at small and medium batches (16- / 32-env tiles: few blocks per CU, the step is a
     // wave's instruction stream), four otherwise; EB_ENV_WAVES=4 switches it off (tuning aid)
     static const int wforce = std::getenv("EB_ENV_WAVES") ? std::atoi(std::getenv("EB_ENV_WAVES")) : 0;
-    const bool w8 = !A.reset && !A.obs_only && wforce != 4 && ET <= 32;
-    const dim3 g((A.n_env + ET - 1) / ET), b(w8 ? 512 : 256);
+    static int n_cu[64];
+    if (!n_cu[dev]) {
+        int cu = 0;
+        n_cu[dev] = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0 ? cu : 256;
+    }
+    const int n_blocks = (A.n_env + ET - 1) / ET;
+    // (a grid of many small tiles — the flow source's 60 candidates force 16-env tiles at any batch size — is throughput again: with
+    // eight waves per block only two blocks fit a CU's registers; measured at 65 536 x 60: 133 us against 104)
+    const bool w8 = !A.reset && !A.obs_only && wforce != 4 && ET <= 32 && (n_blocks <= 3 * n_cu[dev] || wforce == 8);
+    const dim3 g(n_blocks), b(w8 ? 512 : 256);
 #define EB_ENV_STEP_W(T, E, O, AU, W)                                                                                 \
     do {                                                                                                             \
         static size_t granted[64];   /* the > 48 KB opt-in is per kernel and device, and sticky */                   \

@@ -18,7 +18,7 @@ for _ in range(40 if a.wild else 3): env.step(act)
 torch.cuda.synchronize()
 te = 16 if B <= 1024 else 32 if B <= 20480 else 64
 nb = (B + te - 1) // te
-nw = 8 if (te <= 32 and os.environ.get('EB_ENV_WAVES') != '4') else 4      # waves per block of the step kernel (csrc/eb_env_step.hip: launch_env_step)
+nw = 8 if (te <= 32 and nb <= 768 and os.environ.get('EB_ENV_WAVES') != '4') else 4      # waves per block of the step kernel (csrc/eb_env_step.hip: launch_env_step)
 trs = [torch.zeros((nb * nw, 16), dtype=torch.int64, device=env.device) for _ in range(3)]
 for k in range(3):
     lib.eb_debug_set_trace(env._h, C.c_void_p(trs[k].data_ptr())); env.step(act)
