@@ -304,11 +304,19 @@ class Timer(object):
         self.torch.cuda.synchronize()
 
     def measure(self, n_steps, warmup, repeats):
-        """-> dict(dt = [per-repeat seconds, max over ranks], launch_us = event-timed average per launch, launches_timed)"""
+        """-> dict(dt = [per-repeat seconds, max over ranks], launch_us = event-timed duration per launch: the mean within a repeat,
+        the median over the repeats (the statistic of `value`), launch_us_by_repeat, launches_timed)"""
         torch, dist = self.torch, self.dist
         self.run(warmup, False)
+        # the launch forms of the K-step region are built before it is timed (argument tuples / hipGraph of a rollout of this
+        # length: host work, no steps) — a region that is shorter than the warm-up's rollouts would otherwise build them on the clock
+        for h in set(self.segments(n_steps)):
+            if not self.open_loop:
+                self.s.eager_args(h)
+                if not self.eager:
+                    self.s.plan(h)
         torch.cuda.synchronize()
-        dts, ev_ms, ev_launches = [], 0.0, 0
+        dts, per_repeat, ev_launches = [], [], 0
         ms = C.c_float()
         for _ in range(repeats):
             if self.use_dist:
@@ -321,14 +329,18 @@ class Timer(object):
                 dist.barrier()
             torch.cuda.synchronize()
             dts.append(time.perf_counter() - t0)
+            ev_ms, n_l = 0.0, 0
             for k, h in enumerate(segs[:MAX_PAIRS]):
                 self.api.event_elapsed_ms(self.ev[2 * k], self.ev[2 * k + 1], C.byref(ms))
                 ev_ms += ms.value
-                ev_launches += (1 if self.open_loop else h * self.s.lanes)
+                n_l += (1 if self.open_loop else h * self.s.lanes)
+            per_repeat.append(ev_ms * 1e3 / max(1, n_l))
+            ev_launches += n_l
         t = torch.tensor(dts, dtype=torch.float64, device=self.s.model.device if not self.use_dist or dist.get_backend() == 'nccl' else 'cpu')
         if self.use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return dict(dt=[float(x) for x in t.tolist()], launch_us=ev_ms * 1e3 / max(1, ev_launches), launches_timed=ev_launches)
+        return dict(dt=[float(x) for x in t.tolist()], launch_us=sorted(per_repeat)[len(per_repeat) // 2], launch_us_by_repeat=per_repeat,
+                    launches_timed=ev_launches)
 
     def close(self):
         for e in self.ev:
@@ -905,6 +917,9 @@ def main():
                          'frac': frac, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': kernel, 'alg_bytes_per_launch': alg,
                          'avg_launch_us': launch_us, 'launches_timed': r['launches_timed'],
+                         'avg_launch_us_statistic': 'HIP events around every rollout of the timed regions: mean per launch within a '
+                                                    'region, median over the regions (as `value`)',
+                         'avg_launch_us_by_region': {'min': min(r['launch_us_by_repeat']), 'max': max(r['launch_us_by_repeat'])},
                          'working_set_MB': ws / 1e6,
                          'residency': ('working set %.0f MB < 268 MB Infinity Cache: this fraction is cache-assisted; see hbm_resident'
                                        % (ws / 1e6)) if ws < MALL_BYTES else 'working set exceeds the Infinity Cache',

@@ -92,7 +92,7 @@ def composite_case(make, task, B, M, NV, nf, tile=None):
     return got
 
 
-def auto_reset_case(make, task, B, M, NV=None, nf=0, tile=None, close_p=0.02, seed=5, v_light_none=False):
+def auto_reset_case(make, task, B, M, NV=None, nf=0, tile=None, close_p=0.02, seed=5, v_light_none=False, strict=True):
     """eb_env_step(auto_reset) == eb_env_step, then the terminal rows -> final_obs, then eb_env_reset_pool(mask = done != 0) in place —
     every output and every piece of state, bit for bit; done_code keeps the step's codes."""
     from env_build_amd.endtoend import _lane_entry
@@ -126,7 +126,7 @@ def auto_reset_case(make, task, B, M, NV=None, nf=0, tile=None, close_p=0.02, se
     sc, o5, d16, ego1, par1, cand1, obs1, done1 = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=v_light, virtual=virtual,
                                                              respawn=rule)
     fin = done1 != 0
-    assert 0.02 < fin.mean() < 0.9, fin.mean()
+    assert not strict or 0.02 < fin.mean() < 0.9, fin.mean()       # (strict: the case must exercise both kinds of row)
     vl_in = np.zeros(B, np.uint8) if v_light is None else v_light
     e2, p2, r2, vf2, vl2, _, c2, o2 = m.env_reset_pool(tr, 99, 5, 1, ego1, par1, ref, virtual, vl_in, cand1, cmode, obs1, pool,
                                                        mask=fin.astype(np.uint8))
@@ -143,7 +143,7 @@ def auto_reset_case(make, task, B, M, NV=None, nf=0, tile=None, close_p=0.02, se
         assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w, equal_nan=True), names[k]
     # the rows that did not finish are the plain step's; those that did start from a drawn state
     assert np.array_equal(got[6][~fin], obs1[~fin]) and np.array_equal(got[3][~fin], ego1[~fin])
-    assert (got[3][fin][:, 1:3] == 0).all() and not np.array_equal(got[6][fin], obs1[fin])
+    assert (got[3][fin][:, 1:3] == 0).all() and (not fin.any() or not np.array_equal(got[6][fin], obs1[fin]))
     # final_obs left out; auto_reset without the step's own re-entry rule
     g2 = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=v_light, virtual=virtual, respawn=rule,
                     auto_reset=dict(seed=99, counter=5, training=1, pool=pool, final_obs=False))
@@ -177,7 +177,7 @@ def auto_reset_bad_args_case(make, task='left', B=40, M=8):
                    auto_reset=dict(seed=1, counter=1, training=1, pool=pool))
 
 
-def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, seed=3):
+def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, seed=3, strict=True):
     """eb_env_step(flow) == eb_env_step, then eb_traffic_flow_step on what it left — every output and every piece of the flow
     source's state, bit for bit, over a closed loop that starts from an empty junction (emissions, exits, accelerations, the
     light programme all occur on the way); -> the trace of the fused path (for cross-library comparison)."""
@@ -227,7 +227,7 @@ def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, s
         ego, cand, obs = g[3], g[5], g[6]
         active, timer, emitted, sim_step, mode, light = g[8], g[9], g[10], g[11], g[12], g[13]
         trace.append([np.asarray(x) for x in g])
-    assert events['emit'] > B and events['exit'] > 0, events
+    assert not strict or (events['emit'] > B and events['exit'] > 0), events
     return trace
 
 

@@ -234,6 +234,22 @@ def test_plan_graph_replay_and_summary(task, N, B, H):
     assert np.array_equal(dev.episode_summary(o5_d, out_d), s8_d)
 
 
+@pytest.mark.parametrize('B,H', [(1, 1), (3, 5), (255, 4), (256, 25), (257, 3), (1000, 25), (1001, 7), (65536, 25), (65536 + 260, 2)])
+def test_episode_summary_sizes(B, H):
+    """eb_episode_summary against the oracle's float64 sums at ragged sizes — fewer envs than a block, more than the grid covers
+    in one pass — and twice in a row on the same handle (the partials of the first call are scratch)."""
+    host, dev = _pair('left', n_veh=4)
+    rng = np.random.default_rng(B + H)
+    o5 = (rng.random((H, 5, B), dtype=np.float32) - np.float32(0.4)) * np.float32(3.0)
+    o5[:, 2][rng.random((H, B)) < 0.9] = 0.0                      # punish_real: zero most of the time
+    obs = rng.normal(size=(B, 6 + 3 + 4 * 4)).astype(np.float32)                 # task left, 4 slots, no future points: D = 25
+    want = host.episode_summary(o5, obs)
+    for _ in range(2):
+        got = dev.episode_summary(o5, obs)
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+        assert got[3] == want[3] and got[5] == want[5] and got[6] == B and got[7] == H
+
+
 def test_event_marks_measure_stream_time():
     import ctypes as C
     host, dev = _pair('left', n_veh=32)
