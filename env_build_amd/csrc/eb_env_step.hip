@@ -19,7 +19,8 @@
 //             densely, everything else contributes exact zeros.  One lane per (env, candidate): the range filter of
 //             E2E:393-411 as a table-driven, branch-free test -> a tag byte (mode or 0xFF); the 10 m box test of
 //             TRF:263-295 -> per-wave queue -> two-circle test -> per-env collision flag.                   barrier
-//   phase 3   the distinct slot modes are dealt to waves 2, 3, 1, 0; per mode (wave-uniform) and env (lane): the tag row
+//   phase 3   (no barrier in front of it) the distinct slot modes come off a counter in LDS: a wave takes the next one when its
+//             phase-2 work is done; per mode (wave-uniform) and env (lane): the tag row
 //             becomes a 64-bit candidate set (4 tags per LDS dword, zero-byte trick), the mode's slots are filled by
 //             repeated selection over that set (E2E:414-437; typically 0-3 members).  wave 1 first adds up the penalty
 //             partials in vehicle order -> out5 / dict16, then the done predicates that need only the ego (E2E:223-256).
@@ -216,6 +217,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     constexpr int GCH = (NW - 2) * KS + 2, GREC = GCH * 64;                      // chunks / records per staging group (8 / 512, 14 / 896)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_jb[ET];
+    __shared__ int s_modeq;                                                      // the next distinct mode to be walked (fill_slots)
     __shared__ float s_miu[ET], s_r[ET];                                         // miu_r / yaw rate of the step (the stability predicate's inputs)
     // AUTO: the start state a reset would give every env of the tile (drawn at kernel start, under the latency of the first loads),
     // the tile's finished envs as a list, the slot plan as a table
@@ -253,6 +255,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     uint8_t* s_on = reinterpret_cast<uint8_t*>(s_emit + (size_t)ET * 12);        // [64][m_cand]
     ES_MARK(0);
     if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
+    if (tid == 0) s_modeq = 0;
     if (AUTO && tid < EB_VMODE_COUNT) s_dm[tid] = A.dm[tid];
     if (tid < ET) s_col[tid] = (OBS && A.row_mask && !(tid < nE && A.row_mask[e0 + tid] != 0)) ? 1 : 0;   // OBS: 1 = row not to be written
     for (int w = tid; w < ET * TS4; w += NT) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
@@ -703,9 +706,9 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     }
     ES_MARK(6);
     // E2E:340-464 for the lanes with `on` (lane = env): the vehicle slots of this wave's modes -> s_out
-    auto fill_slots = [&](const bool on, const bool light_on) {
+    auto fill_slots = [&](const bool on, const bool light_on, const bool dyn) {
         // E2E:340-464.  The slot plan is scalar: lane s of `slot_mode` holds the mode of slot s, so the distinct modes (first
-        // occurrences: A.first_mask), their owners (waves 2, 3, 1, 0 in turn) and a mode's slots (a ballot) cost no memory
+        // occurrences: A.first_mask), who walks which (dyn: the next mode off s_modeq; else fixed owner waves) and a mode's slots (a ballot) cost no memory
         // access; per mode (wave-uniform) and env (lane) the tag row becomes a candidate set and the slots are filled by
         // repeated selection over it with branch-free key comparisons.
         const float4 eg = s_ego[lane];
@@ -715,14 +718,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         const bool virt = TASK != TASK_RIGHT && light_on && ey < -HALF_CROSS;                                // E2E:386-388
         float* ov = s_out + lane * OS + 6 + T;
         const int nw = (m_cand + 3) >> 2;
-        unsigned long long firsts = A.first_mask;
-        for (int k = 0; firsts; ++k) {
-            const int s = __builtin_ctzll(firsts);
-            firsts &= firsts - 1ull;
-            if ((NW == 4 ? ((0x1e >> (2 * (k & 3))) & 3) : 4 + (k & 3)) != wave) continue;   // owners in turn: waves 2, 3, 1, 0 (NW = 8: 4, 5, 6, 7)
-            const int m = __builtin_amdgcn_readlane(slot_mode, s);
-            unsigned long long slots = __builtin_amdgcn_ballot_w64(slot_mode == m);   // the mode's slots, ascending
-            if (!on) continue;
+        // one distinct mode m (wave-uniform) for the lanes that call it: its slots (ascending, as a bit set) <- the env's candidates of the mode
+        auto one_mode = [&](const int m, unsigned long long slots) {
             // the env's candidates of this mode as a bit set (mode byte == m), 4 bytes per dword; the range filter of
             // E2E:393-411 is applied in the walk below, where the mode is wave-uniform
             unsigned long long elig = 0ull;
@@ -747,7 +744,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     default: slot_pair_walk<TASK, EB_VMODE_RD>(crow, elig, ex, ey, virt, m_cand, ov, sa, sb); break;   // rd rl lu ld: no filter, no key, zero fill
                 }
                 ES_MARK(12);
-                continue;
+                return;
             }
             const KeySpec ks = key_spec(TASK, m);
             // the virtual red-light car of the mode (E2E:386-390), candidate index m_cand
@@ -800,9 +797,33 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 }
                 *reinterpret_cast<f4a4*>(ov + 4 * s2) = f4a4{r.x, r.y, r.z, r.w};
             }
+        };
+        unsigned long long firsts = A.first_mask;
+        const int n_first = __popcll(A.first_mask);
+        for (int k = 0;; ++k) {
+            int s;
+            if (dyn) {
+                // the step proper: a wave takes the next distinct mode off a counter in LDS when its own pair / collision / tracking
+                // work is done — the waves reach this point up to 2 us apart (the reward pairs are one wave's), and a mode is a mode
+                int g = 0;
+                if (lane == 0) g = atomicAdd(&s_modeq, 1);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g >= n_first) break;
+                unsigned long long f = A.first_mask;
+                for (int j = 0; j < g; ++j) f &= f - 1ull;
+                s = __builtin_ctzll(f);
+            } else {
+                if (!firsts) break;
+                s = __builtin_ctzll(firsts);
+                firsts &= firsts - 1ull;
+                if ((NW == 4 ? ((0x1e >> (2 * (k & 3))) & 3) : 4 + (k & 3)) != wave) continue;   // owners in turn: waves 2, 3, 1, 0 (NW = 8: 4, 5, 6, 7)
+            }
+            const int m = __builtin_amdgcn_readlane(slot_mode, s);
+            unsigned long long slots = __builtin_amdgcn_ballot_w64(slot_mode == m);   // the mode's slots, ascending
+            if (on) one_mode(m, slots);      // (no lane leaves the loop early: the counter is read by the whole wave)
         }
     };
-    fill_slots(live, light);
+    fill_slots(live, light, true);
     ES_MARK(3);
     __syncthreads();   // barrier: s_out complete; s_part, s_col, s_jb
     ES_MARK(10);
@@ -991,7 +1012,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         } else {                                                                 // a mode with more than two slots: the step's own slot code
             if (wave == 0 && fin) track_row(reset_path);
-            fill_slots(fin, vflag);
+            fill_slots(fin, vflag, false);
         }
         ES_MARK(14);
         __syncthreads();

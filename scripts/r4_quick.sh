@@ -4,14 +4,14 @@
 tag=${1:-r4x}
 mkdir -p gpurun_out
 if [ "$2" != "notest" ]; then
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_reset_frames.py tests/test_gpu_golden.py -m gpu -x -q -k "env_step or auto_reset or get_obs or g6 or g7 or reset_pool or masked or facade" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_reset_frames.py tests/test_gpu_golden.py -m gpu -x -q -k "env_step or auto_reset or get_obs or g6 or g7 or reset_pool or masked or facade" 2>&1 | tail -3
 fi
-python scripts/trace_env_step.py --n-env 4096 > gpurun_out/${tag}_trace_4096.txt 2>&1
-python scripts/trace_env_step.py --n-env 65536 > gpurun_out/${tag}_trace_65536.txt 2>&1
+timeout 120 python scripts/trace_env_step.py --n-env 4096 > gpurun_out/${tag}_trace_4096.txt 2>&1
+timeout 120 python scripts/trace_env_step.py --n-env 65536 > gpurun_out/${tag}_trace_65536.txt 2>&1
 grep -A13 "^wave 0" gpurun_out/${tag}_trace_4096.txt | cut -c1-135
 grep -A13 "^wave 4" gpurun_out/${tag}_trace_4096.txt | cut -c1-135
 grep -A11 "^wave 2" gpurun_out/${tag}_trace_65536.txt | cut -c1-135
-python bench.py --env-step > gpurun_out/${tag}_bench_env_step.json 2>/dev/null
+timeout 300 python bench.py --env-step > gpurun_out/${tag}_bench_env_step.json 2>/dev/null
 python - <<PY
 import json
 for l in open("gpurun_out/${tag}_bench_env_step.json"):
