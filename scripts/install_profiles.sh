@@ -4,6 +4,7 @@
 set -e
 T=$1; G=gpurun_out/$T
 cp $G/bench.json profiles/${T}_bench.json
+[ -f $G/bench_steps20.json ] && cp $G/bench_steps20.json profiles/${T}_bench_steps20.json
 cp $G/env_step.json profiles/${T}_bench_env_step.json
 cp $G/bench_shield.json profiles/${T}_bench_shield.json
 cp $G/prof_bench.json profiles/${T}_bench_under_rocprof.json

@@ -7,6 +7,7 @@ TAG=${1:-r4m}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_steps20.json 2>> $OUT/bench.err      # the driver's short form
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-side > $OUT/prof_bench.json 2> $OUT/prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_env -o p -- python bench.py --env-step > $OUT/env_step.json 2> $OUT/prof_env.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_f16 -o p -- python scripts/time_rollout.py --n-veh 64 --f16 --iters 400 > $OUT/f16.txt 2> $OUT/prof_f16.err
