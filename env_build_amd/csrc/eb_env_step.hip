@@ -863,6 +863,10 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         }
     };
+    // AUTO, a tile with a finished env: the tail below lets OTHER threads overwrite what this thread stored during the step (candidate
+    // records, params) — those stores left in phases 1-3 and are waited for here, where they have long been acknowledged, instead of
+    // behind the row store, whose acknowledgements would be waited for with them
+    if (AUTO && finmask != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_rows(0);
     if (!OBS && A.flow_on) {
         // eb_traffic_flow_step, the rest: a slot's flag and mode byte for the next step, the entering vehicle into its slot — by the
@@ -904,16 +908,15 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             for (int t = 0; t < k; ++t) mbits &= mbits - 1ull;
             return __builtin_ctzll(mbits);
         };
-        if (A.final_obs)                                                         // the terminal observations: a wave per finished env
-            for (int k = wave; k < n_fin; k += NW) {
-                const int e = nth_fin(k);
-                for (int c = lane; c < D; c += 64) A.final_obs[((size_t)e0 + e) * D + c] = s_out[e * OS + c];
-            }
-        // this thread's stores of the step (ego, params, candidates, rows) are complete before ANOTHER thread overwrites them below,
-        // and everybody's reads of s_out / s_ego / s_cand are over
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // everybody's reads of s_ego / s_cand are over, and (the wait in front of the row store) everybody's candidate / params stores of
+        // the step are complete before ANOTHER thread overwrites them below
         __syncthreads();
         ES_MARK(11);
+        if (A.final_obs && wave >= 2)                                            // the terminal observations: a wave per finished env, next to
+            for (int k = wave - 2; k < n_fin; k += NW - 2) {                     // the new state (waves 0, 1) — s_out is not written before the
+                const int e = nth_fin(k);                                        // next barrier
+                for (int c = lane; c < D; c += 64) A.final_obs[((size_t)e0 + e) * D + c] = s_out[e * OS + c];
+            }
         if (wave == 0 && fin) {                                                  // E2E:100-101, 110-113: the state drawn at kernel start
             const float4 q = s_rst[lane];
             const unsigned fl = s_rflag[lane];
@@ -1015,7 +1018,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             fill_slots(fin, vflag, false);
         }
         ES_MARK(14);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the step's rows have left (phase 4, some 3 us ago) before
+        __syncthreads();                                                         // another thread writes the finished envs' rows again
         for (int k = wave; k < n_fin; k += NW) {                                 // the reset rows: a wave per finished env, a lane per column
             const int e = nth_fin(k);
             for (int c = lane; c < D; c += 64) A.obs_out[((size_t)e0 + e) * D + c] = s_out[e * OS + c];

@@ -11,7 +11,7 @@ VARIANTS = {
     'no_predict': [("            } else if (OBS) s_cand[e * RS4 + c] = v;", "            } else if (OBS || true) s_cand[e * RS4 + c] = v;")],     # (and no candidate store)
     'no_reward_pairs': [("            for (int base = 0; base < n_pairs; base += 64 * 4) {", "            for (int base = 0; base < 0; base += 64 * 4) {")],
     'no_collision': [("            for (int base = 0; base < n_rec; base += 128 * 4) {", "            for (int base = 0; base < 0; base += 128 * 4) {")],
-    'no_slots': [("        unsigned long long firsts = A.first_mask;", "        unsigned long long firsts = 0ull;")],
+    'no_slots': [("        const int n_first = __popcll(A.first_mask);", "        const int n_first = 0;")],
     'no_tracking': [("            if (p < 0) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }", "            if (true) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }")],
     'no_cand_store': [("                else reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;", "                else if (e0 < 0) reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;")],
     'no_row_store': [("        for (int base = tid; base < total; base += 4 * NT) {", "        for (int base = tid; base < 0; base += 4 * NT) {")],

@@ -2,7 +2,7 @@
 """Soak: CrossroadEnd2end (batch) driven for many steps with `reset(mask=done)` after every step — the vectorised driver's loop —
 or (--auto-reset) with the reset of the finished envs inside the step launch.
 Checks on the way: observations finite, done codes in range, reset rows start an episode (done code 0; --auto-reset: their terminal
-rows are in info['final_observation'], NaN elsewhere, and differ from the rows handed out), device memory flat."""
+rows are in info['final_observation'] and differ from the rows handed out), device memory flat."""
 import argparse, collections, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,7 +32,7 @@ for t in range(a.steps):
     if a.auto_reset:
         if t % 1000 == 0:
             fin, d = info['final_observation'].t, done.t != 0
-            assert torch.isfinite(fin[d]).all() and torch.isnan(fin[~d]).all(), 'final_observation rows at step %d' % t
+            assert torch.isfinite(fin[d]).all(), 'final_observation rows at step %d' % t       # (the other rows are not written)
             assert not d.any() or not torch.equal(fin[d], obs.t[d]), 'a finished env kept its terminal row'
             episodes += int(d.sum())
         continue
