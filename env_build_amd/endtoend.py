@@ -674,6 +674,7 @@ class CrossroadEnd2end(object):
         f32 = dict(dtype=torch.float32, device=dev)
         bufs = dict(act=torch.empty((B, 2), **f32), out5=torch.empty((5, B), **f32),
                     obs=torch.empty((B, self.obs_dim), **f32), code=torch.empty((B,), dtype=torch.uint8, device=dev))
+        bufs['rew'] = bufs['out5'][0]                                    # the reward row as a view of its own (made once per set)
         bufs['d16'] = torch.empty((16, B), **f32) if (self._want_d16 or B == 1) else None
         bufs['final'] = torch.empty((B, self.obs_dim), **f32) if self.auto_reset else None
         return bufs
@@ -753,14 +754,14 @@ class CrossroadEnd2end(object):
             c = int(code[0].item())
             self.done_type, done = _capi.DONE_NAMES[c], int(c != 0)                     # E2E:141
         else:
-            self.action, self.obs, reward = DevArray(act), DevArray(obs_out), DevArray(out5[0])
+            self.action, self.obs, reward = DevArray(act), DevArray(obs_out), DevArray(bufs['rew'])
             self.reward_info = _RewardInfo(keys, d16, reward, None if d16 is not None else
                                            (lambda: self._reward_terms(obs_in, act)))   # rows of d16, wrapped on access
             self.done_type, done = DevArray(code), _LazyDone(code)                      # 0 / 1 per env, computed when read
-        all_info = dict(all_vehicles=self.all_vehicles, ego_dynamics=self.ego_dynamics, v_light=self.v_light)
-        all_info.update({'reward_info': self.reward_info,
-                         'ref_index': self.ref_path.ref_index if B == 1 else
-                         DevArray(self._ref_idx.clone() if self.copy_outputs and ar is not None else self._ref_idx)})   # E2E:143
+        all_info = {'all_vehicles': self.all_vehicles, 'ego_dynamics': self.ego_dynamics, 'v_light': self.v_light,
+                    'reward_info': self.reward_info,
+                    'ref_index': self.ref_path.ref_index if B == 1 else
+                    DevArray(self._ref_idx.clone() if self.copy_outputs and ar is not None else self._ref_idx)}   # E2E:143
         if ar is not None:
             all_info['final_observation'] = DevArray(final)      # the terminal rows of the envs with done != 0
             self._injected = False
