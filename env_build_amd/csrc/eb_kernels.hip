@@ -308,7 +308,7 @@ hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const Pat
 // episodic-return summary of a shard (eb_episode_summary): two launches, fixed reduction order
 // ------------------------------------------------------------------------------------------------
 // Stage 1: a block owns 64 envs at a time; its four waves split the `horizon` step records of
-// out5_steps [H, 5, B] (wave w takes steps w, w+4, ...: every load is 64 consecutive floats, four steps
+// out5_steps [H, 5, B] (wave w takes steps w, w+4, ...: every load is 64 consecutive floats, seven steps
 // in flight per lane), accumulating in float64.  The per-env "punished at any step" flags meet in LDS,
 // wave 0 adds the |delta_y| terms, and a shuffle + LDS tree leaves one 6-double partial per block.
 // Stage 2: one block folds the partials in block order.  No atomics: the result depends on the grid
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(SUM_THREADS) void summary_partial_kernel(int n_env,
         if (wave == 0) dyv = obs_final[(size_t)ic * D + 6];          // strided: issued first, used last
         bool any = false;
         double r = 0.0, pt = 0.0, prs = 0.0;
-        constexpr int U = 4;                                          // steps in flight per lane (3 loads each)
+        constexpr int U = 7;                                          // steps in flight per lane (3 loads each): a 25-step horizon is ONE round of loads per wave
         for (int t0 = wave; t0 < horizon; t0 += U * NW) {
             float a[U], b[U], c[U];
 #pragma unroll
@@ -401,10 +401,17 @@ __global__ __launch_bounds__(SUM_THREADS) void summary_final_kernel(int n_part, 
                                                                      float* __restrict__ out8) {
     __shared__ Sum6 s_part[SUM_THREADS / 64];
     Sum6 tot = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int k = threadIdx.x; k < n_part; k += SUM_THREADS) {
-        const double* p = partials + 6 * (size_t)k;
-        const Sum6 x = {p[0], p[1], p[2], p[3], p[4], p[5]};
-        tot = sum6_combine(tot, x);
+    for (int k0 = threadIdx.x; k0 < n_part; k0 += 4 * SUM_THREADS) {     // four records in flight per thread, folded in index order
+        Sum6 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * SUM_THREADS;
+            const double* p = partials + 6 * (size_t)(k < n_part ? k : 0);
+            x[u] = Sum6{p[0], p[1], p[2], p[3], p[4], p[5]};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * SUM_THREADS < n_part) tot = sum6_combine(tot, x[u]);
     }
     const Sum6 f = sum6_block_reduce(tot, s_part);
     if (threadIdx.x == 0) {

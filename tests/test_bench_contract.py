@@ -48,6 +48,10 @@ def test_driver_invocation_times_events_summary_and_repeats():
     assert s[6] == 8192 and s[7] == 20 and s[0] != 0.0                  # n_env, horizon, sum of rewards
     assert ('eager' in line['config']['workload']) != ('hipGraph' in line['config']['workload'])
     assert abs(line['value'] - 8192 * 20 / (line['ms_per_step'] * 1e-3 * 20)) / line['value'] < 1e-9
+    # the per-launch figure: median over the regions, and no region pays for building its launch form (hipGraph / argument tuples of
+    # a 20-step rollout are made before the clock starts — they used to land in the first region when the warm-up was shorter)
+    by = line['roofline']['avg_launch_us_by_region']
+    assert by['min'] <= line['roofline']['avg_launch_us'] <= by['max'] and by['max'] < 3.0 * by['min'], by
 
 
 @pytest.mark.gpu
