@@ -218,6 +218,10 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_jb[ET];
     __shared__ int s_modeq;                                                      // the next distinct mode to be walked (fill_slots)
+    // tiles of up to 32 envs (LDS to spare): the candidates of every (env, mode) as a 64-bit set, OR-ed together by the staging lanes —
+    // the slot pass reads ONE word pair per (env, mode) instead of scanning the env's mode bytes (15 dwords at 60 candidates)
+    constexpr bool ELIG = ET <= 32;
+    __shared__ unsigned s_elig32[ELIG ? ET * EB_VMODE_COUNT * 2 : 2];
     __shared__ float s_miu[ET], s_r[ET];                                         // miu_r / yaw rate of the step (the stability predicate's inputs)
     // AUTO: the start state a reset would give every env of the tile (drawn at kernel start, under the latency of the first loads),
     // the tile's finished envs as a list, the slot plan as a table
@@ -256,6 +260,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     ES_MARK(0);
     if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
     if (tid == 0) s_modeq = 0;
+    if (ELIG)
+        for (int w = tid; w < ET * EB_VMODE_COUNT * 2; w += NT) s_elig32[w] = 0u;
     if (AUTO && tid < EB_VMODE_COUNT) s_dm[tid] = A.dm[tid];
     if (tid < ET) s_col[tid] = (OBS && A.row_mask && !(tid < nE && A.row_mask[e0 + tid] != 0)) ? 1 : 0;   // OBS: 1 = row not to be written
     for (int w = tid; w < ET * TS4; w += NT) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
@@ -454,6 +460,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 else reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;
             }
             s_tag[e * TS4 * 4 + c] = (uint8_t)mode;
+            if (ELIG && (mode & 0xffu) < (unsigned)EB_VMODE_COUNT) atomicOr(&s_elig32[(e * EB_VMODE_COUNT + (int)(mode & 0xffu)) * 2 + (c >> 5)], 1u << (c & 31));
         };
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -723,12 +730,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             // the env's candidates of this mode as a bit set (mode byte == m), 4 bytes per dword; the range filter of
             // E2E:393-411 is applied in the walk below, where the mode is wave-uniform
             unsigned long long elig = 0ull;
-            const unsigned mm = (unsigned)m * 0x01010101u;
-            for (int w = 0; w < nw; ++w) {
-                const unsigned x = trow[w] ^ mm;
-                const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
-                const unsigned nib = (((z >> 7) * 0x01020408u) >> 24) & 0xfu;
-                elig |= (unsigned long long)nib << (4 * w);
+            if (ELIG) {
+                const uint2 w2 = *reinterpret_cast<const uint2*>(&s_elig32[(lane * EB_VMODE_COUNT + (m < EB_VMODE_COUNT ? m : 0)) * 2]);
+                elig = m < EB_VMODE_COUNT ? (unsigned long long)w2.x | (unsigned long long)w2.y << 32 : 0ull;
+            } else {
+                const unsigned mm = (unsigned)m * 0x01010101u;
+                for (int w = 0; w < nw; ++w) {
+                    const unsigned x = trow[w] ^ mm;
+                    const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
+                    const unsigned nib = (((z >> 7) * 0x01020408u) >> 24) & 0xfu;
+                    elig |= (unsigned long long)nib << (4 * w);
+                }
             }
             ES_MARK(7);
             if (__popcll(slots) <= 2) {
@@ -969,11 +981,16 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     const unsigned* trow = s_tag32 + e * TS4;
                     float* ov = s_out + e * OS + 6 + T;
                     unsigned long long elig = 0ull;
-                    const unsigned mm = (unsigned)m * 0x01010101u;
-                    for (int w = 0; w < nw; ++w) {
-                        const unsigned x = trow[w] ^ mm;
-                        const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
-                        elig |= (unsigned long long)((((z >> 7) * 0x01020408u) >> 24) & 0xfu) << (4 * w);
+                    if (ELIG) {
+                        const uint2 w2 = *reinterpret_cast<const uint2*>(&s_elig32[(e * EB_VMODE_COUNT + (m < EB_VMODE_COUNT ? m : 0)) * 2]);
+                        elig = m < EB_VMODE_COUNT ? (unsigned long long)w2.x | (unsigned long long)w2.y << 32 : 0ull;
+                    } else {
+                        const unsigned mm = (unsigned)m * 0x01010101u;
+                        for (int w = 0; w < nw; ++w) {
+                            const unsigned x = trow[w] ^ mm;
+                            const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
+                            elig |= (unsigned long long)((((z >> 7) * 0x01020408u) >> 24) & 0xfu) << (4 * w);
+                        }
                     }
                     if (!act) elig = 0ull;
                     const RangeBox rb = range_box(TASK, m, ex, ey);
