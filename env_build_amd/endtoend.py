@@ -233,7 +233,8 @@ class CrossroadEnd2end(object):
                  device=None, respawn=True, traffic='pool', per_route=5, auto_reset=False, copy_outputs=True, flow_in_step=True,
                  **kwargs):
         """n_env > 1 makes a batch of independent single-ego envs (the reference is one env: every argument before n_env is its).
-        auto_reset (a batch over the traffic pool): step() also resets the envs it has just finished, in the same kernel launch —
+        auto_reset (a batch): step() also resets the envs it has just finished — over the traffic pool in the same kernel launch
+            (eb_auto_reset), over the flow source as the masked reset's launches behind the step's —
             the observation it returns holds their reset observation, info['final_observation'] their terminal one (rows of the
             other envs unspecified), `done` says which.  The vectorised-env convention; hier_decision.py:109-135's loop in one call.
         copy_outputs: True (default) — what step() / reset() hand out are arrays of their own, as in the reference: they can be
@@ -326,10 +327,13 @@ class CrossroadEnd2end(object):
         self._respawn_rule = _capi.EbRespawn(self._entry5.data_ptr(), CROSSROAD_SIZE / 2 + 40., self.POOL_EDGE_SPAN, EXPECTED_V, 0, 0)
         # a reset spreads the pool over the first 60 m of every lane, clear of the ego (eb_env_reset_pool)
         self._reset_rule = _capi.EbRespawn(self._entry5.data_ptr(), 0.0, 60.0, EXPECTED_V, 0, 0, self.POOL_EDGE_SPAN)
-        if self.auto_reset and (B == 1 or traffic != 'pool'):
-            raise ValueError('auto_reset needs a batch (n_env > 1) over the traffic pool')
+        if self.auto_reset and (B == 1 or traffic not in ('pool', 'flows')):
+            raise ValueError('auto_reset needs a batch (n_env > 1) over the traffic pool or the flow source')
         self._auto_rule = None
-        if self.auto_reset:       # eb_auto_reset: the state arrays are fixed, the counters and final_obs are set per step
+        # the flow source: the C-ABI's eb_auto_reset is the pool's (eb_flow_rule excludes it) — step() composes the same contract
+        # from the step launch and the masked reset's launches
+        self._auto_compose = self.auto_reset and traffic == 'flows'
+        if self.auto_reset and traffic == 'pool':       # eb_auto_reset: the state arrays are fixed, the counters and final_obs are set per step
             self._auto_rule = _capi.EbAutoReset(0, 0, 1 if self.mode == 'training' else 0, self._ref_idx.data_ptr(),
                                                 self._virtual.data_ptr(), self._v_light.data_ptr(), self._reset_rule, None)
         if traffic == 'flows':
@@ -484,6 +488,8 @@ class CrossroadEnd2end(object):
                 self._v_light.masked_fill_(mask8 != 0, 0)
         self._injected = False
         self._publish_state()                                                            # E2E:104-115
+        if B > 1:      # eb_get_obs writes the (masked) rows in place: not into the array the last step handed out
+            self._obs = self._obs.clone() if mask8 is not None else torch.empty_like(self._obs)
         self.obs = self._get_obs(row_mask=mask8)                                         # E2E:116 (with the OLD flag)
         self.action = None
         self.reward_info = None
@@ -676,7 +682,7 @@ class CrossroadEnd2end(object):
                     obs=torch.empty((B, self.obs_dim), **f32), code=torch.empty((B,), dtype=torch.uint8, device=dev))
         bufs['rew'] = bufs['out5'][0]                                    # the reward row as a view of its own (made once per set)
         bufs['d16'] = torch.empty((16, B), **f32) if (self._want_d16 or B == 1) else None
-        bufs['final'] = torch.empty((B, self.obs_dim), **f32) if self.auto_reset else None
+        bufs['final'] = torch.empty((B, self.obs_dim), **f32) if self._auto_rule is not None else None
         return bufs
 
     def _step_buffers(self):
@@ -765,6 +771,17 @@ class CrossroadEnd2end(object):
         if ar is not None:
             all_info['final_observation'] = DevArray(final)      # the terminal rows of the envs with done != 0
             self._injected = False
+        elif self._auto_compose:
+            # auto_reset over the flow source: the masked reset's launches behind the step's (env_reset, the flow source's
+            # init_traffic, the masked observation) — same contract as the pool's one-launch form: the observation handed out holds
+            # the reset rows, info['final_observation'] the step's own rows (terminal for the finished envs), `done` / done_type
+            # / reward_info stay the step's
+            kept = (self.action, self.reward_info, self.done_type)
+            obs_ret = self.reset(mask=done)                      # (`done` not read yet: the step's done codes serve as the mask)
+            self.action, self.reward_info, self.done_type = kept
+            all_info['final_observation'] = DevArray(obs_out)
+            all_info['ref_index'] = DevArray(self._ref_idx.clone() if self.copy_outputs else self._ref_idx)
+            return obs_ret, reward, done, all_info
         return self.obs, reward, done, all_info
 
     def _reward_terms(self, obs_in, act):

@@ -17,4 +17,5 @@ sleep 5
 python scripts/fuzz_rollout.py --seconds $S --seed 41 2>&1 | tail -1
 python scripts/fuzz_env_step.py --seconds $S --seed 42 2>&1 | tail -1
 python scripts/fuzz_env.py --seconds $S --seed 43 2>&1 | tail -1
+python scripts/fuzz_env_auto.py --seconds $S --seed 44 2>&1 | tail -1
 kill $BG

@@ -669,6 +669,43 @@ def test_facade_auto_reset_equals_step_then_masked_reset(copy_outputs):
         CrossroadEnd2end(task, n_env=1, auto_reset=True)
 
 
+@pytest.mark.parametrize('copy_outputs', [True, False])
+def test_facade_auto_reset_over_the_flow_source(copy_outputs):
+    """auto_reset over the flow source (composed by the facade: the step's launch, then the masked reset's) == step() followed by
+    reset(mask=done) of an env with the same seed; and a masked reset never writes into the observation the last step handed out."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    B, task = 600, 'left'
+    a = CrossroadEnd2end(task, n_env=B, mode='training', traffic='flows', auto_reset=True, copy_outputs=copy_outputs)
+    b = CrossroadEnd2end(task, n_env=B, mode='training', traffic='flows', copy_outputs=copy_outputs)
+    for env in (a, b):
+        env.seed(5)
+        env.reset()
+        env.reset()
+    assert np.array_equal(a.obs.numpy(), b.obs.numpy())
+    rng = np.random.default_rng(1)
+    finished = 0
+    for t in range(30):
+        act = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+        oa, ra, da, ia = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        fin = db.numpy() != 0
+        term = ob.numpy().copy()
+        ob2 = b.reset(mask=db)
+        assert np.array_equal(ob.numpy(), term), 'reset(mask) wrote into the observation the step handed out'
+        assert np.array_equal(da.numpy(), fin.astype(np.uint8)) and np.array_equal(ra.numpy(), rb.numpy())
+        assert np.array_equal(oa.numpy(), ob2.numpy()), t
+        assert np.array_equal(ia['final_observation'].numpy()[fin], term[fin])
+        assert np.array_equal(a.done_type.numpy() != 0, fin)                   # done_type stays the step's
+        for k in ('_ego', '_params', '_cand_mode', '_ref_idx', '_virtual', '_v_light'):
+            assert np.array_equal(getattr(a, k).cpu().numpy(), getattr(b, k).cpu().numpy()), (t, k)
+        on = a._cand_mode.cpu().numpy() != 255          # (a vacant slot keeps whatever record it held last: the constructors' warm-up
+        assert np.array_equal(a._cand.cpu().numpy()[on], b._cand.cpu().numpy()[on]), t     # steps drew different actions)
+        for k in ('active', 'timer', 'emitted', 'sim_step'):
+            assert np.array_equal(getattr(a._flows, k).cpu().numpy(), getattr(b._flows, k).cpu().numpy()), (t, k)
+        finished += int(fin.sum())
+    assert finished > 5
+
+
 def test_facade_outputs_are_arrays_of_their_own_by_default():
     """what step() hands out can be kept (a rollout list, a replay buffer) — three steps later every stored value still
     holds its own step, `done` and reward_info included when they are first read late; copy_outputs=False is the opt-in
