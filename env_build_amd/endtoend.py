@@ -28,6 +28,7 @@ TRF:263-295, UTL:73-104).  Every one of these is a C-ABI call into libenvbuild_h
 the device buffers.  There is no CPU path.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -228,6 +229,27 @@ class _LazyDone(DevArray):
         self._t = v
 
 
+class _SnapshotOnDemand(DevArray):
+    """A state array that the NEXT step / reset overwrites in place (info['ref_index'] under auto_reset), handed out without a
+    copy: the copy is made when the value is first read or — if the object is still referenced by then — right before the array
+    is written again (CrossroadEnd2end._settle_snapshots).  A driver that drops `info` every step pays nothing."""
+
+    def __init__(self, src):
+        self._src = src
+        self._t = None
+
+    @property
+    def t(self):
+        if self._t is None:
+            self._t = self._src.clone()
+            self._src = None
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = v
+
+
 class CrossroadEnd2end(object):
     def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
                  device=None, respawn=True, traffic='pool', per_route=5, auto_reset=False, copy_outputs=True, flow_in_step=True,
@@ -321,6 +343,7 @@ class CrossroadEnd2end(object):
         self._injected = False
         self._flows = None
         self._bufs, self._buf_i, self._ri1 = None, 0, None
+        self._ri_snapshot = None                     # weakref to the info['ref_index'] handed out last (copy_outputs)
         self._rbufs, self._rbuf_i = None, 0      # reset(mask=...) over the pool: its observation / done-code sets
         # during an episode a vehicle that left the map re-enters at its lane's edge (within POOL_EDGE_SPAN m of the entry
         # point, 60 m from the centre: where no ego is), not somewhere along the lane
@@ -412,6 +435,8 @@ class CrossroadEnd2end(object):
     def reset(self, **kwargs):  # E2E:99-127
         """`mask=` (n_env > 1; bool / uint8 [B]) resets only those envs — the vectorised-env idiom for batched drivers."""
         mask = kwargs.pop('mask', None)
+        if self._ri_snapshot is not None:
+            self._settle_snapshots()                 # (a reset rewrites `_ref_idx` in place)
         if kwargs or self.ref_path is None:
             self.ref_path = ReferencePath(self.training_task, device=self.device, **kwargs)
         elif self.n_env == 1:
@@ -675,6 +700,27 @@ class CrossroadEnd2end(object):
         """done_type strings of the last step for every env of a batch (E2E:208-221)."""
         return [_capi.DONE_NAMES[int(c)] for c in self.done_code.cpu().numpy()]
 
+    def _settle_snapshots(self):
+        """before a call that writes `_ref_idx` in place: a handed-out info['ref_index'] that is still alive gets its own copy now"""
+        w = self._ri_snapshot
+        if w is not None:
+            d = w()
+            if d is not None:
+                d.t
+            self._ri_snapshot = None
+
+    def _ref_index_out(self):
+        """info['ref_index'] of a batch (E2E:143): copy_outputs — a snapshot made on demand (an auto-reset step and every reset()
+        rewrite `_ref_idx` in place and settle it first); otherwise the array itself"""
+        if not self.copy_outputs:
+            return DevArray(self._ref_idx)
+        w = self._ri_snapshot
+        d = w() if w is not None else None
+        if d is None:       # (while nothing has rewritten `_ref_idx` the steps share one object: its value is theirs)
+            d = _SnapshotOnDemand(self._ref_idx)
+            self._ri_snapshot = weakref.ref(d)
+        return d
+
     def _new_step_set(self):
         B, dev = self.n_env, self.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -708,6 +754,8 @@ class CrossroadEnd2end(object):
         left it, the way the reference sees SUMO's state of the step).  Outputs live in two pre-allocated buffer sets used
         in turn (valid until the step after next)."""
         B, dev = self.n_env, self.device
+        if self._ri_snapshot is not None and self._auto_rule is not None:     # (this launch rewrites `_ref_idx`)
+            self._settle_snapshots()
         raw = _unwrap_action(action, B, dev)
         bufs = self._step_buffers()
         act, out5, d16, obs_out, code, final = bufs['act'], bufs['out5'], bufs['d16'], bufs['obs'], bufs['code'], bufs['final']
@@ -767,7 +815,7 @@ class CrossroadEnd2end(object):
         all_info = {'all_vehicles': self.all_vehicles, 'ego_dynamics': self.ego_dynamics, 'v_light': self.v_light,
                     'reward_info': self.reward_info,
                     'ref_index': self.ref_path.ref_index if B == 1 else
-                    DevArray(self._ref_idx.clone() if self.copy_outputs and ar is not None else self._ref_idx)}   # E2E:143
+                    self._ref_index_out()}   # E2E:143
         if ar is not None:
             all_info['final_observation'] = DevArray(final)      # the terminal rows of the envs with done != 0
             self._injected = False
@@ -780,7 +828,7 @@ class CrossroadEnd2end(object):
             obs_ret = self.reset(mask=done)                      # (`done` not read yet: the step's done codes serve as the mask)
             self.action, self.reward_info, self.done_type = kept
             all_info['final_observation'] = DevArray(obs_out)
-            all_info['ref_index'] = DevArray(self._ref_idx.clone() if self.copy_outputs else self._ref_idx)
+            all_info['ref_index'] = self._ref_index_out()
             return obs_ret, reward, done, all_info
         return self.obs, reward, done, all_info
 

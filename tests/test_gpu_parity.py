@@ -706,6 +706,31 @@ def test_facade_auto_reset_over_the_flow_source(copy_outputs):
     assert finished > 5
 
 
+def test_facade_ref_index_is_a_snapshot_made_on_demand():
+    """copy_outputs=True: info['ref_index'] is handed out without a copy and gets one when it is read, or right before a reset /
+    an auto-reset step rewrites the path indices in place — a value read late still holds its own step's indices."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    B = 500
+    rng = np.random.default_rng(4)
+    for auto in (False, True):
+        env = CrossroadEnd2end('left', n_env=B, mode='training', auto_reset=auto)
+        env.seed(3)
+        env.reset()
+        changed = 0
+        for t in range(40):
+            act = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+            o, r, d, info = env.step(act)
+            now = env._ref_idx.cpu().numpy().copy()          # the indices as this step left them
+            kept = info['ref_index']                         # not read yet
+            if auto:
+                env.step(act)                                # the next step rewrites them in place (finished envs draw a new path)
+            else:
+                env.reset(mask=d)
+            assert np.array_equal(kept.numpy(), now), (auto, t)
+            changed += int((env._ref_idx.cpu().numpy() != now).sum())
+        assert changed > 0
+
+
 def test_facade_outputs_are_arrays_of_their_own_by_default():
     """what step() hands out can be kept (a rollout list, a replay buffer) — three steps later every stored value still
     holds its own step, `done` and reward_info included when they are first read late; copy_outputs=False is the opt-in
