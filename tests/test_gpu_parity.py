@@ -182,6 +182,47 @@ def test_headline_size_against_oracle_on_sampled_envs():
         assert (o5_d[1] >= o5_d[2] - 1e-6).all()          # the 3.5 m training margin dominates the 2.5 m real one
 
 
+def test_headline_size_every_row_against_oracle():
+    """BASELINE configs[2] in full — 65 536 envs x 32 vehicles x 25 closed-loop steps, EVERY row: per-step launches on the GPU against
+    the oracle's tape (the oracle runs its rows on all host cores; a second or two)."""
+    task, B, N, H = 'left', 65536, 32, 25
+    host, dev = _pair(task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, H, seed=3)
+    obs0 = _initial_obs(host, inp)
+    out_h, o5_h = host.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    obs_d = obs0
+    for t in range(H):
+        obs_d, o5_d, _ = dev.rollout_step(obs_d, inp['actions'][t], inp['ref_idx'])
+        _check_out5(o5_d, o5_h[t], 'step %d' % t)
+    assert np.array_equal(obs_d, out_h)
+
+
+def test_configs3_size_every_row_against_oracle():
+    """BASELINE configs[3]'s whole batch on one GPU — 262 144 envs x 32 vehicles, 6 closed-loop steps, EVERY row (the multi-GPU job
+    shards exactly these rows: sharding.shard_range), and the shards' episodic summaries folded against the whole batch's."""
+    from env_build_amd.sharding import shard_range
+    task, B, N, H = 'left', 262144, 32, 6
+    host, dev = _pair(task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, H, seed=13)
+    obs0 = _initial_obs(host, inp)
+    out_h, o5_h = host.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    out_d, o5_d = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    assert np.array_equal(out_d, out_h)
+    for t in range(H):
+        _check_out5(o5_d[t], o5_h[t], 'step %d' % t)
+    # 8 shards of 32 768 rows, each through its own call, are the same rows
+    whole = dev.episode_summary(o5_d, out_d)
+    parts = []
+    for r in range(8):
+        lo, hi = shard_range(B, r, 8)
+        out_s, o5_s = dev.rollout_tape(obs0[lo:hi], inp['actions'][:, lo:hi], inp['ref_idx'][lo:hi])
+        assert np.array_equal(out_s, out_d[lo:hi]) and np.array_equal(o5_s, o5_d[:, :, lo:hi])
+        parts.append(dev.episode_summary(o5_s, out_s))
+    parts = np.array(parts, np.float64)
+    np.testing.assert_allclose(parts[:, 0:5].sum(0), whole[0:5], rtol=1e-6)
+    assert parts[:, 5].max() == whole[5] and parts[:, 6].sum() == B
+
+
 @pytest.mark.parametrize('task', TASKS)
 def test_rollout_future_points_and_bad_ref_index(task):
     N, B = 8, 333
@@ -826,6 +867,20 @@ def test_fp16_storage_headline_size_properties():
         v_in, v_out = prev[:, 9:].reshape(B, N, 4), obs_d[:, 9:].reshape(B, N, 4)
         assert np.array_equal(v_in[:, :, 2], v_out[:, :, 2])                  # speeds carried over bit for bit
         assert np.isfinite(obs_d.view(np.float16).astype(np.float32)).all() and np.isfinite(o5_d).all()
+
+
+def test_fp16_storage_headline_size_every_row():
+    """configs[4] in full — 65 536 envs x 64 vehicles, binary16 state, 25 closed-loop steps, EVERY row against the oracle's tape."""
+    task, B, N, H = 'left', 65536, 64, 25
+    host, dev = _pair(task, n_veh=N)
+    inp = make_rollout_inputs(task, B, N, H, seed=8)
+    obs0 = _initial_obs(host, inp).astype(np.float16).view(np.uint16)
+    out_h, o5_h = host.rollout_tape_f16(obs0, inp['actions'], inp['ref_idx'])
+    obs_d = obs0
+    for t in range(H):
+        obs_d, o5_d, _ = dev.rollout_step_f16(obs_d, inp['actions'][t], inp['ref_idx'])
+        _check_out5(o5_d, o5_h[t], 'step %d' % t)
+    assert np.array_equal(obs_d, out_h)
 
 
 def test_environment_model_fp16_state_facade():
