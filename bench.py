@@ -846,15 +846,18 @@ def main():
             # headline's protocol (summary kernels + gather per horizon included).  Ranks share nothing on the data path, so the
             # N-GPU time of a step is the time of its slowest shard: t(262144) / t(262144 / N) is what N GPUs give before RCCL's
             # 32-byte all-gather per horizon (asynchronous, off the launch stream) and rank-to-rank jitter.
-            proj = {}
-            t1 = side_config(torch, dist, m32, STRONG_TOTAL, N_VEH, 1000, side_steps, side_warm, side_rep, with_summary=True)
+            # Regions of 20 horizons whatever --steps says: the projection is about the steady state of a long sharded job, and a
+            # one-horizon region (the driver's --steps 20) charges its launch / wake-up latency to the smallest shard (5.2 x instead of 6).
+            proj, proj_steps = {}, 20 * HORIZON
+            t1 = side_config(torch, dist, m32, STRONG_TOTAL, N_VEH, 1000, proj_steps, side_warm, side_rep, with_summary=True)
             for n in (2, 4, 8):
-                sh = side_config(torch, dist, m32, STRONG_TOTAL // n, N_VEH, 1000, side_steps, side_warm, side_rep, with_summary=True)
+                sh = side_config(torch, dist, m32, STRONG_TOTAL // n, N_VEH, 1000, proj_steps, side_warm, side_rep, with_summary=True)
                 proj[str(n)] = {'n_env_per_gpu': STRONG_TOTAL // n, 'ms_per_step': sh['ms_per_step'], 'avg_launch_us': sh['avg_launch_us'],
                                 'frac': sh['frac'], 'launch_form': sh['launch_form'],
                                 'projected_speedup': t1['ms_per_step'] / sh['ms_per_step']}
             strong['projection'] = {'what': 'per-rank shard of configs[3] at N GPUs timed on this one GPU, same protocol as the headline '
-                                            '(episodic summary + gather per horizon inside the timed region)',
+                                            '(episodic summary + gather per horizon inside the timed region), regions of %d steps' % proj_steps,
+                                    'steps_per_region': proj_steps,
                                     'one_gpu_ms_per_step': t1['ms_per_step'], 'one_gpu_frac': t1['frac'], 'by_n_gpus': proj,
                                     'projected_speedup_at_8': proj['8']['projected_speedup'], 'target': 6.0,
                                     'not_included': 'RCCL all-gather of 8 floats per rank and horizon (asynchronous, on RCCL\'s own stream), '
