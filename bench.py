@@ -833,7 +833,9 @@ def main():
     strong = hbm = None
     extra = []
     if not args.no_side and not args.open_loop:
-        side_steps, side_warm, side_rep = max(HORIZON, min(args.steps, 500)), HORIZON, min(args.repeats, 7)
+        # side measurements: regions of 20 horizons whatever --steps says (a one-horizon region — the driver's --steps 20 — measures its
+        # own launch and wake-up latency: fp16 x 64 read 22.7 us per launch that way against 20.1 in a long region)
+        side_steps, side_warm, side_rep = 20 * HORIZON, HORIZON, min(args.repeats, 7)
         _MODELS[n_veh] = model
         m32 = model_for(torch, EnvironmentModel, dev, N_VEH)
         per = STRONG_TOTAL // world
@@ -846,9 +848,9 @@ def main():
             # headline's protocol (summary kernels + gather per horizon included).  Ranks share nothing on the data path, so the
             # N-GPU time of a step is the time of its slowest shard: t(262144) / t(262144 / N) is what N GPUs give before RCCL's
             # 32-byte all-gather per horizon (asynchronous, off the launch stream) and rank-to-rank jitter.
-            # Regions of 20 horizons whatever --steps says: the projection is about the steady state of a long sharded job, and a
-            # one-horizon region (the driver's --steps 20) charges its launch / wake-up latency to the smallest shard (5.2 x instead of 6).
-            proj, proj_steps = {}, 20 * HORIZON
+            # (regions of 20 horizons, as every side measurement: the projection is about the steady state of a long sharded job — a
+            # one-horizon region charges its launch / wake-up latency to the smallest shard: 5.2 x instead of 6)
+            proj, proj_steps = {}, side_steps
             t1 = side_config(torch, dist, m32, STRONG_TOTAL, N_VEH, 1000, proj_steps, side_warm, side_rep, with_summary=True)
             for n in (2, 4, 8):
                 sh = side_config(torch, dist, m32, STRONG_TOTAL // n, N_VEH, 1000, proj_steps, side_warm, side_rep, with_summary=True)
