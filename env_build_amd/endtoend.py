@@ -751,8 +751,8 @@ class CrossroadEnd2end(object):
         """E2E:132-144 through ONE C-ABI call and — when the candidate tile fits the LDS — ONE kernel launch (eb_env_step,
         csrc/eb_env_step.hip): action scaling -> reward on the current obs -> ego step -> traffic step -> observation ->
         done code -> the traffic pool re-enters the vehicles that left the map (the observation saw the pool as this step
-        left it, the way the reference sees SUMO's state of the step).  Outputs live in two pre-allocated buffer sets used
-        in turn (valid until the step after next)."""
+        left it, the way the reference sees SUMO's state of the step).  What is handed out: arrays of their own (copy_outputs, the
+        default) or two pre-allocated buffer sets used in turn (valid until the step after next) — see __init__."""
         B, dev = self.n_env, self.device
         if self._ri_snapshot is not None and self._auto_rule is not None:     # (this launch rewrites `_ref_idx`)
             self._settle_snapshots()
