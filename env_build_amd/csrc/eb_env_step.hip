@@ -1048,8 +1048,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
 
 template <int TASK, int ET, bool OBS, bool AUTO = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(A); }
-template <int TASK, int ET>
-__global__ __launch_bounds__(256) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true>(A); }
+template <int TASK, int ET, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true, false, NW>(A); }
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
@@ -1063,8 +1063,8 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;
     hipError_t e = hipSuccess;
-    // eight waves per block for the step proper at small and medium batches (16- / 32-env tiles: few blocks per CU, the step is a
-    // wave's instruction stream), four otherwise; EB_ENV_WAVES=4 switches it off (tuning aid)
+    // eight waves per block at small and medium batches (16- / 32-env tiles: few blocks per CU, the launch is a wave's instruction
+    // stream) — the step, the observation and the masked reset alike —, four otherwise; EB_ENV_WAVES=4 switches it off (tuning aid)
     static const int wforce = std::getenv("EB_ENV_WAVES") ? std::atoi(std::getenv("EB_ENV_WAVES")) : 0;
     static int n_cu[64];
     if (!n_cu[dev]) {
@@ -1074,7 +1074,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     const int n_blocks = (A.n_env + ET - 1) / ET;
     // (a grid of many small tiles — the flow source's 60 candidates force 16-env tiles at any batch size — is throughput again: with
     // eight waves per block only two blocks fit a CU's registers; measured at 65 536 x 60: 133 us against 104)
-    const bool w8 = !A.reset && !A.obs_only && wforce != 4 && ET <= 32 && (n_blocks <= 3 * n_cu[dev] || wforce == 8);
+    const bool w8 = wforce != 4 && ET <= 32 && (n_blocks <= 3 * n_cu[dev] || wforce == 8);
     const dim3 g(n_blocks), b(w8 ? 512 : 256);
 #define EB_ENV_STEP_W(T, E, O, AU, W)                                                                                 \
     do {                                                                                                             \
@@ -1086,17 +1086,18 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
         }                                                                                                            \
         if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O, AU, W>), g, b, lds, s, A);                 \
     } while (0)
-#define EB_ENV_STEP(T, E, O, AU) do { if (!(O) && (E) <= 32 && w8) EB_ENV_STEP_W(T, (E) <= 32 ? (E) : 32, false, AU, 8); else EB_ENV_STEP_W(T, E, O, AU, 4); } while (0)
-#define EB_ENV_RESET(T, E)                                                                                            \
+#define EB_ENV_STEP(T, E, O, AU) do { if ((E) <= 32 && w8) EB_ENV_STEP_W(T, (E) <= 32 ? (E) : 32, O, AU, 8); else EB_ENV_STEP_W(T, E, O, AU, 4); } while (0)
+#define EB_ENV_RESET_W(T, E, W)                                                                                       \
     do {                                                                                                             \
         static size_t granted[64];                                                                                   \
         if (lds > 48 * 1024 && lds > granted[dev]) {                                                                 \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_reset_pool_kernel<T, E>),                     \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_reset_pool_kernel<T, E, W>),                  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             if (e == hipSuccess) granted[dev] = lds;                                                                 \
         }                                                                                                            \
-        if (e == hipSuccess) hipLaunchKernelGGL((env_reset_pool_kernel<T, E>), g, b, lds, s, A);                     \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_reset_pool_kernel<T, E, W>), g, b, lds, s, A);                  \
     } while (0)
+#define EB_ENV_RESET(T, E) do { if ((E) <= 32 && w8) EB_ENV_RESET_W(T, (E) <= 32 ? (E) : 32, 8); else EB_ENV_RESET_W(T, E, 4); } while (0)
 #define EB_ENV_STEP_T(T)                                                                                             \
     do {                                                                                                             \
         if (A.reset) { if (ET == 16) EB_ENV_RESET(T, 16); else if (ET == 32) EB_ENV_RESET(T, 32); else EB_ENV_RESET(T, 64); } \
@@ -1111,6 +1112,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     }
 #undef EB_ENV_STEP_T
 #undef EB_ENV_RESET
+#undef EB_ENV_RESET_W
 #undef EB_ENV_STEP
 #undef EB_ENV_STEP_W
     return e != hipSuccess ? e : hipGetLastError();
