@@ -15,7 +15,7 @@ Started WITHOUT a launcher and with --gpus N > 1, bench.py starts its own N rank
 (self_launch_argv); rank 0 still prints the one line.
 
 The K timed steps run as rollouts of min(K, 25) launches (+ a shorter last one when 25 does not divide K), each followed
-by the episodic summary (two small kernels) and its all-gather; the K-step region is bracketed by barrier +
+by the episodic summary (the launches are the accumulating ones, eb_rollout_step_acc: one small fold) and its all-gather; the K-step region is bracketed by barrier +
 synchronize, measured `--repeats` times (default 11) and the MEDIAN is `value` (min / max are reported too).  The
 launches go out either as one hipGraph replay per rollout (eb_plan_*, --graph) or as host calls (--eager); by default
 a short untimed trial picks the faster form and `config.workload` names the one that ran.  Rank 0 prints ONE JSON line:
@@ -165,6 +165,18 @@ class Shard(object):
             torch.cuda.synchronize()          # the buffers above were filled on the current stream
         self.step_fn = self.lib.eb_rollout_step_f16 if f16 else self.lib.eb_rollout_step
         self._eager, self._plans = {}, {}
+        self.acc = None
+
+    def enable_acc(self):
+        """the rollout's launches become the ACCUMULATING ones (eb_rollout_step_acc, ABI 5): the episodic summary's sums are
+        collected by the launches themselves and the per-horizon summary is one small fold (eb_episode_acc_finish)"""
+        assert not self.f16 and self.lanes == 1
+        nb = C.c_int64()
+        self.api.episode_acc_bytes(self.h, self.n_env, C.byref(nb))
+        self.acc = self.torch.empty((max(16, nb.value),), dtype=self.torch.uint8, device=self.model.device)
+        self.step_fn = self.lib.eb_rollout_step_acc
+        self.close()
+        self._eager = {}
 
     def footprint_bytes(self):
         per = self.obs0[0].numel() * self.obs0[0].element_size()
@@ -178,8 +190,10 @@ class Shard(object):
             for l in range(self.lanes):
                 dst = [self.final[l] if (h - 1 - t) % 2 == 0 else self.work[l] for t in range(h)]
                 src = [self.obs0[l]] + dst[:-1]
+                acc = () if self.acc is None else (p(self.acc),)
                 per_lane.append([(self.h, self.n_env, p(src[t]), p(self.tape[t]), p(self.ref_idx), 0, p(dst[t]),
-                                  p(self.out5[l][t]), None, self.sps[l % len(self.sps)]) for t in range(h)])
+                                  p(self.out5[l][t]), None) + (acc + (int(t == 0), int(t == h - 1)) if acc else ()) +
+                                 (self.sps[l % len(self.sps)],) for t in range(h)])
             self._eager[h] = [per_lane[l][t] for t in range(h) for l in range(self.lanes)]   # round-robin over the lanes
         return self._eager[h]
 
@@ -190,7 +204,7 @@ class Shard(object):
             p = lambda t: C.c_void_p(t.data_ptr())
             plan = C.c_void_p()
             self.api.plan_create(self.h, self.n_env, h, p(self.obs0[0]), p(self.tape), p(self.ref_idx), 0, p(self.work[0]),
-                                 p(self.final[0]), p(self.out5[0]), None, C.byref(plan))
+                                 p(self.final[0]), p(self.out5[0]), None, None if self.acc is None else p(self.acc), C.byref(plan))
             self._plans[h] = plan
         return self._plans[h]
 
@@ -243,6 +257,8 @@ class Timer(object):
         self.n_rollouts = 0
         self.eager = True
         self.open_loop = False
+        if with_summary and not shard.f16 and shard.lanes == 1:
+            shard.enable_acc()
 
     @staticmethod
     def segments(n_steps):
@@ -250,7 +266,7 @@ class Timer(object):
         return [HORIZON] * full + ([rem] if rem else [])
 
     def end_of_rollout(self, h):
-        # episodic-return summary of this shard (two small kernels), then the only inter-GPU exchange
+        # episodic-return summary of this shard, then the only inter-GPU exchange
         from env_build_amd.sharding import gather_summaries_async
         s = self.s
         slot = self.n_rollouts & 1
@@ -258,7 +274,10 @@ class Timer(object):
         if self.in_flight[slot] is not None:
             self.gathered = self.in_flight[slot].result()      # the gather of two rollouts ago: long finished
         p = lambda t: C.c_void_p(t.data_ptr())
-        self.api.episode_summary(s.h, s.n_env, h, p(s.out5[0]), p(s.final[0]), p(self.summaries[slot]), s.sp)
+        if s.acc is not None and not self.open_loop:     # the launches have collected the sums: one fold over the per-block records
+            self.api.episode_acc_finish(s.h, s.n_env, h, p(s.acc), p(self.summaries[slot]), s.sp)
+        else:
+            self.api.episode_summary(s.h, s.n_env, h, p(s.out5[0]), p(s.final[0]), p(self.summaries[slot]), s.sp)
         self.in_flight[slot] = gather_summaries_async(self.summaries[slot])   # env_build_amd/sharding.py: 8 floats per rank
 
     def drain(self):
@@ -409,7 +428,7 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
     if f16 and (n_env, n_veh, lanes) == (N_ENV, 64, 1):      # configs[4]: HBM bytes from the PMC passes of scripts/pmc_traffic.sh
         out['traffic'], out['traffic_source'] = pmc_traffic('rollout', 'fp16_x64', 'hbm_bytes_per_launch')
     if with_summary:
-        out['protocol'] = 'episodic summary kernels + their gather once per horizon inside the timed region, as the headline'
+        out['protocol'] = 'accumulating launches + the episodic summary fold + its gather once per horizon inside the timed region, as the headline'
     if tile is not None:
         out['tile_variant'] = tile
         model.api.debug_set_tile(model.handle, -1)

@@ -8,7 +8,7 @@ with the same class to compare the two libraries call-for-call.)
 import ctypes as C
 import os
 
-EB_ABI_VERSION = 4
+EB_ABI_VERSION = 5
 TASK_ID = {'left': 0, 'straight': 1, 'right': 2}
 MODE_TRAINING, MODE_SELECTING = 0, 1
 # vehicle mode ids (EB_VMODE_*), in the order of the twelve lists of E2E:354
@@ -78,7 +78,10 @@ PROTOTYPES = {
     'eb_rollout_step_f16': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape_f16': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_episode_summary': (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
-    'eb_plan_create': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, C.POINTER(_P)]),
+    'eb_episode_acc_bytes': (C.c_int, [_P, _I, C.POINTER(C.c_int64)]),
+    'eb_rollout_step_acc': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
+    'eb_episode_acc_finish': (C.c_int, [_P, _I, _I, _P, _P, _P]),
+    'eb_plan_create': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     'eb_plan_launch': (C.c_int, [_P, _P]),
     'eb_plan_destroy': (C.c_int, [_P]),
     'eb_event_create': (C.c_int, [_P, C.POINTER(_P)]),

@@ -396,6 +396,20 @@ struct GateArgs {
     uint32_t* status;
     int spin;
 };
+// the episodic accumulator of an accumulating rollout step (eb_rollout_step_acc, plans with a summary)
+struct AccArgs {
+    double* records;
+    int first, last;
+};
+static int envs_per_tile(eb_handle h, int variant) {
+    return std::max(1, std::min(64, eb::fused_tile_records(variant) / h->cfg.n_veh));
+}
+// workspace of an accumulating rollout over n_env envs: one record per block of the SMALLEST tile shape (any shape the handle
+// may pick later fits), plus a byte per env (the CPU library keeps its per-env flags there)
+static size_t acc_workspace_bytes(eb_handle h, int32_t n_env) {
+    const int e = envs_per_tile(h, 2);
+    return (size_t)((n_env + e - 1) / e) * eb::ACC_RECORD_DOUBLES * sizeof(double) + (size_t)n_env;
+}
 
 static int pick_variant(eb_handle h, int32_t n_env) {
     static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
@@ -423,7 +437,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16,
                          int tape_horizon = 0,   // > 0: `actions` is a tape [H, n_env, 2], `out5` is [H, 5, n_env], one launch
-                         const GateArgs* gate = nullptr) {
+                         const GateArgs* gate = nullptr, const AccArgs* acc = nullptr) {
     const int NV = h->cfg.n_veh;
     eb::FusedArgs A;
     std::memset(&A, 0, sizeof A);
@@ -440,7 +454,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     A.n_paths = h->pt.n_paths;
     A.n_env = n_env; A.obs_dim = obs_dim(h->cfg); A.n_veh = NV; A.n_future = h->cfg.n_future;
     A.nv_magic = NV == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)NV - 1) / (unsigned)NV);   // 0: item / 1
-    A.envs_per_tile = std::max(1, std::min(64, eb::fused_tile_records(variant) / NV));
+    A.envs_per_tile = envs_per_tile(h, variant);
     A.path_id = path_id;
     A.training = h->cfg.mode == EB_MODE_TRAINING;
     A.actions_raw = actions_raw;
@@ -450,6 +464,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         A.gate_ready = gate->ready; A.gate_done = gate->done; A.gate_obs = gate->obs_steps; A.gate_status = gate->status;
         A.gate_spin = gate->spin;
     }
+    if (acc) { A.acc = acc->records; A.acc_first = acc->first; A.acc_last = acc->last; }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
     if (tape_horizon > 0 && stage_paths_in_lds(h, grid)) A.stage_entries = h->red_total + 4;
     if (tape_horizon > 0) EB_HIP(eb::launch_rollout_tape_fused(h->cfg.task, variant, A, tape_horizon, grid, s));
@@ -460,9 +475,9 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
 static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                           float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16 = 0,
-                          int tape_horizon = 0, const GateArgs* gate = nullptr) {
+                          int tape_horizon = 0, const GateArgs* gate = nullptr, const AccArgs* acc = nullptr) {
     return rollout_fused(h, pick_variant(h, n_env), n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
-                         actions_raw, do_rewards, s, storage_f16, tape_horizon, gate);
+                         actions_raw, do_rewards, s, storage_f16, tape_horizon, gate, acc);
 }
 
 // blocks of a gated rollout over n_env envs, or 0 when they cannot all be resident at once next to a producer: a gated
@@ -510,17 +525,46 @@ int eb_rollout_step(eb_handle h, int32_t n_env, const float* obs_in, const float
                           pick(h, stream));
 }
 
-// H launches of the per-step kernel, ping-ponging so that the last step lands in obs_out (what eb_plan_* records)
+int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int64_t* bytes) {
+    if (!h || n_env < 0 || !bytes) return fail(EB_EINVAL, "eb_episode_acc_bytes: bad argument");
+    *bytes = (int64_t)acc_workspace_bytes(h, n_env);
+    return EB_OK;
+}
+
+int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const float* actions, const int32_t* ref_idx,
+                        int32_t path_id, float* obs_out, float* out5, float* scaled_actions, void* acc, int32_t first,
+                        int32_t last, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_step_acc: null handle");
+    if (rc) return rc;
+    if (n_env < 0 || !obs_in || !actions || !obs_out || !out5 || !acc) return fail(EB_EINVAL, "eb_rollout_step_acc: bad argument");
+    if (((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_rollout_step_acc: acc must be 16-byte aligned");
+    if (obs_in == obs_out) return fail(EB_EINVAL, "eb_rollout_step_acc: in-place update is not supported");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    const AccArgs a{reinterpret_cast<double*>(acc), first != 0, last != 0};
+    return rollout_common(h, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions, 1, 1, pick(h, stream), 0, 0,
+                          nullptr, &a);
+}
+
+int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const void* acc, float* out8, void* stream) {
+    if (!h || n_env < 0 || horizon < 0 || !out8 || (n_env > 0 && !acc)) return fail(EB_EINVAL, "eb_episode_acc_finish: bad argument");
+    EB_HIP(hipSetDevice(h->cfg.device));
+    const int e = envs_per_tile(h, pick_variant(h, n_env));   // the grid the accumulating launches ran on
+    EB_HIP(eb::launch_acc_fold((n_env + e - 1) / e, n_env, horizon, reinterpret_cast<const double*>(acc), out8, pick(h, stream)));
+    return EB_OK;
+}
+
+// H launches of the per-step kernel, ping-ponging so that the last step lands in obs_out (what eb_plan_* records);
+// acc != NULL: accumulating launches (the episodic summary's sums collected on the way)
 static int rollout_tape_stepwise(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                                  const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out,
-                                 float* out5_steps, hipStream_t s, int storage_f16) {
-    const size_t row_bytes = (size_t)obs_dim(h->cfg) * (storage_f16 ? 2 : 4);
-    (void)row_bytes;
+                                 float* out5_steps, hipStream_t s, int storage_f16, double* acc = nullptr) {
     const float* cur = obs_in;
     for (int t = 0; t < horizon; ++t) {
         float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
+        const AccArgs a{acc, t == 0, t == horizon - 1};
         int rc = rollout_common(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
-                                out5_steps + (size_t)t * 5 * n_env, nullptr, 1, 1, s, storage_f16);
+                                out5_steps + (size_t)t * 5 * n_env, nullptr, 1, 1, s, storage_f16, 0, nullptr, acc ? &a : nullptr);
         if (rc) return rc;
         cur = dst;
     }
@@ -1002,6 +1046,7 @@ struct eb_plan_s {
     eb_handle h;
     hipGraph_t graph;
     hipGraphExec_t exec;
+    void* own_acc;            // the accumulator workspace of a plan with a summary whose caller passed none
 };
 
 struct eb_event_s {
@@ -1013,7 +1058,7 @@ extern "C" {
 
 int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                    const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
-                   float* summary8, eb_plan* out) {
+                   float* summary8, void* acc, eb_plan* out) {
     if (!out) return fail(EB_EINVAL, "eb_plan_create: null argument");
     *out = nullptr;
     int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_plan_create: null handle");
@@ -1022,25 +1067,38 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
         return fail(EB_EINVAL, "eb_plan_create: bad argument (n_env >= 1, horizon >= 1, non-null buffers)");
     if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
         return fail(EB_EINVAL, "eb_plan_create: obs_in, obs_work and obs_out must be distinct buffers");
+    if (acc && ((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_plan_create: acc must be 16-byte aligned");
     EB_HIP(hipSetDevice(h->cfg.device));
+    void* own_acc = nullptr;
+    if (summary8 && !acc) {
+        EB_HIP(hipMalloc(&own_acc, acc_workspace_bytes(h, n_env)));
+        acc = own_acc;
+    }
     hipStream_t cs = nullptr;
-    EB_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { (void)hipStreamDestroy(cs); return fail_hip("hipStreamBeginCapture", e); }
-    // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph
-    rc = rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs, 0);
-    if (rc == EB_OK && summary8) rc = eb_episode_summary(h, n_env, horizon, out5_steps, obs_out, summary8, cs);
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) { if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamCreateWithFlags", e); }
+    e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { (void)hipStreamDestroy(cs); if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamBeginCapture", e); }
+    // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph; with a summary (or a
+    // caller's accumulator) they are the accumulating launches and the summary is one small fold behind them
+    rc = rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs, 0,
+                               reinterpret_cast<double*>(acc));
+    if (rc == EB_OK && summary8) rc = eb_episode_acc_finish(h, n_env, horizon, acc, summary8, cs);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(cs, &graph);
     (void)hipStreamDestroy(cs);
-    if (rc != EB_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (e != hipSuccess || !graph) return fail_hip("hipStreamEndCapture", e);
+    if (rc != EB_OK) { if (graph) (void)hipGraphDestroy(graph); if (own_acc) (void)hipFree(own_acc); return rc; }
+    if (e != hipSuccess || !graph) { if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamEndCapture", e); }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { (void)hipGraphDestroy(graph); return fail_hip("hipGraphInstantiate", e); }
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); if (own_acc) (void)hipFree(own_acc); return fail_hip("hipGraphInstantiate", e); }
     eb_plan p = new (std::nothrow) eb_plan_s();
-    if (!p) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); return fail(EB_ENOMEM, "eb_plan_create: out of memory"); }
-    p->h = h; p->graph = graph; p->exec = exec;
+    if (!p) {
+        (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+        if (own_acc) (void)hipFree(own_acc);
+        return fail(EB_ENOMEM, "eb_plan_create: out of memory");
+    }
+    p->h = h; p->graph = graph; p->exec = exec; p->own_acc = own_acc;
     *out = p;
     return EB_OK;
 }
@@ -1058,6 +1116,7 @@ int eb_plan_destroy(eb_plan p) {
     (void)hipDeviceSynchronize();
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->own_acc) (void)hipFree(p->own_acc);
     delete p;
     return EB_OK;
 }

@@ -45,7 +45,15 @@ struct FusedArgs {
     unsigned* gate_status;        // [0] = 1 when a gate was not opened within gate_spin polls (the launch gives up)
     int gate_spin;
     int stage_entries;            // tape / gated kernels: > 0 = copy this many stride-10 table entries (+ 4 readable past the end) into LDS
+    // episodic accumulator (eb_rollout_step_acc; per-step kernel only): one ACC_RECORD_DOUBLES record per block, or NULL.
+    // acc_first: this launch starts a rollout (records are overwritten); acc_last: it ends one (the obs it writes is the final obs)
+    double* acc;
+    int acc_first, acc_last;
 };
+// a block's record: [0..2] = running float64 sums of reward, punish_term_for_training, real_punish_term over its envs and the
+// steps so far, [3] = bit e set once env e of the tile had real_punish_term > 0 (a 64-bit mask in the double's bytes),
+// [4] = sum |delta_y| and [5] = max |delta_y| of the tile's final obs rows (written by the acc_last launch)
+constexpr int ACC_RECORD_DOUBLES = 8;
 // variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 4 x 4 (1024), 2 = 1 x 4 (256)
 int fused_tile_records(int variant);
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s);
@@ -76,6 +84,8 @@ hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const Pat
 constexpr int SUMMARY_MAX_PARTS = 1024;   // blocks of the stage-1 summary reduction (handle scratch: 6 doubles each)
 hipError_t launch_summary(int n_env, int horizon, int D, const float* out5_steps, const float* obs_final,
                           double* partials, int max_parts, float* out8, hipStream_t s);
+// fold of the per-block records an accumulating rollout left (FusedArgs::acc) -> the same 8 floats, one launch
+hipError_t launch_acc_fold(int n_blocks, int n_env, int horizon, const double* acc, float* out8, hipStream_t s);
 
 // real-env step pieces (eb_env_kernels.hip)
 hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, float* next_ego, float* params,

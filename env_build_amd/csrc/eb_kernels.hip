@@ -420,6 +420,42 @@ __global__ __launch_bounds__(SUM_THREADS) void summary_final_kernel(int n_part, 
     }
 }
 
+// The fold behind an ACCUMULATING rollout (eb_rollout_step_acc): the rollout launches have left one record per block — running
+// float64 sums, the "punished at any step" bits of the block's envs, the final rows' |delta_y| sum and maximum — so the summary
+// is one pass over n_blocks x 64 bytes instead of a second pass over out5_steps [H, 5, B].  Same fixed order: records in block
+// order per thread, then the shuffle + LDS tree.
+__global__ __launch_bounds__(SUM_THREADS) void acc_fold_kernel(int n_blocks, int n_env, int horizon,
+                                                                const double* __restrict__ acc, float* __restrict__ out8) {
+    __shared__ Sum6 s_part[SUM_THREADS / 64];
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    Sum6 tot = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k0 = threadIdx.x; k0 < n_blocks; k0 += 2 * SUM_THREADS) {    // two records in flight per thread
+        d2v x[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + u * SUM_THREADS;
+            const d2v* p = reinterpret_cast<const d2v*>(acc + (size_t)ACC_RECORD_DOUBLES * (k < n_blocks ? k : 0));
+            x[u][0] = p[0]; x[u][1] = p[1]; x[u][2] = p[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (k0 + u * SUM_THREADS < n_blocks) {
+                const double cnt = (double)__popcll(__builtin_bit_cast(unsigned long long, x[u][1].y));
+                tot = sum6_combine(tot, Sum6{x[u][0].x, x[u][0].y, x[u][1].x, cnt, x[u][2].x, x[u][2].y});
+            }
+    }
+    const Sum6 f = sum6_block_reduce(tot, s_part);
+    if (threadIdx.x == 0) {
+        out8[0] = (float)f.r; out8[1] = (float)f.pt; out8[2] = (float)f.pr; out8[3] = (float)f.cnt;
+        out8[4] = (float)f.ady; out8[5] = (float)f.mdy; out8[6] = (float)n_env; out8[7] = (float)horizon;
+    }
+}
+
+hipError_t launch_acc_fold(int n_blocks, int n_env, int horizon, const double* acc, float* out8, hipStream_t s) {
+    hipLaunchKernelGGL(acc_fold_kernel, dim3(1), dim3(SUM_THREADS), 0, s, n_blocks, n_env, horizon, acc, out8);
+    return hipGetLastError();
+}
+
 hipError_t launch_summary(int n_env, int horizon, int D, const float* out5_steps, const float* obs_final,
                           double* partials, int max_parts, float* out8, hipStream_t s) {
     int g = (n_env + 63) / 64;

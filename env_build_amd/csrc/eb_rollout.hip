@@ -91,6 +91,41 @@ EB_DEV void lds_wait_until(int* flag, int value) {
     asm volatile("" ::: "memory");
 }
 
+// Wave-wide float64 sum on the DPP network (no LDS traffic), complete in lane 63: an inclusive scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals forwarded (row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3).  Every lane must be active.  A fixed order: the episodic accumulator stays deterministic.
+template <int CTRL, int ROW_MASK>
+EB_DEV double dpp_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+EB_DEV double wave_sum_f64(double v) {
+    v += dpp_f64<0x111, 0xf>(v);
+    v += dpp_f64<0x112, 0xf>(v);
+    v += dpp_f64<0x114, 0xf>(v);
+    v += dpp_f64<0x118, 0xf>(v);
+    v += dpp_f64<0x142, 0xa>(v);
+    v += dpp_f64<0x143, 0xc>(v);
+    return v;
+}
+// the same network for the maximum of non-negative, non-NaN floats (0 is the identity the missing lanes supply)
+template <int CTRL, int ROW_MASK>
+EB_DEV float dpp_max_f32(float v) {
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+    return o > v ? o : v;
+}
+EB_DEV float wave_max_f32(float v) {
+    v = dpp_max_f32<0x111, 0xf>(v);
+    v = dpp_max_f32<0x112, 0xf>(v);
+    v = dpp_max_f32<0x114, 0xf>(v);
+    v = dpp_max_f32<0x118, 0xf>(v);
+    v = dpp_max_f32<0x142, 0xa>(v);
+    v = dpp_max_f32<0x143, 0xc>(v);
+    return v;
+}
+
 // Device-scope accesses of the gated rollout's flags and action words, spelled as global instructions with the sc1 bit
 // (served by L2 / memory, never by this CU's L1 — MI355X_MICROARCH.md, "inter-workgroup visibility").  Inline assembly:
 // the flat-pointer forms of the __hip_atomic builtins do not survive instruction selection here.
@@ -208,6 +243,16 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int pr = A.ref_idx[ge];
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
+    // episodic accumulator (eb_rollout_step_acc): the block's running record — a block-uniform address, fetched now, used last
+    // (a scalar load into SGPRs, spelled out: the compiler takes a vector load for memory the kernel also writes, i.e. eight
+    // VGPRs held through the whole chain; the previous launch's stores are behind a kernel boundary, so the scalar cache is fine)
+    typedef unsigned u8s __attribute__((ext_vector_type(8)));
+    u8s acc_prev = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const bool acc_carry = A.acc && !A.acc_first;
+    if (acc_carry) {
+        const double* rec = A.acc + (size_t)ACC_RECORD_DOUBLES * blockIdx.x;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(acc_prev) : "s"(rec));
+    }
     const int trow = blockIdx.x * (RW + 1);
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
@@ -226,14 +271,16 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     if (A.actions_raw) action_transform(araw.x, araw.y, steer, a_x);        // DAM:120
     else { steer = araw.x; a_x = araw.y; }
     if (act && A.scaled_actions) *reinterpret_cast<f2u*>(A.scaled_actions + 2 * (size_t)ge) = f2u{steer, a_x};
+    float rew = 0.0f;
     if (act && H.do_rewards) {
         const float punish_steer = -sq(steer), punish_a_x = -sq(a_x);       // DAM:198-199
         const float punish_yaw_rate = -sq(st[2]);                           // DAM:202
         const float devi_y = -sq(h1.z);                                     // DAM:205
         const float devi_phi = -sq(deg2rad(h1.w));                          // DAM:206
         const float devi_v = -sq(h8);                                       // DAM:207
-        A.out5[ge] = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
-                     5.0f * punish_steer + 0.05f * punish_a_x;              // DAM:297-298
+        rew = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
+              5.0f * punish_steer + 0.05f * punish_a_x;                     // DAM:297-298
+        A.out5[ge] = rew;
     }
     float nx[6];
     f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);                  // DAM:387
@@ -282,6 +329,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     EB_MARK(A, trow, 5);                                                    // record waves done
 
     // per env: penalty sums in vehicle order (DAM:218-229, 299-300)
+    float pun_t = 0.0f, pun_r = 0.0f;
     if (act) {
         float a35 = 0.0f, a25 = 0.0f;
         unsigned long long m = S.mask[lane];
@@ -293,10 +341,38 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
             a25 += ps.y;
         }
         const size_t n = (size_t)H.n_env;
-        A.out5[n + ge] = a35 + road_t;       // DAM:299
-        A.out5[2 * n + ge] = a25 + road_r;   // DAM:300
+        pun_t = a35 + road_t;                // DAM:299
+        pun_r = a25 + road_r;                // DAM:300
+        A.out5[n + ge] = pun_t;
+        A.out5[2 * n + ge] = pun_r;
         A.out5[3 * n + ge] = a25;
         A.out5[4 * n + ge] = road_r;
+    }
+    // Episodic accumulator: what eb_episode_summary would re-read from out5_steps is in this wave's registers — the tile's three
+    // sums (float64, DPP network, fixed order) join the block's running record, the "punished at any step" bits are OR-ed in, and
+    // the launch that ends the rollout adds the |delta_y| statistics of the rows it has just written (t0 IS the final obs' column 6).
+    if (A.acc) {
+        const double s_r = wave_sum_f64(act ? (double)rew : 0.0);
+        const double s_pt = wave_sum_f64(act ? (double)pun_t : 0.0);
+        const double s_pr = wave_sum_f64(act ? (double)pun_r : 0.0);
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(act && pun_r > 0.0f);
+        double s_dy = 0.0;
+        float m_dy = 0.0f;
+        if (A.acc_last) {
+            const float dy = __builtin_fabsf(Stored<ST>::round(t0));
+            s_dy = wave_sum_f64(act ? (double)dy : 0.0);
+            m_dy = wave_max_f32(act && dy > 0.0f ? dy : 0.0f);               // (a NaN never becomes the maximum, as in the two-pass summary)
+        }
+        if (acc_carry) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(acc_prev));   // the record fetched at the top has long arrived
+        auto prev_f64 = [&](int k) { return __builtin_bit_cast(double, ((unsigned long long)acc_prev[2 * k + 1] << 32) | acc_prev[2 * k]); };
+        const unsigned long long prev_any = ((unsigned long long)acc_prev[7] << 32) | acc_prev[6];
+        if (lane == 63) {
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            d2v* rec = reinterpret_cast<d2v*>(A.acc + (size_t)ACC_RECORD_DOUBLES * blockIdx.x);
+            rec[0] = d2v{prev_f64(0) + s_r, prev_f64(1) + s_pt};
+            rec[1] = d2v{prev_f64(2) + s_pr, __builtin_bit_cast(double, prev_any | any)};
+            if (A.acc_last) rec[2] = d2v{s_dy, (double)m_dy};
+        }
     }
     EB_MARK(A, trow, 6);                                                    // end
 }

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.environ.get('ENVBUILD_LIB', os.path.join(_HERE, '..', 'env_build_amd', 'lib', 'libenvbuild_hip.so'))
 VMODE = {m: i for i, m in enumerate(('dl', 'du', 'dr', 'rd', 'rl', 'ru', 'ur', 'ud', 'ul', 'lu', 'lr', 'ld'))}   # EB_VMODE_*
 TASK = {'left': 0, 'straight': 1, 'right': 2}                                                                 # EB_TASK_*
-BINDING_ABI = 4     # the EB_ABI_VERSION of the include/envbuild.h these prototypes were written against
+BINDING_ABI = 5     # the EB_ABI_VERSION of the include/envbuild.h these prototypes were written against
 
 
 class _Cfg(C.Structure):       # struct eb_config

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EB_ABI_VERSION 4
+#define EB_ABI_VERSION 5
 
 /* error codes */
 #define EB_OK 0
@@ -229,15 +229,34 @@ int eb_gate_feed(eb_handle h, int32_t n_env, int32_t horizon, int32_t n_blocks, 
 int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float* out5_steps,
                        const float* obs_final, float* out8, void* stream);
 
+/* The same summary collected BY the rollout launches (ABI 5) — what the reference's callers do when they add up the
+ * returns of rollout_out step by step (hier_decision.py:96, multi_ego.py:195) instead of re-reading them afterwards:
+ *   eb_rollout_step_acc = eb_rollout_step (DAM:118-126; same outputs, same bits) that also folds the step's rewards,
+ *       punish_term_for_training and real_punish_term (float64, fixed order) and the "real_punish_term > 0" flags of its
+ *       envs into the workspace `acc`.  first != 0: the launch starts a rollout (acc is overwritten, no zero fill needed);
+ *       last != 0: it ends one — the obs it writes is the final obs, whose |delta_y| statistics it records.
+ *   eb_episode_acc_finish: acc -> out8, the 8 floats of eb_episode_summary(out5_steps of those steps, the last obs_out)
+ *       (sums within rtol 1e-6 of it — another fixed float64 order —, count and maximum equal), one small launch.
+ * acc: device memory of eb_episode_acc_bytes(n_env) bytes, 16-byte aligned, private layout, one per rollout in flight; every
+ * step of one rollout must go to the same handle with the same n_env (and the same eb_debug_set_tile setting: a block keeps
+ * its own record).  The HIP library's episodic summary costs one pass over n_blocks x 64 bytes this way instead of a second pass
+ * over out5_steps [horizon, 5, n_env]. */
+int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int64_t* bytes);
+int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
+                        const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
+                        float* scaled_actions, void* acc, int32_t first, int32_t last, void* stream);
+int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const void* acc, float* out8, void* stream);
+
 /* A rollout plan = eb_rollout_tape over FIXED buffers, recorded once and replayed: the HIP library
- * captures the `horizon` launches (plus the episodic summary when summary8 != NULL) into a
- * hipGraph, so that a replay costs one host call instead of `horizon`.  Buffer contents may
- * change between launches, addresses and sizes may not.  The plan borrows every buffer; destroy it
- * before the handle. */
+ * captures the `horizon` launches into a hipGraph, so that a replay costs one host call instead of `horizon`.
+ * summary8 != NULL: the launches are the accumulating ones and eb_episode_acc_finish -> summary8 is part of the plan
+ * (acc NULL: the plan owns its workspace).  summary8 == NULL, acc != NULL (ABI 5): accumulating launches into the caller's
+ * workspace, the caller finishes.  Buffer contents may change between launches, addresses and sizes may not.  The plan
+ * borrows every buffer; destroy it before the handle. */
 typedef struct eb_plan_s* eb_plan;
 int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in,
                    const float* action_tape, const int32_t* ref_idx, int32_t path_id,
-                   float* obs_work, float* obs_out, float* out5_steps, float* summary8,
+                   float* obs_work, float* obs_out, float* out5_steps, float* summary8, void* acc,
                    eb_plan* out);
 int eb_plan_launch(eb_plan p, void* stream);
 int eb_plan_destroy(eb_plan p);

@@ -1182,17 +1182,72 @@ int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float*
     return EB_OK;
 }
 
+/* The accumulating form (ABI 5; include/envbuild.h): the reference's callers add the returns of rollout_out up step by step
+ * (hier_decision.py:96).  Workspace layout of THIS library (private): 8 doubles — sums of reward, punish_term_for_training,
+ * real_punish_term, then sum and max of the final rows' |delta_y| — followed by one "punished at any step" byte per env. */
+static size_t acc_bytes(const eb_config* c, int32_t n_env) {
+    int e = 256 / c->n_veh;                    /* the HIP library's smallest tile (its formula: the two must agree) */
+    if (e < 1) e = 1;
+    if (e > 64) e = 64;
+    return (size_t)((n_env + e - 1) / e) * 64 + (size_t)n_env;
+}
+int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int64_t* bytes) {
+    if (!h || n_env < 0 || !bytes) return fail(EB_EINVAL, "eb_episode_acc_bytes: bad argument");
+    *bytes = (int64_t)acc_bytes(&h->cfg, n_env);
+    return EB_OK;
+}
+int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
+                        const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
+                        float* scaled_actions, void* acc, int32_t first, int32_t last, void* stream) {
+    if (h && n_env == 0) return EB_OK;
+    if (!acc) return fail(EB_EINVAL, "eb_rollout_step_acc: bad argument");
+    if (((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_rollout_step_acc: acc must be 16-byte aligned");
+    int rc = eb_rollout_step(h, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions, stream);
+    if (rc) return rc;
+    double* a = (double*)acc;
+    unsigned char* any = (unsigned char*)acc + 64;
+    if (first) { memset(a, 0, 64); memset(any, 0, (size_t)n_env); }
+    const int D = obs_dim(&h->cfg);
+    double r = 0, pt = 0, pr = 0, ady = 0, mdy = 0;
+    for (int i = 0; i < n_env; ++i) {
+        r += (double)out5[i];
+        pt += (double)out5[(size_t)n_env + i];
+        pr += (double)out5[2 * (size_t)n_env + i];
+        if (out5[2 * (size_t)n_env + i] > 0.0f) any[i] = 1;
+        if (last) {
+            double dy = (double)fabsf(obs_out[(size_t)i * D + 6]);
+            ady += dy;
+            if (dy > mdy) mdy = dy;
+        }
+    }
+    a[0] += r; a[1] += pt; a[2] += pr;
+    if (last) { a[3] = ady; a[4] = mdy; }
+    return EB_OK;
+}
+int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const void* acc, float* out8, void* stream) {
+    (void)stream;
+    if (!h || n_env < 0 || horizon < 0 || !out8 || (n_env > 0 && !acc)) return fail(EB_EINVAL, "eb_episode_acc_finish: bad argument");
+    double z[8] = {0};
+    const double* a = n_env > 0 ? (const double*)acc : z;
+    double cnt = 0;
+    for (int i = 0; i < n_env; ++i) cnt += ((const unsigned char*)acc + 64)[i] ? 1.0 : 0.0;
+    out8[0] = (float)a[0]; out8[1] = (float)a[1]; out8[2] = (float)a[2]; out8[3] = (float)cnt;
+    out8[4] = (float)a[3]; out8[5] = (float)a[4]; out8[6] = (float)n_env; out8[7] = (float)horizon;
+    return EB_OK;
+}
+
 struct eb_plan_s {
     eb_handle h;
     int32_t n_env, horizon, path_id;
     const float *obs_in, *tape;
     const int32_t* ref_idx;
     float *obs_work, *obs_out, *out5_steps, *summary8;
+    void *acc, *own_acc;
 };
 
 int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in,
                    const float* action_tape, const int32_t* ref_idx, int32_t path_id,
-                   float* obs_work, float* obs_out, float* out5_steps, float* summary8, eb_plan* out) {
+                   float* obs_work, float* obs_out, float* out5_steps, float* summary8, void* acc, eb_plan* out) {
     if (!out) return fail(EB_EINVAL, "eb_plan_create: null argument");
     *out = NULL;
     int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_plan_create: null handle");
@@ -1201,25 +1256,40 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
         return fail(EB_EINVAL, "eb_plan_create: bad argument (n_env >= 1, horizon >= 1, non-null buffers)");
     if (obs_work == obs_out || obs_in == obs_work || obs_in == obs_out)
         return fail(EB_EINVAL, "eb_plan_create: obs_in, obs_work and obs_out must be distinct buffers");
+    if (acc && ((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_plan_create: acc must be 16-byte aligned");
     eb_plan p = (eb_plan)calloc(1, sizeof *p);
     if (!p) return fail(EB_ENOMEM, "eb_plan_create: out of memory");
     p->h = h; p->n_env = n_env; p->horizon = horizon; p->path_id = path_id; p->obs_in = obs_in;
     p->tape = action_tape; p->ref_idx = ref_idx; p->obs_work = obs_work; p->obs_out = obs_out;
-    p->out5_steps = out5_steps; p->summary8 = summary8;
+    p->out5_steps = out5_steps; p->summary8 = summary8; p->acc = acc;
+    if (summary8 && !acc) {
+        p->own_acc = aligned_alloc(64, (acc_bytes(&h->cfg, n_env) + 63) / 64 * 64);
+        if (!p->own_acc) { free(p); return fail(EB_ENOMEM, "eb_plan_create: out of memory"); }
+        p->acc = p->own_acc;
+    }
     *out = p;
     return EB_OK;
 }
 
 int eb_plan_launch(eb_plan p, void* stream) {
     if (!p) return fail(EB_EINVAL, "eb_plan_launch: null plan");
-    int rc = eb_rollout_tape(p->h, p->n_env, p->horizon, p->obs_in, p->tape, p->ref_idx, p->path_id,
-                             p->obs_work, p->obs_out, p->out5_steps, stream);
-    if (rc == EB_OK && p->summary8)
-        rc = eb_episode_summary(p->h, p->n_env, p->horizon, p->out5_steps, p->obs_out, p->summary8, stream);
-    return rc;
+    if (!p->acc)
+        return eb_rollout_tape(p->h, p->n_env, p->horizon, p->obs_in, p->tape, p->ref_idx, p->path_id,
+                               p->obs_work, p->obs_out, p->out5_steps, stream);
+    /* the accumulating launches, ping-ponging as eb_rollout_tape does */
+    const float* cur = p->obs_in;
+    for (int t = 0; t < p->horizon; ++t) {
+        float* dst = ((p->horizon - 1 - t) % 2 == 0) ? p->obs_out : p->obs_work;
+        int rc = eb_rollout_step_acc(p->h, p->n_env, cur, p->tape + (size_t)t * p->n_env * 2, p->ref_idx, p->path_id, dst,
+                                     p->out5_steps + (size_t)t * 5 * p->n_env, NULL, p->acc, t == 0, t == p->horizon - 1, stream);
+        if (rc) return rc;
+        cur = dst;
+    }
+    return p->summary8 ? eb_episode_acc_finish(p->h, p->n_env, p->horizon, p->acc, p->summary8, stream) : EB_OK;
 }
 
 int eb_plan_destroy(eb_plan p) {
+    if (p) free(p->own_acc);
     free(p);
     return EB_OK;
 }

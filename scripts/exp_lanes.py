@@ -30,7 +30,7 @@ for l in range(L):
     o = obs0[lo:hi].contiguous(); tp = tape[:, lo:hi].contiguous(); r = ref[lo:hi].contiguous()
     w, f = torch.empty_like(o), torch.empty_like(o); o5 = torch.empty((H, 5, per), device=dev)
     plan = C.c_void_p()
-    api.plan_create(h, per, H, p(o), p(tp), p(r), 0, p(w), p(f), p(o5), None, C.byref(plan))
+    api.plan_create(h, per, H, p(o), p(tp), p(r), 0, p(w), p(f), p(o5), None, None, C.byref(plan))
     lanes.append(dict(plan=plan, stream=torch.cuda.Stream(device=dev), keep=(o, tp, r, w, f, o5)))
 def run():
     for ln in lanes:

@@ -35,7 +35,7 @@ sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 nb = C.c_int32(); api.rollout_gated_blocks(h, B, C.byref(nb)); nb = nb.value
 done = torch.zeros((H, nb, 16), dtype=torch.int32, device=dev)   # the rollout only ever sets these words: no reset between repetitions
 plan = C.c_void_p()
-api.plan_create(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), None, C.byref(plan))
+api.plan_create(h, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), None, None, C.byref(plan))
 dst = [out if (H - 1 - t) % 2 == 0 else work for t in range(H)]
 src = [obs0] + dst[:-1]
 eargs = [(h, B, p(src[t]), p(tape[t]), p(ref), 0, p(dst[t]), p(out5[t]), None, sp) for t in range(H)]

@@ -217,18 +217,44 @@ class HostModel(object):
         self.api.episode_summary(self.h, o5.shape[2], o5.shape[0], self._ptr(o5), self._ptr(ob), self._ptr(out8), self.stream)
         return self._ret(out8)
 
-    def plan_run(self, obs, tape, ref_idx=None, path_id=0, replays=2, with_summary=True):
-        """eb_plan_create + `replays` x eb_plan_launch + destroy -> (obs_out, out5 [H,5,n], summary8)."""
+    def acc_workspace(self, n_env):
+        """the workspace of an accumulating rollout over n_env envs (eb_episode_acc_bytes), filled with 0xFF: a rollout's first
+        launch must not depend on what it finds there"""
+        nb = C.c_int64()
+        self.api.episode_acc_bytes(self.h, int(n_env), C.byref(nb))
+        return self._in(np.full((max(16, nb.value),), 0xFF, np.uint8), np.uint8)
+
+    def rollout_acc(self, obs, tape, ref_idx=None, path_id=0, acc=None):
+        """H x eb_rollout_step_acc (ping-ponging as eb_rollout_tape) + eb_episode_acc_finish -> (obs_out, out5 [H,5,n], summary8)"""
+        ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
+        H, n = tp.shape[0], len(ob)
+        bufs, out5, s8 = [self._out(ob.shape), self._out(ob.shape)], self._out((H, 5, n)), self._out((8,))
+        acc = self.acc_workspace(n) if acc is None else acc
+        cur = ob
+        for t in range(H):
+            dst = bufs[(H - 1 - t) % 2]
+            self.api.rollout_step_acc(self.h, n, self._ptr(cur), self._ptr(tp[t]), self._ptr(ri), int(path_id), self._ptr(dst),
+                                      self._ptr(out5[t]), None, self._ptr(acc), int(t == 0), int(t == H - 1), self.stream)
+            cur = dst
+        self.api.episode_acc_finish(self.h, n, H, self._ptr(acc), self._ptr(s8), self.stream)
+        return self._ret(bufs[0]), self._ret(out5), self._ret(s8)
+
+    def plan_run(self, obs, tape, ref_idx=None, path_id=0, replays=2, with_summary=True, caller_acc=False):
+        """eb_plan_create + `replays` x eb_plan_launch + destroy -> (obs_out, out5 [H,5,n], summary8).  caller_acc: the plan
+        accumulates into a workspace of the caller's, who finishes it (summary8 == NULL, acc != NULL)."""
         ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
         H, n = tp.shape[0], len(ob)
         work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
         s8 = self._out((8,)) if with_summary else None
+        acc = self.acc_workspace(n) if caller_acc else None
         plan = C.c_void_p()
         self.api.plan_create(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work),
-                             self._ptr(out), self._ptr(out5), self._ptr(s8), C.byref(plan))
+                             self._ptr(out), self._ptr(out5), None if caller_acc else self._ptr(s8), self._ptr(acc), C.byref(plan))
         try:
             for _ in range(replays):
                 self.api.plan_launch(plan, self.stream)
+                if caller_acc and with_summary:
+                    self.api.episode_acc_finish(self.h, n, H, self._ptr(acc), self._ptr(s8), self.stream)
             res = self._ret(out), self._ret(out5), (self._ret(s8) if with_summary else None)
         finally:
             self.api.plan_destroy(plan)

@@ -11,7 +11,7 @@ import pytest
 from env_build_amd import _capi, build as eb_build
 from env_build_amd import endtoend_env_utils as U
 from env_build_amd.synthetic import assemble_obs, make_rollout_inputs
-from tests._helpers import golden, ROOT, HostModel, oracle_lib
+from tests._helpers import golden, ROOT, HostModel, oracle_lib, _p
 
 HEADER = os.path.join(ROOT, 'include', 'envbuild.h')
 
@@ -184,7 +184,35 @@ def test_oracle_plan_summary_and_events():
     assert 0.0 <= ms.value < 1000.0
     api.event_destroy(e0); api.event_destroy(e1)
     with pytest.raises(ValueError):
-        api.plan_create(host.h, 0, 5, None, None, None, 0, None, None, None, None, C.byref(C.c_void_p()))
+        api.plan_create(host.h, 0, 5, None, None, None, 0, None, None, None, None, None, C.byref(C.c_void_p()))
+
+
+def test_oracle_accumulating_rollout_equals_the_two_pass_summary():
+    """ABI 5: eb_rollout_step_acc = eb_rollout_step + the episodic sums collected on the way; eb_episode_acc_finish gives
+    eb_episode_summary's 8 floats; plans with a summary (own or caller's workspace) run the same thing."""
+    host = HostModel(oracle_lib(), 'straight', n_veh=9)
+    inp = make_rollout_inputs('straight', 77, 9, 6, seed=12)
+    trk = host.tracking_error(inp['ego'][:, 3], inp['ego'][:, 4], inp['ego'][:, 5], inp['ego'][:, 0], 0, ref_idx=inp['ref_idx'])
+    obs = assemble_obs(inp['ego'], trk, inp['veh'])
+    out_a, o5_a = host.rollout_tape(obs, inp['actions'], inp['ref_idx'])
+    want = host.episode_summary(o5_a, out_a)
+    assert want[3] > 0                                               # the scene does punish somebody
+    acc = host.acc_workspace(77)
+    for _ in range(2):                                               # the second rollout starts over in the used workspace
+        out_b, o5_b, s8 = host.rollout_acc(obs, inp['actions'], inp['ref_idx'], acc=acc)
+        assert np.array_equal(out_a, out_b) and np.array_equal(o5_a, o5_b)
+        np.testing.assert_allclose(s8, want, rtol=1e-6, atol=0)
+        assert s8[3] == want[3] and s8[5] == want[5] and s8[6] == 77 and s8[7] == 6
+    for caller_acc in (False, True):
+        out_c, o5_c, s8_c = host.plan_run(obs, inp['actions'], inp['ref_idx'], caller_acc=caller_acc)
+        assert np.array_equal(out_a, out_c) and np.array_equal(o5_a, o5_c) and np.array_equal(s8_c, s8)
+    api = host.api
+    with pytest.raises(ValueError):
+        api.rollout_step_acc(host.h, 77, _p(obs), _p(inp['actions'][0]), _p(inp['ref_idx']), 0, _p(out_a.copy()), _p(o5_a[0].copy()),
+                             None, None, 1, 1, None)
+    nb = C.c_int64()
+    api.episode_acc_bytes(host.h, 0, C.byref(nb))
+    assert nb.value == 0
 
 
 def test_exit_frame_transforms_match_reference_values():

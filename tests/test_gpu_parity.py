@@ -275,6 +275,49 @@ def test_plan_graph_replay_and_summary(task, N, B, H):
     assert np.array_equal(dev.episode_summary(o5_d, out_d), s8_d)
 
 
+@pytest.mark.parametrize('task,N,B,H,tile', [('left', 32, 2049, 25, -1), ('left', 32, 2049, 3, 0), ('left', 32, 130, 2, 1),
+                                             ('right', 5, 100, 3, -1), ('right', 5, 1, 1, -1), ('straight', 64, 777, 7, 2),
+                                             ('straight', 9, 4097, 4, 0), ('left', 16, 40000, 5, -1)])
+def test_accumulating_rollout_equals_the_two_pass_summary(task, N, B, H, tile):
+    """ABI 5: the episodic summary collected by the rollout launches themselves (eb_rollout_step_acc: per-block float64 records,
+    DPP wave reduction; eb_episode_acc_finish: one fold) — same rows and outputs as eb_rollout_step bit for bit, the 8 floats
+    of eb_episode_summary over the same out5 (sums rtol 1e-6, count and maximum equal), at every tile shape, ragged last tiles,
+    twice in a row in one workspace (a rollout's first launch overwrites it), and through the plan's two forms."""
+    host, dev = _pair(task, n_veh=N)
+    if tile >= 0:
+        dev.set_tile(tile)
+    inp = make_rollout_inputs(task, B, N, H, seed=31 + B)
+    obs0 = _initial_obs(host, inp)
+    out_t, o5_t = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    want = host.episode_summary(o5_t, out_t)
+    acc = dev.acc_workspace(B)
+    for _ in range(2):
+        out_d, o5_d, s8 = dev.rollout_acc(obs0, inp['actions'], inp['ref_idx'], acc=acc)
+        assert np.array_equal(out_d, out_t) and np.array_equal(o5_d, o5_t)
+        np.testing.assert_allclose(s8, want, rtol=1e-6, atol=0)
+        assert s8[3] == want[3] and s8[5] == want[5] and s8[6] == B and s8[7] == H
+    assert np.array_equal(dev.episode_summary(o5_t, out_t)[[3, 5, 6, 7]], s8[[3, 5, 6, 7]])
+    for caller_acc in (False, True):
+        out_p, o5_p, s8_p = dev.plan_run(obs0, inp['actions'], inp['ref_idx'], replays=2, caller_acc=caller_acc)
+        assert np.array_equal(out_p, out_t) and np.array_equal(o5_p, o5_t) and np.array_equal(s8_p, s8)
+    # against the oracle's own accumulating form
+    _, _, s8_h = host.rollout_acc(obs0, inp['actions'], inp['ref_idx'])
+    np.testing.assert_allclose(s8, s8_h, rtol=1e-5, atol=0)
+
+
+def test_accumulating_rollout_ignores_nan_rows_in_the_maximum():
+    """a row whose delta_y is not a number never becomes the maximum (as in eb_episode_summary), the sum carries it"""
+    host, dev = _pair('left', n_veh=8)
+    inp = make_rollout_inputs('left', 200, 8, 2, seed=2)
+    obs0 = _initial_obs(host, inp)
+    obs0[17, 3] = np.nan                                   # ego x: the tracking error of the next obs is NaN
+    out_t, o5_t = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
+    assert np.isnan(out_t[17, 6])
+    want = host.episode_summary(o5_t, out_t)
+    _, _, s8 = dev.rollout_acc(obs0, inp['actions'], inp['ref_idx'])
+    assert s8[5] == want[5] and np.isfinite(s8[5]) and np.isnan(s8[4]) and np.isnan(want[4]) and s8[3] == want[3]
+
+
 @pytest.mark.parametrize('B,H', [(1, 1), (3, 5), (255, 4), (256, 25), (257, 3), (1000, 25), (1001, 7), (65536, 25), (65536 + 260, 2)])
 def test_episode_summary_sizes(B, H):
     """eb_episode_summary against the oracle's float64 sums at ragged sizes — fewer envs than a block, more than the grid covers
