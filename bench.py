@@ -57,6 +57,7 @@ STRONG_TOTAL = 262144                            # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a float4 copy reaches)
 MALL_BYTES = 256 << 20                           # Infinity Cache
 MAX_PAIRS = 64                                   # HIP event pairs per repeat
+TWO_PASS_SUMMARY = False                         # --two-pass-summary (A/B aid)
 
 
 def alg_bytes_per_env_step(n_veh, f16=False):
@@ -172,7 +173,7 @@ class Shard(object):
         collected by the launches themselves and the per-horizon summary is one small fold (eb_episode_acc_finish)"""
         assert not self.f16 and self.lanes == 1
         nb = C.c_int64()
-        self.api.episode_acc_bytes(self.h, self.n_env, C.byref(nb))
+        self.api.episode_acc_bytes(self.h, self.n_env, HORIZON, C.byref(nb))
         self.acc = self.torch.empty((max(16, nb.value),), dtype=self.torch.uint8, device=self.model.device)
         self.step_fn = self.lib.eb_rollout_step_acc
         self.close()
@@ -190,9 +191,9 @@ class Shard(object):
             for l in range(self.lanes):
                 dst = [self.final[l] if (h - 1 - t) % 2 == 0 else self.work[l] for t in range(h)]
                 src = [self.obs0[l]] + dst[:-1]
-                acc = () if self.acc is None else (p(self.acc),)
                 per_lane.append([(self.h, self.n_env, p(src[t]), p(self.tape[t]), p(self.ref_idx), 0, p(dst[t]),
-                                  p(self.out5[l][t]), None) + (acc + (int(t == 0), int(t == h - 1)) if acc else ()) +
+                                  p(self.out5[l][t]), None) +
+                                 ((p(self.acc), t, h, p(self.out5[l][t - 1]) if t else None) if self.acc is not None else ()) +
                                  (self.sps[l % len(self.sps)],) for t in range(h)])
             self._eager[h] = [per_lane[l][t] for t in range(h) for l in range(self.lanes)]   # round-robin over the lanes
         return self._eager[h]
@@ -257,7 +258,7 @@ class Timer(object):
         self.n_rollouts = 0
         self.eager = True
         self.open_loop = False
-        if with_summary and not shard.f16 and shard.lanes == 1:
+        if with_summary and not shard.f16 and shard.lanes == 1 and not TWO_PASS_SUMMARY:
             shard.enable_acc()
 
     @staticmethod
@@ -553,7 +554,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     for t in range(seg):
         src, dst = obs[t & 1], obs[(t + 1) & 1]
         argsets.append((h, ht, B, p(src), p(tape[t]), p(env._ref_idx), 0, p(ego), p(params), M, p(cand), p(env._cand_mode), None,
-                        p(env._v_light), p(env._virtual), p(scaled), p(out5), None, p(dst), p(code), C.byref(rule), None, None, sp))
+                        p(env._v_light), p(env._virtual), p(scaled), p(out5), None, p(dst), p(code), C.byref(rule), None, None, None, sp))
     ev = []
     for _ in range(2 * reps):
         e = C.c_void_p()
@@ -601,7 +602,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
         for k in range(k0, k0 + n_reset):
             rrule.counter = k
             rc = lib.eb_env_reset_pool(h, ht, B, p(gmask), C.c_uint64(99), C.c_uint64(k), 1, p(ego), p(params), p(env._ref_idx), p(env._virtual),
-                                       p(env._v_light), p(code2), M, p(cand), p(env._cand_mode), C.byref(rrule), p(obs[1]), p(obs[0]), p(code), sp)
+                                       p(env._v_light), p(code2), None, M, p(cand), p(env._cand_mode), C.byref(rrule), p(obs[1]), p(obs[0]), p(code), sp)
             if rc != 0:
                 api.check(rc)
     resets(1)
@@ -616,7 +617,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     restore()
     final = torch.empty_like(obs[0])
     ar = _capi.EbAutoReset(4242, 0, 1, env._ref_idx.data_ptr(), env._virtual.data_ptr(), env._v_light.data_ptr(), rrule, final.data_ptr())
-    auto_sets = [a[:-3] + (C.byref(ar), None, sp) for a in argsets]
+    auto_sets = [a[:-4] + (C.byref(ar), None, None, sp) for a in argsets]
 
     def auto_segment(k):
         for a in auto_sets:
@@ -771,6 +772,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget-s', type=float, default=18.0, help='seconds of host time the cpu_baseline leg may use')
     ap.add_argument('--no-side', action='store_true', help='skip hbm_resident / strong / extra (headline line only)')
+    ap.add_argument('--two-pass-summary', action='store_true',
+                    help='A/B aid: plain eb_rollout_step launches + eb_episode_summary (a second pass over out5) per horizon '
+                         'instead of the accumulating launches + one fold')
     ap.add_argument('--open-loop', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
                          'state in registers — VALU-bound, not the HBM-bound closed-loop headline')
@@ -779,6 +783,8 @@ def main():
                     help='SEPARATE figure (SURVEY.md §8(f)2): eb_shield_is_safe — 5 x [policy MLP (137 -> 256 -> 256 -> 4, ELU) -> '
                          'rollout step] per start state; a "step" is one shield pass over the batch; N = 1 only')
     args = ap.parse_args()
+    global TWO_PASS_SUMMARY
+    TWO_PASS_SUMMARY = bool(args.two_pass_summary)
     n_env, n_veh = args.n_env, args.n_veh
     if args.steps < 1 or args.repeats < 1:
         raise SystemExit('--steps and --repeats must be >= 1')

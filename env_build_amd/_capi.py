@@ -19,7 +19,8 @@ EXITS = ('D', 'R', 'U', 'L')                    # EB_EXIT_*: multi_ego.py:33 ROT
 EXIT_ID = {e: i for i, e in enumerate(EXITS)}
 
 DONE_NAMES = ('not_done_yet', 'collision', 'break_road_constrain', 'deviate_too_much',
-              'break_stability', 'break_red_light', 'good_done')  # E2E:208-221
+              'break_stability', 'break_red_light', 'good_done',  # E2E:208-221
+              'time_limit')      # EB_DONE_TIME_LIMIT: gym's TimeLimit (README.md:55-59), not a reference outcome
 
 
 class EbConfig(C.Structure):
@@ -50,6 +51,10 @@ class EbFlowRule(C.Structure):    # struct eb_flow_rule (ABI 4): the flow source
                 ('v_light', C.c_void_p)]
 
 
+class EbTimeLimit(C.Structure):   # struct eb_time_limit (ABI 5): gym's TimeLimit around the registered env, README.md:55-59
+    _fields_ = [('episode_step', C.c_void_p), ('max_episode_steps', C.c_int32)]
+
+
 ACT_ID = {'linear': 0, None: 0, 'relu': 1, 'elu': 2, 'tanh': 3}        # EB_ACT_*
 PENALTY_ID = {'veh2veh4real': 0, 'real_punish_term': 1}                # EB_PENALTY_*
 
@@ -78,8 +83,8 @@ PROTOTYPES = {
     'eb_rollout_step_f16': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_rollout_tape_f16': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     'eb_episode_summary': (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
-    'eb_episode_acc_bytes': (C.c_int, [_P, _I, C.POINTER(C.c_int64)]),
-    'eb_rollout_step_acc': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
+    'eb_episode_acc_bytes': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int64)]),
+    'eb_rollout_step_acc': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     'eb_episode_acc_finish': (C.c_int, [_P, _I, _I, _P, _P, _P]),
     'eb_plan_create': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     'eb_plan_launch': (C.c_int, [_P, _P]),
@@ -99,9 +104,10 @@ PROTOTYPES = {
     'eb_get_obs': (C.c_int, [_P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'eb_exit_frame': (C.c_int, [_P, _I, _P, _I, _P, _P, _P]),
     'eb_judge_done': (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
-    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P]),
-    'eb_env_reset_pool': (C.c_int, [_P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_env_step': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_ego_dynamics': (C.c_int, [_P, _I, _P, _P, _P, _P]),
+    'eb_env_reset': (C.c_int, [_P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'eb_env_reset_pool': (C.c_int, [_P, _P, _I, _P, C.c_uint64, C.c_uint64, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'eb_traffic_respawn': (C.c_int, [_P, _I, _I, _P, _P, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P, _P, _P, C.c_float, _P]),
     'eb_traffic_flow_reset': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I,
                                         C.c_uint64, C.c_uint64, _P, _P, _P]),

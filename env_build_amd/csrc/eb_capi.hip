@@ -396,21 +396,30 @@ struct GateArgs {
     uint32_t* status;
     int spin;
 };
-// the episodic accumulator of an accumulating rollout step (eb_rollout_step_acc, plans with a summary)
+// the episodic accumulator of an accumulating rollout step (eb_rollout_step_acc, plans with a summary): the workspace holds the
+// per-step records [horizon][blocks][ACC_RECORD_DOUBLES], then the last launch's (sum, max) pairs [blocks][2], then a byte per env
+// (the CPU library keeps its per-env flags there) — `blocks` = the grid of the SMALLEST tile shape, so any shape fits
 struct AccArgs {
-    double* records;
-    int first, last;
+    void* workspace;
+    int step, horizon;
+    const float* prev_out5;
 };
 static int envs_per_tile(eb_handle h, int variant) {
     return std::max(1, std::min(64, eb::fused_tile_records(variant) / h->cfg.n_veh));
 }
-// workspace of an accumulating rollout over n_env envs: one record per block of the SMALLEST tile shape (any shape the handle
-// may pick later fits), plus a byte per env (the CPU library keeps its per-env flags there)
-static size_t acc_workspace_bytes(eb_handle h, int32_t n_env) {
+static size_t acc_blocks_max(eb_handle h, int32_t n_env) {
     const int e = envs_per_tile(h, 2);
-    return (size_t)((n_env + e - 1) / e) * eb::ACC_RECORD_DOUBLES * sizeof(double) + (size_t)n_env;
+    return (size_t)((n_env + e - 1) / e);
 }
-
+static size_t acc_workspace_bytes(eb_handle h, int32_t n_env, int32_t horizon) {
+    return acc_blocks_max(h, n_env) * ((size_t)horizon * eb::ACC_RECORD_DOUBLES + 2) * sizeof(double) + (size_t)n_env;
+}
+static double* acc_records(void* ws, int step, size_t grid) {
+    return reinterpret_cast<double*>(ws) + (size_t)step * grid * eb::ACC_RECORD_DOUBLES;
+}
+static double* acc_finals(void* ws, int horizon, size_t grid) {
+    return reinterpret_cast<double*>(ws) + (size_t)horizon * grid * eb::ACC_RECORD_DOUBLES;
+}
 static int pick_variant(eb_handle h, int32_t n_env) {
     static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
     int variant = h->tile_variant >= 0 ? h->tile_variant : forced;
@@ -464,8 +473,12 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         A.gate_ready = gate->ready; A.gate_done = gate->done; A.gate_obs = gate->obs_steps; A.gate_status = gate->status;
         A.gate_spin = gate->spin;
     }
-    if (acc) { A.acc = acc->records; A.acc_first = acc->first; A.acc_last = acc->last; }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
+    if (acc) {   // records are indexed by THIS grid (the same at every step of a rollout: one handle state, one n_env)
+        A.acc_rec = acc_records(acc->workspace, acc->step, (size_t)grid);
+        if (acc->step > 0) { A.prev_out5 = acc->prev_out5; A.prev_rec = acc_records(acc->workspace, acc->step - 1, (size_t)grid); }
+        if (acc->step == acc->horizon - 1) A.acc_final = acc_finals(acc->workspace, acc->horizon, (size_t)grid);
+    }
     if (tape_horizon > 0 && stage_paths_in_lds(h, grid)) A.stage_entries = h->red_total + 4;
     if (tape_horizon > 0) EB_HIP(eb::launch_rollout_tape_fused(h->cfg.task, variant, A, tape_horizon, grid, s));
     else EB_HIP(eb::launch_rollout_fused(h->cfg.task, variant, A, grid, s));
@@ -525,32 +538,37 @@ int eb_rollout_step(eb_handle h, int32_t n_env, const float* obs_in, const float
                           pick(h, stream));
 }
 
-int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int64_t* bytes) {
-    if (!h || n_env < 0 || !bytes) return fail(EB_EINVAL, "eb_episode_acc_bytes: bad argument");
-    *bytes = (int64_t)acc_workspace_bytes(h, n_env);
+int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int32_t horizon, int64_t* bytes) {
+    if (!h || n_env < 0 || horizon < 0 || !bytes) return fail(EB_EINVAL, "eb_episode_acc_bytes: bad argument");
+    *bytes = (int64_t)acc_workspace_bytes(h, n_env, horizon);
     return EB_OK;
 }
 
 int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const float* actions, const int32_t* ref_idx,
-                        int32_t path_id, float* obs_out, float* out5, float* scaled_actions, void* acc, int32_t first,
-                        int32_t last, void* stream) {
+                        int32_t path_id, float* obs_out, float* out5, float* scaled_actions, void* acc, int32_t step,
+                        int32_t horizon, const float* prev_out5, void* stream) {
     if (h && n_env == 0) return EB_OK;
     int rc = check_rollout(h, n_env, ref_idx, path_id, "eb_rollout_step_acc: null handle");
     if (rc) return rc;
-    if (n_env < 0 || !obs_in || !actions || !obs_out || !out5 || !acc) return fail(EB_EINVAL, "eb_rollout_step_acc: bad argument");
+    if (n_env < 0 || !obs_in || !actions || !obs_out || !out5 || !acc || horizon < 1 || step < 0 || step >= horizon ||
+        (step > 0 && !prev_out5) || prev_out5 == out5)
+        return fail(EB_EINVAL, "eb_rollout_step_acc: bad argument (0 <= step < horizon; prev_out5 = the previous step's out5 for step > 0)");
     if (((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_rollout_step_acc: acc must be 16-byte aligned");
     if (obs_in == obs_out) return fail(EB_EINVAL, "eb_rollout_step_acc: in-place update is not supported");
     EB_HIP(hipSetDevice(h->cfg.device));
-    const AccArgs a{reinterpret_cast<double*>(acc), first != 0, last != 0};
+    const AccArgs a{acc, step, horizon, prev_out5};
     return rollout_common(h, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions, 1, 1, pick(h, stream), 0, 0,
                           nullptr, &a);
 }
 
 int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const void* acc, float* out8, void* stream) {
-    if (!h || n_env < 0 || horizon < 0 || !out8 || (n_env > 0 && !acc)) return fail(EB_EINVAL, "eb_episode_acc_finish: bad argument");
+    if (!h || n_env < 0 || horizon < 1 || !out8 || (n_env > 0 && !acc)) return fail(EB_EINVAL, "eb_episode_acc_finish: bad argument");
     EB_HIP(hipSetDevice(h->cfg.device));
     const int e = envs_per_tile(h, pick_variant(h, n_env));   // the grid the accumulating launches ran on
-    EB_HIP(eb::launch_acc_fold((n_env + e - 1) / e, n_env, horizon, reinterpret_cast<const double*>(acc), out8, pick(h, stream)));
+    const size_t grid = (size_t)((n_env + e - 1) / e);
+    void* ws = const_cast<void*>(acc);
+    EB_HIP(eb::launch_acc_fold((int)grid, n_env, horizon, acc_records(ws, 0, grid), acc_finals(ws, horizon, grid), out8,
+                               pick(h, stream)));
     return EB_OK;
 }
 
@@ -558,11 +576,11 @@ int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const voi
 // acc != NULL: accumulating launches (the episodic summary's sums collected on the way)
 static int rollout_tape_stepwise(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                                  const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out,
-                                 float* out5_steps, hipStream_t s, int storage_f16, double* acc = nullptr) {
+                                 float* out5_steps, hipStream_t s, int storage_f16, void* acc = nullptr) {
     const float* cur = obs_in;
     for (int t = 0; t < horizon; ++t) {
         float* dst = ((horizon - 1 - t) % 2 == 0) ? obs_out : obs_work;
-        const AccArgs a{acc, t == 0, t == horizon - 1};
+        const AccArgs a{acc, t, horizon, t > 0 ? out5_steps + (size_t)(t - 1) * 5 * n_env : nullptr};
         int rc = rollout_common(h, n_env, cur, action_tape + (size_t)t * n_env * 2, ref_idx, path_id, dst,
                                 out5_steps + (size_t)t * 5 * n_env, nullptr, 1, 1, s, storage_f16, 0, nullptr, acc ? &a : nullptr);
         if (rc) return rc;
@@ -831,7 +849,8 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow, void* stream) {
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow,
+                const eb_time_limit* time_limit, void* stream) {
     // every check first: an error return leaves ego / params / cand untouched
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
     if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
@@ -859,6 +878,8 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             !flow->sim_step || !flow->lane || !flow->period || !flow->v_max || !v_light || flow->v_light != v_light || flow->cand_mode != cand_mode)
             return fail(EB_EINVAL, "eb_env_step: bad flow rule (m_cand == 12 * per_route <= 64, every array given, cand_mode / v_light the call's own)");
     }
+    if (time_limit && (!time_limit->episode_step || time_limit->max_episode_steps < 1))
+        return fail(EB_EINVAL, "eb_env_step: bad time limit (episode_step given, max_episode_steps >= 1)");
     if (n_env == 0) return EB_OK;
     hipStream_t s = pick(h, stream);
     EB_HIP(hipSetDevice(h->cfg.device));
@@ -896,6 +917,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             A.flow_mode_out = flow->cand_mode; A.v_light_out = flow->v_light;
             A.k_magic = magic(flow->per_route);
         }
+        if (time_limit) { A.episode_step = time_limit->episode_step; A.max_episode_steps = time_limit->max_episode_steps; }
         EB_HIP(eb::launch_env_step(h->cfg.task, A, s));
         return EB_OK;
     }
@@ -928,13 +950,15 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         EB_HIP(eb::launch_judge_done(h->cfg.task, n_env, D, ego, params, obs_out, m_cand, cand, cand_mode,
                                      cand_lw, v_light, done_code, s));                                          /* E2E:141 */
     }
+    if (time_limit) EB_HIP(eb::launch_time_limit(n_env, time_limit->episode_step, time_limit->max_episode_steps, done_code, s));
     if (respawn)
         EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
                                           respawn->seed, respawn->counter, nullptr, nullptr, s));
     if (const eb_auto_reset* ar = auto_reset) {   // the same composition the header spells out, as launches of their own
         if (ar->final_obs) EB_HIP(eb::launch_copy_rows_masked(n_env, D, done_code, obs_out, ar->final_obs, s));
         return eb_env_reset_pool(h, traffic, n_env, done_code, ar->seed, ar->counter, ar->training, ego, params, ar->ref_idx,
-                                 ar->virtual_flag, ar->v_light, nullptr, m_cand, cand, cand_mode, &ar->pool, obs_out, nullptr, nullptr, stream);
+                                 ar->virtual_flag, ar->v_light, nullptr, nullptr, m_cand, cand, cand_mode, &ar->pool, obs_out, nullptr,
+                                 nullptr, stream);   // (the time limit above has restarted the finished envs' counts)
     }
     if (flow)
         EB_HIP(eb::launch_traffic_flow_step(n_env, flow->per_route, cand, flow->active, flow->timer, flow->emitted, flow->sim_step, flow->lane,
@@ -944,21 +968,30 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
 }
 
 int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter, int32_t training,
-                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code, void* stream) {
+                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code, int32_t* episode_step,
+                 void* stream) {
     int rc = check_paths(h, "eb_env_reset: null handle");
     if (rc) return rc;
     if (n_env < 0 || (n_env > 0 && (!ego || !params || !ref_idx))) return fail(EB_EINVAL, "eb_env_reset: bad argument");
     if (n_env == 0) return EB_OK;
     EB_HIP(hipSetDevice(h->cfg.device));
     EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx,
-                                virtual_next, done_code, pick(h, stream)));
+                                virtual_next, done_code, pick(h, stream), nullptr, episode_step));
+    return EB_OK;
+}
+
+int eb_ego_dynamics(eb_handle h, int32_t n, const float* ego, const float* params, float* out, void* stream) {
+    if (!h || n < 0 || (n > 0 && (!ego || !params || !out))) return fail(EB_EINVAL, "eb_ego_dynamics: bad argument");
+    if (n == 0) return EB_OK;
+    EB_HIP(hipSetDevice(h->cfg.device));
+    EB_HIP(eb::launch_ego_dynamics(n, ego, params, out, pick(h, stream)));
     return EB_OK;
 }
 
 int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
                       int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
-                      uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
-                      float* obs, const float* obs_src, const uint8_t* done_src, void* stream) {
+                      uint8_t* done_code, int32_t* episode_step, int32_t m_cand, float* cand, const uint8_t* cand_mode,
+                      const eb_respawn* pool, float* obs, const float* obs_src, const uint8_t* done_src, void* stream) {
     if (!h || !traffic || !pool || !pool->entry) return fail(EB_EINVAL, "eb_env_reset_pool: null argument");
     if (n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!ego || !params || !ref_idx || !virtual_flag || !cand || !cand_mode || !obs)))
         return fail(EB_EINVAL, "eb_env_reset_pool: bad argument");
@@ -977,7 +1010,8 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
         // same order per row, as the four launches below
         const eb::EnvResetArgs R{seed, counter, training ? 1 : 0, params, ref_idx, virtual_flag, v_light, done_code, pool->entry,
                                  pool->span, pool->v_max, pool->edge_span, pool->seed, pool->counter,
-                                 mask && obs_src != obs ? obs_src : nullptr, mask && done_code && done_src != done_code ? done_src : nullptr};
+                                 mask && obs_src != obs ? obs_src : nullptr, mask && done_code && done_src != done_code ? done_src : nullptr,
+                                 episode_step};
         EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ref_idx, 0,
                                   m_cand, cand, cand_mode, nullptr, virtual_flag, obs, pick(h, stream), nullptr, nullptr, nullptr, nullptr,
                                   nullptr, mask, &R, forced_env_tile(h)));
@@ -997,7 +1031,7 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
     // (an unaligned candidate buffer or a tile that does not fit the LDS) four launches behind one call: state + flags, pool
     // re-entry (clear of the ego), masked observation, flag swap
     EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, mask, seed, counter, training ? 1 : 0, ego, params, ref_idx, d_vnext,
-                                done_code, s, v_light));
+                                done_code, s, v_light, episode_step));
     EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, pool->entry, -1.0f, pool->span, pool->v_max, pool->seed, pool->counter, mask,
                                       nullptr, s, ego, pool->edge_span));
     EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ref_idx, 0,
@@ -1071,7 +1105,7 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
     EB_HIP(hipSetDevice(h->cfg.device));
     void* own_acc = nullptr;
     if (summary8 && !acc) {
-        EB_HIP(hipMalloc(&own_acc, acc_workspace_bytes(h, n_env)));
+        EB_HIP(hipMalloc(&own_acc, acc_workspace_bytes(h, n_env, horizon)));
         acc = own_acc;
     }
     hipStream_t cs = nullptr;
@@ -1081,8 +1115,7 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
     if (e != hipSuccess) { (void)hipStreamDestroy(cs); if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamBeginCapture", e); }
     // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph; with a summary (or a
     // caller's accumulator) they are the accumulating launches and the summary is one small fold behind them
-    rc = rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs, 0,
-                               reinterpret_cast<double*>(acc));
+    rc = rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs, 0, acc);
     if (rc == EB_OK && summary8) rc = eb_episode_acc_finish(h, n_env, horizon, acc, summary8, cs);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(cs, &graph);

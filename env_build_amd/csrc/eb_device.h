@@ -112,6 +112,8 @@ EB_DEV void action_transform(float a0, float a1, float& steer, float& a_x) {
 struct VehParams {  // DAM:37-45
     static constexpr float C_f = -155495.0f, C_r = -155495.0f, a = 1.19f, b = 1.46f, mass = 1520.0f,
                            I_z = 2642.0f, miu = 0.8f, g = 9.81f;
+    // vehicle_params' F_zf / F_zr (DAM:48: float64, b * mass * g / (a + b) in that order) rounded to fp32 — what E2E:164-166 read
+    static constexpr float F_zf = (float)(1.46 * 1520.0 * 9.81 / (1.19 + 1.46)), F_zr = (float)(1.19 * 1520.0 * 9.81 / (1.19 + 1.46));
 };
 
 // sn/cs = sin/cos of deg2rad(st[5]) (shared with the reward's ego circle centres, DAM:211)

@@ -184,22 +184,31 @@ EB_DEV bool collision_with(const EgoCircles& E, float x, float y, const float4 v
 
 // the rest of _judge_done (E2E:200-256) in two parts: the predicates that need only the ego state (a bit set) and the
 // priority chain once the collision flag and delta_y are known — the one-launch step evaluates the parts on different waves
-enum { JB_FEASIBLE = 1, JB_STABLE = 2, JB_RED = 4, JB_GOAL = 8 };
-EB_DEV unsigned judge_bits(int task, float v_x, float r, float x, float y, float phi, float miu_r, bool red_light) {
+enum { JB_FEASIBLE = 1, JB_STABLE = 2, JB_RED = 4, JB_GOAL = 8, JB_TIMEOUT = 16 };
+// _get_ego_dynamics' derived entries (E2E:150-183), one function each — judge_bits and eb_ego_dynamics evaluate the same code
+EB_DEV float ego_r_bound(float miu_r, float v_x) { return miu_r * 9.81f / (__builtin_fabsf(v_x) + 1e-8f); }   // E2E:167
+EB_DEV float ego_alpha_bound(float miu, float f_z, float c) { return 3.0f * miu * f_z / c; }                  // E2E:164-166
+// corner q of the ego's box (E2E:171-176: (+l/2, +w/2), (+l/2, -w/2), (-l/2, +w/2), (-l/2, -w/2)) through
+// rotate_and_shift_coordination(cx, cy, 0, -x, -y, -phi) (UTL:152-157); rs / rc = sin / cos of -phi in radians
+EB_DEV void ego_corner(int q, float x, float y, float rs, float rc, float& X, float& Y) {
     const float EGO_L = 4.8f, EGO_W = 2.0f;
+    const float cx = (q < 2 ? EGO_L : -EGO_L) / 2, cy = ((q & 1) ? -EGO_W : EGO_W) / 2;
+    const float tx = cx * rc + cy * rs;
+    const float ty = -cx * rs + cy * rc;
+    X = tx - (-x); Y = ty - (-y);
+}
+EB_DEV unsigned judge_bits(int task, float v_x, float r, float x, float y, float phi, float miu_r, bool red_light) {
     // corner points (E2E:171-176, UTL:120-157) through judge_feasible
     float rs, rc;
     sincos_det(-phi * PI_F / 180.0f, rs, rc);
     bool feasible = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float cx = (q < 2 ? EGO_L : -EGO_L) / 2, cy = ((q & 1) ? -EGO_W : EGO_W) / 2;
-        const float tx = cx * rc + cy * rs;
-        const float ty = -cx * rs + cy * rc;
-        const float X = tx - (-x), Y = ty - (-y);
+        float X, Y;
+        ego_corner(q, x, y, rs, rc, X, Y);
         feasible = feasible && judge_feasible(X, Y, task);
     }
-    const float r_bound = miu_r * 9.81f / (__builtin_fabsf(v_x) + 1e-8f);   // E2E:167
+    const float r_bound = ego_r_bound(miu_r, v_x);
     bool goal;
     if (task == TASK_LEFT) goal = x < -HALF_CROSS - 10.0f && 0.0f < y && y < 3.0f * LANE_W;
     else if (task == TASK_RIGHT) goal = x > HALF_CROSS + 10.0f && -3.0f * LANE_W < y && y < 0.0f;
@@ -207,6 +216,8 @@ EB_DEV unsigned judge_bits(int task, float v_x, float r, float x, float y, float
     return (feasible ? JB_FEASIBLE : 0u) | ((-r_bound < r && r < r_bound) ? JB_STABLE : 0u) |
            ((red_light && y > -HALF_CROSS && task != TASK_RIGHT) ? JB_RED : 0u) | (goal ? JB_GOAL : 0u);
 }
+// JB_TIMEOUT (eb_time_limit): the episode's step count has reached max_episode_steps — gym's TimeLimit wrapper around the
+// registered env (README.md:55-59, max_episode_steps = 200): it ends an episode NO reference outcome has ended
 EB_DEV uint8_t judge_merge(unsigned bits, bool collision, float delta_y) {
     if (collision) return EB_DONE_COLLISION;
     if (!(bits & JB_FEASIBLE)) return EB_DONE_BREAK_ROAD;
@@ -214,6 +225,7 @@ EB_DEV uint8_t judge_merge(unsigned bits, bool collision, float delta_y) {
     if (!(bits & JB_STABLE)) return EB_DONE_STABILITY;
     if (bits & JB_RED) return EB_DONE_RED_LIGHT;
     if (bits & JB_GOAL) return EB_DONE_GOOD;
+    if (bits & JB_TIMEOUT) return EB_DONE_TIME_LIMIT;
     return EB_DONE_NOT_YET;
 }
 EB_DEV uint8_t judge_code(int task, bool collision, float v_x, float r, float x, float y, float phi, float miu_r,

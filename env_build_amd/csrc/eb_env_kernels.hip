@@ -583,7 +583,7 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
             A.v_light = nullptr; A.v_light_out = reset->v_light; A.done_code = reset->done_code;
             A.pool_entry = reset->entry; A.pool_span = reset->span; A.pool_v_max = reset->v_max; A.edge_span = reset->edge_span;
             A.pool_seed = reset->pool_seed; A.pool_counter = reset->pool_counter;
-            A.obs = reset->obs_src; A.done_src = reset->done_src;
+            A.obs = reset->obs_src; A.done_src = reset->done_src; A.episode_step = reset->episode_step;
         }
         return launch_env_step(task, A, s);
     }
@@ -664,7 +664,7 @@ hipError_t launch_traffic_respawn(int n_env, int m_cand, float* cand, const floa
 __global__ void env_reset_kernel(int task, int n_env, PathTables pt, const uint8_t* __restrict__ mask, uint64_t seed,
                                  uint64_t counter, int training, float* __restrict__ ego, float* __restrict__ params,
                                  int* __restrict__ ref_idx, uint8_t* __restrict__ virtual_next, uint8_t* __restrict__ done_code,
-                                 uint8_t* __restrict__ v_light) {
+                                 uint8_t* __restrict__ v_light, int* __restrict__ episode_step) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_env) return;
     if (mask && !mask[e]) return;
@@ -684,6 +684,7 @@ __global__ void env_reset_kernel(int task, int n_env, PathTables pt, const uint8
     if (virtual_next) virtual_next[e] = (training && u3 > 0.9f) ? 1 : 0;  // E2E:120-126
     if (done_code) done_code[e] = EB_DONE_NOT_YET;                         // E2E:119
     if (v_light) v_light[e] = 0;                                           // (eb_env_reset_pool: an episode starts at phase 0)
+    if (episode_step) episode_step[e] = 0;                                 // eb_time_limit's count
 }
 
 // eb_env_reset_pool's last stage: the flags eb_env_reset drew replace the old ones AFTER the reset observation (E2E:120-126)
@@ -699,10 +700,49 @@ hipError_t launch_flag_swap(int n_env, const uint8_t* mask, const uint8_t* next,
 
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
                             int training, float* ego, float* params, int* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
-                            hipStream_t s, uint8_t* v_light) {
+                            hipStream_t s, uint8_t* v_light, int* episode_step) {
     if (n_env <= 0) return hipSuccess;
     hipLaunchKernelGGL(env_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, s, task, n_env, pt, mask, seed, counter,
-                       training, ego, params, ref_idx, virtual_next, done_code, v_light);
+                       training, ego, params, ref_idx, virtual_next, done_code, v_light, episode_step);
+    return hipGetLastError();
+}
+
+// eb_time_limit behind eb_judge_done (eb_env_step as separate launches): gym's TimeLimit — count the step, end the episode
+// nothing else has ended when the count reaches the limit, restart the count of a finished env
+__global__ void time_limit_kernel(int n_env, int* __restrict__ episode_step, int max_episode_steps, uint8_t* __restrict__ done_code) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_env) return;
+    const int cnt = episode_step[e] + 1;
+    uint8_t code = done_code[e];
+    if (code == EB_DONE_NOT_YET && cnt >= max_episode_steps) { code = EB_DONE_TIME_LIMIT; done_code[e] = code; }
+    episode_step[e] = code != EB_DONE_NOT_YET ? 0 : cnt;
+}
+hipError_t launch_time_limit(int n_env, int* episode_step, int max_episode_steps, uint8_t* done_code, hipStream_t s) {
+    if (n_env <= 0) return hipSuccess;
+    hipLaunchKernelGGL(time_limit_kernel, dim3((n_env + 255) / 256), dim3(256), 0, s, n_env, episode_step, max_episode_steps, done_code);
+    return hipGetLastError();
+}
+
+// a15: CrossroadEnd2end._get_ego_dynamics (E2E:150-183) for a batch, one thread per env — the functions judge_bits evaluates
+// (eb_env_device.h): what the done code is decided on is what this entry exports
+__global__ void ego_dynamics_kernel(int n, const float* __restrict__ ego, const float* __restrict__ params, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* e = ego + 6 * (size_t)i;
+    const float v_x = e[0], x = e[3], y = e[4], phi = e[5];
+    const float miu_f = params[4 * (size_t)i + 2], miu_r = params[4 * (size_t)i + 3];
+    float* o = out + 11 * (size_t)i;
+    o[0] = ego_alpha_bound(miu_f, VehParams::F_zf, VehParams::C_f);          // E2E:164-165
+    o[1] = ego_alpha_bound(miu_r, VehParams::F_zr, VehParams::C_r);          // E2E:166
+    o[2] = ego_r_bound(miu_r, v_x);                                          // E2E:167
+    float rs, rc;
+    sincos_det(-phi * PI_F / 180.0f, rs, rc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ego_corner(q, x, y, rs, rc, o[3 + 2 * q], o[4 + 2 * q]);   // E2E:171-176
+}
+hipError_t launch_ego_dynamics(int n, const float* ego, const float* params, float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ego_dynamics_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n, ego, params, out);
     return hipGetLastError();
 }
 

@@ -316,6 +316,9 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     const int path_pre = (!RESET && wave == 0 && live) ? row_path(A.pt, A.ref_idx, A.path_id, i) : -1;
     const bool vflag = live && A.virtual_flag && A.virtual_flag[i] != 0;
     const bool light = red_light || vflag;                                      // E2E:387-388
+    // eb_time_limit (wave 3, which owns the ego-only done predicates): the episode's step count with this step in it
+    int ep_cnt = 0;
+    if (!OBS && wave == 3 && live && A.episode_step) ep_cnt = A.episode_step[i] + 1;
     float nx[6] = {0, 0, 0, 0, 0, 0};                                        // wave 0
     float steer = 0.0f, a_x = 0.0f, o9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // wave 1
     float road_t = 0.0f, road_r = 0.0f;
@@ -343,6 +346,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         reinterpret_cast<float4*>(A.params)[i] = make_float4(0.0f, 0.0f, VehParams::miu, VehParams::miu);   // E2E:110-113
         A.ref_idx_out[i] = reset_path;
         if (RESET && A.done_code) A.done_code[i] = EB_DONE_NOT_YET;     // E2E:119 (AUTO: done_code keeps the step's codes)
+        if (RESET && A.episode_step) A.episode_step[i] = 0;             // (AUTO: the step itself has restarted the count)
         if (A.v_light_out) A.v_light_out[i] = 0;
         s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
     };
@@ -709,7 +713,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     }
     if (!OBS && wave == 3 && lane < ET) {   // the done predicates that need only the new ego state (E2E:223-256): a byte for the merge
         const float4 eg = s_ego[lane];      // behind barrier 3 (wave 3, after its share of the collision pass: wave 0 has the tracking chain)
-        s_jb[lane] = live ? (uint8_t)judge_bits(TASK, eg.w, s_r[lane], eg.x, eg.y, eg.z, s_miu[lane], red_light) : (uint8_t)0xff;
+        s_jb[lane] = live ? (uint8_t)(judge_bits(TASK, eg.w, s_r[lane], eg.x, eg.y, eg.z, s_miu[lane], red_light) |
+                                      (A.episode_step && ep_cnt >= A.max_episode_steps ? JB_TIMEOUT : 0u)) : (uint8_t)0xff;
     }
     ES_MARK(6);
     // E2E:340-464 for the lanes with `on` (lane = env): the vehicle slots of this wave's modes -> s_out
@@ -846,6 +851,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         uint8_t code = EB_DONE_NOT_YET;
         if (lane < ET && s_jb[lane] != 0xff) code = judge_merge(s_jb[lane], s_col[lane] != 0, s_out[lane * OS + 6]);
         if (wave == 0 && live) A.done_code[i] = code;
+        if (wave == 3 && live && A.episode_step) A.episode_step[i] = code != EB_DONE_NOT_YET ? 0 : ep_cnt;   // a finished env's next step is step 1 of its next episode
         finmask = __builtin_amdgcn_ballot_w64(code != EB_DONE_NOT_YET);
     }
 

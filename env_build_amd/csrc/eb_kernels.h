@@ -45,15 +45,18 @@ struct FusedArgs {
     unsigned* gate_status;        // [0] = 1 when a gate was not opened within gate_spin polls (the launch gives up)
     int gate_spin;
     int stage_entries;            // tape / gated kernels: > 0 = copy this many stride-10 table entries (+ 4 readable past the end) into LDS
-    // episodic accumulator (eb_rollout_step_acc; per-step kernel only): one ACC_RECORD_DOUBLES record per block, or NULL.
-    // acc_first: this launch starts a rollout (records are overwritten); acc_last: it ends one (the obs it writes is the final obs)
-    double* acc;
-    int acc_first, acc_last;
+    // episodic accumulator (eb_rollout_step_acc; per-step kernel only; all NULL / 0 otherwise).  Store-only: a launch leaves one
+    // ACC_RECORD_DOUBLES record per block and step — no read-modify-write, nothing to fetch before the kernel's first load.
+    double* acc_rec;           // this step's records [grid][ACC_RECORD_DOUBLES] (travels as a kernel parameter of its own: FusedHot)
+    const float* prev_out5;    // the out5 array of the rollout's PREVIOUS step (NULL for its first): that step's record is made by
+                               // THIS launch, under the wait for the record waves — the values come back as three coalesced loads
+    double* prev_rec;          // where the previous step's records go
+    double* acc_final;         // non-NULL in the rollout's last launch: [grid][2] = (sum, max) of |delta_y| of the rows it writes;
+                               // that launch also makes its own step's record, at its tail
 };
-// a block's record: [0..2] = running float64 sums of reward, punish_term_for_training, real_punish_term over its envs and the
-// steps so far, [3] = bit e set once env e of the tile had real_punish_term > 0 (a 64-bit mask in the double's bytes),
-// [4] = sum |delta_y| and [5] = max |delta_y| of the tile's final obs rows (written by the acc_last launch)
-constexpr int ACC_RECORD_DOUBLES = 8;
+// a block's record of one step: [0..2] = float64 sums of reward, punish_term_for_training, real_punish_term over its envs,
+// [3] = bit e set when env e of the tile had real_punish_term > 0 in that step (a 64-bit mask in the double's bytes)
+constexpr int ACC_RECORD_DOUBLES = 4;
 // variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 4 x 4 (1024), 2 = 1 x 4 (256)
 int fused_tile_records(int variant);
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s);
@@ -84,8 +87,10 @@ hipError_t launch_ss(int task, int n_env, int D, int n_future, int NV, const Pat
 constexpr int SUMMARY_MAX_PARTS = 1024;   // blocks of the stage-1 summary reduction (handle scratch: 6 doubles each)
 hipError_t launch_summary(int n_env, int horizon, int D, const float* out5_steps, const float* obs_final,
                           double* partials, int max_parts, float* out8, hipStream_t s);
-// fold of the per-block records an accumulating rollout left (FusedArgs::acc) -> the same 8 floats, one launch
-hipError_t launch_acc_fold(int n_blocks, int n_env, int horizon, const double* acc, float* out8, hipStream_t s);
+// fold of the records an accumulating rollout left — records [horizon][n_blocks][ACC_RECORD_DOUBLES], finals [n_blocks][2] —
+// -> the same 8 floats, one launch
+hipError_t launch_acc_fold(int n_blocks, int n_env, int horizon, const double* records, const double* finals, float* out8,
+                           hipStream_t s);
 
 // real-env step pieces (eb_env_kernels.hip)
 hipError_t launch_env_ego_step(int n, const float* ego, const float* actions, float* next_ego, float* params,
@@ -113,7 +118,11 @@ hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const E
                              hipStream_t s);
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
                             int training, float* ego, float* params, int* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
-                            hipStream_t s, uint8_t* v_light = nullptr);
+                            hipStream_t s, uint8_t* v_light = nullptr, int* episode_step = nullptr);
+// eb_env_step's separate-launch path: the step counts and the time-limit code behind eb_judge_done (eb_time_limit)
+hipError_t launch_time_limit(int n_env, int* episode_step, int max_episode_steps, uint8_t* done_code, hipStream_t s);
+// _get_ego_dynamics (E2E:150-183) for a batch: out [n, 11] = alpha_f_bound, alpha_r_bound, r_bound, 4 corner points (x, y)
+hipError_t launch_ego_dynamics(int n, const float* ego, const float* params, float* out, hipStream_t s);
 hipError_t launch_copy_rows_masked(int n_env, int D, const uint8_t* mask, const float* src, float* dst, hipStream_t s);
 hipError_t launch_flag_swap(int n_env, const uint8_t* mask, const uint8_t* next, uint8_t* flag, hipStream_t s);
 hipError_t launch_traffic_flow_reset(int n_env, int K, const uint8_t* mask, const float* ego, float* cand, uint8_t* active,
@@ -192,6 +201,11 @@ struct EnvStepArgs {
     const float* flow_v_max;
     float flow_dt, flow_exit_range, flow_accel, flow_lane_len;
     uint8_t* flow_mode_out;
+    // eb_time_limit (eb_env_step, ABI 5): per-env steps of the running episode, + 1 per step; an env NO reference outcome has
+    // finished takes EB_DONE_TIME_LIMIT when the count reaches max_episode_steps; the count of a finished env restarts at 0.
+    // reset = 1 (eb_env_reset_pool): the masked rows' counts are cleared (max_episode_steps unused)
+    int* episode_step;
+    int max_episode_steps;
 };
 struct EnvResetArgs {                      // launch_get_obs(..., reset): what eb_env_reset_pool adds to a masked observation pass
     uint64_t seed, counter;                // eb_env_reset's
@@ -206,6 +220,7 @@ struct EnvResetArgs {                      // launch_get_obs(..., reset): what e
     uint64_t pool_seed, pool_counter;
     const float* obs_src;                  // nullable: the observation rows of the envs outside the mask
     const uint8_t* done_src;               // nullable: their done codes
+    int* episode_step;                     // nullable: the masked rows' episode step counts are cleared
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow = false);
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand);

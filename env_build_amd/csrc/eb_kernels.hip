@@ -420,39 +420,64 @@ __global__ __launch_bounds__(SUM_THREADS) void summary_final_kernel(int n_part, 
     }
 }
 
-// The fold behind an ACCUMULATING rollout (eb_rollout_step_acc): the rollout launches have left one record per block — running
-// float64 sums, the "punished at any step" bits of the block's envs, the final rows' |delta_y| sum and maximum — so the summary
-// is one pass over n_blocks x 64 bytes instead of a second pass over out5_steps [H, 5, B].  Same fixed order: records in block
-// order per thread, then the shuffle + LDS tree.
-__global__ __launch_bounds__(SUM_THREADS) void acc_fold_kernel(int n_blocks, int n_env, int horizon,
-                                                                const double* __restrict__ acc, float* __restrict__ out8) {
-    __shared__ Sum6 s_part[SUM_THREADS / 64];
-    typedef double d2v __attribute__((ext_vector_type(2)));
+// The fold behind an ACCUMULATING rollout (eb_rollout_step_acc): the rollout launches have left one 32-byte record per block and
+// step — the tile's float64 sums of the step and its "punished in this step" bits — and the last one a (sum, max) pair of the
+// final rows' |delta_y| per block, so the summary is one pass over horizon x n_blocks x 32 bytes (0.8 MB at the headline size)
+// instead of a second pass over out5_steps [H, 5, B] (20 MB).  A thread owns a block's column: its records in step order (four
+// steps in flight), the bits OR-ed; then the shuffle + LDS tree over the threads.  Fixed order, no atomics.
+constexpr int FOLD_THREADS = 1024;
+__global__ __launch_bounds__(FOLD_THREADS) void acc_fold_kernel(int n_blocks, int n_env, int horizon, const double* __restrict__ records,
+                                                                 const double* __restrict__ finals, float* __restrict__ out8) {
+    __shared__ Sum6 s_part[FOLD_THREADS / 64];
+    // (the record as 16-byte integer pairs, the sums re-typed one scalar at a time: __builtin_bit_cast applied to an ELEMENT of a
+    // double vector read the vector's first element here — the count came out as the popcount of a sum)
+    typedef unsigned long long q2v __attribute__((ext_vector_type(2)));
+    auto f64 = [](unsigned long long b) { return __builtin_bit_cast(double, b); };
     Sum6 tot = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int k0 = threadIdx.x; k0 < n_blocks; k0 += 2 * SUM_THREADS) {    // two records in flight per thread
-        d2v x[2][3];
+    for (int b = threadIdx.x; b < n_blocks; b += FOLD_THREADS) {
+        double r = 0.0, pt = 0.0, pr = 0.0;
+        unsigned long long any = 0ull;
+        constexpr int U = 4;
+        for (int t0 = 0; t0 < horizon; t0 += U) {
+            q2v x[U][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int k = k0 + u * SUM_THREADS;
-            const d2v* p = reinterpret_cast<const d2v*>(acc + (size_t)ACC_RECORD_DOUBLES * (k < n_blocks ? k : 0));
-            x[u][0] = p[0]; x[u][1] = p[1]; x[u][2] = p[2];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (k0 + u * SUM_THREADS < n_blocks) {
-                const double cnt = (double)__popcll(__builtin_bit_cast(unsigned long long, x[u][1].y));
-                tot = sum6_combine(tot, Sum6{x[u][0].x, x[u][0].y, x[u][1].x, cnt, x[u][2].x, x[u][2].y});
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u < horizon ? t0 + u : horizon - 1;
+                const q2v* p = reinterpret_cast<const q2v*>(records + ((size_t)t * n_blocks + b) * ACC_RECORD_DOUBLES);
+                x[u][0] = p[0]; x[u][1] = p[1];
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (t0 + u < horizon) {
+                    const unsigned long long a0 = x[u][0].x, a1 = x[u][0].y, a2 = x[u][1].x, a3 = x[u][1].y;
+                    r += f64(a0); pt += f64(a1); pr += f64(a2); any |= a3;
+                }
+        }
+        const q2v fin = reinterpret_cast<const q2v*>(finals)[b];
+        const unsigned long long f0 = fin.x, f1 = fin.y;
+        tot = sum6_combine(tot, Sum6{r, pt, pr, (double)__popcll(any), f64(f0), f64(f1)});
     }
-    const Sum6 f = sum6_block_reduce(tot, s_part);
+    // sum6_block_reduce's tree for this block size
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Sum6 o;
+        o.r = __shfl_down(tot.r, off, 64); o.pt = __shfl_down(tot.pt, off, 64); o.pr = __shfl_down(tot.pr, off, 64);
+        o.cnt = __shfl_down(tot.cnt, off, 64); o.ady = __shfl_down(tot.ady, off, 64); o.mdy = __shfl_down(tot.mdy, off, 64);
+        tot = sum6_combine(tot, o);
+    }
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = tot;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        Sum6 f = tot;
+        for (int w = 1; w < FOLD_THREADS / 64; ++w) f = sum6_combine(f, s_part[w]);
         out8[0] = (float)f.r; out8[1] = (float)f.pt; out8[2] = (float)f.pr; out8[3] = (float)f.cnt;
         out8[4] = (float)f.ady; out8[5] = (float)f.mdy; out8[6] = (float)n_env; out8[7] = (float)horizon;
     }
 }
 
-hipError_t launch_acc_fold(int n_blocks, int n_env, int horizon, const double* acc, float* out8, hipStream_t s) {
-    hipLaunchKernelGGL(acc_fold_kernel, dim3(1), dim3(SUM_THREADS), 0, s, n_blocks, n_env, horizon, acc, out8);
+hipError_t launch_acc_fold(int n_blocks, int n_env, int horizon, const double* records, const double* finals, float* out8,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(acc_fold_kernel, dim3(1), dim3(FOLD_THREADS), 0, s, n_blocks, n_env, horizon, records, finals, out8);
     return hipGetLastError();
 }
 

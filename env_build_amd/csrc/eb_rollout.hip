@@ -152,6 +152,7 @@ struct FusedHot {
     int n_env, obs_dim, n_veh, envs_per_tile;
     unsigned nv_magic;
     int do_rewards;
+    double* acc_rec;                      // episodic accumulator: this step's records, or NULL (FusedArgs::acc_rec)
 };
 
 // item / n_veh by the multiplicative inverse nv_magic = ceil(2^32 / n_veh) (exact for item < 65 536, checked; items stay
@@ -243,15 +244,13 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int pr = A.ref_idx[ge];
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
-    // episodic accumulator (eb_rollout_step_acc): the block's running record — a block-uniform address, fetched now, used last
-    // (a scalar load into SGPRs, spelled out: the compiler takes a vector load for memory the kernel also writes, i.e. eight
-    // VGPRs held through the whole chain; the previous launch's stores are behind a kernel boundary, so the scalar cache is fine)
-    typedef unsigned u8s __attribute__((ext_vector_type(8)));
-    u8s acc_prev = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    const bool acc_carry = A.acc && !A.acc_first;
-    if (acc_carry) {
-        const double* rec = A.acc + (size_t)ACC_RECORD_DOUBLES * blockIdx.x;
-        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(acc_prev) : "s"(rec));
+    // episodic accumulator: the PREVIOUS step's reward / punish_train / punish_real of this env (three coalesced loads next to the
+    // head's) — that step's record is made further down, while this wave would only wait for the record waves
+    const bool acc_prev = H.acc_rec && A.prev_out5;
+    float pv_r = 0.0f, pv_t = 0.0f, pv_p = 0.0f;
+    if (acc_prev && act) {
+        const size_t n = (size_t)H.n_env;
+        pv_r = A.prev_out5[ge]; pv_t = A.prev_out5[n + ge]; pv_p = A.prev_out5[2 * n + ge];
     }
     const int trow = blockIdx.x * (RW + 1);
     EB_MARK(A, trow, 0);                                                    // loads issued
@@ -325,6 +324,21 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     float road_t = 0.0f, road_r = 0.0f;
     road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
     road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
+    // one step's record of the episodic accumulator: the tile's three sums (float64 on the DPP network, a fixed order) and the
+    // "punished in this step" bits — 32 bytes from lane 63, no read-modify-write
+    auto acc_record = [&](double* recs, float v_r, float v_t, float v_p) {
+        const double s_r = wave_sum_f64(act ? (double)v_r : 0.0);
+        const double s_t = wave_sum_f64(act ? (double)v_t : 0.0);
+        const double s_p = wave_sum_f64(act ? (double)v_p : 0.0);
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(act && v_p > 0.0f);
+        if (lane == 63) {
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            d2v* rec = reinterpret_cast<d2v*>(recs + (size_t)ACC_RECORD_DOUBLES * blockIdx.x);
+            rec[0] = d2v{s_r, s_t};
+            rec[1] = d2v{s_p, __builtin_bit_cast(double, any)};
+        }
+    };
+    if (acc_prev) acc_record(A.prev_rec, pv_r, pv_t, pv_p);                 // the previous step's, in the shadow of the wait below
     lds_wait_until(&S.waves_done, RW);                                      // ---- hand-off 2 ----
     EB_MARK(A, trow, 5);                                                    // record waves done
 
@@ -348,30 +362,16 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         A.out5[3 * n + ge] = a25;
         A.out5[4 * n + ge] = road_r;
     }
-    // Episodic accumulator: what eb_episode_summary would re-read from out5_steps is in this wave's registers — the tile's three
-    // sums (float64, DPP network, fixed order) join the block's running record, the "punished at any step" bits are OR-ed in, and
-    // the launch that ends the rollout adds the |delta_y| statistics of the rows it has just written (t0 IS the final obs' column 6).
-    if (A.acc) {
-        const double s_r = wave_sum_f64(act ? (double)rew : 0.0);
-        const double s_pt = wave_sum_f64(act ? (double)pun_t : 0.0);
-        const double s_pr = wave_sum_f64(act ? (double)pun_r : 0.0);
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(act && pun_r > 0.0f);
-        double s_dy = 0.0;
-        float m_dy = 0.0f;
-        if (A.acc_last) {
-            const float dy = __builtin_fabsf(Stored<ST>::round(t0));
-            s_dy = wave_sum_f64(act ? (double)dy : 0.0);
-            m_dy = wave_max_f32(act && dy > 0.0f ? dy : 0.0f);               // (a NaN never becomes the maximum, as in the two-pass summary)
-        }
-        if (acc_carry) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(acc_prev));   // the record fetched at the top has long arrived
-        auto prev_f64 = [&](int k) { return __builtin_bit_cast(double, ((unsigned long long)acc_prev[2 * k + 1] << 32) | acc_prev[2 * k]); };
-        const unsigned long long prev_any = ((unsigned long long)acc_prev[7] << 32) | acc_prev[6];
+    // The launch that ends a rollout has no successor to make its record: it makes it here, and adds the |delta_y| statistics of
+    // the rows it has just written (t0 IS the final obs' column 6) — once per horizon.
+    if (H.acc_rec && A.acc_final) {
+        acc_record(H.acc_rec, rew, pun_t, pun_r);
+        const float dy = __builtin_fabsf(Stored<ST>::round(t0));
+        const double s_dy = wave_sum_f64(act ? (double)dy : 0.0);
+        const float m_dy = wave_max_f32(act && dy > 0.0f ? dy : 0.0f);       // (a NaN never becomes the maximum, as in the two-pass summary)
         if (lane == 63) {
             typedef double d2v __attribute__((ext_vector_type(2)));
-            d2v* rec = reinterpret_cast<d2v*>(A.acc + (size_t)ACC_RECORD_DOUBLES * blockIdx.x);
-            rec[0] = d2v{prev_f64(0) + s_r, prev_f64(1) + s_pt};
-            rec[1] = d2v{prev_f64(2) + s_pr, __builtin_bit_cast(double, prev_any | any)};
-            if (A.acc_last) rec[2] = d2v{s_dy, (double)m_dy};
+            reinterpret_cast<d2v*>(A.acc_final)[blockIdx.x] = d2v{s_dy, (double)m_dy};
         }
     }
     EB_MARK(A, trow, 6);                                                    // end
@@ -961,8 +961,8 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
     template <int TASK, bool FAST, typename ST>                                                          \
     __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
-        unsigned nv_magic, int do_rewards, const FusedArgs A) {                                          \
-        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards}; \
+        unsigned nv_magic, int do_rewards, double* acc_rec, const FusedArgs A) {                         \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards, acc_rec}; \
         fused_body<TASK, RW, RPT, FAST, ST>(H, A);                                                       \
     }
 EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
@@ -974,7 +974,7 @@ EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 8, 64)
     __global__ __launch_bounds__((RW + (GATED ? 3 : 1)) * 64, WAVES) void NAME(                          \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
         unsigned nv_magic, int horizon, const FusedArgs A) {                                             \
-        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1};        \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1, nullptr}; \
         tape_body<TASK, RW, RPT, FAST, GATED, ST>(H, A, horizon);                                        \
     }
 EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, false, 6)
@@ -994,7 +994,7 @@ int fused_tile_records(int variant) {
 }
 
 #define EB_HOT_ARGS(ST) reinterpret_cast<const ST*>(A.obs_in), reinterpret_cast<ST*>(A.obs_out), A.n_env, A.obs_dim, A.n_veh, \
-                        A.envs_per_tile, A.nv_magic, A.do_rewards
+                        A.envs_per_tile, A.nv_magic, A.do_rewards, A.acc_rec
 #define EB_LAUNCH_TASK(KERNEL, FAST_, ST)                                                                       \
     switch (task) {                                                                                             \
         case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \

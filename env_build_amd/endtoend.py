@@ -210,6 +210,10 @@ class _LazyInitState(dict):
         self['ego']; return (dict, (dict(dict.items(self)),))
 
 
+_TIME_LIMIT_CODE = _capi.DONE_NAMES.index('time_limit')     # EB_DONE_TIME_LIMIT
+MAX_EPISODE_STEPS = 200     # the reference's registration of 'CrossroadEnd2end-v0' (README.md:55-59)
+
+
 class _LazyDone(DevArray):
     """done of a batch: uint8 0 / 1 per env = (done code != 0) — the one small kernel that makes it runs when the value
     is first read (`.t`, `.numpy()`, indexing, reset(mask=done), ...), not on every step."""
@@ -222,6 +226,24 @@ class _LazyDone(DevArray):
     def t(self):
         if self._t is None:
             self._t = self._code.clamp(max=1)
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = v
+
+
+class _LazyTruncated(DevArray):
+    """info['TimeLimit.truncated'] of a batch: uint8 0 / 1 per env = (done code == EB_DONE_TIME_LIMIT), made when first read"""
+
+    def __init__(self, code):
+        self._code = code
+        self._t = None
+
+    @property
+    def t(self):
+        if self._t is None:
+            self._t = (self._code == _TIME_LIMIT_CODE).to(torch.uint8)
         return self._t
 
     @t.setter
@@ -253,8 +275,13 @@ class _SnapshotOnDemand(DevArray):
 class CrossroadEnd2end(object):
     def __init__(self, training_task, num_future_data=0, mode='training', multi_display=False, n_env=1, n_cand=None,
                  device=None, respawn=True, traffic='pool', per_route=5, auto_reset=False, copy_outputs=True, flow_in_step=True,
-                 **kwargs):
+                 max_episode_steps=None, **kwargs):
         """n_env > 1 makes a batch of independent single-ego envs (the reference is one env: every argument before n_env is its).
+        max_episode_steps: None — the bare class, as `CrossroadEnd2end(...)` in the reference; an int — the env as its callers get it
+            from gym.make('CrossroadEnd2end-v0') (README.md:55-59 registers it with max_episode_steps = 200; `make()` below), i.e.
+            inside gym's TimeLimit: an episode nothing else has ended ends at that many steps with done_type 'time_limit' and
+            info['TimeLimit.truncated'] set; the count lives on the device, is kept by the step's own kernel launch
+            (eb_time_limit) and restarts with every reset.
         auto_reset (a batch): step() also resets the envs it has just finished — over the traffic pool in the same kernel launch
             (eb_auto_reset), over the flow source as the masked reset's launches behind the step's —
             the observation it returns holds their reset observation, info['final_observation'] their terminal one (rows of the
@@ -340,6 +367,12 @@ class CrossroadEnd2end(object):
         self._ego_exit = None
         self._reset_counter = 0
         self.done_code = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self.max_episode_steps = None if max_episode_steps is None else int(max_episode_steps)
+        if self.max_episode_steps is not None and self.max_episode_steps < 1:
+            raise ValueError('max_episode_steps must be >= 1')
+        self._episode_step = torch.zeros((B,), dtype=torch.int32, device=dev)     # gym's TimeLimit._elapsed_steps, per env
+        self._time_limit = None if self.max_episode_steps is None else \
+            _capi.EbTimeLimit(self._episode_step.data_ptr(), self.max_episode_steps)
         self._injected = False
         self._flows = None
         self._bufs, self._buf_i, self._ri1 = None, 0, None
@@ -421,13 +454,15 @@ class CrossroadEnd2end(object):
             self._ego.copy_(torch.from_numpy(ego))
             self._params.copy_(torch.tensor([[0., 0., miu, miu]], dtype=torch.float32))  # E2E:110-113
             self._ref_idx.fill_(ref)
+            if self._time_limit is not None:
+                self._episode_step.zero_()                                               # TimeLimit.reset
             e0 = ego[0]
         else:
             self._reset_counter += 1
             self.api.env_reset(self._h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
                                C.c_uint64(self._reset_counter), 1 if self.mode == 'training' else 0, _ptr(self._ego),
                                _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual_next), _ptr(self.done_code),
-                               self._sp())
+                               _ptr(self._episode_step) if self._time_limit is not None else None, self._sp())
             return _LazyInitState(self._ego, self.ego_l, self.ego_w, route)     # env 0's values, copied from the device on first access
         return dict(ego=dict(v_x=e0[0], v_y=0, r=0, x=e0[3], y=e0[4], phi=e0[5], l=self.ego_l,
                              w=self.ego_w, routeID=route))
@@ -480,7 +515,8 @@ class CrossroadEnd2end(object):
             self.api.env_reset_pool(self._h, self._traffic.h, B, _ptr(mask8), C.c_uint64(self._respawn_seed ^ self._RESET_SALT),
                                     C.c_uint64(self._reset_counter - 1), 1 if self.mode == 'training' else 0, _ptr(self._ego),
                                     _ptr(self._params), _ptr(self._ref_idx), _ptr(self._virtual), _ptr(self._v_light),
-                                    _ptr(rb['code']), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), C.byref(rule),
+                                    _ptr(rb['code']), _ptr(self._episode_step) if self._time_limit is not None else None,
+                                    self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), C.byref(rule),
                                     _ptr(rb['obs']), _ptr(self._obs), _ptr(self.done_code), sp)
             self._obs, self.done_code = rb['obs'], rb['code']
             route = {'left': 'dl', 'straight': 'du', 'right': 'dr'}[self.training_task]
@@ -561,6 +597,14 @@ class CrossroadEnd2end(object):
                         for sx, sy in ((1, 1), (1, -1), (-1, 1), (-1, -1)))
         out.update(dict(alpha_f_bound=alpha_f_bound, alpha_r_bound=alpha_r_bound, r_bound=r_bound, Corner_point=corners))
         return out
+
+    def ego_dynamics_batch(self):
+        """_get_ego_dynamics' derived entries for every env of the batch (eb_ego_dynamics, E2E:150-183) -> dict of DevArrays:
+        alpha_f_bound, alpha_r_bound, r_bound [B] and Corner_point [B, 4, 2] — the values the done judge decides on."""
+        out = torch.empty((self.n_env, 11), dtype=torch.float32, device=self.device)
+        self.api.ego_dynamics(self._h, self.n_env, _ptr(self._ego), _ptr(self._params), _ptr(out), self._sp())
+        return dict(alpha_f_bound=DevArray(out[:, 0]), alpha_r_bound=DevArray(out[:, 1]), r_bound=DevArray(out[:, 2]),
+                    Corner_point=DevArray(out[:, 3:].reshape(self.n_env, 4, 2)))
 
     def _absorb_injected(self, exit_):
         """multi_display seam (multi_ego.py:94-96): the caller assigned ego_dynamics / all_vehicles / v_light."""
@@ -790,7 +834,8 @@ class CrossroadEnd2end(object):
                           _ptr(self._params), self.n_cand, _ptr(self._cand), _ptr(self._cand_mode), _ptr(lw),
                           _ptr(self._v_light), _ptr(self._virtual), _ptr(act), _ptr(out5), _ptr(d16), _ptr(obs_out),
                           _ptr(code), C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None,
-                          C.byref(fr) if fr is not None else None, sp)
+                          C.byref(fr) if fr is not None else None,
+                          C.byref(self._time_limit) if self._time_limit is not None else None, sp)
         self._obs, self.done_code = obs_out, code
         if self._flows is not None:
             if not self.flow_in_step:          # (the same rule as a launch of its own: eb_traffic_flow_step)
@@ -816,6 +861,8 @@ class CrossroadEnd2end(object):
                     'reward_info': self.reward_info,
                     'ref_index': self.ref_path.ref_index if B == 1 else
                     self._ref_index_out()}   # E2E:143
+        if self._time_limit is not None:     # gym's TimeLimit: info['TimeLimit.truncated'] = not done (E: the limit ended the episode)
+            all_info['TimeLimit.truncated'] = (c == _TIME_LIMIT_CODE) if B == 1 else _LazyTruncated(code)
         if ar is not None:
             all_info['final_observation'] = DevArray(final)      # the terminal rows of the envs with done != 0
             self._injected = False
@@ -827,6 +874,7 @@ class CrossroadEnd2end(object):
             kept = (self.action, self.reward_info, self.done_type)
             obs_ret = self.reset(mask=done)                      # (`done` not read yet: the step's done codes serve as the mask)
             self.action, self.reward_info, self.done_type = kept
+            self.done_code = code                                # (reset() left its own array, the finished envs' codes cleared)
             all_info['final_observation'] = DevArray(obs_out)
             all_info['ref_index'] = self._ref_index_out()
             return obs_ret, reward, done, all_info
@@ -841,3 +889,14 @@ class CrossroadEnd2end(object):
         d16 = torch.empty((16, B), dtype=torch.float32, device=self.device)
         self.api.compute_rewards(self._h, B, _ptr(obs_in), _ptr(act), _ptr(out5), _ptr(d16), self._sp())
         return d16
+
+
+def make(env_id='CrossroadEnd2end-v0', **kwargs):
+    """gym.make's role for the one id the reference registers (README.md:55-59: `register(id='CrossroadEnd2end-v0',
+    entry_point='endtoend:CrossroadEnd2end', max_episode_steps=200)`; caller: mpc/main.py:542-576 `gym.make('CrossroadEnd2end-v0',
+    training_task=..., num_future_data=...)`): the env inside its episode step limit — here the limit is the env's own
+    `max_episode_steps` (the step kernel keeps the count), not a wrapper object."""
+    if env_id != 'CrossroadEnd2end-v0':
+        raise ValueError("unknown env id %r (the reference registers 'CrossroadEnd2end-v0' only)" % (env_id,))
+    kwargs.setdefault('max_episode_steps', MAX_EPISODE_STEPS)
+    return CrossroadEnd2end(**kwargs)

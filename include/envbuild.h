@@ -78,6 +78,9 @@ extern "C" {
 #define EB_DONE_STABILITY 4
 #define EB_DONE_RED_LIGHT 5
 #define EB_DONE_GOOD 6
+/* not a reference outcome: the episode's step count reached eb_time_limit.max_episode_steps (gym's TimeLimit wrapper around the
+ * registered env, README.md:55-59: max_episode_steps = 200) while every predicate above said "not done yet" */
+#define EB_DONE_TIME_LIMIT 7
 
 /* exit of the crossroad an ego enters from — the 12-ego scene's frames (multi_env/multi_ego.py:33 ROTATE_ANGLE =
  * D 0, R 90, U 180, L -90 degrees; E2E:345-348 name_settings) */
@@ -231,20 +234,24 @@ int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float*
 
 /* The same summary collected BY the rollout launches (ABI 5) — what the reference's callers do when they add up the
  * returns of rollout_out step by step (hier_decision.py:96, multi_ego.py:195) instead of re-reading them afterwards:
- *   eb_rollout_step_acc = eb_rollout_step (DAM:118-126; same outputs, same bits) that also folds the step's rewards,
- *       punish_term_for_training and real_punish_term (float64, fixed order) and the "real_punish_term > 0" flags of its
- *       envs into the workspace `acc`.  first != 0: the launch starts a rollout (acc is overwritten, no zero fill needed);
- *       last != 0: it ends one — the obs it writes is the final obs, whose |delta_y| statistics it records.
+ *   eb_rollout_step_acc = eb_rollout_step (DAM:118-126; same outputs, same bits) as step `step` of a rollout of `horizon`
+ *       steps that also leaves, in the workspace `acc`, the per-tile float64 sums of a step's rewards, punish_term_for_training
+ *       and real_punish_term and the "real_punish_term > 0" flags of its envs.  prev_out5 = the out5 array the rollout's
+ *       PREVIOUS step wrote (NULL for step 0): the HIP library sums a step's outputs in the launch of the NEXT step, where they
+ *       cost three coalesced loads and a wait the kernel has anyway, and the rollout's last launch (step == horizon - 1) adds its
+ *       own and the |delta_y| statistics of the final obs it writes.  Nothing is read from acc: no zero fill, no step order
+ *       beyond the data dependence of the rollout itself.
  *   eb_episode_acc_finish: acc -> out8, the 8 floats of eb_episode_summary(out5_steps of those steps, the last obs_out)
  *       (sums within rtol 1e-6 of it — another fixed float64 order —, count and maximum equal), one small launch.
- * acc: device memory of eb_episode_acc_bytes(n_env) bytes, 16-byte aligned, private layout, one per rollout in flight; every
- * step of one rollout must go to the same handle with the same n_env (and the same eb_debug_set_tile setting: a block keeps
- * its own record).  The HIP library's episodic summary costs one pass over n_blocks x 64 bytes this way instead of a second pass
- * over out5_steps [horizon, 5, n_env]. */
-int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int64_t* bytes);
+ * acc: device memory of eb_episode_acc_bytes(n_env, horizon) bytes, 16-byte aligned, private layout, one per rollout in flight;
+ * every step of one rollout must go to the same handle with the same n_env and horizon (and the same eb_debug_set_tile
+ * setting: a block writes its own records).  The HIP library's episodic summary costs one pass over horizon x n_blocks x 32 bytes
+ * this way instead of a second pass over out5_steps [horizon, 5, n_env]. */
+int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int32_t horizon, int64_t* bytes);
 int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                         const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
-                        float* scaled_actions, void* acc, int32_t first, int32_t last, void* stream);
+                        float* scaled_actions, void* acc, int32_t step, int32_t horizon, const float* prev_out5,
+                        void* stream);
 int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const void* acc, float* out8, void* stream);
 
 /* A rollout plan = eb_rollout_tape over FIXED buffers, recorded once and replayed: the HIP library
@@ -371,7 +378,7 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
  *   final_obs[e, :] = obs_out[e, :] for the masked envs (nullable; the other rows of final_obs are not touched) — the
  *       terminal observation, Gym-vector's `final_observation`;
  *   eb_env_reset_pool(h, traffic, n_env, mask, seed, counter, training, ego, params, ref_idx, virtual_flag, v_light,
- *       NULL, m_cand, cand, cand_mode, &pool, obs_out, NULL, NULL): fresh state and flags, the pool re-entered clear of the
+ *       NULL, NULL, m_cand, cand, cand_mode, &pool, obs_out, NULL, NULL): fresh state and flags, the pool re-entered clear of the
  *       new ego, v_light cleared, the reset observation (built with the OLD flag, E2E:116) in place of the terminal one,
  *       the drawn flag swapped in (E2E:120-126) — for the masked envs only.
  * done_code keeps the step's codes (what the driver reads to know who finished and why).  ref_idx / virtual_flag /
@@ -420,11 +427,33 @@ typedef struct eb_auto_reset {
     eb_respawn pool;         /* the pool's part of reset: entry, span, v_max, seed, counter, edge_span (limit unused) */
     float* final_obs;        /* nullable [n_env, D]: the terminal observation rows of the finished envs */
 } eb_auto_reset;
+/* time_limit (nullable, ABI 5): the episode step limit of the REGISTERED env — callers reach CrossroadEnd2end through
+ * gym.make('CrossroadEnd2end-v0') with max_episode_steps = 200 (README.md:55-59, mpc/main.py:542-576), i.e. inside gym's TimeLimit
+ * wrapper: elapsed += 1 per step; elapsed >= max_episode_steps ends the episode, info['TimeLimit.truncated'] = not done.  Here:
+ * episode_step [n_env] int32 (the caller's, zero at the start) is incremented by every step; an env whose done code came out
+ * EB_DONE_NOT_YET takes EB_DONE_TIME_LIMIT once its count has reached max_episode_steps — below every reference outcome in
+ * priority, so 'truncated' == (done_code == EB_DONE_TIME_LIMIT); a finished env (any code) is finished for auto_reset too, and its
+ * count restarts at 0.  eb_env_reset / eb_env_reset_pool clear the counts of the rows they reset (their episode_step argument). */
+typedef struct eb_time_limit {
+    int32_t* episode_step;
+    int32_t max_episode_steps; /* >= 1; the reference's registration: 200 */
+} eb_time_limit;
 int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs, const float* actions,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow, void* stream);
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow,
+                const eb_time_limit* time_limit, void* stream);
+
+/* CrossroadEnd2end._get_ego_dynamics (E2E:150-183) for a batch: the derived entries of the reference's ego dict from the ego state
+ * [n, 6] and the tyre parameters [n, 4] = (alpha_f, alpha_r, miu_f, miu_r) as eb_env_ego_step / eb_env_step / eb_env_reset write them:
+ *   out [n, 11] = alpha_f_bound, alpha_r_bound = 3 miu F_z / C (E2E:164-166; F_zf, F_zr the float64 values of vehicle_params,
+ *   DAM:48, rounded to fp32), r_bound = miu_r g / (|v_x| + 1e-8) (E2E:167), then the four corner points (x, y) in the order of
+ *   E2E:171-176 — (+l/2, +w/2), (+l/2, -w/2), (-l/2, +w/2), (-l/2, -w/2) through rotate_and_shift_coordination (UTL:152-157).
+ * fp32 with the deterministic sin / cos; r_bound and the corners are the very values eb_judge_done / eb_env_step decide
+ * 'break_stability' and 'break_road_constrain' on (the same device functions).  The copied entries of the dict (v_x ... miu_r,
+ * l = 4.8, w = 2.0) are the inputs themselves. */
+int eb_ego_dynamics(eb_handle h, int32_t n, const float* ego, const float* params, float* out, void* stream);
 
 /* CrossroadEnd2end.reset (E2E:99-127) with _reset_init_state (E2E:472-499) for the envs of a batch whose mask byte is
  * non-zero (mask NULL = every env); the other envs keep their state.  Per env, with u_k in [0, 1) the counter-based
@@ -436,13 +465,15 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
  *   params  = (0, 0, 0.8, 0.8)                                 (E2E:110-113: alpha_f, alpha_r, miu, miu)
  *   virtual_next = training ? (u_3 > 0.9) : 0                  (E2E:120-126 — the reference redraws the flag AFTER the
  *             reset observation; the caller swaps virtual_next in after its eb_get_obs)
- *   done_code = EB_DONE_NOT_YET. */
+ *   done_code = EB_DONE_NOT_YET;
+ *   episode_step (nullable, ABI 5) = 0: eb_time_limit's count. */
 int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter, int32_t training,
-                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code, void* stream);
+                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
+                 int32_t* episode_step, void* stream);
 
 /* CrossroadEnd2end.reset (E2E:99-127) over the traffic POOL for the envs of a batch whose mask byte is non-zero (NULL = all),
  * as ONE call — what a vectorised driver issues after every step for the envs that finished:
- *   eb_env_reset(h, n_env, mask, seed, counter, training, ego, params, ref_idx, <next flags>, done_code)        E2E:100-101, 119
+ *   eb_env_reset(h, n_env, mask, seed, counter, training, ego, params, ref_idx, <next flags>, done_code, episode_step)   E2E:100-101, 119
  *   eb_traffic_respawn(traffic, n_env, m_cand, cand, pool->entry, -1 (unconditional), pool->span, pool->v_max,
  *                      pool->seed, pool->counter, mask, NULL, ego, pool->edge_span)      E2E:102-103 (init_traffic, TRF:151-195)
  *   v_light[e] = 0 (nullable): the pool has no light programme, an episode starts at phase 0
@@ -456,8 +487,8 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
  * The HIP library runs all of it as ONE launch (csrc/eb_env_step.hip, env_reset_pool_kernel) under the conditions of eb_env_step. */
 int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
                       int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
-                      uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
-                      float* obs, const float* obs_src, const uint8_t* done_src, void* stream);
+                      uint8_t* done_code, int32_t* episode_step, int32_t m_cand, float* cand, const uint8_t* cand_mode,
+                      const eb_respawn* pool, float* obs, const float* obs_src, const uint8_t* done_src, void* stream);
 
 /* The traffic pool's re-entry rule (the SUMO flows' role for the batched env, TRF:37-238 is out of scope): every
  * candidate of cand [n_env, m_cand, 4] that has left the square |x|, |y| <= limit is put back on its entry lane,

@@ -1153,6 +1153,35 @@ int eb_judge_done(eb_handle h, int32_t n_env, const float* ego, const float* par
     return EB_OK;
 }
 
+/* a15: CrossroadEnd2end._get_ego_dynamics (E2E:150-183) for a batch — the derived entries: the slip-angle bounds (E2E:164-166, with
+ * vehicle_params' float64 F_zf / F_zr of DAM:48 rounded to fp32), r_bound (E2E:167) and the four corner points (E2E:171-176 through
+ * rotate_and_shift_coordination, UTL:152-157), fp32 in the order eb_judge_done above evaluates them */
+int eb_ego_dynamics(eb_handle h, int32_t n, const float* ego, const float* params, float* out, void* stream) {
+    (void)stream;
+    if (!h || n < 0 || (n > 0 && (!ego || !params || !out))) return fail(EB_EINVAL, "eb_ego_dynamics: bad argument");
+    const float EGO_L = 4.8f, EGO_W = 2.0f;
+    const float F_zf = (float)(1.46 * 1520.0 * 9.81 / (1.19 + 1.46)), F_zr = (float)(1.19 * 1520.0 * 9.81 / (1.19 + 1.46));   /* DAM:48 */
+    for (int i = 0; i < n; ++i) {
+        const float* e = ego + 6 * (size_t)i;
+        const float v_x = e[0], x = e[3], y = e[4], phi = e[5];
+        const float miu_f = params[4 * (size_t)i + 2], miu_r = params[4 * (size_t)i + 3];
+        float* o = out + 11 * (size_t)i;
+        o[0] = 3.0f * miu_f * F_zf / VP.C_f;                              /* E2E:164-165 */
+        o[1] = 3.0f * miu_r * F_zr / VP.C_r;                              /* E2E:166 */
+        o[2] = miu_r * 9.81f / (fabsf(v_x) + 1e-8f);                      /* E2E:167 */
+        float rs, rc_;
+        eb_sincosf(-phi * PI_F / 180.0f, &rs, &rc_);
+        for (int q = 0; q < 4; ++q) {                                     /* E2E:171-176 */
+            float cx = (q < 2 ? EGO_L : -EGO_L) / 2, cy = ((q & 1) ? -EGO_W : EGO_W) / 2;
+            float tx = cx * rc_ + cy * rs;
+            float ty = -cx * rs + cy * rc_;
+            o[3 + 2 * q] = tx - (-x);
+            o[4 + 2 * q] = ty - (-y);
+        }
+    }
+    return EB_OK;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* episodic summary, rollout plans, timing marks (no reference counterpart; include/envbuild.h) */
 /* ------------------------------------------------------------------------------------------ */
@@ -1185,29 +1214,32 @@ int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float*
 /* The accumulating form (ABI 5; include/envbuild.h): the reference's callers add the returns of rollout_out up step by step
  * (hier_decision.py:96).  Workspace layout of THIS library (private): 8 doubles — sums of reward, punish_term_for_training,
  * real_punish_term, then sum and max of the final rows' |delta_y| — followed by one "punished at any step" byte per env. */
-static size_t acc_bytes(const eb_config* c, int32_t n_env) {
+static size_t acc_bytes(const eb_config* c, int32_t n_env, int32_t horizon) {
     int e = 256 / c->n_veh;                    /* the HIP library's smallest tile (its formula: the two must agree) */
     if (e < 1) e = 1;
     if (e > 64) e = 64;
-    return (size_t)((n_env + e - 1) / e) * 64 + (size_t)n_env;
+    return (size_t)((n_env + e - 1) / e) * ((size_t)horizon * 4 + 2) * sizeof(double) + (size_t)n_env;
 }
-int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int64_t* bytes) {
-    if (!h || n_env < 0 || !bytes) return fail(EB_EINVAL, "eb_episode_acc_bytes: bad argument");
-    *bytes = (int64_t)acc_bytes(&h->cfg, n_env);
+int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int32_t horizon, int64_t* bytes) {
+    if (!h || n_env < 0 || horizon < 0 || !bytes) return fail(EB_EINVAL, "eb_episode_acc_bytes: bad argument");
+    *bytes = (int64_t)acc_bytes(&h->cfg, n_env, horizon);
     return EB_OK;
 }
 int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                         const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
-                        float* scaled_actions, void* acc, int32_t first, int32_t last, void* stream) {
+                        float* scaled_actions, void* acc, int32_t step, int32_t horizon, const float* prev_out5,
+                        void* stream) {
     if (h && n_env == 0) return EB_OK;
-    if (!acc) return fail(EB_EINVAL, "eb_rollout_step_acc: bad argument");
+    if (!acc || horizon < 1 || step < 0 || step >= horizon || (step > 0 && !prev_out5) || prev_out5 == out5)
+        return fail(EB_EINVAL, "eb_rollout_step_acc: bad argument (0 <= step < horizon; prev_out5 = the previous step's out5 for step > 0)");
     if (((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_rollout_step_acc: acc must be 16-byte aligned");
     int rc = eb_rollout_step(h, n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions, stream);
     if (rc) return rc;
+    if (acc_bytes(&h->cfg, n_env, horizon) < 64 + (size_t)n_env) return fail(EB_EINVAL, "eb_rollout_step_acc: workspace too small");
     double* a = (double*)acc;
     unsigned char* any = (unsigned char*)acc + 64;
-    if (first) { memset(a, 0, 64); memset(any, 0, (size_t)n_env); }
-    const int D = obs_dim(&h->cfg);
+    if (step == 0) { memset(a, 0, 64); memset(any, 0, (size_t)n_env); }
+    const int D = obs_dim(&h->cfg), last = step == horizon - 1;
     double r = 0, pt = 0, pr = 0, ady = 0, mdy = 0;
     for (int i = 0; i < n_env; ++i) {
         r += (double)out5[i];
@@ -1226,7 +1258,7 @@ int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const f
 }
 int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const void* acc, float* out8, void* stream) {
     (void)stream;
-    if (!h || n_env < 0 || horizon < 0 || !out8 || (n_env > 0 && !acc)) return fail(EB_EINVAL, "eb_episode_acc_finish: bad argument");
+    if (!h || n_env < 0 || horizon < 1 || !out8 || (n_env > 0 && !acc)) return fail(EB_EINVAL, "eb_episode_acc_finish: bad argument");
     double z[8] = {0};
     const double* a = n_env > 0 ? (const double*)acc : z;
     double cnt = 0;
@@ -1263,7 +1295,7 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
     p->tape = action_tape; p->ref_idx = ref_idx; p->obs_work = obs_work; p->obs_out = obs_out;
     p->out5_steps = out5_steps; p->summary8 = summary8; p->acc = acc;
     if (summary8 && !acc) {
-        p->own_acc = aligned_alloc(64, (acc_bytes(&h->cfg, n_env) + 63) / 64 * 64);
+        p->own_acc = aligned_alloc(64, (acc_bytes(&h->cfg, n_env, horizon) + 63) / 64 * 64);
         if (!p->own_acc) { free(p); return fail(EB_ENOMEM, "eb_plan_create: out of memory"); }
         p->acc = p->own_acc;
     }
@@ -1281,7 +1313,8 @@ int eb_plan_launch(eb_plan p, void* stream) {
     for (int t = 0; t < p->horizon; ++t) {
         float* dst = ((p->horizon - 1 - t) % 2 == 0) ? p->obs_out : p->obs_work;
         int rc = eb_rollout_step_acc(p->h, p->n_env, cur, p->tape + (size_t)t * p->n_env * 2, p->ref_idx, p->path_id, dst,
-                                     p->out5_steps + (size_t)t * 5 * p->n_env, NULL, p->acc, t == 0, t == p->horizon - 1, stream);
+                                     p->out5_steps + (size_t)t * 5 * p->n_env, NULL, p->acc, t, p->horizon,
+                                     t > 0 ? p->out5_steps + (size_t)(t - 1) * 5 * p->n_env : NULL, stream);
         if (rc) return rc;
         cur = dst;
     }
@@ -1322,7 +1355,8 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
                 const int32_t* ref_idx, int32_t path_id, float* ego, float* params, int32_t m_cand, float* cand,
                 const uint8_t* cand_mode, const float* cand_lw, const uint8_t* v_light, const uint8_t* virtual_flag,
                 float* scaled_actions, float* out5, float* out_dict16, float* obs_out, uint8_t* done_code,
-                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow, void* stream) {
+                const eb_respawn* respawn, const eb_auto_reset* auto_reset, const eb_flow_rule* flow,
+                const eb_time_limit* time_limit, void* stream) {
     if (!h || !traffic) return fail(EB_EINVAL, "eb_env_step: null handle");
     if (n_env < 0 || !obs || !actions || !ego || !params || !out5 || !obs_out || !done_code || obs == obs_out ||
         m_cand < 0 || m_cand > 256 || (m_cand > 0 && (!cand || !cand_mode)))
@@ -1349,6 +1383,8 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             !flow->sim_step || !flow->lane || !flow->period || !flow->v_max || !v_light || flow->v_light != v_light || flow->cand_mode != cand_mode)
             return fail(EB_EINVAL, "eb_env_step: bad flow rule (m_cand == 12 * per_route <= 64, every array given, cand_mode / v_light the call's own)");
     }
+    if (time_limit && (!time_limit->episode_step || time_limit->max_episode_steps < 1))
+        return fail(EB_EINVAL, "eb_env_step: bad time limit (episode_step given, max_episode_steps >= 1)");
     if (n_env == 0) return EB_OK;
     float* own_scaled = NULL;
     if (!scaled_actions) {                                                                       /* nullable output */
@@ -1363,6 +1399,13 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!rc) rc = eb_veh_predict(traffic, n_env, cand, cand, stream);                            /* TRF:220-238's role */
     if (!rc) rc = eb_get_obs(h, n_env, ego, ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, NULL, NULL, obs_out, stream);   /* E2E:140 */
     if (!rc) rc = eb_judge_done(h, n_env, ego, params, obs_out, m_cand, cand, cand_mode, cand_lw, v_light, done_code, stream);   /* E2E:141 */
+    if (!rc && time_limit)   /* gym's TimeLimit around the registered env (README.md:55-59): elapsed += 1; elapsed >= max ends an episode
+                              * nothing else has ended ('truncated'); the count of a finished env restarts */
+        for (int e = 0; e < n_env; ++e) {
+            const int cnt = time_limit->episode_step[e] + 1;
+            if (done_code[e] == EB_DONE_NOT_YET && cnt >= time_limit->max_episode_steps) done_code[e] = EB_DONE_TIME_LIMIT;
+            time_limit->episode_step[e] = done_code[e] != EB_DONE_NOT_YET ? 0 : cnt;
+        }
     if (!rc && respawn)   /* the pool's re-entry, after the observation saw this step's state */
         rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
                                 respawn->seed, respawn->counter, NULL, NULL, NULL, 0.0f, stream);
@@ -1376,7 +1419,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             if (mask[e] && ar->final_obs) memcpy(ar->final_obs + D * e, obs_out + D * e, D * sizeof(float));   /* the terminal observation */
         }
         rc = eb_env_reset_pool(h, traffic, n_env, mask, ar->seed, ar->counter, ar->training, ego, params, ar->ref_idx, ar->virtual_flag,
-                               ar->v_light, NULL, m_cand, cand, cand_mode, &ar->pool, obs_out, NULL, NULL, stream);
+                               ar->v_light, NULL, NULL, m_cand, cand, cand_mode, &ar->pool, obs_out, NULL, NULL, stream);
         free(mask);
     }
     if (!rc && flow)   /* TRF:220-238's role for the flow source: exits, accelerations, emissions, clock and light, after the observation */
@@ -1494,7 +1537,8 @@ int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, 
 
 /* a18: CrossroadEnd2end.reset + _reset_init_state for the masked envs of a batch (E2E:99-127, 472-499) */
 int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter, int32_t training,
-                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code, void* stream) {
+                 float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_next, uint8_t* done_code,
+                 int32_t* episode_step, void* stream) {
     (void)stream;
     int rc = check_paths(h, "eb_env_reset: null handle");
     if (rc) return rc;
@@ -1516,6 +1560,7 @@ int eb_env_reset(eb_handle h, int32_t n_env, const uint8_t* mask, uint64_t seed,
         ref_idx[e] = p;
         if (virtual_next) virtual_next[e] = (training && u3 > 0.9f) ? 1 : 0;   /* E2E:120-126 */
         if (done_code) done_code[e] = EB_DONE_NOT_YET;                  /* E2E:119 */
+        if (episode_step) episode_step[e] = 0;                          /* eb_time_limit's count (TimeLimit.reset) */
     }
     return EB_OK;
 }
@@ -1526,8 +1571,8 @@ int eb_traffic_respawn(eb_handle h, int32_t n_env, int32_t m_cand, float* cand, 
 /* the masked reset over the pool as one call: the composition its header comment spells out */
 int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8_t* mask, uint64_t seed, uint64_t counter,
                       int32_t training, float* ego, float* params, int32_t* ref_idx, uint8_t* virtual_flag, uint8_t* v_light,
-                      uint8_t* done_code, int32_t m_cand, float* cand, const uint8_t* cand_mode, const eb_respawn* pool,
-                      float* obs, const float* obs_src, const uint8_t* done_src, void* stream) {
+                      uint8_t* done_code, int32_t* episode_step, int32_t m_cand, float* cand, const uint8_t* cand_mode,
+                      const eb_respawn* pool, float* obs, const float* obs_src, const uint8_t* done_src, void* stream) {
     if (!h || !traffic || !pool || !pool->entry) return fail(EB_EINVAL, "eb_env_reset_pool: null argument");
     if (n_env < 0 || m_cand < 1 || m_cand > 64 || (n_env > 0 && (!ego || !params || !ref_idx || !virtual_flag || !cand || !cand_mode || !obs)))
         return fail(EB_EINVAL, "eb_env_reset_pool: bad argument");
@@ -1543,7 +1588,7 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
     /* the rows outside the mask: carried over from the caller's previous arrays */
     if (mask && obs_src && obs_src != obs) memcpy(obs, obs_src, (size_t)n_env * (size_t)obs_dim(&h->cfg) * sizeof(float));
     if (mask && done_src && done_code && done_src != done_code) memcpy(done_code, done_src, (size_t)n_env);
-    rc = eb_env_reset(h, n_env, mask, seed, counter, training, ego, params, ref_idx, vnext, done_code, stream);
+    rc = eb_env_reset(h, n_env, mask, seed, counter, training, ego, params, ref_idx, vnext, done_code, episode_step, stream);
     if (!rc) rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, pool->entry, -1.0f, pool->span, pool->v_max, pool->seed,
                                      pool->counter, mask, NULL, ego, pool->edge_span, stream);
     if (!rc && v_light)

@@ -23,7 +23,7 @@ for B in [int(x) for x in a.sizes.split(',')]:
         def call(k):
             rule.seed, rule.counter = 7, k
             env.api.env_reset_pool(env._h, env._traffic.h, B, _ptr(mask), C.c_uint64(11), C.c_uint64(k), 1, _ptr(env._ego), _ptr(env._params),
-                                   _ptr(env._ref_idx), _ptr(env._virtual), _ptr(env._v_light), _ptr(code2), env.n_cand, _ptr(env._cand),
+                                   _ptr(env._ref_idx), _ptr(env._virtual), _ptr(env._v_light), _ptr(code2), None, env.n_cand, _ptr(env._cand),
                                    _ptr(env._cand_mode), C.byref(rule), _ptr(obs2), _ptr(env._obs), _ptr(env.done_code), sp)
         for k in range(10): call(k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -357,3 +357,80 @@ def wrap_guard_case(m):
         assert np.array_equal(o[big], phis[big], equal_nan=True) and (np.abs(o[~big & np.isfinite(phis)]) <= 180.0).all()
     assert (np.abs(out[-1][:6]) <= 180.0).all()         # the ego step wraps what it can
     return out
+
+
+def time_limit_case(make, task, B, M, tile=None, max_steps=200, seed=8):
+    """ABI 5, eb_time_limit — gym's TimeLimit around the registered env (README.md:55-59): the step counts rise by one; an env no
+    reference predicate has finished takes EB_DONE_TIME_LIMIT when its count reaches the limit; a finished env's count restarts;
+    nothing else about the step changes.  With auto_reset the truncated envs are reset like the others; the resets clear the
+    counts of the rows they touch.  -> the outputs of the limited step + auto reset (for cross-library comparison)."""
+    from env_build_amd.endtoend import _lane_entry
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    entry = np.array([list(_lane_entry(m)[:3]) + list(_lane_entry(m)[3]) for m in modes], np.float32)
+    ego, cand, _, _, light, _, ref = random_scene(task, B, M, seed)
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    rng = np.random.default_rng(seed + 1)
+    raw = rng.uniform(-1.2, 1.2, (B, 2)).astype(np.float32)
+    virtual = (rng.random(B) < 0.3).astype(np.uint8)
+    steps = rng.integers(0, max_steps + 5, B).astype(np.int32)
+    steps[::3] = max_steps - 1                                       # a third of the envs are about to be truncated
+    steps[1::7] = max_steps - 2                                      # ... and some one step short of it
+    m, tr = make(task, mode='training'), make(task, n_veh=M, modes=modes)
+    if tile is not None:
+        m.set_tile(tile)
+    obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    plain = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=light, virtual=virtual)
+    got = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=light, virtual=virtual, time_limit=(steps, max_steps))
+    done0 = plain[7]
+    want_code = np.where((done0 == 0) & (steps + 1 >= max_steps), np.uint8(7), done0)
+    want_steps = np.where(want_code != 0, 0, steps + 1).astype(np.int32)
+    assert (want_code == 7).any() and (done0 != 0).any() and (want_code == 0).any()
+    for k in range(7):                                               # scaled, out5, dict16, ego, params, cand, obs: the plain step's
+        assert np.array_equal(got[k], plain[k]), k
+    assert np.array_equal(got[7], want_code) and np.array_equal(got[-1], want_steps)
+    # with the reset of the finished envs in the same call: the truncated envs are finished envs
+    pool = dict(entry=entry, span=60.0, v_max=8.0, seed=4242, counter=17, edge_span=5.0)
+    auto = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=light, virtual=virtual,
+                      auto_reset=dict(seed=99, counter=5, training=1, pool=pool), time_limit=(steps, max_steps))
+    fin = want_code != 0
+    e2, p2, r2, vf2, vl2, _, c2, o2, s2 = m.env_reset_pool(tr, 99, 5, 1, plain[3], plain[4], ref, virtual, light, plain[5], cmode, plain[6],
+                                                           pool, mask=fin.astype(np.uint8), episode_step=want_steps + 3 * (~fin))
+    final = np.where(fin[:, None], plain[6], np.float32(np.nan))
+    want = [plain[0], plain[1], plain[2], e2, p2, c2, o2, want_code, r2, vf2, vl2, final, want_steps]
+    for k, (g, w) in enumerate(zip(auto, want)):
+        assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w, equal_nan=True), k
+    assert np.array_equal(s2, np.where(fin, 0, want_steps + 3))    # eb_env_reset_pool clears the counts of the rows it resets, only those
+    # eb_env_reset likewise
+    rs = m.env_reset(B, 5, 6, 1, ego, plain[4], ref, mask=fin.astype(np.uint8), episode_step=steps + 1)
+    assert np.array_equal(rs[5], np.where(fin, 0, steps + 1))
+    return auto
+
+
+def parked_ego_case(make, task='left', B=3, max_steps=200):
+    """An ego parked on its approach lane (v_x = 0, nothing near it, no light) satisfies no reference predicate — without the step
+    limit its episode never ends.  201 closed-loop steps: 'not done yet' for 199 steps, EB_DONE_TIME_LIMIT at step 200, count back
+    at 0, step 201 is step 1 of the next count."""
+    m, tr = make(task, mode='training'), make(task, n_veh=2, modes=[VEHICLE_MODE_LIST[task][0]] * 2)
+    ref = np.zeros(B, np.int32)
+    x, y, phi = {'left': (1.875, -40.0, 90.0), 'straight': (5.625, -40.0, 90.0), 'right': (9.375, -40.0, 90.0)}[task]
+    ego = np.tile(np.array([0.0, 0.0, 0.0, x, y, phi], np.float32), (B, 1))
+    cand = np.zeros((B, 2, 4), np.float32)
+    cmode = np.full((B, 2), _capi.VMODE_EMPTY, np.uint8)
+    light = np.zeros(B, np.uint8)
+    raw = np.tile(np.array([0.0, -1.0], np.float32), (B, 1))        # full brake: v_x stays at its floor (E2E:281)
+    steps = np.array([0, 150, 199][:B], np.int32)
+    obs = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    codes = []
+    for t in range(max_steps + 1):
+        out = m.env_step(tr, obs, raw, ego, cand, cmode, ref_idx=ref, v_light=light, time_limit=(steps, max_steps), want_dict=False)
+        ego, obs, code, steps = out[3], out[6], out[7], out[-1]
+        codes.append(code.copy())
+    codes = np.array(codes)                                           # [201, B]
+    assert (ego[:, 0] == 0).all() and np.array_equal(ego[:, 3:], np.tile(np.array([x, y, phi], np.float32), (B, 1)))
+    for b, s0 in enumerate([0, 150, 199][:B]):
+        hits = np.flatnonzero(codes[:, b])
+        first = max_steps - 1 - s0                                    # the step whose count reaches the limit
+        want_hits = [first] + ([first + max_steps] if first + max_steps <= max_steps else [])
+        assert hits.tolist() == want_hits and (codes[hits, b] == 7).all(), (b, hits)
+    return codes

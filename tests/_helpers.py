@@ -217,11 +217,11 @@ class HostModel(object):
         self.api.episode_summary(self.h, o5.shape[2], o5.shape[0], self._ptr(o5), self._ptr(ob), self._ptr(out8), self.stream)
         return self._ret(out8)
 
-    def acc_workspace(self, n_env):
-        """the workspace of an accumulating rollout over n_env envs (eb_episode_acc_bytes), filled with 0xFF: a rollout's first
-        launch must not depend on what it finds there"""
+    def acc_workspace(self, n_env, horizon):
+        """the workspace of an accumulating rollout of `horizon` steps over n_env envs (eb_episode_acc_bytes), filled with 0xFF:
+        nothing may depend on what a rollout finds there"""
         nb = C.c_int64()
-        self.api.episode_acc_bytes(self.h, int(n_env), C.byref(nb))
+        self.api.episode_acc_bytes(self.h, int(n_env), int(horizon), C.byref(nb))
         return self._in(np.full((max(16, nb.value),), 0xFF, np.uint8), np.uint8)
 
     def rollout_acc(self, obs, tape, ref_idx=None, path_id=0, acc=None):
@@ -229,12 +229,13 @@ class HostModel(object):
         ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
         H, n = tp.shape[0], len(ob)
         bufs, out5, s8 = [self._out(ob.shape), self._out(ob.shape)], self._out((H, 5, n)), self._out((8,))
-        acc = self.acc_workspace(n) if acc is None else acc
+        acc = self.acc_workspace(n, H) if acc is None else acc
         cur = ob
         for t in range(H):
             dst = bufs[(H - 1 - t) % 2]
             self.api.rollout_step_acc(self.h, n, self._ptr(cur), self._ptr(tp[t]), self._ptr(ri), int(path_id), self._ptr(dst),
-                                      self._ptr(out5[t]), None, self._ptr(acc), int(t == 0), int(t == H - 1), self.stream)
+                                      self._ptr(out5[t]), None, self._ptr(acc), t, H, self._ptr(out5[t - 1]) if t else None,
+                                      self.stream)
             cur = dst
         self.api.episode_acc_finish(self.h, n, H, self._ptr(acc), self._ptr(s8), self.stream)
         return self._ret(bufs[0]), self._ret(out5), self._ret(s8)
@@ -246,7 +247,7 @@ class HostModel(object):
         H, n = tp.shape[0], len(ob)
         work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
         s8 = self._out((8,)) if with_summary else None
-        acc = self.acc_workspace(n) if caller_acc else None
+        acc = self.acc_workspace(n, H) if caller_acc else None
         plan = C.c_void_p()
         self.api.plan_create(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work),
                              self._ptr(out), self._ptr(out5), None if caller_acc else self._ptr(s8), self._ptr(acc), C.byref(plan))
@@ -292,20 +293,29 @@ class HostModel(object):
         self.api.exit_frame(self.h, len(eg), self._ptr(ex), int(bool(inverse)), self._ptr(eg), self._ptr(out), self.stream)
         return self._ret(out)
 
-    def env_reset(self, n_env, seed, counter, training, ego, params, ref_idx, mask=None):
-        """-> (ego, params, ref_idx, virtual_next, done_code) after eb_env_reset on copies of the given state"""
+    def env_reset(self, n_env, seed, counter, training, ego, params, ref_idx, mask=None, episode_step=None):
+        """-> (ego, params, ref_idx, virtual_next, done_code[, episode_step]) after eb_env_reset on copies of the given state"""
         eg, pr, ri = self._in(np.array(ego, np.float32)), self._in(np.array(params, np.float32)), self._in(np.array(ref_idx, np.int32), np.int32)
         mk = self._in(mask, np.uint8)
         vn, dc = self._out((n_env,), np.uint8), self._out((n_env,), np.uint8)
+        es = None if episode_step is None else self._in(np.array(episode_step, np.int32), np.int32)
         for t in (vn, dc):
             t[...] = 7
         self.api.env_reset(self.h, n_env, self._ptr(mk), C.c_uint64(seed), C.c_uint64(counter), int(training), self._ptr(eg),
-                           self._ptr(pr), self._ptr(ri), self._ptr(vn), self._ptr(dc), self.stream)
-        return self._ret(eg), self._ret(pr), self._ret(ri), self._ret(vn), self._ret(dc)
+                           self._ptr(pr), self._ptr(ri), self._ptr(vn), self._ptr(dc), self._ptr(es), self.stream)
+        res = self._ret(eg), self._ret(pr), self._ret(ri), self._ret(vn), self._ret(dc)
+        return res if es is None else res + (self._ret(es),)
+
+    def ego_dynamics(self, ego, params):
+        """eb_ego_dynamics -> [n, 11] = alpha_f_bound, alpha_r_bound, r_bound, 4 corner points (x, y)"""
+        eg, pr = self._in(ego), self._in(params)
+        out = self._out((len(eg), 11))
+        self.api.ego_dynamics(self.h, len(eg), self._ptr(eg), self._ptr(pr), self._ptr(out), self.stream)
+        return self._ret(out)
 
     def env_reset_pool(self, traffic, seed, counter, training, ego, params, ref_idx, virtual, v_light, cand, cand_mode, obs, pool,
-                       mask=None, obs_src=None, done_src=None):
-        """eb_env_reset_pool on copies of the state -> (ego, params, ref_idx, virtual, v_light, done_code, cand, obs)"""
+                       mask=None, obs_src=None, done_src=None, episode_step=None):
+        """eb_env_reset_pool on copies of the state -> (ego, params, ref_idx, virtual, v_light, done_code, cand, obs[, episode_step])"""
         cp = lambda a, t: self._in(np.array(a, t))          # in/out arguments: explicit copies (the oracle writes in place)
         eg, pr, ri = cp(ego, np.float32), cp(params, np.float32), self._in(np.array(ref_idx, np.int32), np.int32)
         vf, vl, mk = self._in(np.array(virtual, np.uint8), np.uint8), self._in(np.array(v_light, np.uint8), np.uint8), self._in(mask, np.uint8)
@@ -317,10 +327,11 @@ class HostModel(object):
         osrc, dsrc = self._in(obs_src), self._in(done_src, np.uint8)
         rs = _capi.EbRespawn(self._ptr(en).value, 0.0, float(pool['span']), float(pool['v_max']), int(pool['seed']), int(pool['counter']),
                              float(pool['edge_span']))
+        es = None if episode_step is None else self._in(np.array(episode_step, np.int32), np.int32)
         self.api.env_reset_pool(self.h, traffic.h, n, self._ptr(mk), C.c_uint64(seed), C.c_uint64(counter), int(training), self._ptr(eg),
-                                self._ptr(pr), self._ptr(ri), self._ptr(vf), self._ptr(vl), self._ptr(dc), m, self._ptr(cd), self._ptr(cm),
-                                C.byref(rs), self._ptr(ob), self._ptr(osrc), self._ptr(dsrc), self.stream)
-        return [self._ret(x) for x in (eg, pr, ri, vf, vl, dc, cd, ob)]
+                                self._ptr(pr), self._ptr(ri), self._ptr(vf), self._ptr(vl), self._ptr(dc), self._ptr(es), m, self._ptr(cd),
+                                self._ptr(cm), C.byref(rs), self._ptr(ob), self._ptr(osrc), self._ptr(dsrc), self.stream)
+        return [self._ret(x) for x in (eg, pr, ri, vf, vl, dc, cd, ob) + (() if es is None else (es,))]
 
     def tracking_error(self, xs, ys, phis, vs, n_future, ref_idx=None, path_id=0):
         x, y, ph, v, ri = self._in(xs), self._in(ys), self._in(phis), self._in(vs), self._in(ref_idx, np.int32)
@@ -360,13 +371,15 @@ class HostModel(object):
         return self._ret(out)
 
     def env_step(self, traffic, obs, raw, ego, cand, cand_mode, ref_idx=None, path_id=0, cand_lw=None, v_light=None,
-                 virtual=None, respawn=None, want_scaled=True, want_dict=True, scale_in_place=False, auto_reset=None, flow=None):
+                 virtual=None, respawn=None, want_scaled=True, want_dict=True, scale_in_place=False, auto_reset=None, flow=None,
+                 time_limit=None):
         """eb_env_step on copies of the state -> (scaled, out5, d16, ego, params, cand, obs_out, done_code).
         scale_in_place: the scaled actions overwrite the (copy of the) raw action array.
         respawn: dict(entry [M, 5], limit, span, v_max, seed, counter) — the pool's re-entry as the step's last stage.
         auto_reset: dict(seed, counter, training, pool=dict(entry, span, v_max, seed, counter, edge_span), final_obs=bool) — the
         envs the step finishes are reset in the same call (ABI 4); the result gains (ref_idx, virtual, v_light, final_obs),
-        final_obs pre-filled with NaN."""
+        final_obs pre-filled with NaN.
+        time_limit: (episode_step [B] int32, max_episode_steps) — ABI 5; the result gains the step counts after the call (last)."""
         B, M = len(ego), cand.shape[1]
         e_io, c_io = self._in(np.array(ego, np.float32)), self._in(np.array(cand, np.float32))
         ob, rw, ri = self._in(obs), self._in(raw), self._in(ref_idx, np.int32)
@@ -415,11 +428,16 @@ class HostModel(object):
                                   vp(self._out((B, M), np.uint8)) if 'mode' in flow.get('wrong', ()) else vp(cm),
                                   vp(self._out((B,), np.uint8)) if 'v_light' in flow.get('wrong', ()) else vp(vl))
             extra = extra + (f_act, f_tim, f_emi, f_sim, cm, vl)
+        tl = None
+        if time_limit is not None:
+            es = self._in(np.array(time_limit[0], np.int32), np.int32)
+            tl = _capi.EbTimeLimit(self._ptr(es).value, int(time_limit[1]))
+            extra = extra + (es,)
         self.api.env_step(self.h, traffic.h, B, self._ptr(ob), self._ptr(rw), self._ptr(ri), int(path_id), self._ptr(e_io),
                           self._ptr(par), M, self._ptr(c_io), self._ptr(cm), self._ptr(lw), self._ptr(vl), self._ptr(vf),
                           self._ptr(sc), self._ptr(out5), self._ptr(dd), self._ptr(obs_o), self._ptr(code),
                           C.byref(rs) if rs is not None else None, C.byref(ar) if ar is not None else None,
-                          C.byref(fl) if fl is not None else None, self.stream)
+                          C.byref(fl) if fl is not None else None, C.byref(tl) if tl is not None else None, self.stream)
         return [None if x is None else self._ret(x) for x in (sc, out5, dd, e_io, par, c_io, obs_o, code) + extra]
 
     def traffic_respawn(self, cand, entry, limit, span, v_max, seed, counter, mask=None, ego=None, edge_span=0.0):

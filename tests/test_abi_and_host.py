@@ -197,7 +197,7 @@ def test_oracle_accumulating_rollout_equals_the_two_pass_summary():
     out_a, o5_a = host.rollout_tape(obs, inp['actions'], inp['ref_idx'])
     want = host.episode_summary(o5_a, out_a)
     assert want[3] > 0                                               # the scene does punish somebody
-    acc = host.acc_workspace(77)
+    acc = host.acc_workspace(77, 6)
     for _ in range(2):                                               # the second rollout starts over in the used workspace
         out_b, o5_b, s8 = host.rollout_acc(obs, inp['actions'], inp['ref_idx'], acc=acc)
         assert np.array_equal(out_a, out_b) and np.array_equal(o5_a, o5_b)
@@ -209,9 +209,12 @@ def test_oracle_accumulating_rollout_equals_the_two_pass_summary():
     api = host.api
     with pytest.raises(ValueError):
         api.rollout_step_acc(host.h, 77, _p(obs), _p(inp['actions'][0]), _p(inp['ref_idx']), 0, _p(out_a.copy()), _p(o5_a[0].copy()),
-                             None, None, 1, 1, None)
+                             None, None, 0, 1, None, None)
+    with pytest.raises(ValueError):                                  # a later step without the previous step's out5
+        api.rollout_step_acc(host.h, 77, _p(obs), _p(inp['actions'][0]), _p(inp['ref_idx']), 0, _p(out_a.copy()), _p(o5_a[0].copy()),
+                             None, _p(np.zeros(1 << 16, np.uint8)), 1, 6, None, None)
     nb = C.c_int64()
-    api.episode_acc_bytes(host.h, 0, C.byref(nb))
+    api.episode_acc_bytes(host.h, 0, 6, C.byref(nb))
     assert nb.value == 0
 
 

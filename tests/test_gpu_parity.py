@@ -280,9 +280,10 @@ def test_plan_graph_replay_and_summary(task, N, B, H):
                                              ('straight', 9, 4097, 4, 0), ('left', 16, 40000, 5, -1)])
 def test_accumulating_rollout_equals_the_two_pass_summary(task, N, B, H, tile):
     """ABI 5: the episodic summary collected by the rollout launches themselves (eb_rollout_step_acc: per-block float64 records,
-    DPP wave reduction; eb_episode_acc_finish: one fold) — same rows and outputs as eb_rollout_step bit for bit, the 8 floats
-    of eb_episode_summary over the same out5 (sums rtol 1e-6, count and maximum equal), at every tile shape, ragged last tiles,
-    twice in a row in one workspace (a rollout's first launch overwrites it), and through the plan's two forms."""
+    DPP wave reduction, a step's record made by the next step's launch; eb_episode_acc_finish: one fold) — same rows and outputs
+    as eb_rollout_step bit for bit, the 8 floats of eb_episode_summary over the same out5 (sums rtol 1e-6, count and maximum equal),
+    at every tile shape, ragged last tiles, one-step rollouts, twice in a row in one workspace (nothing is read from it), and through
+    the plan's two forms."""
     host, dev = _pair(task, n_veh=N)
     if tile >= 0:
         dev.set_tile(tile)
@@ -290,7 +291,7 @@ def test_accumulating_rollout_equals_the_two_pass_summary(task, N, B, H, tile):
     obs0 = _initial_obs(host, inp)
     out_t, o5_t = dev.rollout_tape(obs0, inp['actions'], inp['ref_idx'])
     want = host.episode_summary(o5_t, out_t)
-    acc = dev.acc_workspace(B)
+    acc = dev.acc_workspace(B, H)
     for _ in range(2):
         out_d, o5_d, s8 = dev.rollout_acc(obs0, inp['actions'], inp['ref_idx'], acc=acc)
         assert np.array_equal(out_d, out_t) and np.array_equal(o5_d, o5_t)
@@ -432,6 +433,25 @@ def test_g6_env_logic_on_gpu(task):
     assert np.array_equal(done == 1, g['collision'] != 0)
 
 
+@pytest.mark.parametrize('task', TASKS)
+def test_g6_ego_dynamics_on_gpu(task):
+    """a15: eb_ego_dynamics on the GPU — the device functions judge_bits runs (ego_r_bound, ego_corner) — equals the oracle bit for
+    bit and the reference's own `_get_ego_dynamics` outputs (fixture G6: r_bound, Corner_point) within north_star's tolerance;
+    the batched facade hands the same values out."""
+    g = golden('g6_env_logic_%s' % task)
+    host, dev = _pair(task)
+    got, want = dev.ego_dynamics(g['ego'], g['params']), host.ego_dynamics(g['ego'], g['params'])
+    assert np.array_equal(got, want)
+    close(got[:, 2], g['r_bound'], 1e-5, 0.0, 'GPU G6 _get_ego_dynamics r_bound')
+    close(got[:, 3:].reshape(-1, 4, 2), g['corners'], 1e-5, 2e-5, 'GPU G6 _get_ego_dynamics corner points')
+    rng = np.random.default_rng(3)                              # and on random states, incl. v_x = 0 (r_bound = miu g / 1e-8)
+    ego = np.stack([rng.uniform(0, 9, 5000), rng.normal(0, 1, 5000), rng.normal(0, 1, 5000), rng.uniform(-60, 60, 5000),
+                    rng.uniform(-60, 60, 5000), rng.uniform(-400, 400, 5000)], 1).astype(np.float32)
+    ego[::50, 0] = 0.0
+    par = np.stack([rng.normal(0, 0.1, 5000), rng.normal(0, 0.1, 5000), rng.uniform(0.2, 0.8, 5000), rng.uniform(0.2, 0.8, 5000)], 1).astype(np.float32)
+    assert np.array_equal(dev.ego_dynamics(ego, par), host.ego_dynamics(ego, par))
+
+
 def test_g7_config1_single_env_200_steps_on_gpu():
     """BASELINE configs[0] on the GPU: one env, 8 vehicles, 200 steps, against the reference's trace."""
     g = golden('g7_config1_left')
@@ -560,6 +580,109 @@ def test_env_step_with_auto_reset(task, B, M, NV, nf, vln, tile):
     _compare_auto_reset(want, got, B, 'auto reset')
 
 
+@pytest.mark.parametrize('task,B,M', [('left', 700, 16), ('right', 130, 20), ('straight', 260, 60)])
+@pytest.mark.parametrize('tile', [0, 1, 2])
+def test_env_step_with_the_episode_step_limit(task, B, M, tile):
+    """ABI 5, eb_time_limit in the step's own launch (wave 3 keeps the counts next to the ego-only done predicates): gym's TimeLimit
+    around the registered env (README.md:55-59) — asserted against the plain step inside the case, against the oracle's composite
+    here; with the reset of the finished (incl. truncated) envs in the same launch; every tile shape."""
+    from tests._env_step_check import time_limit_case
+    want = time_limit_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B, M)
+    got = time_limit_case(lambda t, **kw: DeviceModel(t, **kw), task, B, M, tile=tile)
+    _compare_auto_reset(want[:12], got[:12], B, 'time limit + auto reset')
+    assert np.array_equal(want[12], got[12])
+
+
+def test_parked_ego_is_truncated_at_the_step_limit_on_gpu():
+    """201 closed-loop steps of an ego parked on its approach lane: no reference predicate ever fires; code 7 at step 200"""
+    from tests._env_step_check import parked_ego_case
+    want = parked_ego_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw))
+    got = parked_ego_case(lambda t, **kw: DeviceModel(t, **kw))
+    assert np.array_equal(want, got)
+
+
+def test_time_limit_on_the_separate_launch_path():
+    """candidates that are not 16-byte aligned: the step's separate launches + the time-limit kernel — the one-launch kernel's bits"""
+    import ctypes as C
+    import torch
+    task, B, M = 'left', 300, 12
+    native = VEHICLE_MODE_LIST[task]
+    modes = [native[i % len(native)] for i in range(M)]
+    ego, cand, _, _, light, _, ref = _random_scene(task, B, M, 23)
+    cmode = np.tile(np.array([_capi.VMODE_ID[m] for m in modes], np.uint8), (B, 1))
+    rng = np.random.default_rng(4)
+    raw = rng.uniform(-1.2, 1.2, (B, 2)).astype(np.float32)
+    steps = rng.integers(0, 9, B).astype(np.int32)
+    m, tr = DeviceModel(task, mode='training'), DeviceModel(task, n_veh=M, modes=modes)
+    obs0 = m.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    want = m.env_step(tr, obs0, raw, ego, cand, cmode, ref_idx=ref, v_light=light, time_limit=(steps, 7))
+    t, p = torch, lambda x: C.c_void_p(x.data_ptr())
+    big = m._in(np.concatenate([np.zeros(1, np.float32), cand.ravel()]))
+    c_io = big[1:].view(B, M, 4)                                          # 4 bytes off a 16-byte boundary
+    assert c_io.data_ptr() % 16 != 0
+    e_io, ob, rw, ri = m._in(ego.copy()), m._in(obs0), m._in(raw), m._in(ref, np.int32)
+    cm, vl, es = m._in(cmode, np.uint8), m._in(light, np.uint8), m._in(steps, np.int32)
+    par, sc, out5, dd = m._out((B, 4)), m._out((B, 2)), m._out((5, B)), m._out((16, B))
+    obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
+    tl = _capi.EbTimeLimit(es.data_ptr(), 7)
+    m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), None, p(sc), p(out5), p(dd),
+                   p(obs_o), p(code), None, None, None, C.byref(tl), m.stream)
+    t.cuda.synchronize()
+    got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code, es)]
+    assert (got[7] == 7).any() and (got[7] == 0).any()
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w), k
+
+
+@pytest.mark.parametrize('traffic', ['pool', 'flows'])
+def test_facade_episode_step_limit(traffic):
+    """make('CrossroadEnd2end-v0') = the env inside its registered step limit (README.md:55-59): done_type 'time_limit' and
+    info['TimeLimit.truncated'] when nothing else ended the episode, the count kept on the device, restarted by every reset —
+    with the reset in the step's launch (pool), composed by the facade (flows), and issued by the caller."""
+    from env_build_amd.endtoend import MAX_EPISODE_STEPS, make
+    assert MAX_EPISODE_STEPS == 200
+    assert make(training_task='left', n_env=4).max_episode_steps == 200
+    with pytest.raises(ValueError):
+        make('CartPole-v0')
+    B, L = 300, 6
+    env = make(training_task='left', n_env=B, mode='training', traffic=traffic, auto_reset=True, max_episode_steps=L)
+    man = make(training_task='left', n_env=B, mode='training', traffic=traffic, max_episode_steps=L)
+    for e in (env, man):
+        e.seed(9)
+        e.reset()
+        e.reset()
+    assert (env._episode_step.cpu().numpy() == 0).all()
+    count = np.zeros(B, np.int64)
+    rng = np.random.default_rng(2)
+    n_trunc = 0
+    for t in range(3 * L + 2):
+        act = rng.uniform(-0.3, 0.3, (B, 2)).astype(np.float32)
+        _, _, done, info = env.step(act)
+        _, _, done_m, info_m = man.step(act)
+        code = env.done_type.numpy()
+        count += 1
+        trunc = info['TimeLimit.truncated'].numpy() != 0
+        assert np.array_equal(trunc, code == 7) and np.array_equal(done.numpy() != 0, code != 0)
+        assert np.array_equal(trunc, (count >= L) & ~np.isin(code, [1, 2, 3, 4, 5, 6]))
+        count[code != 0] = 0
+        assert np.array_equal(env._episode_step.cpu().numpy(), count)
+        assert np.array_equal(man.done_type.numpy(), code) and np.array_equal(info_m['TimeLimit.truncated'].numpy() != 0, trunc)
+        man.reset(mask=done_m)
+        assert np.array_equal(man._episode_step.cpu().numpy(), count)
+        n_trunc += int(trunc.sum())
+    assert n_trunc > B                                                    # most envs ran into the limit, more than once
+    one = make(training_task='left', max_episode_steps=3)                 # the reference-shaped single env
+    one.reset()
+    for t in range(3):
+        _, _, d, info = one.step(np.array([0.0, 0.0], np.float32))
+        assert info['TimeLimit.truncated'] is (one.done_type == 'time_limit') and d == int(one.done_type != 'not_done_yet')
+        if d:
+            break
+    assert d == 1 and (one.done_type == 'time_limit') == (t == 2 and info['TimeLimit.truncated'])
+    one.reset()
+    assert int(one._episode_step.item()) == 0
+
+
 def test_auto_reset_argument_checks_on_the_gpu():
     from tests._env_step_check import auto_reset_bad_args_case
     auto_reset_bad_args_case(lambda t, **kw: DeviceModel(t, **kw))
@@ -600,7 +723,7 @@ def test_auto_reset_on_the_separate_launch_path():
     rs = _capi.EbRespawn(en.data_ptr(), 0.0, 60.0, 8.0, 4242, 17, 5.0)
     a = _capi.EbAutoReset(99, 5, 1, ri.data_ptr(), vf.data_ptr(), vl.data_ptr(), rs, fo.data_ptr())
     m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), p(vf), p(sc), p(out5), p(dd),
-                   p(obs_o), p(code), None, C.byref(a), None, m.stream)
+                   p(obs_o), p(code), None, C.byref(a), None, None, m.stream)
     t.cuda.synchronize()
     got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code, ri, vf, vl, fo)]
     for k, (g, w) in enumerate(zip(got, want)):
@@ -671,7 +794,7 @@ def test_env_step_separate_launches_equal_the_one_launch_kernel():
     obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
     rs = _capi.EbRespawn(en.data_ptr(), 65.0, 60.0, 8.0, 77, 3)
     m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), None, p(sc), p(out5), p(dd),
-                   p(obs_o), p(code), C.byref(rs), None, None, m.stream)
+                   p(obs_o), p(code), C.byref(rs), None, None, None, m.stream)
     t.cuda.synchronize()
     got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code)]
     for k, (g, w) in enumerate(zip(got, want)):
@@ -780,6 +903,7 @@ def test_facade_auto_reset_over_the_flow_source(copy_outputs):
         assert np.array_equal(oa.numpy(), ob2.numpy()), t
         assert np.array_equal(ia['final_observation'].numpy()[fin], term[fin])
         assert np.array_equal(a.done_type.numpy() != 0, fin)                   # done_type stays the step's
+        assert np.array_equal(a.done_code.cpu().numpy() != 0, fin)             # ... and so does the public done_code array
         for k in ('_ego', '_params', '_cand_mode', '_ref_idx', '_virtual', '_v_light'):
             assert np.array_equal(getattr(a, k).cpu().numpy(), getattr(b, k).cpu().numpy()), (t, k)
         on = a._cand_mode.cpu().numpy() != 255          # (a vacant slot keeps whatever record it held last: the constructors' warm-up

@@ -3,7 +3,8 @@ equals its own single calls — the same check the GPU suite runs on the one-lau
 import pytest
 
 from tests._env_step_check import (CASES, auto_reset_bad_args_case, auto_reset_case, composite_case, flow_rule_bad_args_case,
-                                   flow_rule_case, masked_obs_case, reset_pool_case, respawn_conflict_case, wrap_guard_case)
+                                   flow_rule_case, masked_obs_case, parked_ego_case, reset_pool_case, respawn_conflict_case,
+                                   time_limit_case, wrap_guard_case)
 from tests._helpers import HostModel
 
 
@@ -31,6 +32,16 @@ def test_oracle_reset_pool_composite(oracle, task):
 def test_oracle_step_with_auto_reset(oracle, task, B, M, NV, nf, vln):
     """ABI 4: eb_env_step(auto_reset) == eb_env_step + terminal rows + eb_env_reset_pool(mask = done != 0)"""
     auto_reset_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B, M, NV=NV, nf=nf, v_light_none=vln)
+
+
+@pytest.mark.parametrize('task,B,M', [('left', 400, 16), ('right', 130, 20)])
+def test_oracle_step_with_the_episode_step_limit(oracle, task, B, M):
+    """ABI 5: eb_time_limit = gym's TimeLimit around the registered env (README.md:55-59, max_episode_steps = 200)"""
+    time_limit_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B, M)
+
+
+def test_oracle_parked_ego_is_truncated_at_the_step_limit(oracle):
+    parked_ego_case(lambda t, **kw: HostModel(oracle, t, **kw))
 
 
 def test_oracle_auto_reset_argument_checks(oracle):
@@ -65,7 +76,7 @@ def test_reset_pool_refuses_a_mask_that_is_an_output(oracle):
     cand, cmode, obs, entry = f32(B, M, 4), np.zeros((B, M), np.uint8), f32(B, m.D), f32(M, 5)
     rule = _capi.EbRespawn(entry.ctypes.data, 0.0, 60.0, 8.0, 1, 1, 5.0)
     p = lambda a: C.c_void_p(a.ctypes.data)
-    args = lambda mask, dc: (m.h, tr.h, B, p(mask), C.c_uint64(1), C.c_uint64(1), 1, p(ego), p(params), p(ref), p(virt), p(vl), p(dc), M, p(cand),
+    args = lambda mask, dc: (m.h, tr.h, B, p(mask), C.c_uint64(1), C.c_uint64(1), 1, p(ego), p(params), p(ref), p(virt), p(vl), p(dc), None, M, p(cand),
                              p(cmode), C.byref(rule), p(obs), None, None, None)
     with pytest.raises(ValueError, match='mask must not be'):          # EB_EINVAL surfaces as ValueError (_capi.check)
         oracle.env_reset_pool(*args(done, done))
