@@ -525,7 +525,7 @@ def env_step_alg_bytes(D, m_cand):
     return 8 * D + 33 * m_cand + 105
 
 
-def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
+def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40, tile=None, waves=0):
     """The env-side step (E2E:132-144 = action scaling, reward, ego step, traffic step, observation,
     done code, pool re-entry) through the raw C entry eb_env_step: pre-allocated ping-pong observation buffers, no Python
     allocation in the loop.  `reps` segments of `seg` steps from the same reset state (restored between segments, outside
@@ -537,6 +537,10 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40):
     env.seed(0)
     env.reset()
     api, lib = env.api, env.api.lib
+    if tile is not None:      # tuning aids (scripts/sweep_env_tile.py): eb_debug_set_tile / eb_debug_set_env_waves on the env's handle
+        api.debug_set_tile(env._h, int(tile))
+    if waves:
+        api.debug_set_env_waves(env._h, int(waves))
     B, M, D = n_env, env.n_cand, env.obs_dim
     g = torch.Generator(device='cpu').manual_seed(3)
     tape = torch.stack([torch.rand((seg, B), generator=g) * 0.6 - 0.3, torch.rand((seg, B), generator=g) * 0.8 - 0.2], 2).to(dev).contiguous()

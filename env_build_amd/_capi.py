@@ -113,7 +113,9 @@ PROTOTYPES = {
                                         C.c_uint64, C.c_uint64, _P, _P, _P]),
     'eb_debug_set_tile': (C.c_int, [_P, _I]),
     'eb_debug_set_tape_stepwise': (C.c_int, [_P, _I]),
-    'eb_debug_set_trace': (C.c_int, [_P, _P]),
+    'eb_debug_set_trace': (C.c_int, [_P, _P, C.c_int64]),
+    'eb_debug_set_stage_paths': (C.c_int, [_P, _I]),
+    'eb_debug_set_env_waves': (C.c_int, [_P, _I]),
     'eb_traffic_flow_step': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                        _I, C.c_uint64, C.c_uint64, _P, _P, _P]),
     'eb_mlp_create': (C.c_int, [C.POINTER(EbMlpConfig), C.POINTER(_P)]),

@@ -53,6 +53,9 @@ struct eb_handle_s {
     eb::VehModes modes;
     int modes_set;
     long long* trace;         // profiling aid, see eb_debug_set_trace
+    long long trace_words;    //   its capacity in 64-bit words
+    int stage_paths;          // -1 = by grid size; 0 / 1: the tape / gated kernels' LDS copy of the path tables off / on (eb_debug_set_stage_paths)
+    int env_waves;            // 0 = by grid size; 4 / 8: waves per block of the one-launch env step (eb_debug_set_env_waves)
     eb::ExitConsts xc;        // cos / sin of the exit angles (eb_get_obs with exit ids, eb_exit_frame)
     hipStream_t gate_stream;  // producer stream of gated rollouts (high priority: a hardware queue of its own), made on first use
     hipEvent_t gate_event;    // orders eb_gate_feed behind the caller's stream (after_stream)
@@ -151,6 +154,7 @@ int eb_create(const eb_config* cfg, eb_handle* out) {
     std::memset(h, 0, sizeof *h);
     h->cfg = *cfg;
     h->tile_variant = -1;
+    h->stage_paths = -1;
     {   // rotate_coordination's coordi_rotate_d * math.pi / 180 and math.cos / math.sin (UTL:130-132), by the host's libm
         const int ang[4] = {0, 90, 180, -90};   // multi_ego.py:33
         for (int k = 0; k < 4; ++k) {
@@ -398,7 +402,7 @@ struct GateArgs {
 };
 // the episodic accumulator of an accumulating rollout step (eb_rollout_step_acc, plans with a summary): the workspace holds the
 // per-step records [horizon][blocks][ACC_RECORD_DOUBLES], then the last launch's (sum, max) pairs [blocks][2], then a byte per env
-// (the CPU library keeps its per-env flags there) — `blocks` = the grid of the SMALLEST tile shape, so any shape fits
+// and 64 more (the CPU library keeps 8 doubles and its per-env flags there) — `blocks` = the grid of the SMALLEST tile shape, so any shape fits
 struct AccArgs {
     void* workspace;
     int step, horizon;
@@ -412,7 +416,7 @@ static size_t acc_blocks_max(eb_handle h, int32_t n_env) {
     return (size_t)((n_env + e - 1) / e);
 }
 static size_t acc_workspace_bytes(eb_handle h, int32_t n_env, int32_t horizon) {
-    return acc_blocks_max(h, n_env) * ((size_t)horizon * eb::ACC_RECORD_DOUBLES + 2) * sizeof(double) + (size_t)n_env;
+    return acc_blocks_max(h, n_env) * ((size_t)horizon * eb::ACC_RECORD_DOUBLES + 2) * sizeof(double) + (size_t)n_env + 64;
 }
 static double* acc_records(void* ws, int step, size_t grid) {
     return reinterpret_cast<double*>(ws) + (size_t)step * grid * eb::ACC_RECORD_DOUBLES;
@@ -421,8 +425,7 @@ static double* acc_finals(void* ws, int horizon, size_t grid) {
     return reinterpret_cast<double*>(ws) + (size_t)horizon * grid * eb::ACC_RECORD_DOUBLES;
 }
 static int pick_variant(eb_handle h, int32_t n_env) {
-    static const int forced = std::getenv("EB_ROLLOUT") ? std::atoi(std::getenv("EB_ROLLOUT")) : -1;   // tuning aid: tile shape
-    int variant = h->tile_variant >= 0 ? h->tile_variant : forced;
+    int variant = h->tile_variant;                                        // eb_debug_set_tile
     if (variant < 0 || variant > 2) {
         // the largest tile that still gives every CU two blocks; small batches take small tiles
         variant = 2;
@@ -436,10 +439,9 @@ static int pick_variant(eb_handle h, int32_t n_env) {
 
 // Small grids (at most two blocks per CU) keep the stride-10 path tables in LDS for the whole launch: their steps are bound
 // by the env wave's chain of dependent table reads, not by throughput.  Larger ones leave the LDS to occupancy.  ONE
-// decision for the launch (rollout_fused) and for the residency query (gated_blocks): EB_STAGE_PATHS=0 / 1 forces it.
+// decision for the launch (rollout_fused) and for the residency query (gated_blocks): eb_debug_set_stage_paths forces it.
 static bool stage_paths_in_lds(eb_handle h, int grid) {
-    static const int stage = std::getenv("EB_STAGE_PATHS") ? std::atoi(std::getenv("EB_STAGE_PATHS")) : -1;   // tuning aid
-    return stage < 0 ? grid <= 2 * h->n_cu : stage != 0;
+    return h->stage_paths < 0 ? grid <= 2 * h->n_cu : h->stage_paths != 0;
 }
 
 static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* obs_in, const float* actions,
@@ -468,7 +470,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     A.training = h->cfg.mode == EB_MODE_TRAINING;
     A.actions_raw = actions_raw;
     A.do_rewards = do_rewards;
-    A.trace = h->trace;
+    A.trace = h->trace; A.trace_words = h->trace_words;
     if (gate) {
         A.gate_ready = gate->ready; A.gate_done = gate->done; A.gate_obs = gate->obs_steps; A.gate_status = gate->status;
         A.gate_spin = gate->spin;
@@ -590,12 +592,11 @@ static int rollout_tape_stepwise(eb_handle h, int32_t n_env, int32_t horizon, co
 }
 
 // Open loop over a tape: ONE launch of the tape kernel (state in registers across the steps); bit-identical to the
-// H per-step launches (EB_TAPE_STEPWISE=1 forces those, for A/B checks).
+// H per-step launches (eb_debug_set_tape_stepwise forces those, for A/B checks).
 static int rollout_tape_any(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in, const float* action_tape,
                             const int32_t* ref_idx, int32_t path_id, float* obs_work, float* obs_out, float* out5_steps,
                             hipStream_t s, int storage_f16) {
-    static const int stepwise = std::getenv("EB_TAPE_STEPWISE") ? std::atoi(std::getenv("EB_TAPE_STEPWISE")) : 0;
-    if (stepwise || h->tape_stepwise)
+    if (h->tape_stepwise)
         return rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, s,
                                      storage_f16);
     return rollout_common(h, n_env, obs_in, action_tape, ref_idx, path_id, obs_out, out5_steps, nullptr, 1, 1, s, storage_f16,
@@ -820,7 +821,8 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
     // (exit ids live in device memory: the kernel masks them to 0..3 instead of a host-side range check)
     EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
                               ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, pick(h, stream),
-                              nullptr, nullptr, nullptr, exit_id, &h->xc, row_mask, nullptr, forced_env_tile(h)));
+                              nullptr, nullptr, nullptr, exit_id, &h->xc, row_mask, nullptr, forced_env_tile(h), h->env_waves, h->trace,
+                              h->trace_words));
     return EB_OK;
 }
 
@@ -897,8 +899,8 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         A.obs = obs; A.raw = actions; A.ref_idx = ref_idx; A.ego = ego; A.params = params; A.cand = cand; A.cand_mode = cand_mode;
         A.cand_lw = cand_lw; A.v_light = v_light; A.virtual_flag = virtual_flag; A.scaled = scaled_actions; A.out5 = out5;
         A.d16 = out_dict16; A.obs_out = obs_out; A.done_code = done_code;
-        A.trace = h->trace;
-        A.tile_envs = forced_env_tile(h);
+        A.trace = h->trace; A.trace_words = h->trace_words;
+        A.tile_envs = forced_env_tile(h); A.waves = h->env_waves;
         if (respawn) {
             A.respawn_entry = respawn->entry; A.limit = respawn->limit; A.span = respawn->span; A.v_max = respawn->v_max;
             A.seed = respawn->seed; A.counter = respawn->counter;
@@ -1014,7 +1016,7 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
                                  episode_step};
         EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ref_idx, 0,
                                   m_cand, cand, cand_mode, nullptr, virtual_flag, obs, pick(h, stream), nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, mask, &R, forced_env_tile(h)));
+                                  nullptr, mask, &R, forced_env_tile(h), h->env_waves, h->trace, h->trace_words));
         return EB_OK;
     }
     hipStream_t s = pick(h, stream);
@@ -1042,9 +1044,22 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
 
 // Diagnostics (include/envbuild.h, last section): device buffer of [n_waves][8] int64 that the rollout kernel
 // fills with per-wave wall-clock marks (100 MHz) — scripts/trace_rollout.py.  NULL switches it off.
-int eb_debug_set_trace(eb_handle h, long long* device_buf) {
-    if (!h) return fail(EB_EINVAL, "eb_debug_set_trace: null handle");
+int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words) {
+    if (!h || (device_buf && capacity_words < 0)) return fail(EB_EINVAL, "eb_debug_set_trace: bad argument");
     h->trace = device_buf;
+    h->trace_words = device_buf ? capacity_words : 0;
+    return EB_OK;
+}
+
+int eb_debug_set_stage_paths(eb_handle h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return fail(EB_EINVAL, "eb_debug_set_stage_paths: bad argument (-1 = by grid size, 0 = off, 1 = on)");
+    h->stage_paths = mode;
+    return EB_OK;
+}
+
+int eb_debug_set_env_waves(eb_handle h, int32_t waves) {
+    if (!h || (waves != 0 && waves != 4 && waves != 8)) return fail(EB_EINVAL, "eb_debug_set_env_waves: bad argument (0 = by grid size, 4, 8)");
+    h->env_waves = waves;
     return EB_OK;
 }
 

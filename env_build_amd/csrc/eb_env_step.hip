@@ -31,8 +31,6 @@
 // Nothing but the tile's LDS is shared between waves: no cross-block traffic, no XCD consideration beyond "a tile's lines
 // belong to one workgroup".  The arithmetic is the same device functions the single-entry kernels run (eb_env_device.h,
 // eb_device.h): bit-identical to the six (seven) calls — tests/_env_step_check.py holds it to that.
-#include <cstdlib>
-
 #include "eb_env_device.h"
 
 #pragma clang fp contract(off)
@@ -102,7 +100,10 @@ bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float
 }
 
 // profiling aid (eb_debug_set_trace on the model handle): slot k of this wave's row [16] <- the 100 MHz wall clock, lane 0 only
-#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
+// (rows of 16 words, one per wave: [n_blocks * NW][16] — NW is 4 or 8 by grid size, so a caller sizes the buffer for 8 and passes
+// its capacity; a mark past the capacity is dropped)
+#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) { const long long w_ = ((long long)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (k); \
+                        if (w_ < A.trace_words) A.trace[w_] = wall_clock64(); } } while (0)
 
 // A per-wave queue of 16-bit item ids: `hit` lanes append (ballot / mbcnt), and whenever 64 are waiting the wave runs
 // `body(item)` on a full set of lanes; flush() runs the rest.
@@ -1059,10 +1060,6 @@ __global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(const EnvStepAr
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
-    static const int force = std::getenv("EB_ENV_TILE") ? std::atoi(std::getenv("EB_ENV_TILE")) : 0;   // tuning aid
-    if (force == 16 || force == 32 || force == 64) ET = force;
-    static const int rforce = std::getenv("EB_RESET_TILE") ? std::atoi(std::getenv("EB_RESET_TILE")) : 0;   // tuning aid (the masked reset only)
-    if (A.reset && (rforce == 16 || rforce == 32 || rforce == 64)) ET = rforce;
     if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0) > 150 * 1024) ET = 16;     // a forced shape that does not fit
     const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0);
     int dev = 0;
@@ -1070,8 +1067,8 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     dev = dev < 0 || dev >= 64 ? 0 : dev;
     hipError_t e = hipSuccess;
     // eight waves per block at small and medium batches (16- / 32-env tiles: few blocks per CU, the launch is a wave's instruction
-    // stream) — the step, the observation and the masked reset alike —, four otherwise; EB_ENV_WAVES=4 switches it off (tuning aid)
-    static const int wforce = std::getenv("EB_ENV_WAVES") ? std::atoi(std::getenv("EB_ENV_WAVES")) : 0;
+    // stream) — the step, the observation and the masked reset alike —, four otherwise; A.waves = 4 / 8 forces it (eb_debug_set_env_waves)
+    const int wforce = A.waves;
     static int n_cu[64];
     if (!n_cu[dev]) {
         int cu = 0;

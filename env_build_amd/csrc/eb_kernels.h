@@ -38,6 +38,7 @@ struct FusedArgs {
     int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
     int do_rewards;            // 0: compute_next_obses only
     long long* trace;          // profiling aid (eb_debug_set_trace): [n_waves][8] s_memrealtime marks, or NULL
+    long long trace_words;     //   its capacity in 64-bit words: a mark past it is dropped
     // step gates of eb_rollout_gated (tape kernel only; all NULL / 0 otherwise)
     const unsigned* gate_ready;   // [horizon]: step t may start once gate_ready[t] != 0 (written by the action producer)
     unsigned* gate_done;          // [horizon]: += 1 per block once step t's outputs are visible device-wide
@@ -113,7 +114,8 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
                           float* obs_out, hipStream_t s, const float* params = nullptr, const float* cand_lw = nullptr,
                           uint8_t* done_code = nullptr, const uint8_t* exit_id = nullptr, const ExitConsts* xc = nullptr,
                           const uint8_t* row_mask = nullptr, const EnvResetArgs* reset = nullptr,
-                          int tile_envs = 0);   // tile_envs: EnvStepArgs::tile_envs for the one-launch machinery
+                          int tile_envs = 0, int env_waves = 0, long long* trace = nullptr, long long trace_words = 0);
+                          // tile_envs / env_waves / trace: EnvStepArgs::tile_envs / waves / trace for the one-launch machinery
 hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const ExitConsts& xc, const float* ego, float* out,
                              hipStream_t s);
 hipError_t launch_env_reset(int task, int n_env, const PathTables& pt, const uint8_t* mask, uint64_t seed, uint64_t counter,
@@ -166,7 +168,9 @@ struct EnvStepArgs {
     const float* respawn_entry;            // NULL: no re-entry stage
     float limit, span, v_max;
     uint64_t seed, counter;
-    long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * 4][8] wall-clock marks, or NULL
+    long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * waves per block (4 or 8)][16] wall-clock marks, or NULL
+    long long trace_words;                 //   its capacity in 64-bit words: a mark past it is dropped
+    int waves;                             // 0: by grid size (launch_env_step); 4 / 8: forced (eb_debug_set_env_waves)
     int obs_only;                          // 1: eb_get_obs — ego / cand are inputs, only obs_out is written
     const uint8_t* row_mask;               // obs_only: nullable [n_env]; rows with a zero byte are left alone
     int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 32 / 64: forced (eb_debug_set_tile 2 / 1 / 0)

@@ -543,14 +543,22 @@ int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const u
                           uint64_t seed, uint64_t counter, uint8_t* cand_mode, uint8_t* v_light, void* stream);
 
 /* ---- diagnostics (tests and profiling scripts; no reference counterpart) ----
+ * Every tuning knob of the HIP library is a setting of the HANDLE (ABI 5: no environment variable is read by the library).
  * eb_debug_set_tile: force the rollout kernel's tile shape — 0: 2048-record tiles, 1: 1024, 2: 256; -1: by batch size
- * (every shape computes the same bits); the one-launch eb_env_step takes 64- / 32- / 16-env tiles for 0 / 1 / 2 and
- * picks by batch size otherwise.  eb_debug_set_tape_stepwise: 1 = eb_rollout_tape[_f16] as `horizon` per-step
- * launches, 0 = the one-launch tape kernel.  eb_debug_set_trace: device buffer [n_waves][8] int64 the rollout kernel ([n_blocks * 4][16] for the one-launch env step)
- * fills with wall-clock marks (NULL = off).  The oracle accepts and ignores all three. */
+ * (every shape computes the same bits); the one-launch eb_env_step / eb_get_obs / eb_env_reset_pool take 64- / 32- / 16-env
+ * tiles for 0 / 1 / 2 and pick by batch size otherwise.  eb_debug_set_env_waves: 4 / 8 waves per block of those kernels
+ * (0: eight on grids of at most three blocks per CU with tiles of at most 32 envs, four otherwise).  eb_debug_set_tape_stepwise:
+ * 1 = eb_rollout_tape[_f16] as `horizon` per-step launches, 0 = the one-launch tape kernel.  eb_debug_set_stage_paths: the tape /
+ * gated kernels' LDS copy of the stride-10 path tables on (1) / off (0) / by grid size (-1).
+ * eb_debug_set_trace: a device buffer of capacity_words int64 the kernels fill with wall-clock marks (NULL = off): the rollout
+ * kernel writes rows of 8 words, one per wave — [n_blocks * waves per block][8] —, the one-launch env step rows of 16 —
+ * [n_blocks * W][16] with W = 4 or 8 as above: size it for 8.  A mark that would land at or past capacity_words is dropped.
+ * The oracle accepts and ignores all of them. */
 int eb_debug_set_tile(eb_handle h, int32_t variant);
+int eb_debug_set_env_waves(eb_handle h, int32_t waves);
 int eb_debug_set_tape_stepwise(eb_handle h, int32_t on);
-int eb_debug_set_trace(eb_handle h, long long* device_buf);
+int eb_debug_set_stage_paths(eb_handle h, int32_t mode);
+int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words);
 
 /* ---- the policy in the loop: MLPNet + LoadPolicy.run_batch + the safety shield ----
  *

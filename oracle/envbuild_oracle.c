@@ -1218,7 +1218,7 @@ static size_t acc_bytes(const eb_config* c, int32_t n_env, int32_t horizon) {
     int e = 256 / c->n_veh;                    /* the HIP library's smallest tile (its formula: the two must agree) */
     if (e < 1) e = 1;
     if (e > 64) e = 64;
-    return (size_t)((n_env + e - 1) / e) * ((size_t)horizon * 4 + 2) * sizeof(double) + (size_t)n_env;
+    return (size_t)((n_env + e - 1) / e) * ((size_t)horizon * 4 + 2) * sizeof(double) + (size_t)n_env + 64;
 }
 int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int32_t horizon, int64_t* bytes) {
     if (!h || n_env < 0 || horizon < 0 || !bytes) return fail(EB_EINVAL, "eb_episode_acc_bytes: bad argument");
@@ -1685,7 +1685,9 @@ int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const u
 /* diagnostics of the HIP library: accepted and ignored here */
 int eb_debug_set_tile(eb_handle h, int32_t variant) { (void)variant; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_tile: null handle"); }
 int eb_debug_set_tape_stepwise(eb_handle h, int32_t on) { (void)on; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_tape_stepwise: null handle"); }
-int eb_debug_set_trace(eb_handle h, long long* device_buf) { (void)device_buf; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_trace: null handle"); }
+int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words) { (void)device_buf; (void)capacity_words; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_trace: null handle"); }
+int eb_debug_set_stage_paths(eb_handle h, int32_t mode) { (void)mode; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_stage_paths: null handle"); }
+int eb_debug_set_env_waves(eb_handle h, int32_t waves) { (void)waves; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_env_waves: null handle"); }
 
 int eb_traffic_flow_step(eb_handle h, int32_t n_env, int32_t per_route, float* cand, uint8_t* active, float* timer,
                          int32_t* emitted, int32_t* sim_step, const float* lane, const float* period,

@@ -2,8 +2,9 @@
 """Randomised parity sweep (not part of the test suite) of the two ABI-4 forms of eb_env_step: auto_reset (the step that resets
 the envs it finished, against step + final rows + eb_env_reset_pool, and against the CPU oracle) and flow (the step that carries
 the flow source's rule, against step + eb_traffic_flow_step over a closed loop, and against the CPU oracle) — random task, env
-count, candidate / slot counts, future points, tile shape, collision density, light programme.  (The library reads EB_ENV_WAVES
-once per process: run the sweep a second time under EB_ENV_WAVES=4 for the four-wave blocks at these sizes.)"""
+count, candidate / slot counts, future points, tile shape, collision density, light programme.  --waves 4 / 8 forces the waves
+per block of the one-launch kernels (eb_debug_set_env_waves): run the sweep a second time with --waves 4 for the four-wave blocks
+at these sizes."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,8 +12,9 @@ import numpy as np
 from tests._helpers import DeviceModel, HostModel, oracle_lib
 from tests._env_step_check import auto_reset_case, flow_rule_case
 
-ap = argparse.ArgumentParser(); ap.add_argument('--seconds', type=float, default=120.0); ap.add_argument('--seed', type=int, default=0)
+ap = argparse.ArgumentParser(); ap.add_argument('--seconds', type=float, default=120.0); ap.add_argument('--seed', type=int, default=0); ap.add_argument('--waves', type=int, default=0)
 a = ap.parse_args()
+DeviceModel.ENV_WAVES = a.waves
 rng = np.random.default_rng(a.seed)
 on_gpu, on_cpu = (lambda t, **kw: DeviceModel(t, **kw)), (lambda t, **kw: HostModel(oracle_lib(), t, **kw))
 t_end = time.time() + a.seconds

@@ -6,23 +6,26 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from env_build_amd import _capi
 from env_build_amd.endtoend import CrossroadEnd2end
-ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16); ap.add_argument('--auto', action='store_true'); ap.add_argument('--wild', action='store_true', help='full-range random actions: many envs finish per step (the reset tail runs in most tiles)')
+ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16); ap.add_argument('--auto', action='store_true'); ap.add_argument('--waves', type=int, default=0, help='eb_debug_set_env_waves: 4 / 8 waves per block (0: by grid size)'); ap.add_argument('--wild', action='store_true', help='full-range random actions: many envs finish per step (the reset tail runs in most tiles)')
 a = ap.parse_args()
 B = a.n_env
 env = CrossroadEnd2end('left', n_env=B, multi_display=True, traffic='pool', n_cand=a.n_cand, auto_reset=a.auto, copy_outputs=False)
 env.seed(0); env.reset()
 act = (torch.rand((B, 2), device=env.device) * (2.0 if a.wild else 0.6) - (1.0 if a.wild else 0.3)).contiguous()
 lib = env.api.lib
-lib.eb_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
+env.api.debug_set_env_waves(env._h, a.waves)
 for _ in range(40 if a.wild else 3): env.step(act)
 torch.cuda.synchronize()
 te = 16 if B <= 1024 else 32 if B <= 20480 else 64
 nb = (B + te - 1) // te
-nw = 8 if (te <= 32 and nb <= 768 and os.environ.get('EB_ENV_WAVES') != '4') else 4      # waves per block of the step kernel (csrc/eb_env_step.hip: launch_env_step)
-trs = [torch.zeros((nb * nw, 16), dtype=torch.int64, device=env.device) for _ in range(3)]
+# rows of 16 words per wave, 4 or 8 waves per block (by grid size, csrc/eb_env_step.hip: launch_env_step): sized for 8, the count is
+# read off the marks (wave rows 4-7 of a four-wave launch stay zero)
+trs = [torch.zeros((nb * 8, 16), dtype=torch.int64, device=env.device) for _ in range(3)]
 for k in range(3):
-    lib.eb_debug_set_trace(env._h, C.c_void_p(trs[k].data_ptr())); env.step(act)
-torch.cuda.synchronize(); lib.eb_debug_set_trace(env._h, None)
+    env.api.debug_set_trace(env._h, C.c_void_p(trs[k].data_ptr()), trs[k].numel()); env.step(act)
+torch.cuda.synchronize(); env.api.debug_set_trace(env._h, None, 0)
+nw = 8 if int((trs[1][:, 0] != 0).sum().item()) > nb * 4 else 4
+trs = [x[:nb * nw] for x in trs]
 sp = []
 for x in trs:
     x = x.cpu().numpy(); sp.append((x[:, 0].min(), max(x[:, 4].max(), x[:, 15].max())))

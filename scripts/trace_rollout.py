@@ -24,23 +24,22 @@ bufs = [torch.empty_like(obs0), torch.empty_like(obs0)]; out5 = torch.empty((25,
 p = lambda t: C.c_void_p(t.data_ptr())
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib = m.api.lib
-lib.eb_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
 def step(t):
     src = obs0 if t == 0 else bufs[(t - 1) & 1]
     assert lib.eb_rollout_step(m.handle, a.n_env, p(src), p(tape[t]), p(ref), 1, p(bufs[t & 1]), p(out5[t]), None, sp) == 0
 for t in range(10): step(t)
 torch.cuda.synchronize()
 tr = torch.zeros((65536 * W // 8, 8), dtype=torch.int64, device=dev)
-lib.eb_debug_set_trace(m.handle, p(tr))
+m.api.debug_set_trace(m.handle, p(tr), tr.numel())
 step(10); step(11)          # warm the marked code path
 torch.cuda.synchronize()
 tr.zero_(); torch.cuda.synchronize()
 # three back-to-back launches, each with its own mark buffer: the dead time between consecutive kernels
 trs = [torch.zeros_like(tr) for _ in range(3)]
 for k in range(3):
-    lib.eb_debug_set_trace(m.handle, p(trs[k])); step(12 + k)
+    m.api.debug_set_trace(m.handle, p(trs[k]), trs[k].numel()); step(12 + k)
 torch.cuda.synchronize()
-lib.eb_debug_set_trace(m.handle, None)
+m.api.debug_set_trace(m.handle, None, 0)
 spans = []
 for x in trs:
     x = x.cpu().numpy(); used = x[x[:, 0] > 0]

@@ -16,13 +16,13 @@ obs0 = torch.cat([ego, trk, torch.from_numpy(inp['veh']).to(dev)], 1).contiguous
 tape = torch.from_numpy(inp['actions']).to(dev)
 work, out = torch.empty_like(obs0), torch.empty_like(obs0); out5 = torch.empty((H, 5, B), device=dev)
 p = lambda t: C.c_void_p(t.data_ptr()); sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-lib = m.api.lib; lib.eb_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
+lib = m.api.lib
 run = lambda: lib.eb_rollout_tape(m.handle, B, H, p(obs0), p(tape), p(ref), 0, p(work), p(out), p(out5), sp)
 for _ in range(3): assert run() == 0
 torch.cuda.synchronize()
 tr = torch.zeros((B * W // 8, 8), dtype=torch.int64, device=dev)
-lib.eb_debug_set_trace(m.handle, p(tr)); run(); torch.cuda.synchronize(); tr.zero_(); run(); torch.cuda.synchronize()
-lib.eb_debug_set_trace(m.handle, None)
+m.api.debug_set_trace(m.handle, p(tr), tr.numel()); run(); torch.cuda.synchronize(); tr.zero_(); run(); torch.cuda.synchronize()
+m.api.debug_set_trace(m.handle, None, 0)
 t = tr.cpu().numpy().astype(np.float64); nb = int((t[:, 0] > 0).sum()) // W; t = t[:nb * W]
 t0 = t[:, 0].min(); start, end, wait = (t[:, 0] - t0) / 100, (t[:, 1] - t0) / 100, t[:, 2] / 100
 q = lambda x: ' '.join('%7.2f' % v for v in np.percentile(x, [0, 10, 50, 90, 100]))

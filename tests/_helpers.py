@@ -482,6 +482,8 @@ class DeviceModel(HostModel):
         self.dev = torch.device('cuda', 0)
         HostModel.__init__(self, _capi.hip_api(), task, **kw)
         self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if DeviceModel.ENV_WAVES:
+            self.api.debug_set_env_waves(self.h, DeviceModel.ENV_WAVES)
 
     def set_tape_stepwise(self, on):
         """eb_rollout_tape as H per-step launches (True) or one tape-kernel launch (False, the default)."""
@@ -490,6 +492,8 @@ class DeviceModel(HostModel):
     def set_tile(self, variant):
         """Force the rollout kernel's tile shape (eb_debug_set_tile; -1 = pick by batch size)."""
         self.api.debug_set_tile(self.h, int(variant))
+
+    ENV_WAVES = 0     # eb_debug_set_env_waves for every DeviceModel made from now on (scripts/fuzz_env_auto.py --waves)
 
     _TD = {np.dtype(np.float32): 'float32', np.dtype(np.int32): 'int32', np.dtype(np.uint8): 'uint8',
            np.dtype(np.int16): 'int16'}

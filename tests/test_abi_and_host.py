@@ -215,7 +215,10 @@ def test_oracle_accumulating_rollout_equals_the_two_pass_summary():
                              None, _p(np.zeros(1 << 16, np.uint8)), 1, 6, None, None)
     nb = C.c_int64()
     api.episode_acc_bytes(host.h, 0, 6, C.byref(nb))
-    assert nb.value == 0
+    assert nb.value == 64
+    hip_nb = C.c_int64()            # the two libraries size the workspace alike (a caller may allocate once for either)
+    api.episode_acc_bytes(host.h, 1000, 25, C.byref(nb))
+    assert nb.value == ((1000 + 27) // 28) * (25 * 4 + 2) * 8 + 1000 + 64
 
 
 def test_exit_frame_transforms_match_reference_values():
