@@ -450,6 +450,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
                          int tape_horizon = 0,   // > 0: `actions` is a tape [H, n_env, 2], `out5` is [H, 5, n_env], one launch
                          const GateArgs* gate = nullptr, const AccArgs* acc = nullptr) {
     const int NV = h->cfg.n_veh;
+    if (tape_horizon > 0 && !gate) variant = eb::tape_tile_variant(variant, NV, storage_f16);
     eb::FusedArgs A;
     std::memset(&A, 0, sizeof A);
     A.storage_f16 = storage_f16;
@@ -886,7 +887,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     hipStream_t s = pick(h, stream);
     EB_HIP(hipSetDevice(h->cfg.device));
     const int D = obs_dim(h->cfg);
-    if (eb::env_step_is_fused(D, h->cfg.n_veh, m_cand, cand, ego, actions, scaled_actions, params)) {
+    if (eb::env_step_is_fused(D, h->cfg.n_veh, m_cand, cand, ego, actions, scaled_actions, params, flow != nullptr)) {
         // the whole step — the six calls and the pool's re-entry — as ONE launch (csrc/eb_env_step.hip)
         eb::EnvStepArgs A;
         std::memset(&A, 0, sizeof A);

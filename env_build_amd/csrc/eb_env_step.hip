@@ -66,8 +66,8 @@ size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow) {
 // Measured (16 candidates, us per step at tiles of 16 / 32 / 64 envs, round 4 — profiles/r4_env_tile_sweep.txt): 2 048 envs
 // 7.3 / 7.2 / 11.0; 4 096: 7.5 / 7.3 / 11.1; 8 192: 8.5 / 7.6 / 11.4; 16 384: 14.9 / 9.2 / 11.9; 24 576: 21.4 / 14.3 / 13.2;
 // 32 768: 27.4 / 16.4 / 13.6; 65 536: 51.7 / 29.4 / 18.2.  (Round 3, four waves everywhere: 4 096: 10.8 / 11.4 / 13.2.)
-int env_step_tile_envs(int n_env, int D, int NV, int m_cand) {
-    if (env_step_lds_bytes(D, NV, m_cand, 64) > 40 * 1024) return 16;
+int env_step_tile_envs(int n_env, int D, int NV, int m_cand, bool flow) {
+    if (env_step_lds_bytes(D, NV, m_cand, 64, flow) > 40 * 1024) return 16;
     return n_env <= 1024 ? 16 : n_env <= 20480 ? 32 : 64;
 }
 
@@ -92,10 +92,13 @@ void env_step_slot_plan(const VehModes& modes, int NV, EnvStepArgs& A) {
 
 // cand and params are accessed as float4, ego / actions / scaled actions as float2: a buffer that is not aligned to its vector
 // access (an offset view handed in through the C-ABI) takes the separate launches instead
+// (the gate counts what the launch will ask for: the flow rule's arrays when the call carries one, and — ES_STATIC_LDS — the
+// kernel's statically allocated tables, so that a shape just under the limit takes the separate launches instead of failing)
+constexpr size_t ES_STATIC_LDS = 6 * 1024;
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego, const float* actions,
-                       const float* scaled, const float* params) {
+                       const float* scaled, const float* params, bool flow) {
     auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    return m_cand >= 1 && m_cand <= 64 && env_step_lds_bytes(D, NV, m_cand, 16) <= 150 * 1024 &&
+    return m_cand >= 1 && m_cand <= 64 && env_step_lds_bytes(D, NV, m_cand, 16, flow) + ES_STATIC_LDS <= 156 * 1024 &&
            al(cand, 16) && al(ego, 8) && al(actions, 8) && al(scaled, 8) && al(params, 16);
 }
 
@@ -1059,8 +1062,9 @@ template <int TASK, int ET, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true, false, NW>(A); }
 
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
-    int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand);
-    if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0) > 150 * 1024) ET = 16;     // a forced shape that does not fit
+    int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs
+                                                                           : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand, A.flow_on != 0);
+    if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0) + ES_STATIC_LDS > 156 * 1024) ET = 16;   // a forced shape that does not fit
     const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0);
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -60,6 +60,8 @@ struct FusedArgs {
 constexpr int ACC_RECORD_DOUBLES = 4;
 // variant: 0 = 4 record waves x 8 records per lane (2048-record tiles), 1 = 4 x 4 (1024), 2 = 1 x 4 (256)
 int fused_tile_records(int variant);
+// the tile shape the open-loop tape kernel takes when the per-step kernel would take `variant` (eb_rollout.hip)
+int tape_tile_variant(int variant, int n_veh, int storage_f16);
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s);
 // open-loop rollout of `horizon` steps in one launch: A.actions = tape [horizon, n_env, 2], A.out5 = [horizon, 5, n_env]
 hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, int horizon, int grid, hipStream_t s);
@@ -227,9 +229,10 @@ struct EnvResetArgs {                      // launch_get_obs(..., reset): what e
     int* episode_step;                     // nullable: the masked rows' episode step counts are cleared
 };
 size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow = false);
-int env_step_tile_envs(int n_env, int D, int NV, int m_cand);
+int env_step_tile_envs(int n_env, int D, int NV, int m_cand, bool flow = false);
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego = nullptr, const float* actions = nullptr,
-                       const float* scaled = nullptr, const float* params = nullptr);   // NULL: not an argument of the call at hand
+                       const float* scaled = nullptr, const float* params = nullptr,   // NULL: not an argument of the call at hand
+                       bool flow = false);                                             // the call carries an eb_flow_rule
 void env_step_slot_plan(const VehModes& modes, int NV, EnvStepArgs& A);   // first_mask, dm, n_dm, dm_ok, dm_magic
 hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s);
 

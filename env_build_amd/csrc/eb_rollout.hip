@@ -126,6 +126,21 @@ EB_DEV float wave_max_f32(float v) {
     return v;
 }
 
+// One step's record of the episodic accumulator (eb_rollout_step_acc): the tile's three sums (float64 on the DPP network, a fixed
+// order) and its "punished in this step" bits — 32 bytes from lane 63, no read-modify-write.  lane = env of the tile; every lane active.
+EB_DEV void acc_record(double* recs, bool act, int lane, float v_r, float v_t, float v_p) {
+    const double s_r = wave_sum_f64(act ? (double)v_r : 0.0);
+    const double s_t = wave_sum_f64(act ? (double)v_t : 0.0);
+    const double s_p = wave_sum_f64(act ? (double)v_p : 0.0);
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(act && v_p > 0.0f);
+    if (lane == 63) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        d2v* rec = reinterpret_cast<d2v*>(recs + (size_t)ACC_RECORD_DOUBLES * blockIdx.x);
+        rec[0] = d2v{s_r, s_t};
+        rec[1] = d2v{s_p, __builtin_bit_cast(double, any)};
+    }
+}
+
 // Device-scope accesses of the gated rollout's flags and action words, spelled as global instructions with the sc1 bit
 // (served by L2 / memory, never by this CU's L1 — MI355X_MICROARCH.md, "inter-workgroup visibility").  Inline assembly:
 // the flat-pointer forms of the __hip_atomic builtins do not survive instruction selection here.
@@ -244,14 +259,6 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int pr = A.ref_idx[ge];
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
-    // episodic accumulator: the PREVIOUS step's reward / punish_train / punish_real of this env (three coalesced loads next to the
-    // head's) — that step's record is made further down, while this wave would only wait for the record waves
-    const bool acc_prev = H.acc_rec && A.prev_out5;
-    float pv_r = 0.0f, pv_t = 0.0f, pv_p = 0.0f;
-    if (acc_prev && act) {
-        const size_t n = (size_t)H.n_env;
-        pv_r = A.prev_out5[ge]; pv_t = A.prev_out5[n + ge]; pv_p = A.prev_out5[2 * n + ge];
-    }
     const int trow = blockIdx.x * (RW + 1);
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
@@ -324,26 +331,6 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     float road_t = 0.0f, road_r = 0.0f;
     road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
     road_terms<TASK>(st[3] - LWS * ec, st[4] - LWS * es, road_t, road_r);
-    // one step's record of the episodic accumulator: the tile's three sums (float64 on the DPP network, a fixed order) and the
-    // "punished in this step" bits — 32 bytes from lane 63, no read-modify-write
-    auto acc_record = [&](double* recs, float v_r, float v_t, float v_p) {
-        const double s_r = wave_sum_f64(act ? (double)v_r : 0.0);
-        const double s_t = wave_sum_f64(act ? (double)v_t : 0.0);
-        const double s_p = wave_sum_f64(act ? (double)v_p : 0.0);
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(act && v_p > 0.0f);
-        if (lane == 63) {
-            typedef double d2v __attribute__((ext_vector_type(2)));
-            d2v* rec = reinterpret_cast<d2v*>(recs + (size_t)ACC_RECORD_DOUBLES * blockIdx.x);
-            rec[0] = d2v{s_r, s_t};
-            rec[1] = d2v{s_p, __builtin_bit_cast(double, any)};
-        }
-    };
-    if (acc_prev) {                                                         // the previous step's, in the shadow of the wait below
-        // (the values are first TOUCHED here: without this the float -> double conversions — and with them the wait for the three
-        // loads — are hoisted to the top of the wave, in front of the head's own arrival: + 0.4 us per launch, measured)
-        asm volatile("" : "+v"(pv_r), "+v"(pv_t), "+v"(pv_p));
-        acc_record(A.prev_rec, pv_r, pv_t, pv_p);
-    }
     lds_wait_until(&S.waves_done, RW);                                      // ---- hand-off 2 ----
     EB_MARK(A, trow, 5);                                                    // record waves done
 
@@ -370,7 +357,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     // The launch that ends a rollout has no successor to make its record: it makes it here, and adds the |delta_y| statistics of
     // the rows it has just written (t0 IS the final obs' column 6) — once per horizon.
     if (H.acc_rec && A.acc_final) {
-        acc_record(H.acc_rec, rew, pun_t, pun_r);
+        acc_record(H.acc_rec, act, lane, rew, pun_t, pun_r);
         const float dy = __builtin_fabsf(Stored<ST>::round(t0));
         const double s_dy = wave_sum_f64(act ? (double)dy : 0.0);
         const float m_dy = wave_max_f32(act && dy > 0.0f ? dy : 0.0f);       // (a NaN never becomes the maximum, as in the two-pass summary)
@@ -455,6 +442,16 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         }
     };
     if (full_tile) load_records(std::true_type{}); else load_records(std::false_type{});
+    // Episodic accumulator: the PREVIOUS step's record is made by this launch's first record wave (lane = env of the tile) — three
+    // coalesced loads behind its records now, the sums at its very end, when it would otherwise just leave: the env wave, whose
+    // chain IS the block's duration, does not see any of it (in the env wave the same ~110 instructions cost 0.4 us per launch)
+    const bool acc_prev = w == 0 && H.acc_rec && A.prev_out5;
+    float pv_r = 0.0f, pv_t = 0.0f, pv_p = 0.0f;
+    if (acc_prev && lane < nE) {
+        const size_t n = (size_t)H.n_env;
+        const float* po = A.prev_out5 + e0 + lane;
+        pv_r = po[0]; pv_t = po[n]; pv_p = po[2 * n];
+    }
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
@@ -538,7 +535,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         }
     };
     if (full_tile) main_loop(std::true_type{}); else main_loop(std::false_type{});
-    if (!H.do_rewards) return;
+    if (!H.do_rewards) return;   // (eb_compute_next_obses: never an accumulating launch)
     if (test_near && k_late < RPT) {
         for (int k = k_late; k < RPT; ++k) {       // not unrolled: rare path
             drain();
@@ -554,6 +551,12 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     drain();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // ---- hand-off 2: partial sums are in LDS ----
     if (lane == 0) atomicAdd(&S.waves_done, 1);
+    if (acc_prev) {
+        // (the values are first TOUCHED here: otherwise the float -> double conversions — and the wait for the three loads — are
+        // hoisted to the top of the wave, in front of the records' own arrival)
+        asm volatile("" : "+v"(pv_r), "+v"(pv_t), "+v"(pv_p));
+        acc_record(A.prev_rec, lane < nE, lane, pv_r, pv_t, pv_p);
+    }
     EB_MARK(A, trow, 5);                                                    // end
 }
 
@@ -990,6 +993,14 @@ EB_TAPE_KERNEL(rollout_gated_4x8, 4, 8, true, 4)
 EB_TAPE_KERNEL(rollout_gated_4x4, 4, 4, true, 1)
 EB_TAPE_KERNEL(rollout_gated_1x4, 1, 4, true, 1)
 
+// The open-loop tape kernel's tile for a slot count that does not divide the 256 record lanes (the native 9 and 5) with fp32
+// rows: the 4 x 8 tile's per-record item / env / offset / turn state for eight records per lane does not fit six waves per SIMD
+// (it spilled 1 008 bytes of scratch per lane, and unbounded it takes 256 VGPRs) — such tapes run on the 4 x 4 tile (93 VGPRs, no
+// scratch; every tile shape computes the same bits).  That instantiation of rollout_tape_4x8 does not exist.
+int tape_tile_variant(int variant, int n_veh, int storage_f16) {
+    return (variant == 0 && !storage_f16 && (4 * 64) % n_veh != 0) ? 1 : variant;
+}
+
 int fused_tile_records(int variant) {
     switch (variant) {
         case 0: return 4 * 64 * 8;
@@ -1116,7 +1127,13 @@ hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, 
         return hipGetLastError();
     }
     switch (variant) {
-        case 0: EB_TAPE_LAUNCH(rollout_tape_4x8, 4, 0) break;
+        case 0: {
+            const dim3 g(grid), b((4 + 1) * 64);
+            const size_t dyn = (size_t)A.stage_entries * 12;
+            if (A.storage_f16) { EB_TAPE_FAST(rollout_tape_4x8, 4, _Float16) }
+            else if ((4 * 64) % A.n_veh == 0) { EB_TAPE_TASK(rollout_tape_4x8, true, float) }
+            else return hipErrorInvalidValue;            // the host routes these to the 4 x 4 tile (tape_tile_variant)
+        } break;
         case 1: EB_TAPE_LAUNCH(rollout_tape_4x4, 4, 0) break;
         default: EB_TAPE_LAUNCH(rollout_tape_1x4, 1, 0) break;
     }

@@ -104,6 +104,44 @@ class DevArray(object):
     __hash__ = None
 
 
+class _RowOf(DevArray):
+    """Row k of a [rows, B] device tensor (one of rollout_out's five per-env outputs) — or, with shape given, a reshaped window of it —
+    as a DevArray whose view tensor is made when the value is first used: handing out five of them costs five small Python
+    objects per call, not five tensor-indexing operations."""
+
+    def __init__(self, base, k, rows=1, shape=None):
+        self._base, self._k, self._rows, self._shape = base, k, rows, shape
+        self._t = None
+
+    @property
+    def t(self):
+        if self._t is None:
+            b = self._base
+            self._t = b[self._k] if self._shape is None else b[self._k:self._k + self._rows].view(self._shape)
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = v
+
+
+class _OutSet(object):
+    """One set of rollout_out's outputs: the next obs [B, D], and ONE [7, B] tensor holding the five per-env outputs (rows 0-4,
+    the C entry's out5) and the scaled actions (rows 5-6 viewed as [B, 2]); the device addresses the C call needs; the 6-tuple."""
+    __slots__ = ('obs', 'out7', 'obs_ptr', 'out5_ptr', 'scaled_ptr', 'ret', 'actions', 'obses')
+
+    def __init__(self, like, B, device):
+        self.obs = torch.empty_like(like)
+        self.out7 = torch.empty((7, B), dtype=torch.float32, device=device)
+        self.obs_ptr = self.obs.data_ptr()
+        self.out5_ptr = self.out7.data_ptr()
+        self.scaled_ptr = self.out5_ptr + 5 * B * 4
+        self.obses = DevArray(self.obs)
+        o7 = self.out7
+        self.ret = (self.obses, _RowOf(o7, 0), _RowOf(o7, 1), _RowOf(o7, 2), _RowOf(o7, 3), _RowOf(o7, 4))
+        self.actions = _RowOf(o7, 5, 2, (B, 2))
+
+
 def _unwrap(x):
     return x.t if isinstance(x, DevArray) else x
 
@@ -330,7 +368,11 @@ class EnvironmentModel(object):  # DAM:90-427
     VEHICLE_MODE_LIST[task]) and `device`."""
 
     def __init__(self, training_task, num_future_data=0, mode='training', n_veh=None, device=None,
-                 state_dtype='float32'):
+                 state_dtype='float32', copy_outputs=True):
+        """copy_outputs: True (default) — what rollout_out hands out are arrays of their own, as in the reference: they can be kept
+        in a list.  False — the outputs live in two pre-allocated sets used in turn (zero allocations per call; the reference's
+        callers consume them at once, hier_decision.py:91-96): a value handed out by a call stays valid until the call AFTER the
+        next one and must be consumed or copied by then."""
         if training_task not in ('left', 'straight', 'right'):
             raise ValueError("training_task must be 'left', 'straight' or 'right'")
         if state_dtype not in ('float32', 'float16'):
@@ -366,6 +408,9 @@ class EnvironmentModel(object):  # DAM:90-427
         # the raw entry point of the hot call (the checked wrapper costs a Python closure per call)
         self._step_fn = (self.api.lib.eb_rollout_step_f16 if self.state_dtype == torch.float16
                          else self.api.lib.eb_rollout_step)
+        self.copy_outputs = bool(copy_outputs)
+        self._sets, self._set_i = None, 0
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     # -- state ------------------------------------------------------------------------------
     def _obs(self, obses, dtype=torch.float32):
@@ -408,6 +453,8 @@ class EnvironmentModel(object):  # DAM:90-427
 
     # -- the hot path -----------------------------------------------------------------------
     def rollout_out(self, actions):  # DAM:118-126
+        """One C call, one kernel launch.  Per call on the host: the argument checks, (copy_outputs) two allocations, one ctypes
+        call; the 6-tuple's members are DevArrays whose row views are made on first use."""
         obs = self.obses.t if type(self.obses) is DevArray else None
         if obs is None or obs.dtype != self.state_dtype or obs.device != self.device or not obs.is_contiguous():
             obs = self._obs(self.obses, self.state_dtype)
@@ -416,21 +463,34 @@ class EnvironmentModel(object):  # DAM:90-427
                 and act.is_contiguous()):
             act = _dev(act, self.device)
         B = obs.shape[0]
-        ri, pid = self._path_args()
-        obs_out = torch.empty_like(obs)
-        out5 = torch.empty((5, B), dtype=torch.float32, device=self.device)
-        scaled = torch.empty((B, 2), dtype=torch.float32, device=self.device)
-        rc = self._step_fn(self.handle, B, obs.data_ptr(), act.data_ptr(), ri.data_ptr() if ri is not None else None, pid,
-                           obs_out.data_ptr(), out5.data_ptr(), scaled.data_ptr(),
-                           _stream(self.device))
+        if self.mode == 'training':
+            ri = self._ref_idx_dev
+            if ri is None:
+                raise ValueError("mode='training' needs ref_indexes: call reset(obses, ref_indexes) (DAM:344)")
+            ri_ptr, pid = ri.data_ptr(), 0
+        else:
+            ri, pid = self._path_args()
+            ri_ptr = None
+        if self.copy_outputs:
+            st = _OutSet(obs, B, self.device)
+        else:
+            sets = self._sets
+            if sets is None or sets[0].obs.shape != obs.shape or sets[0].obs.dtype != obs.dtype:
+                sets = self._sets = [_OutSet(obs, B, self.device) for _ in range(2)]
+            self._set_i ^= 1
+            st = sets[self._set_i]
+            if st.obs_ptr == obs.data_ptr():            # (the caller put one of our own arrays back as the state: the other set)
+                self._set_i ^= 1
+                st = sets[self._set_i]
+        rc = self._step_fn(self.handle, B, obs.data_ptr(), act.data_ptr(), ri_ptr, pid, st.obs_ptr, st.out5_ptr, st.scaled_ptr,
+                           _raw_stream(self._dev_index) if _raw_stream is not None else _stream(self.device))
         if rc != 0:
             self.api.check(rc)
-        self.actions = DevArray(scaled)
-        self.obses = DevArray(obs_out)
+        self.actions = st.actions
+        self.obses = st.obses
         if self.mode == 'training':   # the reference's loop leaves ref_path.path on the last path, DAM:345-346
             self.ref_path.path = self.ref_path.path_list[-1]
-        return (self.obses, DevArray(out5[0]), DevArray(out5[1]), DevArray(out5[2]), DevArray(out5[3]),
-                DevArray(out5[4]))
+        return st.ret
 
     def rollout_tape(self, action_tape):
         """Open-loop rollout over an action tape [H, B, 2] (the MPC callers' cost_function,

@@ -48,16 +48,18 @@ class PendingGather:
         return self._out
 
 
-def gather_summaries_async(summary8, group=None):
+def gather_summaries_async(summary8, group=None, copy=True):
     """gather_summaries without stalling the launch stream: the collective runs on the backend's own stream,
     ordered after the work already queued on the current stream, while the next rollout's kernels go on.
     The caller must not overwrite `summary8` before result() — keep one buffer per gather in flight.  Without a process group
-    (one GPU) there is nothing to exchange: result() is `summary8` itself viewed as [1, 8] — no copy, no launch — and the same
-    rule about overwriting covers it."""
+    (one GPU) there is nothing to exchange: result() is a copy of `summary8` as [1, 8] made now (one 32-byte device copy), so that
+    it stays what it was when the caller reuses the buffer — as the gathered tensor of an N-GPU job does.  copy=False: result()
+    is `summary8` itself viewed as [1, 8] — no copy, no launch — for a caller that keeps the rule above on one GPU too."""
     if summary8.numel() != SUMMARY_LEN:
         raise ValueError('summary must have %d floats' % SUMMARY_LEN)
     if not (dist.is_available() and dist.is_initialized()):
-        return PendingGather(None, summary8.reshape(1, SUMMARY_LEN), None)
+        one = summary8.reshape(1, SUMMARY_LEN)
+        return PendingGather(None, one.clone() if copy else one, None)
     world = dist.get_world_size(group)
     if summary8.is_cuda and dist.get_backend(group) != 'nccl':
         # a backend without device collectives (gloo in tests): through host memory, synchronously

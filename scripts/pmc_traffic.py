@@ -37,7 +37,13 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
               'rollout_bytes_per_launch': k_kib * 1024.0 * factor}
 read_b, write_b = res['FETCH_SIZE']['rollout_bytes_per_launch'], res['WRITE_SIZE']['rollout_bytes_per_launch']
 alg = (104 + 32 * 32) * 65536
-summary = {'kernel_source_hash': {k: _build.kernel_hash(k) for k in _build.KERNEL_SOURCES},   # bench.py checks these against the sources it runs
+# the sources that were MEASURED (stamped by pmc_traffic.sh next to the counter files), never the tree this summary happens to run in
+try:
+    measured_hash = json.load(open(os.path.join(out, 'kernel_hash.json')))
+except OSError:
+    measured_hash = {k: None for k in _build.KERNEL_SOURCES}
+    print('(no kernel_hash.json next to the counter files: the summary carries no source hash and bench.py will not use it)')
+summary = {'kernel_source_hash': measured_hash,   # bench.py checks these against the sources it runs
            'hbm_bytes_per_launch': read_b + write_b, 'read_bytes_per_launch': read_b, 'write_bytes_per_launch': write_b,
            'algorithmic_bytes_per_launch': alg, 'traffic_over_algorithmic': (read_b + write_b) / alg,
            'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace; KiB per dispatch x 1024 x '

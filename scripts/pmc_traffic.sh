@@ -8,6 +8,9 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 [ -x scripts/micro/copybench ] || make -s -C scripts/micro copybench
+# the hash of the kernel sources these passes measure, stamped HERE, at measurement time (pmc_traffic.py carries it into the JSON;
+# bench.py refuses the bytes of other code)
+python -c "import json; from env_build_amd import build as b; json.dump({k: b.kernel_hash(k) for k in b.KERNEL_SOURCES}, open('$OUT/kernel_hash.json', 'w'))"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/bench_$c -o p -- python bench.py --steps 50 --warmup 25 --no-cpu-baseline --no-side > $OUT/bench_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/copy_$c -o p -- scripts/micro/copybench calib > $OUT/copy_$c.log 2>&1

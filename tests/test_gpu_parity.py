@@ -1067,6 +1067,48 @@ def test_environment_model_fp16_state_facade():
         assert np.array_equal(rewards.numpy(), o5_h[0])
 
 
+@pytest.mark.parametrize('mode', ['training', 'selecting'])
+def test_environment_model_rollout_out_output_sets(mode):
+    """EnvironmentModel.rollout_out (DAM:118-126) through the drop-in class: copy_outputs=True hands out arrays of its own every
+    call (a list of them keeps every step's values), copy_outputs=False the same values from two sets used in turn — valid until
+    the call after next; the 6-tuple, `.obses` and `.actions` (the scaled actions, DAM:120) are the oracle's."""
+    import torch
+    from env_build_amd.dynamics_and_models import EnvironmentModel
+    task, B, N, H = 'left', 300, 8, 6
+    host = HostModel(oracle_lib(), task, n_veh=N, mode=mode)
+    inp = make_rollout_inputs(task, B, N, H, seed=8)
+    ref = inp['ref_idx'] if mode == 'training' else None
+    obs0 = _initial_obs(HostModel(oracle_lib(), task, n_veh=N), inp)
+    a, b = EnvironmentModel(task, mode=mode), EnvironmentModel(task, mode=mode, copy_outputs=False)
+    for m in (a, b):
+        if mode == 'training':
+            m.reset(obs0, ref)
+        else:
+            m.add_traj(obs0, 1)
+    kept_a, kept_b, o_h = [], [], obs0
+    for t in range(H):
+        ra, rb = a.rollout_out(inp['actions'][t]), b.rollout_out(torch.from_numpy(inp['actions'][t]).cuda())
+        o_h, o5_h, sc_h = host.rollout_step(o_h, inp['actions'][t], ref, path_id=1)
+        for r, m in ((ra, a), (rb, b)):
+            assert len(r) == 6 and r[0] is m.obses
+            assert np.array_equal(r[0].numpy(), o_h) and np.array_equal(m.actions.numpy(), sc_h)
+            _check_out5(np.stack([x.numpy() for x in r[1:]]), o5_h, 'facade step %d' % t)
+        assert (ra[3] + 1.0).numpy().shape == (B,) and float(ra[1][0]) == ra[1].numpy()[0]      # what hier_decision.py:96 does with them
+        kept_a.append(ra); kept_b.append((rb, [x.numpy().copy() for x in rb]))
+    # arrays of their own: every step's values are still there
+    o_h = obs0
+    for t in range(H):
+        o_h, o5_h, _ = host.rollout_step(o_h, inp['actions'][t], ref, path_id=1)
+        assert np.array_equal(kept_a[t][0].numpy(), o_h)
+    assert len({r[0].data_ptr() for r in kept_a}) == H
+    # two sets in turn: the last two calls' values are intact, older ones have been overwritten by later steps
+    assert len({r[0].data_ptr() for r, _ in kept_b}) == 2
+    for t in (H - 2, H - 1):
+        for x, c in zip(*kept_b[t]):
+            assert np.array_equal(x.numpy(), c)
+    assert not np.array_equal(kept_b[0][0][0].numpy(), kept_b[0][1][0])
+
+
 # ---- open-loop tape kernel (eb_rollout_tape: H steps in one launch, state in registers) -----------------------
 @pytest.mark.parametrize('tile', [-1, 0, 1, 2])
 @pytest.mark.parametrize('task,N,nf,H', [('left', 32, 0, 25), ('straight', 9, 2, 7), ('right', 64, 0, 3), ('left', 16, 0, 1),

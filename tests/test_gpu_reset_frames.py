@@ -148,7 +148,7 @@ def test_reset_pool_unaligned_candidates_take_the_four_launches():
     tm, tcm, ten = t(mask), t(cmode), t(entry)
     rule = _capi.EbRespawn(ten.data_ptr(), 0.0, 60.0, 8.0, 7, 3, 5.0)
     P = lambda x: C.c_void_p(x.data_ptr())
-    dev.api.env_reset_pool(dev.h, tr.h, B, P(tm), C.c_uint64(11), C.c_uint64(2), 1, P(te), P(tp), P(tr_), P(tv), P(tl), P(dc), M,
+    dev.api.env_reset_pool(dev.h, tr.h, B, P(tm), C.c_uint64(11), C.c_uint64(2), 1, P(te), P(tp), P(tr_), P(tv), P(tl), P(dc), None, M,
                            P(cand_u), P(tcm), C.byref(rule), P(to), None, None, None)
     torch.cuda.synchronize()
     got = [te, tp, tr_, tv, tl, dc, cand_u, to]
@@ -474,7 +474,7 @@ def test_env_step_validates_before_it_launches_and_set_paths_failure_keeps_the_o
         with pytest.raises(ValueError):
             dev.api.env_step(dev.h, tr.h, B, p(dev._in(obs0)), p(dev._in(raw)), p(dev._in(bad['ref'], np.int32)), bad['path_id'],
                              p(e_io), p(par), M, p(c_io), p(dev._in(cmode, np.uint8)) if 'cmode' not in bad else None, None, None,
-                             None, p(sc), p(out5), None, p(obs_o), p(code), None, None, None, dev.stream)
+                             None, p(sc), p(out5), None, p(obs_o), p(code), None, None, None, None, dev.stream)
         assert np.array_equal(dev._ret(e_io), ego) and np.array_equal(dev._ret(c_io), cand) and (dev._ret(par) == 5.0).all()
     unset = DeviceModel.__new__(DeviceModel)               # a traffic handle without slot modes: EB_ESTATE before any launch
     import torch
@@ -482,7 +482,7 @@ def test_env_step_validates_before_it_launches_and_set_paths_failure_keeps_the_o
     unset.h = dev.api.create(task, M, 0, _capi.MODE_SELECTING)
     with pytest.raises(_capi.EbError):
         dev.api.env_step(dev.h, unset.h, B, p(dev._in(obs0)), p(dev._in(raw)), p(dev._in(ref, np.int32)), 0, p(e_io), p(par), M,
-                         p(c_io), p(dev._in(cmode, np.uint8)), None, None, None, p(sc), p(out5), None, p(obs_o), p(code), None, None, None, dev.stream)
+                         p(c_io), p(dev._in(cmode, np.uint8)), None, None, None, p(sc), p(out5), None, p(obs_o), p(code), None, None, None, None, dev.stream)
     assert np.array_equal(dev._ret(e_io), ego) and np.array_equal(dev._ret(c_io), cand)
     dev.api.destroy(unset.h)
     unset.h = None                                        # (its __del__ then destroys NULL: a no-op)
