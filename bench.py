@@ -871,6 +871,12 @@ def main():
         for b in (N_ENV, 4096):
             print(json.dumps(env_step_bench(torch, torch.device('cuda', 0), b)))
         return
+    if args.facade:
+        import torch
+        from env_build_amd.dynamics_and_models import EnvironmentModel
+        for b, nv, sd in ((N_ENV, N_VEH, 21), (4096, 16, 22)):
+            print(json.dumps(facade_rollout_bench(torch, EnvironmentModel, torch.device('cuda', 0), b, nv, sd)))
+        return
 
     import torch
     import torch.distributed as dist
