@@ -40,7 +40,10 @@ class EbRespawn(C.Structure):     # struct eb_respawn: the pool's re-entry rule 
 
 class EbAutoReset(C.Structure):   # struct eb_auto_reset (ABI 4): eb_env_step resets the envs it has just finished, same call
     _fields_ = [('seed', C.c_uint64), ('counter', C.c_uint64), ('training', C.c_int32), ('ref_idx', C.c_void_p),
-                ('virtual_flag', C.c_void_p), ('v_light', C.c_void_p), ('pool', EbRespawn), ('final_obs', C.c_void_p)]
+                ('virtual_flag', C.c_void_p), ('v_light', C.c_void_p), ('pool', EbRespawn), ('final_obs', C.c_void_p),
+                # with a flow rule (ABI 5): the flow source's part of reset instead of the pool's
+                ('flow_cand_len', C.c_void_p), ('flow_phase0', C.c_void_p), ('flow_random_phase', C.c_int32),
+                ('flow_seed', C.c_uint64), ('flow_counter', C.c_uint64)]
 
 
 class EbFlowRule(C.Structure):    # struct eb_flow_rule (ABI 4): the flow source's step as the last stage of eb_env_step
@@ -116,6 +119,7 @@ PROTOTYPES = {
     'eb_debug_set_trace': (C.c_int, [_P, _P, C.c_int64]),
     'eb_debug_set_stage_paths': (C.c_int, [_P, _I]),
     'eb_debug_set_env_waves': (C.c_int, [_P, _I]),
+    'eb_debug_set_scan_prefetch': (C.c_int, [_P, _I]),
     'eb_traffic_flow_step': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                        _I, C.c_uint64, C.c_uint64, _P, _P, _P]),
     'eb_mlp_create': (C.c_int, [C.POINTER(EbMlpConfig), C.POINTER(_P)]),

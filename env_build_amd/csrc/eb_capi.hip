@@ -56,6 +56,7 @@ struct eb_handle_s {
     long long trace_words;    //   its capacity in 64-bit words
     int stage_paths;          // -1 = by grid size; 0 / 1: the tape / gated kernels' LDS copy of the path tables off / on (eb_debug_set_stage_paths)
     int env_waves;            // 0 = by grid size; 4 / 8: waves per block of the one-launch env step (eb_debug_set_env_waves)
+    int scan_one_trip;        // 1: the closest-point range scan one group of table entries per loop trip, as rounds 1-4 (eb_debug_set_scan_prefetch 0)
     eb::ExitConsts xc;        // cos / sin of the exit angles (eb_get_obs with exit ids, eb_exit_frame)
     hipStream_t gate_stream;  // producer stream of gated rollouts (high priority: a hardware queue of its own), made on first use
     hipEvent_t gate_event;    // orders eb_gate_feed behind the caller's stream (after_stream)
@@ -471,7 +472,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     A.training = h->cfg.mode == EB_MODE_TRAINING;
     A.actions_raw = actions_raw;
     A.do_rewards = do_rewards;
-    A.trace = h->trace; A.trace_words = h->trace_words;
+    A.trace = h->trace; A.trace_words = h->trace_words; A.scan_one_trip = h->scan_one_trip;
     if (gate) {
         A.gate_ready = gate->ready; A.gate_done = gate->done; A.gate_obs = gate->obs_steps; A.gate_status = gate->status;
         A.gate_spin = gate->spin;
@@ -823,7 +824,7 @@ int eb_get_obs(eb_handle h, int32_t n_env, const float* ego, const int32_t* ref_
     EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego,
                               ref_idx, path_id, m_cand, cand, cand_mode, v_light, virtual_flag, obs_out, pick(h, stream),
                               nullptr, nullptr, nullptr, exit_id, &h->xc, row_mask, nullptr, forced_env_tile(h), h->env_waves, h->trace,
-                              h->trace_words));
+                              h->trace_words, h->scan_one_trip));
     return EB_OK;
 }
 
@@ -869,14 +870,16 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (rc) return rc;
     if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (const eb_auto_reset* ar = auto_reset) {
-        if (!ar->pool.entry || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
+        if ((!flow && !ar->pool.entry) || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
             ar->virtual_flag != virtual_flag || ar->v_light != v_light)
             return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
+        if (flow && (!ar->flow_cand_len || !ar->flow_phase0))
+            return fail(EB_EINVAL, "eb_env_step: auto_reset over the flow source needs flow_cand_len and flow_phase0");
         if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))
             return fail(EB_EINVAL, "eb_env_step: final_obs must be an array of its own");
     }
     if (flow) {
-        if (respawn || auto_reset) return fail(EB_EINVAL, "eb_env_step: the flow rule excludes respawn / auto_reset (the pool's rules)");
+        if (respawn) return fail(EB_EINVAL, "eb_env_step: the flow rule excludes respawn (the pool's rule)");
         if (flow->per_route < 1 || 12 * flow->per_route != m_cand || m_cand > 64 || !flow->active || !flow->timer || !flow->emitted ||
             !flow->sim_step || !flow->lane || !flow->period || !flow->v_max || !v_light || flow->v_light != v_light || flow->cand_mode != cand_mode)
             return fail(EB_EINVAL, "eb_env_step: bad flow rule (m_cand == 12 * per_route <= 64, every array given, cand_mode / v_light the call's own)");
@@ -901,7 +904,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         A.cand_lw = cand_lw; A.v_light = v_light; A.virtual_flag = virtual_flag; A.scaled = scaled_actions; A.out5 = out5;
         A.d16 = out_dict16; A.obs_out = obs_out; A.done_code = done_code;
         A.trace = h->trace; A.trace_words = h->trace_words;
-        A.tile_envs = forced_env_tile(h); A.waves = h->env_waves;
+        A.tile_envs = forced_env_tile(h); A.waves = h->env_waves; A.scan_one_trip = h->scan_one_trip;
         if (respawn) {
             A.respawn_entry = respawn->entry; A.limit = respawn->limit; A.span = respawn->span; A.v_max = respawn->v_max;
             A.seed = respawn->seed; A.counter = respawn->counter;
@@ -911,6 +914,8 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
             A.ref_idx_out = ar->ref_idx; A.virtual_out = ar->virtual_flag; A.v_light_out = ar->v_light; A.final_obs = ar->final_obs;
             A.pool_entry = ar->pool.entry; A.pool_span = ar->pool.span; A.pool_v_max = ar->pool.v_max; A.edge_span = ar->pool.edge_span;
             A.pool_seed = ar->pool.seed; A.pool_counter = ar->pool.counter;
+            A.flow_cand_len = ar->flow_cand_len; A.flow_phase0 = ar->flow_phase0; A.flow_random_phase = ar->flow_random_phase ? 1 : 0;
+            A.flow_reset_seed = ar->flow_seed; A.flow_reset_counter = ar->flow_counter;
         }
         if (flow) {   // the flow source's step rides on the way out of the same launch
             A.flow_on = 1; A.flow_K = flow->per_route; A.flow_active = flow->active; A.flow_timer = flow->timer; A.flow_emitted = flow->emitted;
@@ -957,6 +962,27 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (respawn)
         EB_HIP(eb::launch_traffic_respawn(n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
                                           respawn->seed, respawn->counter, nullptr, nullptr, s));
+    if (flow && auto_reset) {   // the flow source: its step first, then the masked reset's launches (eb_env_reset, the source's own reset, obs, flags)
+        const eb_auto_reset* ar = auto_reset;
+        EB_HIP(eb::launch_traffic_flow_step(n_env, flow->per_route, cand, flow->active, flow->timer, flow->emitted, flow->sim_step, flow->lane,
+                                            flow->period, flow->v_max, flow->dt, flow->exit_range, flow->accel, flow->lane_len,
+                                            flow->light_cycle, flow->seed, flow->counter, flow->cand_mode, flow->v_light, s));
+        if (ar->final_obs) EB_HIP(eb::launch_copy_rows_masked(n_env, D, done_code, obs_out, ar->final_obs, s));
+        uint8_t* d_vnext = nullptr;
+        EB_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_vnext), (size_t)n_env, s));
+        struct ReleaseV { uint8_t* p; hipStream_t s; ~ReleaseV() { (void)hipFreeAsync(p, s); } } release_v{d_vnext, s};
+        EB_HIP(eb::launch_env_reset(h->cfg.task, n_env, h->pt, done_code, ar->seed, ar->counter, ar->training ? 1 : 0, ego, params, ar->ref_idx,
+                                    d_vnext, nullptr, s));
+        EB_HIP(eb::launch_traffic_flow_reset(n_env, flow->per_route, done_code, ego, cand, flow->active, flow->timer, flow->emitted, flow->sim_step,
+                                             ar->flow_phase0, flow->lane, flow->period, flow->v_max, ar->flow_cand_len, flow->lane_len,
+                                             ar->flow_random_phase ? 1 : 0, ar->training ? 1 : 0, ar->flow_seed, ar->flow_counter,
+                                             flow->cand_mode, flow->v_light, s));
+        EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, D, h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ar->ref_idx, 0, m_cand, cand,
+                                  flow->cand_mode, flow->v_light, ar->virtual_flag, obs_out, s, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  done_code));
+        EB_HIP(eb::launch_flag_swap(n_env, done_code, d_vnext, ar->virtual_flag, s));
+        return EB_OK;
+    }
     if (const eb_auto_reset* ar = auto_reset) {   // the same composition the header spells out, as launches of their own
         if (ar->final_obs) EB_HIP(eb::launch_copy_rows_masked(n_env, D, done_code, obs_out, ar->final_obs, s));
         return eb_env_reset_pool(h, traffic, n_env, done_code, ar->seed, ar->counter, ar->training, ego, params, ar->ref_idx,
@@ -1017,7 +1043,7 @@ int eb_env_reset_pool(eb_handle h, eb_handle traffic, int32_t n_env, const uint8
                                  episode_step};
         EB_HIP(eb::launch_get_obs(h->cfg.task, n_env, obs_dim(h->cfg), h->cfg.n_future, h->cfg.n_veh, h->pt, h->modes, ego, ref_idx, 0,
                                   m_cand, cand, cand_mode, nullptr, virtual_flag, obs, pick(h, stream), nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, mask, &R, forced_env_tile(h), h->env_waves, h->trace, h->trace_words));
+                                  nullptr, mask, &R, forced_env_tile(h), h->env_waves, h->trace, h->trace_words, h->scan_one_trip));
         return EB_OK;
     }
     hipStream_t s = pick(h, stream);
@@ -1055,6 +1081,12 @@ int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_word
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return fail(EB_EINVAL, "eb_debug_set_stage_paths: bad argument (-1 = by grid size, 0 = off, 1 = on)");
     h->stage_paths = mode;
+    return EB_OK;
+}
+
+int eb_debug_set_scan_prefetch(eb_handle h, int32_t on) {
+    if (!h) return fail(EB_EINVAL, "eb_debug_set_scan_prefetch: null handle");
+    h->scan_one_trip = on ? 0 : 1;
     return EB_OK;
 }
 

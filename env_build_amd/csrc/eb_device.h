@@ -330,6 +330,57 @@ EB_DEV int row_path(const PathTables& pt, const int* ref_idx, int path_id, int i
     return (p >= 0 && p < pt.n_paths) ? p : -1;
 }
 
+// ---- closest point inside the index range a grid cell names (eb_capi.hip:build_cell_grid), one lane per env ----
+// The reference's argmin (DAM:712-714) restricted to entries [lo, hi] of a path's stride-10 table: index order, the reference's fp32
+// expression, a strict '<' (first minimum) -> the index and the table point itself (x, y, heading).  xy: the path's (x, y) pairs,
+// ph: its headings, both readable 4 entries past the path's end.
+// The first PRE groups of four entries are fetched in ONE round trip, whatever the range's length (6-10 entries on the paths'
+// corridor, i.e. two or three groups): this chain of dependent reads — cell word, then the range — is the critical path of a wave
+// that has one lane per env, and every round trip queues behind the record streams of the same CU.  (Round 5: the groups used to be
+// fetched one per loop trip, a round trip each.)  Same comparisons in the same order: same index, same bits.
+template <int PRE = 3>
+EB_DEV int closest_in_range(const float* xy, const float* ph, int lo, int hi, float px, float py, float& rx, float& ry, float& rphi) {
+    typedef float f4x __attribute__((ext_vector_type(4), aligned(4)));
+    float best = __builtin_inff();
+    int bi = 0;
+    rx = xy[0]; ry = xy[1]; rphi = ph[0];   // index 0 unless a distance compares below +inf, as in the full scan
+    if constexpr (PRE == 0) {               // a group per loop trip (the tape / gated kernels: no registers to spare)
+        for (int r = lo; r <= hi; r += 4) {
+            const f4x a = *reinterpret_cast<const f4x*>(xy + 2 * r), b = *reinterpret_cast<const f4x*>(xy + 2 * r + 4);
+            const f4x hh = *reinterpret_cast<const f4x*>(ph + r);
+            const float d0 = sq(px - a.x) + sq(py - a.y), d1 = sq(px - a.z) + sq(py - a.w);   // DAM:712
+            const float d2 = sq(px - b.x) + sq(py - b.y), d3 = sq(px - b.z) + sq(py - b.w);
+            if (d0 < best) { best = d0; bi = r; rx = a.x; ry = a.y; rphi = hh.x; }                  // first minimum, DAM:714
+            if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; rx = a.z; ry = a.w; rphi = hh.y; }
+            if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; rx = b.x; ry = b.y; rphi = hh.z; }
+            if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; rx = b.z; ry = b.w; rphi = hh.w; }
+        }
+        return bi;
+    }
+    constexpr int NPRE = PRE > 0 ? PRE : 1;
+    f4x q01[NPRE], q23[NPRE], h[NPRE];
+#pragma unroll
+    for (int g = 0; g < PRE; ++g) {
+        const int r = min(lo + 4 * g, hi);   // a group past the range re-reads the range's last entries (in bounds); nothing of it is compared
+        q01[g] = *reinterpret_cast<const f4x*>(xy + 2 * r);
+        q23[g] = *reinterpret_cast<const f4x*>(xy + 2 * r + 4);
+        h[g] = *reinterpret_cast<const f4x*>(ph + r);
+    }
+    auto group = [&](int r, const f4x a, const f4x b, const f4x hh) {
+        const float d0 = sq(px - a.x) + sq(py - a.y), d1 = sq(px - a.z) + sq(py - a.w);   // DAM:712
+        const float d2 = sq(px - b.x) + sq(py - b.y), d3 = sq(px - b.z) + sq(py - b.w);
+        if (r <= hi && d0 < best) { best = d0; bi = r; rx = a.x; ry = a.y; rphi = hh.x; }   // first minimum, DAM:714
+        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; rx = a.z; ry = a.w; rphi = hh.y; }
+        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; rx = b.x; ry = b.y; rphi = hh.z; }
+        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; rx = b.z; ry = b.w; rphi = hh.w; }
+    };
+#pragma unroll
+    for (int g = 0; g < PRE; ++g) group(lo + 4 * g, q01[g], q23[g], h[g]);
+    for (int r = lo + 4 * PRE; r <= hi; r += 4)   // a long range (off the corridor): one group per trip, as before
+        group(r, *reinterpret_cast<const f4x*>(xy + 2 * r), *reinterpret_cast<const f4x*>(xy + 2 * r + 4), *reinterpret_cast<const f4x*>(ph + r));
+    return bi;
+}
+
 // ---- closest point, one lane per env ---------------------------------------------------------------
 // EXACTLY the index the reference's full scan + argmin returns (DAM:702-715) while visiting ~1/5 of
 // the table.  The stride-10 table is cut into blocks of 16 consecutive points; for block b the host

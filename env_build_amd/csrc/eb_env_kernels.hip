@@ -552,7 +552,8 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
                           const float* cand, const uint8_t* cand_mode, const uint8_t* v_light, const uint8_t* virtual_flag,
                           float* obs_out, hipStream_t s, const float* params, const float* cand_lw,
                           uint8_t* done_code, const uint8_t* exit_id, const ExitConsts* xc, const uint8_t* row_mask,
-                          const EnvResetArgs* reset, int tile_envs, int env_waves, long long* trace, long long trace_words) {
+                          const EnvResetArgs* reset, int tile_envs, int env_waves, long long* trace, long long trace_words,
+                          int scan_one_trip) {
     if (reset && (exit_id || done_code || !env_step_is_fused(D, NV, m_cand, cand, ego, nullptr, nullptr, reset->params))) return hipErrorInvalidValue;
     if (exit_id) {
         if (done_code || !xc) return hipErrorInvalidValue;
@@ -576,7 +577,7 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
         env_step_slot_plan(modes, NV, A);
         A.ref_idx = ref_idx; A.ego = const_cast<float*>(ego); A.cand = const_cast<float*>(cand); A.cand_mode = cand_mode;
         A.v_light = v_light; A.virtual_flag = virtual_flag; A.obs_out = obs_out; A.obs_only = 1; A.row_mask = row_mask;
-        A.tile_envs = tile_envs; A.waves = env_waves; A.trace = trace; A.trace_words = trace_words;
+        A.tile_envs = tile_envs; A.waves = env_waves; A.trace = trace; A.trace_words = trace_words; A.scan_one_trip = scan_one_trip;
         if (reset) {   // eb_env_reset_pool: the masked rows' state is drawn in the same launch
             A.reset = 1; A.training = reset->training; A.reset_seed = reset->seed; A.reset_counter = reset->counter;
             A.params = reset->params; A.ref_idx_out = reset->ref_idx; A.virtual_flag = reset->virtual_flag; A.virtual_out = reset->virtual_flag;

@@ -351,7 +351,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         A.ref_idx_out[i] = reset_path;
         if (RESET && A.done_code) A.done_code[i] = EB_DONE_NOT_YET;     // E2E:119 (AUTO: done_code keeps the step's codes)
         if (RESET && A.episode_step) A.episode_step[i] = 0;             // (AUTO: the step itself has restarted the count)
-        if (A.v_light_out) A.v_light_out[i] = 0;
+        if (A.v_light_out && !(AUTO && A.flow_on)) A.v_light_out[i] = 0;   // (the flow source's reset sets its own light, below)
         s_ego[lane] = make_float4(nx[3], nx[4], nx[5], nx[0]);
     };
     auto draw_reset = [&]() {
@@ -544,20 +544,9 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 float rx, ry, rphi;
                 if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) {
                     const unsigned cw = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
-                    const int lo = (int)(cw & 0xffffu), hi = (int)(cw >> 16);
-                    float best = __builtin_inff();
-                    rx = red[0].x; ry = red[0].y; rphi = ph10[0];   // index 0 unless a distance compares below +inf, as in the full scan
-                    for (int r = lo; r <= hi; r += 4) {        // same order, same strict '<' as the full scan: same index
-                        typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
-                        const f4a8 q01 = *reinterpret_cast<const f4a8*>(red + r), q23 = *reinterpret_cast<const f4a8*>(red + r + 2);
-                        const f4a4 h = *reinterpret_cast<const f4a4*>(ph10 + r);
-                        const float d0 = sq(ex - q01.x) + sq(ey - q01.y), d1 = sq(ex - q01.z) + sq(ey - q01.w);
-                        const float d2 = sq(ex - q23.x) + sq(ey - q23.y), d3 = sq(ex - q23.z) + sq(ey - q23.w);
-                        if (d0 < best) { best = d0; bi = r; rx = q01.x; ry = q01.y; rphi = h.x; }
-                        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; rx = q01.z; ry = q01.w; rphi = h.y; }
-                        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; rx = q23.x; ry = q23.y; rphi = h.z; }
-                        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; rx = q23.z; ry = q23.w; rphi = h.w; }
-                    }
+                    // same order, same strict '<' as the full scan: same index (eb_device.h: the range's first two groups in one round trip — three cost this kernel a wave of occupancy)
+                    if (A.scan_one_trip) bi = closest_in_range<0>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
+                    else bi = closest_in_range<2>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
                 } else {
                     bi = closest_reduced_index(red, pt.rad + 32 * p, pt.red_len[p], ex, ey);
                     rx = red[bi].x; ry = red[bi].y; rphi = ph10[bi];
@@ -919,6 +908,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         }
     }
+    if (AUTO && A.flow_on && finmask != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the flow rule's stores, before the tail rewrites the finished envs' slots
     ES_MARK(4);
     if (AUTO) {
         // ---- the envs this step finished start their next episode (E2E:99-127) — eb_env_reset_pool's arithmetic on those rows ----
@@ -951,9 +941,58 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             s_finlist[__popcll(finmask & ((1ull << lane) - 1ull))] = (uint8_t)lane;
         // E2E:102-103 (init_traffic, TRF:151-195): the pool of the finished envs re-enters clear of the NEW ego (s_rst: written before
         // barrier 1) — one lane per (finished env, candidate), not a sweep over the tile's records
-        for (int q = tid; q < n_fin * m_cand; q += NT) {
-            const int k = fast_div(q, A.m_magic);
-            respawn_fresh(nth_fin(k), q - k * m_cand, s_rst);
+        if (!A.flow_on) {
+            for (int q = tid; q < n_fin * m_cand; q += NT) {
+                const int k = fast_div(q, A.m_magic);
+                respawn_fresh(nth_fin(k), q - k * m_cand, s_rst);
+            }
+        } else {
+            // the flow source (ABI 5): Traffic.init_traffic's role for the finished envs = eb_traffic_flow_reset's arithmetic, one lane
+            // per (finished env, route): presence draws, depart position / speed, the conflict test against the NEW ego (TRF:168-192),
+            // timers, clock, light — to HBM and to the tile's LDS copy (records, mode bytes, the route's candidate set), from which
+            // the reset observation is built below.  (A route's slots carry the route's id as their mode: the lane owns that mode's
+            // words of s_elig32 outright.)
+            const int K = A.flow_K;
+            for (int q = tid; q < n_fin * 12; q += NT) {
+                const int k = q / 12, r = q - 12 * k, e = nth_fin(k), ge = e0 + e;
+                const uint64_t env_base = (A.flow_reset_counter << 32) + (uint64_t)ge * 256u;
+                float expect = A.flow_lane_len / 7.5f / A.flow_period[r];
+                if (expect > (float)K) expect = (float)K;
+                const float pp = expect / (float)K;
+                const float4 eg = s_rst[e];
+                const float ego6[6] = {eg.w, 0.0f, 0.0f, eg.x, eg.y, eg.z};
+                unsigned long long set = 0ull;
+                for (int k2 = 0; k2 < K; ++k2) {
+                    const int j = r * K + k2;
+                    const size_t sidx = (size_t)ge * m_cand + j;
+                    const float u0 = u01(A.flow_reset_seed, env_base + 4u * j), u1 = u01(A.flow_reset_seed, env_base + 4u * j + 1),
+                                u2 = u01(A.flow_reset_seed, env_base + 4u * j + 2);
+                    bool on = u0 < pp;
+                    if (on) {
+                        const float* ln = A.flow_lane + 5 * j;
+                        const float along = u1 * A.flow_lane_len;
+                        const float4 c = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
+                        reinterpret_cast<float4*>(A.cand)[sidx] = c;
+                        s_cand[e * RS4 + j] = c;
+                        if (init_conflict(ego6, 4.8f, c.x, c.y, c.w, c.z, A.flow_cand_len[j])) on = false;
+                    }
+                    A.flow_active[sidx] = on ? 1 : 0;
+                    A.flow_mode_out[sidx] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+                    s_tag[e * TS4 * 4 + j] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+                    if (on) set |= 1ull << j;
+                }
+                if (ELIG) { s_elig32[(e * EB_VMODE_COUNT + r) * 2] = (unsigned)set; s_elig32[(e * EB_VMODE_COUNT + r) * 2 + 1] = (unsigned)(set >> 32); }
+                A.flow_timer[(size_t)ge * 12 + r] = u01(A.flow_reset_seed, env_base + 4u * (r * K) + 3) * A.flow_period[r];
+                A.flow_emitted[(size_t)ge * 12 + r] = 0;
+                if (r == 0) {
+                    A.flow_sim_step[ge] = 0;
+                    const uint8_t ph = (A.flow_random_phase && u01(A.flow_reset_seed, env_base + 255u) > 0.5f) ? 2 : 0;   // TRF:158-161
+                    A.flow_phase0[ge] = ph;
+                    const uint8_t nl = A.training ? ph : 0;                                                           // TRF:222-223
+                    A.v_light_out[ge] = nl;
+                    s_col[e] = nl;            // (the step's collision flags are spent: the merge above read them) — the reset observation's light
+                }
+            }
         }
         ES_MARK(13);
         __syncthreads();   // barrier: the re-entered candidates, s_ego, the list
@@ -986,7 +1025,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     const int m = (int)(dm & 0xffu), sa = (int)((dm >> 8) & 0xffu), sb = (int)((dm >> 16) & 0xffu);
                     const float4 eg = s_rst[e];
                     const float ex = eg.x, ey = eg.y;
-                    const bool virt = TASK != TASK_RIGHT && ((vmask >> e) & 1ull) && ey < -HALF_CROSS;      // E2E:386-388
+                    const bool lit = ((vmask >> e) & 1ull) || (A.flow_on && s_col[e] != 0);                 // E2E:387-388: the OLD flag, or the light the flow source's reset set
+                    const bool virt = TASK != TASK_RIGHT && lit && ey < -HALF_CROSS;                        // E2E:386-388
                     const float4* crow = s_cand + e * RS4;
                     const unsigned* trow = s_tag32 + e * TS4;
                     float* ov = s_out + e * OS + 6 + T;
@@ -1042,7 +1082,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         } else {                                                                 // a mode with more than two slots: the step's own slot code
             if (wave == 0 && fin) track_row(reset_path);
-            fill_slots(fin, vflag, false);
+            fill_slots(fin, vflag || (A.flow_on && lane < ET && s_col[lane < ET ? lane : 0] != 0), false);
         }
         ES_MARK(14);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the step's rows have left (phase 4, some 3 us ago) before

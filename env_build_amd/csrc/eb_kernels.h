@@ -39,6 +39,7 @@ struct FusedArgs {
     int do_rewards;            // 0: compute_next_obses only
     long long* trace;          // profiling aid (eb_debug_set_trace): [n_waves][8] s_memrealtime marks, or NULL
     long long trace_words;     //   its capacity in 64-bit words: a mark past it is dropped
+    int scan_one_trip;         // A/B aid (eb_debug_set_scan_prefetch 0): the closest-point range one group of entries per loop trip, as rounds 1-4
     // step gates of eb_rollout_gated (tape kernel only; all NULL / 0 otherwise)
     const unsigned* gate_ready;   // [horizon]: step t may start once gate_ready[t] != 0 (written by the action producer)
     unsigned* gate_done;          // [horizon]: += 1 per block once step t's outputs are visible device-wide
@@ -116,7 +117,8 @@ hipError_t launch_get_obs(int task, int n_env, int D, int n_future, int NV, cons
                           float* obs_out, hipStream_t s, const float* params = nullptr, const float* cand_lw = nullptr,
                           uint8_t* done_code = nullptr, const uint8_t* exit_id = nullptr, const ExitConsts* xc = nullptr,
                           const uint8_t* row_mask = nullptr, const EnvResetArgs* reset = nullptr,
-                          int tile_envs = 0, int env_waves = 0, long long* trace = nullptr, long long trace_words = 0);
+                          int tile_envs = 0, int env_waves = 0, long long* trace = nullptr, long long trace_words = 0,
+                          int scan_one_trip = 0);
                           // tile_envs / env_waves / trace: EnvStepArgs::tile_envs / waves / trace for the one-launch machinery
 hipError_t launch_exit_frame(int n, const uint8_t* exit_id, int inverse, const ExitConsts& xc, const float* ego, float* out,
                              hipStream_t s);
@@ -173,6 +175,7 @@ struct EnvStepArgs {
     long long* trace;                      // profiling aid (eb_debug_set_trace): [n_blocks * waves per block (4 or 8)][16] wall-clock marks, or NULL
     long long trace_words;                 //   its capacity in 64-bit words: a mark past it is dropped
     int waves;                             // 0: by grid size (launch_env_step); 4 / 8: forced (eb_debug_set_env_waves)
+    int scan_one_trip;                     // A/B aid (eb_debug_set_scan_prefetch 0), as FusedArgs::scan_one_trip
     int obs_only;                          // 1: eb_get_obs — ego / cand are inputs, only obs_out is written
     const uint8_t* row_mask;               // obs_only: nullable [n_env]; rows with a zero byte are left alone
     int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 32 / 64: forced (eb_debug_set_tile 2 / 1 / 0)
@@ -207,6 +210,12 @@ struct EnvStepArgs {
     const float* flow_v_max;
     float flow_dt, flow_exit_range, flow_accel, flow_lane_len;
     uint8_t* flow_mode_out;
+    // flow_on && auto_reset (ABI 5): the flow source's part of reset — eb_traffic_flow_reset's arithmetic for the finished envs —
+    // instead of the pool's re-entry (pool_* unused)
+    const float* flow_cand_len;
+    uint8_t* flow_phase0;
+    int flow_random_phase;
+    uint64_t flow_reset_seed, flow_reset_counter;
     // eb_time_limit (eb_env_step, ABI 5): per-env steps of the running episode, + 1 per step; an env NO reference outcome has
     // finished takes EB_DONE_TIME_LIMIT when the count reaches max_episode_steps; the count of a finished env restarts at 0.
     // reset = 1 (eb_env_reset_pool): the masked rows' counts are cleared (max_episode_steps unused)

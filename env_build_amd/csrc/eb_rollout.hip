@@ -197,6 +197,9 @@ constexpr int TAPE_QCAP = 192;   // the tape kernel drains when more than 64 ent
 // Returns the table index and the table point itself (x, y, heading).
 // xy10 / phi10: the stride-10 tables — in global memory (the per-step kernel: L1/L2 resident), or the copy a block of the
 // tape / gated kernels keeps in LDS for its whole launch (north_star: "LDS staging of the reference path per block")
+// PRE: groups of four table entries fetched in one round trip (eb_device.h:closest_in_range) — 3 in the per-step kernel, whose tables
+// sit in L2; 0 — a group per loop trip, as before — in the tape / gated kernels (their register budget is the records', and small grids read the tables from LDS)
+template <int PRE = 3>
 EB_DEV int closest_cell_index(const FusedArgs& A, const float* xy10, const float* phi10, int p, int roff, float px, float py,
                               float& rx, float& ry, float& rphi) {
     const float* xy = xy10 + 2 * roff;
@@ -209,21 +212,8 @@ EB_DEV int closest_cell_index(const FusedArgs& A, const float* xy10, const float
         return bi;
     }
     const unsigned c = A.cells[(p * A.gny + (int)fy) * A.gnx + (int)fx];
-    const int lo = (int)(c & 0xffffu), hi = (int)(c >> 16);
-    float best = __builtin_inff();
-    int bi = 0;
-    rx = xy[0]; ry = xy[1]; rphi = ph[0];   // index 0 unless a distance compares below +inf, as in the full scan
-    for (int r = lo; r <= hi; r += 4) {
-        const f4u q01 = *reinterpret_cast<const f4u*>(xy + 2 * r), q23 = *reinterpret_cast<const f4u*>(xy + 2 * r + 4);
-        const f4u h = *reinterpret_cast<const f4u*>(ph + r);
-        const float d0 = sq(px - q01.x) + sq(py - q01.y), d1 = sq(px - q01.z) + sq(py - q01.w);   // DAM:712
-        const float d2 = sq(px - q23.x) + sq(py - q23.y), d3 = sq(px - q23.z) + sq(py - q23.w);
-        if (d0 < best) { best = d0; bi = r; rx = q01.x; ry = q01.y; rphi = h.x; }                  // first minimum, DAM:714
-        if (r + 1 <= hi && d1 < best) { best = d1; bi = r + 1; rx = q01.z; ry = q01.w; rphi = h.y; }
-        if (r + 2 <= hi && d2 < best) { best = d2; bi = r + 2; rx = q23.x; ry = q23.y; rphi = h.z; }
-        if (r + 3 <= hi && d3 < best) { best = d3; bi = r + 3; rx = q23.z; ry = q23.w; rphi = h.w; }
-    }
-    return bi;
+    if (PRE > 0 && A.scan_one_trip) return closest_in_range<0>(xy, ph, (int)(c & 0xffffu), (int)(c >> 16), px, py, rx, ry, rphi);
+    return closest_in_range<PRE>(xy, ph, (int)(c & 0xffffu), (int)(c >> 16), px, py, rx, ry, rphi);
 }
 
 template <int RW, int RPT>
@@ -770,7 +760,7 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         int bi = 0;
         if (p >= 0) {                                                       // DAM:334-353
             float rx = 0.0f, ry = 0.0f, rphi = 0.0f;
-            bi = closest_cell_index(A, xy10, phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
+            bi = closest_cell_index<0>(A, xy10, phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
             t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                       // DAM:758
             t1 = deal_with_phi_diff(nx[5] - rphi);                          // DAM:759
             t2 = nx[0] - EXP_V;                                             // DAM:760
@@ -964,7 +954,7 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
 // One kernel per tile shape, with the VGPR budget spelled out.  2048-record tiles run 4 blocks x 5 waves per
 // CU at the headline size = 5 waves per SIMD on average, but a block's 5 waves land 2-1-1-1 on the SIMDs from
 // a varying start, so one SIMD can be asked for a 6th: budget for 6 (80 VGPRs) or that block waits a whole
-// round.  The smaller tiles fill all 8 wave slots of a SIMD (64 VGPRs).
+// round.  (The smaller tiles had 64 VGPRs for 8 waves per SIMD until round 5: see below.)
 #define EB_FUSED_KERNEL(NAME, RW, RPT, WAVES, VGPRS)                                                     \
     template <int TASK, bool FAST, typename ST>                                                          \
     __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
@@ -974,8 +964,8 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
         fused_body<TASK, RW, RPT, FAST, ST>(H, A);                                                       \
     }
 EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
-EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 8, 64)
-EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 8, 64)
+EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 6, 80)   // (round 5: 64 -> 80 VGPRs — the env wave keeps three groups of table entries in flight;
+EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 6, 80)   //  these tiles run on grids of a few blocks per CU: latency, not occupancy)
 
 #define EB_TAPE_KERNEL(NAME, RW, RPT, GATED, WAVES)                                                      \
     template <int TASK, bool FAST, typename ST>                                                          \

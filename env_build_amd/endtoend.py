@@ -386,9 +386,9 @@ class CrossroadEnd2end(object):
         if self.auto_reset and (B == 1 or traffic not in ('pool', 'flows')):
             raise ValueError('auto_reset needs a batch (n_env > 1) over the traffic pool or the flow source')
         self._auto_rule = None
-        # the flow source: the C-ABI's eb_auto_reset is the pool's (eb_flow_rule excludes it) — step() composes the same contract
-        # from the step launch and the masked reset's launches
-        self._auto_compose = self.auto_reset and traffic == 'flows'
+        # the flow source with its rule as a launch of its own (flow_in_step=False): step() composes the same contract from the step
+        # launch and the masked reset's launches; with the rule inside the step's launch the reset rides there too (ABI 5)
+        self._auto_compose = self.auto_reset and traffic == 'flows' and not self.flow_in_step
         if self.auto_reset and traffic == 'pool':       # eb_auto_reset: the state arrays are fixed, the counters and final_obs are set per step
             self._auto_rule = _capi.EbAutoReset(0, 0, 1 if self.mode == 'training' else 0, self._ref_idx.data_ptr(),
                                                 self._virtual.data_ptr(), self._v_light.data_ptr(), self._reset_rule, None)
@@ -397,6 +397,12 @@ class CrossroadEnd2end(object):
             self._flows = FlowTraffic(B, dev, None, self.training_task, mode=self.mode, per_route=per_route,
                                       step_time=self.step_time)
             self._flows.seed = self._respawn_seed
+            if self.auto_reset and self.flow_in_step:   # eb_auto_reset over the flow source: the source's own arrays (its light is the env's)
+                fl = self._flows
+                self._auto_rule = _capi.EbAutoReset(0, 0, 1 if self.mode == 'training' else 0, self._ref_idx.data_ptr(),
+                                                    self._virtual.data_ptr(), fl.v_light().data_ptr(), self._reset_rule, None,
+                                                    fl.veh_len.data_ptr(), fl.phase0.data_ptr(),
+                                                    1 if self.training_task == 'right' else 0, 0, 0)
         self.init_state = self._reset_init_state()
         if not multi_display:                                                           # E2E:84-93
             self.reset()
@@ -820,10 +826,18 @@ class CrossroadEnd2end(object):
             rs = self._respawn_rule
             rs.seed, rs.counter = self._respawn_seed, self._respawn_counter
         ar = self._auto_rule
-        if ar is not None:     # the envs this step finishes start their next episode in the same launch: the draws reset(mask=done) would make
+        if ar is not None and self._flows is None:   # the envs this step finishes start their next episode in the same launch: the draws reset(mask=done) would make
             self._reset_counter += 2
             ar.seed, ar.counter = self._respawn_seed ^ self._RESET_SALT, self._reset_counter - 1
             ar.pool.seed, ar.pool.counter = self._respawn_seed ^ self._POOL_SALT, self._reset_counter
+            ar.final_obs = final.data_ptr()
+        elif ar is not None:                         # ... over the flow source: eb_env_reset's and eb_traffic_flow_reset's draws of that reset
+            from .traffic import RESET_SALT
+            self._reset_counter += 1
+            self._flows.reset_counter += 1
+            ar.seed, ar.counter = self._respawn_seed ^ self._RESET_SALT, self._reset_counter
+            ar.flow_seed, ar.flow_counter = self._flows.seed ^ RESET_SALT, self._flows.reset_counter
+            ar.v_light = self._v_light.data_ptr()
             ar.final_obs = final.data_ptr()
         fr = None
         if self._flows is not None:    # exits, emissions, the new mode bytes and the light for the NEXT step ride on the way out of the

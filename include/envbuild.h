@@ -397,7 +397,11 @@ typedef struct eb_respawn {
     uint64_t counter;
     float edge_span;    /* eb_env_reset_pool only: where a candidate goes that would start on top of the ego (eb_traffic_respawn) */
 } eb_respawn;
-/* flow (nullable, ABI 4; not together with respawn / auto_reset): the step of the SUMO-free FLOW traffic source as the last stage
+/* flow (nullable, ABI 4; not together with respawn; together with auto_reset since ABI 5 — "step, then reset the envs it finished"
+ * over the flow source: after the flow step below, with mask[e] = (done_code[e] != 0): final_obs rows; eb_env_reset(h, n_env, mask, seed,
+ * counter, training, ego, params, ref_idx, <next flags>, NULL, NULL); eb_traffic_flow_reset as spelled out at eb_auto_reset; eb_get_obs(h,
+ * ..., v_light, virtual_flag, NULL, mask, obs_out) with the OLD flags (E2E:116) and the light the reset has just set; the drawn flags
+ * swapped in — ONE launch in the HIP library under the conditions of eb_env_step): the step of the SUMO-free FLOW traffic source as the last stage
  * of the call — eb_traffic_flow_step(traffic, n_env, per_route, cand, active, timer, emitted, sim_step, lane, period, v_max, dt,
  * exit_range, accel, lane_len, light_cycle, seed, counter, cand_mode, v_light) AFTER the observation and the done code were taken
  * (they see the slots as this step's prediction left them and the modes / light the call was given; the exits, accelerations,
@@ -426,6 +430,14 @@ typedef struct eb_auto_reset {
     uint8_t* v_light;        /* == the v_light argument (nullable): cleared for the finished envs */
     eb_respawn pool;         /* the pool's part of reset: entry, span, v_max, seed, counter, edge_span (limit unused) */
     float* final_obs;        /* nullable [n_env, D]: the terminal observation rows of the finished envs */
+    /* together with a flow rule (ABI 5; pool is then unused): the FLOW source's part of reset for the finished envs —
+     * eb_traffic_flow_reset(traffic, n_env, flow->per_route, mask, ego, cand, flow->active, flow->timer, flow->emitted, flow->sim_step,
+     * flow_phase0, flow->lane, flow->period, flow->v_max, flow_cand_len, flow->lane_len, flow_random_phase, training, flow_seed,
+     * flow_counter, cand_mode, v_light) in the place of the pool's re-entry: Traffic.init_traffic (TRF:151-195) */
+    const float* flow_cand_len; /* [m_cand] vehicle length per slot */
+    uint8_t* flow_phase0;       /* [n_env] */
+    int32_t flow_random_phase;
+    uint64_t flow_seed, flow_counter;
 } eb_auto_reset;
 /* time_limit (nullable, ABI 5): the episode step limit of the REGISTERED env — callers reach CrossroadEnd2end through
  * gym.make('CrossroadEnd2end-v0') with max_episode_steps = 200 (README.md:55-59, mpc/main.py:542-576), i.e. inside gym's TimeLimit
@@ -549,7 +561,9 @@ int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const u
  * tiles for 0 / 1 / 2 and pick by batch size otherwise.  eb_debug_set_env_waves: 4 / 8 waves per block of those kernels
  * (0: eight on grids of at most three blocks per CU with tiles of at most 32 envs, four otherwise).  eb_debug_set_tape_stepwise:
  * 1 = eb_rollout_tape[_f16] as `horizon` per-step launches, 0 = the one-launch tape kernel.  eb_debug_set_stage_paths: the tape /
- * gated kernels' LDS copy of the stride-10 path tables on (1) / off (0) / by grid size (-1).
+ * gated kernels' LDS copy of the stride-10 path tables on (1) / off (0) / by grid size (-1).  eb_debug_set_scan_prefetch: 0 = the
+ * closest-point search reads its index range one group of four table entries per loop trip (a memory round trip each, rounds 1-4's
+ * form: A/B aid), 1 (default) = the first groups in one round trip; same comparisons, same bits.
  * eb_debug_set_trace: a device buffer of capacity_words int64 the kernels fill with wall-clock marks (NULL = off): the rollout
  * kernel writes rows of 8 words, one per wave — [n_blocks * waves per block][8] —, the one-launch env step rows of 16 —
  * [n_blocks * W][16] with W = 4 or 8 as above: size it for 8.  A mark that would land at or past capacity_words is dropped.
@@ -558,6 +572,7 @@ int eb_debug_set_tile(eb_handle h, int32_t variant);
 int eb_debug_set_env_waves(eb_handle h, int32_t waves);
 int eb_debug_set_tape_stepwise(eb_handle h, int32_t on);
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode);
+int eb_debug_set_scan_prefetch(eb_handle h, int32_t on);
 int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words);
 
 /* ---- the policy in the loop: MLPNet + LoadPolicy.run_batch + the safety shield ----

@@ -1371,14 +1371,16 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (auto_reset) {   /* the same checks as the HIP library, before anything is written */
         const eb_auto_reset* ar = auto_reset;
-        if (!ar->pool.entry || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
+        if ((!flow && !ar->pool.entry) || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
             ar->virtual_flag != virtual_flag || ar->v_light != v_light)
             return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
+        if (flow && (!ar->flow_cand_len || !ar->flow_phase0))
+            return fail(EB_EINVAL, "eb_env_step: auto_reset over the flow source needs flow_cand_len and flow_phase0");
         if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))
             return fail(EB_EINVAL, "eb_env_step: final_obs must be an array of its own");
     }
     if (flow) {   /* the same checks as the HIP library, before anything is written */
-        if (respawn || auto_reset) return fail(EB_EINVAL, "eb_env_step: the flow rule excludes respawn / auto_reset (the pool's rules)");
+        if (respawn) return fail(EB_EINVAL, "eb_env_step: the flow rule excludes respawn (the pool's rule)");
         if (flow->per_route < 1 || 12 * flow->per_route != m_cand || m_cand > 64 || !flow->active || !flow->timer || !flow->emitted ||
             !flow->sim_step || !flow->lane || !flow->period || !flow->v_max || !v_light || flow->v_light != v_light || flow->cand_mode != cand_mode)
             return fail(EB_EINVAL, "eb_env_step: bad flow rule (m_cand == 12 * per_route <= 64, every array given, cand_mode / v_light the call's own)");
@@ -1409,6 +1411,32 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!rc && respawn)   /* the pool's re-entry, after the observation saw this step's state */
         rc = eb_traffic_respawn(traffic, n_env, m_cand, cand, respawn->entry, respawn->limit, respawn->span, respawn->v_max,
                                 respawn->seed, respawn->counter, NULL, NULL, NULL, 0.0f, stream);
+    if (!rc && flow && auto_reset) {   /* ABI 5, the flow source: its step, then E2E:99-127 for the finished envs with the source's own reset */
+        const eb_auto_reset* ar = auto_reset;
+        const size_t D = (size_t)obs_dim(&h->cfg);
+        rc = eb_traffic_flow_step(traffic, n_env, flow->per_route, cand, flow->active, flow->timer, flow->emitted, flow->sim_step, flow->lane,
+                                  flow->period, flow->v_max, flow->dt, flow->exit_range, flow->accel, flow->lane_len, flow->light_cycle,
+                                  flow->seed, flow->counter, flow->cand_mode, flow->v_light, stream);
+        uint8_t* mask = (uint8_t*)malloc((size_t)n_env * 2);
+        if (!mask) return fail(EB_ENOMEM, "eb_env_step: out of memory");
+        uint8_t* vnext = mask + n_env;
+        for (int e = 0; e < n_env; ++e) {
+            mask[e] = done_code[e] != 0;
+            if (mask[e] && ar->final_obs) memcpy(ar->final_obs + D * e, obs_out + D * e, D * sizeof(float));
+        }
+        if (!rc) rc = eb_env_reset(h, n_env, mask, ar->seed, ar->counter, ar->training, ego, params, ar->ref_idx, vnext, NULL, NULL, stream);   /* E2E:100-101 */
+        if (!rc) rc = eb_traffic_flow_reset(traffic, n_env, flow->per_route, mask, ego, cand, flow->active, flow->timer, flow->emitted,
+                                            flow->sim_step, ar->flow_phase0, flow->lane, flow->period, flow->v_max, ar->flow_cand_len,
+                                            flow->lane_len, ar->flow_random_phase, ar->training, ar->flow_seed, ar->flow_counter,
+                                            flow->cand_mode, flow->v_light, stream);                                                          /* E2E:102-103 */
+        if (!rc) rc = eb_get_obs(h, n_env, ego, ar->ref_idx, 0, m_cand, cand, flow->cand_mode, flow->v_light, ar->virtual_flag, NULL, mask,
+                                 obs_out, stream);                                                                                             /* E2E:116 */
+        if (!rc)
+            for (int e = 0; e < n_env; ++e)
+                if (mask[e]) ar->virtual_flag[e] = vnext[e];                                                                                   /* E2E:120-126 */
+        free(mask);
+        return rc;
+    }
     if (!rc && auto_reset) {   /* hier_decision.py:109-135 / E2E:99-127: the envs this step finished start their next episode */
         const eb_auto_reset* ar = auto_reset;
         const size_t D = (size_t)obs_dim(&h->cfg);
@@ -1687,6 +1715,7 @@ int eb_debug_set_tile(eb_handle h, int32_t variant) { (void)variant; return h ? 
 int eb_debug_set_tape_stepwise(eb_handle h, int32_t on) { (void)on; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_tape_stepwise: null handle"); }
 int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words) { (void)device_buf; (void)capacity_words; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_trace: null handle"); }
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode) { (void)mode; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_stage_paths: null handle"); }
+int eb_debug_set_scan_prefetch(eb_handle h, int32_t on) { (void)on; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_scan_prefetch: null handle"); }
 int eb_debug_set_env_waves(eb_handle h, int32_t waves) { (void)waves; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_env_waves: null handle"); }
 
 int eb_traffic_flow_step(eb_handle h, int32_t n_env, int32_t per_route, float* cand, uint8_t* active, float* timer,

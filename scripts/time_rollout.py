@@ -10,7 +10,7 @@ from env_build_amd.synthetic import make_rollout_inputs
 ap = argparse.ArgumentParser()
 ap.add_argument('--task', default='left'); ap.add_argument('--n-env', type=int, default=65536)
 ap.add_argument('--n-veh', type=int, default=32); ap.add_argument('--mode', default='training')
-ap.add_argument('--iters', type=int, default=200); ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one'); ap.add_argument('--lanes', type=int, default=1, help='independent env sets stepped round-robin (8: the working set leaves the Infinity Cache)'); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])'); ap.add_argument('--tile', type=int, default=-1, help='eb_debug_set_tile: 0 = 4x8 (2048 records), 1 = 4x4, 2 = 1x4, -1 = by batch size'); ap.add_argument('--stage-paths', type=int, default=-1, help='eb_debug_set_stage_paths: the tape / gated kernels keep the path tables in LDS (1) or not (0); -1 = by grid size')
+ap.add_argument('--iters', type=int, default=200); ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one'); ap.add_argument('--lanes', type=int, default=1, help='independent env sets stepped round-robin (8: the working set leaves the Infinity Cache)'); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])'); ap.add_argument('--tile', type=int, default=-1, help='eb_debug_set_tile: 0 = 4x8 (2048 records), 1 = 4x4, 2 = 1x4, -1 = by batch size'); ap.add_argument('--scan-prefetch', type=int, default=1, help='eb_debug_set_scan_prefetch: 0 = one group of table entries per loop trip (rounds 1-4), 1 = the first groups in one round trip'); ap.add_argument('--stage-paths', type=int, default=-1, help='eb_debug_set_stage_paths: the tape / gated kernels keep the path tables in LDS (1) or not (0); -1 = by grid size')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 if a.lib:
@@ -20,6 +20,7 @@ inp = make_rollout_inputs(a.task, a.n_env, a.n_veh, 25, seed=0)
 m = EnvironmentModel(a.task, 0, mode=a.mode, n_veh=a.n_veh, device=dev)
 m.api.debug_set_tile(m.handle, a.tile)
 m.api.debug_set_stage_paths(m.handle, a.stage_paths)
+m.api.debug_set_scan_prefetch(m.handle, a.scan_prefetch)
 ego = torch.from_numpy(inp['ego']).to(dev); ref = torch.from_numpy(inp['ref_idx']).to(dev)
 if a.mode != 'training': m.ref_path.set_path(1)
 trk = m.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(),

@@ -434,3 +434,72 @@ def parked_ego_case(make, task='left', B=3, max_steps=200):
         want_hits = [first] + ([first + max_steps] if first + max_steps <= max_steps else [])
         assert hits.tolist() == want_hits and (codes[hits, b] == 7).all(), (b, hits)
     return codes
+
+
+def flow_auto_reset_case(make, task, B=260, K=5, steps=12, tile=None, seed=13, strict=True):
+    """ABI 5 — eb_env_step(flow + auto_reset): the step over the flow source that also resets the envs it finished == eb_env_step(flow),
+    then the terminal rows -> final_obs, eb_env_reset(mask), eb_traffic_flow_reset(mask, new ego), eb_get_obs(row_mask, OLD flags, the
+    light the reset set), flag swap — every output and every piece of state, bit for bit, over a closed loop in which egos do finish;
+    -> the trace of the one-call path (for cross-library comparison)."""
+    from env_build_amd.traffic import ACCEL, EXIT_RANGE, FLOWS, LANE_START, ROUTES, VTYPES, approach_lane
+    M = 12 * K
+    slot_modes = [r for r in ROUTES for _ in range(K)]
+    lane = np.array([list(approach_lane(m)[0]) + list(approach_lane(m)[1]) for m in slot_modes], np.float32)
+    period = (np.array([3600.0 / FLOWS[r][0] for r in ROUTES], np.float32) / 8).astype(np.float32)
+    vmax = np.array([VTYPES[FLOWS[m][1]][2] for m in slot_modes], np.float32)
+    clen = np.array([VTYPES[FLOWS[m][1]][0] for m in slot_modes], np.float32)
+    lw = np.tile(np.array([[VTYPES[FLOWS[m][1]][0], VTYPES[FLOWS[m][1]][1]] for m in slot_modes], np.float32), (B, 1, 1))
+    rng = np.random.default_rng(seed)
+    inp = make_rollout_inputs(task, B, 8, 1, seed=seed)
+    ego, ref = inp['ego'].copy(), inp['ref_idx'].copy()
+    ego[::6, 3] += rng.uniform(7, 12, len(ego[::6])) * rng.choice([-1, 1], len(ego[::6]))      # a sixth of the egos off the road: they finish at once
+    m, tr = make(task, mode='training'), make(task, n_veh=M, modes=slot_modes)
+    if tile is not None:
+        m.set_tile(tile)
+    active = (rng.random((B, M)) < 0.4).astype(np.uint8)
+    along = rng.uniform(0, 95, (B, M)).astype(np.float32)
+    cand = np.stack([lane[None, :, 0] + along * lane[None, :, 3], lane[None, :, 1] + along * lane[None, :, 4],
+                     rng.uniform(0, 9, (B, M)).astype(np.float32), np.broadcast_to(lane[None, :, 2], (B, M))], 2).astype(np.float32)
+    mode = np.where(active != 0, np.array([_capi.VMODE_ID[x] for x in slot_modes], np.uint8)[None, :], _capi.VMODE_EMPTY).astype(np.uint8)
+    timer = (rng.random((B, 12)) * period).astype(np.float32)
+    emitted, sim_step = np.zeros((B, 12), np.int32), rng.integers(0, 600, B).astype(np.int32)
+    light = rng.integers(0, 4, B).astype(np.uint8)
+    virtual = (rng.random(B) < 0.3).astype(np.uint8)
+    phase0 = np.full(B, 9, np.uint8)
+    obs = m.get_obs(ego, cand, mode, light, ref_idx=ref, virtual=virtual)
+    rp = 1 if task == 'right' else 0
+    const = dict(per_route=K, lane=lane, period=period, v_max=vmax, dt=0.1, exit_range=EXIT_RANGE, accel=ACCEL, lane_len=LANE_START - 25.0,
+                 light_cycle=0, seed=99)
+    trace, n_fin = [], 0
+    for t in range(steps):
+        raw = rng.uniform(-1.0, 1.0, (B, 2)).astype(np.float32)
+        flow = dict(const, active=active, timer=timer, emitted=emitted, sim_step=sim_step, counter=t + 1)
+        # the step with the flow rule (flow_rule_case holds it to step + eb_traffic_flow_step), then the reset's calls
+        a = m.env_step(tr, obs, raw, ego, cand, mode, ref_idx=ref, cand_lw=lw, v_light=light, virtual=virtual, flow=flow)
+        sc, o5, d16, ego1, par1, cand1, obs1, done1, act1, tim1, emi1, sim1, mode1, light1 = a
+        mask = (done1 != 0).astype(np.uint8)
+        ego2, par2, ref2, vnext, _ = m.env_reset(B, 777, t + 1, 1, ego1, par1, ref, mask=mask)
+        cand2, act2, tim2, emi2, sim2, ph2, mode2, light2 = tr.traffic_flow_reset(K, mask, ego2, cand1, act1, tim1, emi1, sim1, phase0, lane, period,
+                                                                                  vmax, clen, LANE_START - 25.0, rp, 1, 4242, t + 1, mode1, light1)
+        obs2 = m.get_obs(ego2, cand2, mode2, light2, ref_idx=ref2, virtual=virtual, row_mask=mask, obs_init=obs1)
+        virt2 = np.where(mask != 0, vnext, virtual).astype(np.uint8)
+        final = np.where(mask[:, None] != 0, obs1, np.float32(np.nan))
+        # the one call
+        g = m.env_step(tr, obs, raw, ego, cand, mode, ref_idx=ref, cand_lw=lw, v_light=light, virtual=virtual, flow=flow,
+                       auto_reset=dict(seed=777, counter=t + 1, training=1,
+                                       flow=dict(cand_len=clen, phase0=phase0, random_phase=rp, seed=4242, counter=t + 1)))
+        want = [sc, o5, d16, ego2, par2, cand2, obs2, done1, ref2, virt2, light2, final, ph2, act2, tim2, emi2, sim2, mode2, light2]
+        names = ['scaled', 'out5', 'dict16', 'ego', 'params', 'cand', 'obs', 'done', 'ref_idx', 'virtual', 'v_light', 'final_obs', 'phase0',
+                 'active', 'timer', 'emitted', 'sim_step', 'cand_mode', 'v_light (flow)']
+        assert len(g) == len(want)
+        for k, (x, y) in enumerate(zip(g, want)):
+            if names[k] == 'cand':       # a vacant slot keeps whatever record it held: compare the occupied ones and the vacated ones' stale records alike
+                assert np.array_equal(np.asarray(x).reshape(y.shape), y), (t, names[k])
+                continue
+            assert np.array_equal(np.asarray(x).reshape(np.asarray(y).shape), y, equal_nan=True), (t, names[k])
+        n_fin += int(mask.sum())
+        ego, cand, obs, ref, virtual, phase0 = g[3], g[5], g[6], g[8], g[9], g[12]
+        active, timer, emitted, sim_step, mode, light = g[13], g[14], g[15], g[16], g[17], g[18]
+        trace.append([np.asarray(x) for x in g])
+    assert not strict or n_fin > B // 8, n_fin
+    return trace

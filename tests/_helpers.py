@@ -394,31 +394,36 @@ class HostModel(object):
             entry = self._in(respawn['entry'])
             rs = _capi.EbRespawn(self._ptr(entry).value, float(respawn['limit']),
                                  float(respawn['span']), float(respawn['v_max']), int(respawn['seed']), int(respawn['counter']))
-        ar, extra = None, ()
-        if auto_reset is not None:
-            pool = auto_reset['pool']
-            pentry = self._in(pool['entry'])
-            ri = None if ref_idx is None else self._in(np.array(ref_idx, np.int32), np.int32)   # (copies: the call writes them)
-            vf = self._in(np.array(virtual, np.uint8), np.uint8)
+        ar, fl, extra = None, None, ()
+        vp = lambda t: None if t is None else self._ptr(t).value
+        if auto_reset is not None or flow is not None:      # the arrays the call rewrites: explicit copies, shared by the two structs
             vl = None if v_light is None else self._in(np.array(v_light, np.uint8), np.uint8)
+        if auto_reset is not None:
+            pool = auto_reset.get('pool')
+            pentry = None if pool is None else self._in(pool['entry'])
+            ri = None if ref_idx is None else self._in(np.array(ref_idx, np.int32), np.int32)
+            vf = self._in(np.array(virtual, np.uint8), np.uint8)
             fo = self._in(np.full(np.asarray(obs).shape, np.nan, np.float32)) if auto_reset.get('final_obs', True) else None
-            pr = _capi.EbRespawn(self._ptr(pentry).value, 0.0, float(pool['span']), float(pool['v_max']), int(pool['seed']),
-                                 int(pool['counter']), float(pool['edge_span']))
-            vp = lambda t: None if t is None else self._ptr(t).value
+            pr = _capi.EbRespawn() if pool is None else _capi.EbRespawn(self._ptr(pentry).value, 0.0, float(pool['span']), float(pool['v_max']),
+                                                                        int(pool['seed']), int(pool['counter']), float(pool['edge_span']))
             ar = _capi.EbAutoReset(int(auto_reset['seed']), int(auto_reset['counter']), int(auto_reset['training']), vp(ri), vp(vf),
                                    vp(vl), pr, vp(fo))
+            fr_extra = ()
+            if 'flow' in auto_reset:       # ABI 5: the flow source's part of reset — dict(cand_len [M], phase0 [B], random_phase, seed, counter)
+                fr = auto_reset['flow']
+                f_len, f_ph = self._in(fr['cand_len']), self._in(np.array(fr['phase0'], np.uint8), np.uint8)
+                ar.flow_cand_len, ar.flow_phase0, ar.flow_random_phase = vp(f_len), vp(f_ph), int(fr['random_phase'])
+                ar.flow_seed, ar.flow_counter = int(fr['seed']), int(fr['counter'])
+                fr_extra = (f_ph,)
             for k in ('ref_idx', 'virtual', 'v_light'):                  # test hook: a pointer that is NOT the call's argument
                 if k in auto_reset.get('wrong', ()):
                     setattr(ar, {'virtual': 'virtual_flag'}.get(k, k), vp(self._out((B,), np.int32 if k == 'ref_idx' else np.uint8)))
-            extra = (ri, vf, vl, fo)
-        fl = None
+            extra = (ri, vf, vl, fo) + fr_extra
         if flow is not None:
             # flow: dict(per_route, active, timer, emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len, light_cycle,
             # seed, counter) — eb_traffic_flow_step as the call's last stage; the result gains (active, timer, emitted, sim_step,
             # cand_mode, v_light) after it
-            vp = lambda t: None if t is None else self._ptr(t).value
-            cm = self._in(np.array(cand_mode, np.uint8), np.uint8)          # (copies: the call rewrites them)
-            vl = self._in(np.array(v_light, np.uint8), np.uint8)
+            cm = self._in(np.array(cand_mode, np.uint8), np.uint8)          # (a copy: the call rewrites it)
             f_act, f_tim = self._in(np.array(flow['active'], np.uint8), np.uint8), self._in(np.array(flow['timer'], np.float32))
             f_emi, f_sim = self._in(np.array(flow['emitted'], np.int32), np.int32), self._in(np.array(flow['sim_step'], np.int32), np.int32)
             f_lane, f_per, f_vm = self._in(flow['lane']), self._in(flow['period']), self._in(flow['v_max'])
@@ -448,6 +453,22 @@ class HostModel(object):
         self.api.traffic_respawn(self.h, B, M, self._ptr(cd), self._ptr(en), C.c_float(limit), C.c_float(span), C.c_float(v_max),
                                  C.c_uint64(seed), C.c_uint64(counter), self._ptr(mk), self._ptr(flags), self._ptr(eg), C.c_float(edge_span), self.stream)
         return self._ret(cd), self._ret(flags)
+
+    def traffic_flow_reset(self, K, mask, ego, cand, active, timer, emitted, sim_step, phase0, lane, period, v_max, cand_len, lane_len,
+                           random_phase, training, seed, counter, cand_mode, v_light):
+        """eb_traffic_flow_reset on copies of the state -> (cand, active, timer, emitted, sim_step, phase0, cand_mode, v_light)"""
+        cp = lambda a, t, tt=None: self._in(np.array(a, t), tt or t)
+        cd, ac, tm = cp(cand, np.float32), cp(active, np.uint8), cp(timer, np.float32)
+        em, ss, ph = cp(emitted, np.int32), cp(sim_step, np.int32), cp(phase0, np.uint8)
+        md, vl = cp(cand_mode, np.uint8), cp(v_light, np.uint8)
+        mk, eg = self._in(mask, np.uint8), self._in(ego)
+        ln, pe, vm, cl = self._in(lane), self._in(period), self._in(v_max), self._in(cand_len)
+        B = cd.shape[0]
+        self.api.traffic_flow_reset(self.h, B, int(K), self._ptr(mk), self._ptr(eg), self._ptr(cd), self._ptr(ac), self._ptr(tm), self._ptr(em),
+                                    self._ptr(ss), self._ptr(ph), self._ptr(ln), self._ptr(pe), self._ptr(vm), self._ptr(cl), C.c_float(lane_len),
+                                    int(random_phase), int(training), C.c_uint64(seed), C.c_uint64(counter), self._ptr(md), self._ptr(vl),
+                                    self.stream)
+        return [self._ret(x) for x in (cd, ac, tm, em, ss, ph, md, vl)]
 
     def traffic_flow_step(self, K, cand, active, timer, emitted, sim_step, lane, period, v_max, dt, exit_range, accel, lane_len,
                           light_cycle, seed, counter, v_light):

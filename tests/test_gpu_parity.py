@@ -742,6 +742,76 @@ def test_env_step_with_the_flow_rule(task, K, tile):
         _compare_auto_reset(a, b, 300, 'flow rule, step %d' % t)
 
 
+@pytest.mark.parametrize('task,K,tile', [('left', 5, -1), ('left', 5, 1), ('straight', 5, 2), ('right', 2, 0), ('left', 1, -1), ('right', 3, 1)])
+def test_env_step_with_the_flow_rule_and_auto_reset(task, K, tile):
+    """ABI 5 — the step over the flow source that also resets the envs it finished, ONE launch (the flow source's reset —
+    Traffic.init_traffic's role, TRF:151-195 — in the step kernel's tail): equal to eb_env_step(flow) -> final rows -> eb_env_reset ->
+    eb_traffic_flow_reset -> eb_get_obs(mask) -> flag swap on the HIP library (asserted inside the case) and to the oracle's composite
+    bit for bit at every step of a closed loop in which egos do finish; 12 .. 60 slots, every tile shape that fits."""
+    from tests._env_step_check import flow_auto_reset_case
+    want = flow_auto_reset_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B=260, K=K)
+    got = flow_auto_reset_case(lambda t, **kw: DeviceModel(t, **kw), task, B=260, K=K, tile=tile)
+    for t, (a, b) in enumerate(zip(want, got)):
+        _compare_auto_reset(a, b, 260, 'flow rule + auto reset, step %d' % t)
+
+
+def test_flow_rule_and_auto_reset_on_the_separate_launch_path():
+    """candidates that are not 16-byte aligned: eb_env_step(flow + auto_reset) as the step's separate launches, eb_traffic_flow_step and
+    the masked reset's launches — the one-launch kernel's bits"""
+    import ctypes as C
+    import torch
+    from env_build_amd.traffic import ACCEL, EXIT_RANGE, FLOWS, LANE_START, ROUTES, VTYPES, approach_lane
+    task, B, K = 'left', 200, 2
+    M = 12 * K
+    slot_modes = [r for r in ROUTES for _ in range(K)]
+    lane = np.array([list(approach_lane(x)[0]) + list(approach_lane(x)[1]) for x in slot_modes], np.float32)
+    period = (np.array([3600.0 / FLOWS[r][0] for r in ROUTES], np.float32) / 8).astype(np.float32)
+    vmax = np.array([VTYPES[FLOWS[x][1]][2] for x in slot_modes], np.float32)
+    clen = np.array([VTYPES[FLOWS[x][1]][0] for x in slot_modes], np.float32)
+    rng = np.random.default_rng(5)
+    inp = make_rollout_inputs(task, B, 8, 1, seed=5)
+    ego, ref = inp['ego'].copy(), inp['ref_idx'].copy()
+    ego[::4, 3] += 9.0
+    m, tr = DeviceModel(task, mode='training'), DeviceModel(task, n_veh=M, modes=slot_modes)
+    active = (rng.random((B, M)) < 0.5).astype(np.uint8)
+    along = rng.uniform(0, 95, (B, M)).astype(np.float32)
+    cand = np.stack([lane[None, :, 0] + along * lane[None, :, 3], lane[None, :, 1] + along * lane[None, :, 4],
+                     rng.uniform(0, 9, (B, M)).astype(np.float32), np.broadcast_to(lane[None, :, 2], (B, M))], 2).astype(np.float32)
+    mode = np.where(active != 0, np.array([_capi.VMODE_ID[x] for x in slot_modes], np.uint8)[None, :], _capi.VMODE_EMPTY).astype(np.uint8)
+    timer = (rng.random((B, 12)) * period).astype(np.float32)
+    emitted, sim_step = np.zeros((B, 12), np.int32), rng.integers(0, 600, B).astype(np.int32)
+    light, virtual, phase0 = rng.integers(0, 4, B).astype(np.uint8), (rng.random(B) < 0.3).astype(np.uint8), np.full(B, 9, np.uint8)
+    raw = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+    obs0 = m.get_obs(ego, cand, mode, light, ref_idx=ref, virtual=virtual)
+    flow = dict(per_route=K, lane=lane, period=period, v_max=vmax, dt=0.1, exit_range=EXIT_RANGE, accel=ACCEL, lane_len=LANE_START - 25.0,
+                light_cycle=1, seed=99, counter=3, active=active, timer=timer, emitted=emitted, sim_step=sim_step)
+    auto = dict(seed=777, counter=4, training=1, flow=dict(cand_len=clen, phase0=phase0, random_phase=0, seed=4242, counter=4))
+    want = m.env_step(tr, obs0, raw, ego, cand, mode, ref_idx=ref, v_light=light, virtual=virtual, flow=flow, auto_reset=auto)
+    assert (want[7] != 0).sum() > 20
+    t, p = torch, lambda x: C.c_void_p(x.data_ptr())
+    big = m._in(np.concatenate([np.zeros(1, np.float32), cand.ravel()]))
+    c_io = big[1:].view(B, M, 4)
+    assert c_io.data_ptr() % 16 != 0
+    e_io, ob, rw, ri = m._in(ego.copy()), m._in(obs0), m._in(raw), m._in(ref.copy(), np.int32)
+    cm, vl, vf = m._in(mode.copy(), np.uint8), m._in(light.copy(), np.uint8), m._in(virtual.copy(), np.uint8)
+    f_act, f_tim, f_emi, f_sim = m._in(active.copy(), np.uint8), m._in(timer.copy()), m._in(emitted.copy(), np.int32), m._in(sim_step.copy(), np.int32)
+    f_lane, f_per, f_vm, f_len, f_ph = m._in(lane), m._in(period), m._in(vmax), m._in(clen), m._in(phase0.copy(), np.uint8)
+    par, sc, out5, dd = m._out((B, 4)), m._out((B, 2)), m._out((5, B)), m._out((16, B))
+    obs_o, code = m._out(obs0.shape), m._out((B,), np.uint8)
+    fo = m._in(np.full(obs0.shape, np.nan, np.float32))
+    d = lambda x: x.data_ptr()
+    fl = _capi.EbFlowRule(K, d(f_act), d(f_tim), d(f_emi), d(f_sim), d(f_lane), d(f_per), d(f_vm), 0.1, EXIT_RANGE, ACCEL, LANE_START - 25.0, 1, 99, 3,
+                          d(cm), d(vl))
+    ar = _capi.EbAutoReset(777, 4, 1, d(ri), d(vf), d(vl), _capi.EbRespawn(), d(fo), d(f_len), d(f_ph), 0, 4242, 4)
+    m.api.env_step(m.h, tr.h, B, p(ob), p(rw), p(ri), 0, p(e_io), p(par), M, p(c_io), p(cm), None, p(vl), p(vf), p(sc), p(out5), p(dd),
+                   p(obs_o), p(code), None, C.byref(ar), C.byref(fl), None, m.stream)
+    t.cuda.synchronize()
+    got = [x.cpu().numpy() for x in (sc, out5, dd, e_io, par, c_io.contiguous(), obs_o, code, ri, vf, vl, fo, f_ph, f_act, f_tim, f_emi, f_sim, cm, vl)]
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(np.asarray(g).reshape(np.asarray(w).shape), w, equal_nan=True), k
+
+
 def test_flow_rule_argument_checks_on_the_gpu():
     from tests._env_step_check import flow_rule_bad_args_case
     flow_rule_bad_args_case(lambda t, **kw: DeviceModel(t, **kw))

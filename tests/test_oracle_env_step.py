@@ -3,8 +3,8 @@ equals its own single calls — the same check the GPU suite runs on the one-lau
 import pytest
 
 from tests._env_step_check import (CASES, auto_reset_bad_args_case, auto_reset_case, composite_case, flow_rule_bad_args_case,
-                                   flow_rule_case, masked_obs_case, parked_ego_case, reset_pool_case, respawn_conflict_case,
-                                   time_limit_case, wrap_guard_case)
+                                   flow_auto_reset_case, flow_rule_case, masked_obs_case, parked_ego_case, reset_pool_case,
+                                   respawn_conflict_case, time_limit_case, wrap_guard_case)
 from tests._helpers import HostModel
 
 
@@ -52,6 +52,12 @@ def test_oracle_auto_reset_argument_checks(oracle):
 def test_oracle_step_with_the_flow_rule(oracle, task, K):
     """ABI 4: eb_env_step(flow) == eb_env_step + eb_traffic_flow_step over a closed loop"""
     flow_rule_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B=120, K=K, steps=30)
+
+
+@pytest.mark.parametrize('task,K', [('left', 5), ('right', 2)])
+def test_oracle_step_with_the_flow_rule_and_auto_reset(oracle, task, K):
+    """ABI 5: eb_env_step(flow + auto_reset) == eb_env_step(flow) + eb_env_reset + eb_traffic_flow_reset + eb_get_obs(mask) + flag swap"""
+    flow_auto_reset_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B=120, K=K, steps=8)
 
 
 def test_oracle_flow_rule_argument_checks(oracle):
