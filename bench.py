@@ -15,7 +15,7 @@ Started WITHOUT a launcher and with --gpus N > 1, bench.py starts its own N rank
 (self_launch_argv); rank 0 still prints the one line.
 
 The K timed steps run as rollouts of min(K, 25) launches (+ a shorter last one when 25 does not divide K), each followed
-by the episodic summary (the launches are the accumulating ones, eb_rollout_step_acc: one small fold) and its all-gather; the K-step region is bracketed by barrier +
+by the episodic summary (eb_episode_summary: two small kernels; --acc-summary: accumulating launches + one fold) and its all-gather; the K-step region is bracketed by barrier +
 synchronize, measured `--repeats` times (default 11) and the MEDIAN is `value` (min / max are reported too).  The
 launches go out either as one hipGraph replay per rollout (eb_plan_*, --graph) or as host calls (--eager); by default
 a short untimed trial picks the faster form and `config.workload` names the one that ran.  Rank 0 prints ONE JSON line:
@@ -57,7 +57,7 @@ STRONG_TOTAL = 262144                            # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a float4 copy reaches)
 MALL_BYTES = 256 << 20                           # Infinity Cache
 MAX_PAIRS = 64                                   # HIP event pairs per repeat
-TWO_PASS_SUMMARY = False                         # --two-pass-summary (A/B aid)
+TWO_PASS_SUMMARY = True                          # False: --acc-summary (A/B aid)
 
 
 def alg_bytes_per_env_step(n_veh, f16=False):
@@ -431,7 +431,7 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
     if f16 and (n_env, n_veh, lanes) == (N_ENV, 64, 1):      # configs[4]: HBM bytes from the PMC passes of scripts/pmc_traffic.sh
         out['traffic'], out['traffic_source'] = pmc_traffic('rollout', 'fp16_x64', 'hbm_bytes_per_launch')
     if with_summary:
-        out['protocol'] = 'accumulating launches + the episodic summary fold + its gather once per horizon inside the timed region, as the headline'
+        out['protocol'] = 'episodic summary kernels + their gather once per horizon inside the timed region, as the headline'
     if tile is not None:
         out['tile_variant'] = tile
         model.api.debug_set_tile(model.handle, -1)
@@ -746,6 +746,106 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40, tile=None, wav
                                      'frac': roofline_of(alg, median(auto_us))[1]}}
 
 
+def env_step_flows_bench(torch, dev, n_env, per_route=5, seg=10, reps=24):
+    """The env-side step over the SUMO-free FLOW traffic source (12 routes x per_route slots = 60 candidates per env; traffic.py,
+    sumo_files/cross.rou.xml:18-44) through the raw C entry: (a) eb_env_step(flow) — the step with the flow rule in its launch — in
+    short segments from a restored state, (b) eb_env_step(flow + auto_reset), ABI 5 — the self-sustaining loop: the step, the flow
+    rule AND the reset of the envs it finished (eb_env_reset + the flow source's init_traffic + reset observation) as ONE launch.
+    Algorithmic bytes per env-step: the step's 8 D + 33 M + 105 (env_step_alg_bytes: 2 413 B at D = 41, M = 60) + the flow rule's
+    bookkeeping — active flags read + written 2 M, mode bytes rewritten M, twelve timers read + written 96, clock 8 — = 3 M + 104."""
+    from env_build_amd.endtoend import CrossroadEnd2end
+    from env_build_amd.traffic import RESET_SALT
+    env = CrossroadEnd2end(TASK, n_env=n_env, multi_display=True, traffic='flows', per_route=per_route, auto_reset=True,
+                           copy_outputs=False, device=dev)
+    env.seed(0)
+    env.reset()
+    api, lib, fl = env.api, env.api.lib, env._flows
+    B, M, D = n_env, env.n_cand, env.obs_dim
+    g = torch.Generator(device='cpu').manual_seed(3)
+    tape = torch.stack([torch.rand((seg, B), generator=g) * 0.6 - 0.3, torch.rand((seg, B), generator=g) * 0.8 - 0.2], 2).to(dev).contiguous()
+    for t in range(60):                   # a junction in mid-traffic (the source starts with what the approach lanes hold)
+        env.step(tape[t % seg])
+    torch.cuda.synchronize()
+    state = dict(_obs=env._obs, _ego=env._ego, _params=env._params, _cand=env._cand, active=fl.active, timer=fl.timer, emitted=fl.emitted,
+                 sim_step=fl.sim_step, _mode=fl._mode, _vlight=fl._vlight, _ref=env._ref_idx, _virt=env._virtual)
+    keep = {k: v.clone() for k, v in state.items()}
+    obs = [env._obs.clone(), torch.empty_like(env._obs)]
+    f32 = dict(dtype=torch.float32, device=dev)
+    scaled, out5, code = torch.empty((B, 2), **f32), torch.empty((5, B), **f32), torch.empty((B,), dtype=torch.uint8, device=dev)
+    final = torch.empty_like(obs[0])
+    p = lambda t: C.c_void_p(t.data_ptr())
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rule, ar = fl.step_rule(), env._auto_rule
+    ar.final_obs, ar.v_light = final.data_ptr(), fl._vlight.data_ptr()
+    lw = fl.cand_lw()
+    h, ht, fn = env._h, env._traffic.h, lib.eb_env_step
+    base = lambda t, auto: (h, ht, B, p(obs[t & 1]), p(tape[t]), p(env._ref_idx), 0, p(env._ego), p(env._params), M, p(env._cand), p(fl._mode),
+                            p(lw), p(fl._vlight), p(env._virtual), p(scaled), p(out5), None, p(obs[(t + 1) & 1]), p(code), None,
+                            C.byref(ar) if auto else None, C.byref(rule), None, sp)
+    sets = {a: [base(t, a) for t in range(seg)] for a in (False, True)}
+    ev = []
+    for _ in range(2 * reps):
+        e = C.c_void_p()
+        api.event_create(h, C.byref(e))
+        ev.append(e)
+
+    def restore():
+        for k, v in state.items():
+            v.copy_(keep[k])
+        obs[0].copy_(keep['_obs'])
+
+    def segment(k, auto):
+        for a in sets[auto]:
+            k += 1
+            rule.counter = k
+            ar.seed, ar.counter, ar.flow_seed, ar.flow_counter = 4242, k, fl.seed ^ RESET_SALT, k
+            rc = fn(*a)
+            if rc != 0:
+                api.check(rc)
+        return k
+
+    ms, res, k = C.c_float(), {}, 100000
+    for auto in (False, True):
+        for _ in range(3):
+            restore(); k = segment(k, auto)
+        torch.cuda.synchronize()
+        for r in range(reps):
+            if not auto:
+                restore()               # (the self-sustaining loop needs none: finished envs restart inside the launch)
+            lib.eb_event_record(ev[2 * r], sp)
+            k = segment(k, auto)
+            lib.eb_event_record(ev[2 * r + 1], sp)
+        torch.cuda.synchronize()
+        us = []
+        for r in range(reps):
+            api.event_elapsed_ms(ev[2 * r], ev[2 * r + 1], C.byref(ms))
+            us.append(ms.value * 1e3 / seg)
+        res[auto] = us
+    for e in ev:
+        api.event_destroy(e)
+    fin = float((code != 0).float().mean().item())
+    step_b, rule_b = env_step_alg_bytes(D, M), 3 * M + 104
+    alg = (step_b + rule_b) * B
+    us0, us1 = median(res[False]), median(res[True])
+    out = {'workload': 'env_step_flows: CrossroadEnd2end.step over the flow traffic source, N_env=%d x %d candidates (12 routes x %d slots; task %s, '
+                       'D=%d): eb_env_step(flow) = ONE launch (the step + the flow rule: exits, accelerations, emissions, mode bytes, clock, light)'
+                       % (B, M, per_route, TASK, D),
+           'n_env_per_gpu': B, 'n_cand': M, 'obs_dim': D, 'dtype': 'f32', 'value': B / (us0 * 1e-6), 'unit': 'env-steps/s',
+           'avg_launch_us': us0, 'launches_timed': reps * seg,
+           'segments': {'n': reps, 'steps_each': seg, 'statistic': 'median', 'us_per_step_min': min(res[False]), 'us_per_step_max': max(res[False])},
+           'alg_bytes_per_env_step': step_b + rule_b, 'alg_bytes_step': step_b, 'alg_bytes_flow_rule': rule_b, 'alg_bytes_per_launch': alg,
+           'achieved_GBs': roofline_of(alg, us0)[0], 'frac': roofline_of(alg, us0)[1],
+           'step_with_auto_reset': {'entry': 'eb_env_step(flow + auto_reset), ABI 5 — ONE launch: the step, the flow rule, the terminal rows to '
+                                             'final_obs and the reset of the envs it finished (eb_env_reset, the flow source\'s init_traffic, reset '
+                                             'observation, flag swap)',
+                                    'us_per_step': us1, 'us_per_step_min': min(res[True]), 'us_per_step_max': max(res[True]),
+                                    'launches_timed': reps * seg, 'finished_fraction_last_step': fin,
+                                    'value': B / (us1 * 1e-6), 'unit': 'env-steps/s', 'frac': roofline_of(alg, us1)[1]}}
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
 def shield_bench(args):
     """The model-predictive safety shield with the policy network on the GPU (hier_decision.py:89-97): one JSON line in
     the same format; the roofline object is the policy kernel's (f32 matrix cores), the bound of this loop."""
@@ -847,9 +947,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget-s', type=float, default=18.0, help='seconds of host time the cpu_baseline leg may use')
     ap.add_argument('--no-side', action='store_true', help='skip hbm_resident / strong / extra (headline line only)')
-    ap.add_argument('--two-pass-summary', action='store_true',
-                    help='A/B aid: plain eb_rollout_step launches + eb_episode_summary (a second pass over out5) per horizon '
-                         'instead of the accumulating launches + one fold')
+    ap.add_argument('--acc-summary', action='store_true',
+                    help='A/B aid: the accumulating launches (eb_rollout_step_acc, ABI 5) + one fold per horizon instead of plain launches '
+                         '+ eb_episode_summary — same-box A/B, round 5 (profiles/r5_ab_acc_summary.txt): the in-launch accumulation costs '
+                         '0.2 us per launch, more than the second pass over out5 it removes (0.1 us per step slower overall)')
     ap.add_argument('--open-loop', action='store_true',
                     help='SEPARATE figure (SURVEY.md §8(f)1): eb_rollout_tape, the whole 25-step tape in one launch with the '
                          'state in registers — VALU-bound, not the HBM-bound closed-loop headline')
@@ -860,7 +961,7 @@ def main():
                          'rollout step] per start state; a "step" is one shield pass over the batch; N = 1 only')
     args = ap.parse_args()
     global TWO_PASS_SUMMARY
-    TWO_PASS_SUMMARY = bool(args.two_pass_summary)
+    TWO_PASS_SUMMARY = not args.acc_summary
     n_env, n_veh = args.n_env, args.n_veh
     if args.steps < 1 or args.repeats < 1:
         raise SystemExit('--steps and --repeats must be >= 1')
@@ -870,6 +971,7 @@ def main():
         import torch
         for b in (N_ENV, 4096):
             print(json.dumps(env_step_bench(torch, torch.device('cuda', 0), b)))
+        print(json.dumps(env_step_flows_bench(torch, torch.device('cuda', 0), N_ENV)))
         return
     if args.facade:
         import torch
@@ -966,7 +1068,7 @@ def main():
                                 'projected_speedup': t1['ms_per_step'] / sh['ms_per_step']}
             strong['projection'] = {'kind': 'ONE-GPU EXTRAPOLATION, NOT a multi-GPU measurement: no RCCL, no second rank ran',
                                     'what': 'per-rank shard of configs[3] at N GPUs timed on this one GPU, same protocol as the headline '
-                                            '(accumulating launches + summary fold + gather per horizon inside the timed region), regions of '
+                                            '(episodic summary + gather per horizon inside the timed region), regions of '
                                             '%d steps; ratio = this box\'s own t(262144) / t(262144 / N)' % proj_steps,
                                     'steps_per_region': proj_steps,
                                     'one_gpu_ms_per_step': t1['ms_per_step'], 'one_gpu_frac': t1['frac'], 'by_n_gpus': proj,
@@ -999,6 +1101,7 @@ def main():
                                           side_rep, f16=True), workload='configs[4]: N_env=65536, N_veh=64, fp16 state / fp32 reward accumulate'))
             extra.append(env_step_bench(torch, dev, N_ENV))      # the env-side step (endtoend.py), one launch per step
             extra.append(env_step_bench(torch, dev, 4096))
+            extra.append(env_step_flows_bench(torch, dev, N_ENV))     # ... over the flow traffic source (60 candidates per env)
             # the drop-in call itself ("H consecutive rollout_out calls"), host-side cost included
             extra.append({'facade_rollout_out': [facade_rollout_bench(torch, EnvironmentModel, dev, N_ENV, N_VEH, 21),
                                                  facade_rollout_bench(torch, EnvironmentModel, dev, 4096, 16, 22)]})

@@ -1151,20 +1151,19 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
         return fail(EB_EINVAL, "eb_plan_create: obs_in, obs_work and obs_out must be distinct buffers");
     if (acc && ((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_plan_create: acc must be 16-byte aligned");
     EB_HIP(hipSetDevice(h->cfg.device));
-    void* own_acc = nullptr;
-    if (summary8 && !acc) {
-        EB_HIP(hipMalloc(&own_acc, acc_workspace_bytes(h, n_env, horizon)));
-        acc = own_acc;
-    }
+    void* own_acc = nullptr;   // (kept for a plan that owns a workspace; none does at present)
     hipStream_t cs = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
     if (e != hipSuccess) { if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamCreateWithFlags", e); }
     e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { (void)hipStreamDestroy(cs); if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamBeginCapture", e); }
-    // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph; with a summary (or a
-    // caller's accumulator) they are the accumulating launches and the summary is one small fold behind them
+    // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph.  With a caller's accumulator they
+    // are the accumulating launches and the summary (if asked for) is the fold behind them; without one the summary is
+    // eb_episode_summary's second pass over out5 — the faster of the two on this GPU (profiles/r5_ab_acc_summary.txt)
     rc = rollout_tape_stepwise(h, n_env, horizon, obs_in, action_tape, ref_idx, path_id, obs_work, obs_out, out5_steps, cs, 0, acc);
-    if (rc == EB_OK && summary8) rc = eb_episode_acc_finish(h, n_env, horizon, acc, summary8, cs);
+    if (rc == EB_OK && summary8)
+        rc = acc ? eb_episode_acc_finish(h, n_env, horizon, acc, summary8, cs)
+                 : eb_episode_summary(h, n_env, horizon, out5_steps, obs_out, summary8, cs);
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(cs, &graph);
     (void)hipStreamDestroy(cs);

@@ -287,7 +287,11 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int roff = p == 0 ? A.red_off[0] : p == 1 ? A.red_off[1] : A.red_off[2];
         EB_MARK(A, trow, 2);                                                // bicycle step done
         float rx = 0.0f, ry = 0.0f, rphi = 0.0f;                            // == path[bi * 10]: bi * 10 < len always
-        const int bi = closest_cell_index(A, A.xy10, A.phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
+        // (the range's first groups of table entries in one round trip on the small tiles — same-box A/B, round 5: 16 384 x 32 on
+        // 4 x 4 tiles 6.61 -> 6.43 us; nothing at 4 096 x 16 and 32 768 x 32; the 2048-record tile, whose env wave shares its 80
+        // VGPRs with eight records per lane, is 0.1-0.2 us FASTER with a group per trip: profiles/r5_ab_scan.txt)
+        constexpr int SCAN_PRE = RW * RPT >= 32 ? 0 : 3;
+        const int bi = closest_cell_index<SCAN_PRE>(A, A.xy10, A.phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
         t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                           // DAM:758
         if (A.trace) { asm volatile("" :: "v"(t0)); EB_MARK(A, trow, 3); }  // closest point found
         t1 = deal_with_phi_diff(nx[5] - rphi);                              // DAM:759

@@ -245,8 +245,9 @@ int eb_episode_summary(eb_handle h, int32_t n_env, int32_t horizon, const float*
  *       (sums within rtol 1e-6 of it — another fixed float64 order —, count and maximum equal), one small launch.
  * acc: device memory of eb_episode_acc_bytes(n_env, horizon) bytes, 16-byte aligned, private layout, one per rollout in flight;
  * every step of one rollout must go to the same handle with the same n_env and horizon (and the same eb_debug_set_tile
- * setting: a block writes its own records).  The HIP library's episodic summary costs one pass over horizon x n_blocks x 32 bytes
- * this way instead of a second pass over out5_steps [horizon, 5, n_env]. */
+ * setting: a block writes its own records).  The summary is then one pass over horizon x n_blocks x 32 bytes instead of a second
+ * pass over out5_steps [horizon, 5, n_env] — for a caller that does not keep out5_steps around; where it is kept anyway (the plans,
+ * bench.py) the second pass is the cheaper form on an MI355X: the accumulating launch costs 0.2 us more than the plain one. */
 int eb_episode_acc_bytes(eb_handle h, int32_t n_env, int32_t horizon, int64_t* bytes);
 int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                         const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
@@ -256,10 +257,10 @@ int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const voi
 
 /* A rollout plan = eb_rollout_tape over FIXED buffers, recorded once and replayed: the HIP library
  * captures the `horizon` launches into a hipGraph, so that a replay costs one host call instead of `horizon`.
- * summary8 != NULL: the launches are the accumulating ones and eb_episode_acc_finish -> summary8 is part of the plan
- * (acc NULL: the plan owns its workspace).  summary8 == NULL, acc != NULL (ABI 5): accumulating launches into the caller's
- * workspace, the caller finishes.  Buffer contents may change between launches, addresses and sizes may not.  The plan
- * borrows every buffer; destroy it before the handle. */
+ * acc != NULL (ABI 5): the launches are the accumulating ones into the caller's workspace; summary8 != NULL then adds
+ * eb_episode_acc_finish -> summary8 to the plan, summary8 == NULL leaves the fold to the caller.  acc == NULL, summary8 != NULL:
+ * eb_episode_summary(out5_steps, obs_out) -> summary8 behind the launches.  Buffer contents may change between launches,
+ * addresses and sizes may not.  The plan borrows every buffer; destroy it before the handle. */
 typedef struct eb_plan_s* eb_plan;
 int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs_in,
                    const float* action_tape, const int32_t* ref_idx, int32_t path_id,

@@ -1294,20 +1294,19 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
     p->h = h; p->n_env = n_env; p->horizon = horizon; p->path_id = path_id; p->obs_in = obs_in;
     p->tape = action_tape; p->ref_idx = ref_idx; p->obs_work = obs_work; p->obs_out = obs_out;
     p->out5_steps = out5_steps; p->summary8 = summary8; p->acc = acc;
-    if (summary8 && !acc) {
-        p->own_acc = aligned_alloc(64, (acc_bytes(&h->cfg, n_env, horizon) + 63) / 64 * 64);
-        if (!p->own_acc) { free(p); return fail(EB_ENOMEM, "eb_plan_create: out of memory"); }
-        p->acc = p->own_acc;
-    }
     *out = p;
     return EB_OK;
 }
 
 int eb_plan_launch(eb_plan p, void* stream) {
     if (!p) return fail(EB_EINVAL, "eb_plan_launch: null plan");
-    if (!p->acc)
-        return eb_rollout_tape(p->h, p->n_env, p->horizon, p->obs_in, p->tape, p->ref_idx, p->path_id,
-                               p->obs_work, p->obs_out, p->out5_steps, stream);
+    if (!p->acc) {
+        int rc0 = eb_rollout_tape(p->h, p->n_env, p->horizon, p->obs_in, p->tape, p->ref_idx, p->path_id,
+                                  p->obs_work, p->obs_out, p->out5_steps, stream);
+        if (rc0 == EB_OK && p->summary8)
+            rc0 = eb_episode_summary(p->h, p->n_env, p->horizon, p->out5_steps, p->obs_out, p->summary8, stream);
+        return rc0;
+    }
     /* the accumulating launches, ping-ponging as eb_rollout_tape does */
     const float* cur = p->obs_in;
     for (int t = 0; t < p->horizon; ++t) {

@@ -13,3 +13,4 @@ for l in open('$OUT/facade.jsonl'):
     d = json.loads(l)
     print(d['workload'][:60], {k: (round(v['host_us'], 2), round(v['with_drain_us'], 2)) for k, v in d.items() if isinstance(v, dict) and 'host_us' in v}, d.get('facade_over_c_abi'))
 PY
+bash scripts/r5_ab_scan.sh $TAG 2>&1 | grep -v "^build"

@@ -6,17 +6,17 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from env_build_amd import _capi
 from env_build_amd.endtoend import CrossroadEnd2end
-ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16); ap.add_argument('--auto', action='store_true'); ap.add_argument('--waves', type=int, default=0, help='eb_debug_set_env_waves: 4 / 8 waves per block (0: by grid size)'); ap.add_argument('--wild', action='store_true', help='full-range random actions: many envs finish per step (the reset tail runs in most tiles)')
+ap = argparse.ArgumentParser(); ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-cand', type=int, default=16); ap.add_argument('--auto', action='store_true'); ap.add_argument('--flows', action='store_true', help='the flow traffic source (60 candidates) instead of the pool'); ap.add_argument('--waves', type=int, default=0, help='eb_debug_set_env_waves: 4 / 8 waves per block (0: by grid size)'); ap.add_argument('--wild', action='store_true', help='full-range random actions: many envs finish per step (the reset tail runs in most tiles)')
 a = ap.parse_args()
 B = a.n_env
-env = CrossroadEnd2end('left', n_env=B, multi_display=True, traffic='pool', n_cand=a.n_cand, auto_reset=a.auto, copy_outputs=False)
+env = CrossroadEnd2end('left', n_env=B, multi_display=True, traffic='flows' if a.flows else 'pool', n_cand=None if a.flows else a.n_cand, auto_reset=a.auto, copy_outputs=False)
 env.seed(0); env.reset()
 act = (torch.rand((B, 2), device=env.device) * (2.0 if a.wild else 0.6) - (1.0 if a.wild else 0.3)).contiguous()
 lib = env.api.lib
 env.api.debug_set_env_waves(env._h, a.waves)
 for _ in range(40 if a.wild else 3): env.step(act)
 torch.cuda.synchronize()
-te = 16 if B <= 1024 else 32 if B <= 20480 else 64
+te = 16 if (B <= 1024 or a.flows) else 32 if B <= 20480 else 64
 nb = (B + te - 1) // te
 # rows of 16 words per wave, 4 or 8 waves per block (by grid size, csrc/eb_env_step.hip: launch_env_step): sized for 8, the count is
 # read off the marks (wave rows 4-7 of a four-wave launch stay zero)

@@ -241,20 +241,22 @@ class HostModel(object):
         return self._ret(bufs[0]), self._ret(out5), self._ret(s8)
 
     def plan_run(self, obs, tape, ref_idx=None, path_id=0, replays=2, with_summary=True, caller_acc=False):
-        """eb_plan_create + `replays` x eb_plan_launch + destroy -> (obs_out, out5 [H,5,n], summary8).  caller_acc: the plan
-        accumulates into a workspace of the caller's, who finishes it (summary8 == NULL, acc != NULL)."""
+        """eb_plan_create + `replays` x eb_plan_launch + destroy -> (obs_out, out5 [H,5,n], summary8).  caller_acc: the plan's
+        launches accumulate into a workspace of the caller's — True: the fold is part of the plan, 'finish': the caller folds
+        (summary8 == NULL, acc != NULL); False: plain launches + eb_episode_summary."""
         ob, tp, ri = self._in(obs), self._in(tape), self._in(ref_idx, np.int32)
         H, n = tp.shape[0], len(ob)
         work, out, out5 = self._out(ob.shape), self._out(ob.shape), self._out((H, 5, n))
         s8 = self._out((8,)) if with_summary else None
         acc = self.acc_workspace(n, H) if caller_acc else None
         plan = C.c_void_p()
+        fold_outside = caller_acc == 'finish'       # the plan leaves the fold to the caller (summary8 == NULL, acc != NULL)
         self.api.plan_create(self.h, n, H, self._ptr(ob), self._ptr(tp), self._ptr(ri), int(path_id), self._ptr(work),
-                             self._ptr(out), self._ptr(out5), None if caller_acc else self._ptr(s8), self._ptr(acc), C.byref(plan))
+                             self._ptr(out), self._ptr(out5), None if fold_outside else self._ptr(s8), self._ptr(acc), C.byref(plan))
         try:
             for _ in range(replays):
                 self.api.plan_launch(plan, self.stream)
-                if caller_acc and with_summary:
+                if fold_outside and with_summary:
                     self.api.episode_acc_finish(self.h, n, H, self._ptr(acc), self._ptr(s8), self.stream)
             res = self._ret(out), self._ret(out5), (self._ret(s8) if with_summary else None)
         finally:

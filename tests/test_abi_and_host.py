@@ -203,7 +203,7 @@ def test_oracle_accumulating_rollout_equals_the_two_pass_summary():
         assert np.array_equal(out_a, out_b) and np.array_equal(o5_a, o5_b)
         np.testing.assert_allclose(s8, want, rtol=1e-6, atol=0)
         assert s8[3] == want[3] and s8[5] == want[5] and s8[6] == 77 and s8[7] == 6
-    for caller_acc in (False, True):
+    for caller_acc in (True, 'finish'):
         out_c, o5_c, s8_c = host.plan_run(obs, inp['actions'], inp['ref_idx'], caller_acc=caller_acc)
         assert np.array_equal(out_a, out_c) and np.array_equal(o5_a, o5_c) and np.array_equal(s8_c, s8)
     api = host.api

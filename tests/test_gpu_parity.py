@@ -298,7 +298,7 @@ def test_accumulating_rollout_equals_the_two_pass_summary(task, N, B, H, tile):
         np.testing.assert_allclose(s8, want, rtol=1e-6, atol=0)
         assert s8[3] == want[3] and s8[5] == want[5] and s8[6] == B and s8[7] == H
     assert np.array_equal(dev.episode_summary(o5_t, out_t)[[3, 5, 6, 7]], s8[[3, 5, 6, 7]])
-    for caller_acc in (False, True):
+    for caller_acc in (True, 'finish'):
         out_p, o5_p, s8_p = dev.plan_run(obs0, inp['actions'], inp['ref_idx'], replays=2, caller_acc=caller_acc)
         assert np.array_equal(out_p, out_t) and np.array_equal(o5_p, o5_t) and np.array_equal(s8_p, s8)
     # against the oracle's own accumulating form
