@@ -103,10 +103,10 @@ bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float
 }
 
 // profiling aid (eb_debug_set_trace on the model handle): slot k of this wave's row [16] <- the 100 MHz wall clock, lane 0 only
-// (rows of 16 words, one per wave: [n_blocks * NW][16] — NW is 4 or 8 by grid size, so a caller sizes the buffer for 8 and passes
-// its capacity; a mark past the capacity is dropped)
-#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) { const long long w_ = ((long long)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (k); \
-                        if (w_ < A.trace_words) A.trace[w_] = wall_clock64(); } } while (0)
+// (rows of 16 words, one per wave: [n_blocks * NW][16] — NW is 4 or 8 by grid size, so a caller sizes the buffer for 8 and passes its
+// capacity; launch_env_step drops a buffer that is too small for the launch at hand.  No bounds test in here: one — even on 32-bit
+// indices — cost the step kernel two VGPRs, 95 -> 97, i.e. a wave of occupancy: 18.5 -> 26.7 us at 65 536 envs)
+#define ES_MARK(k) do { if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
 
 // A per-wave queue of 16-bit item ids: `hit` lanes append (ballot / mbcnt), and whenever 64 are waiting the wave runs
 // `body(item)` on a full set of lanes; flush() runs the rest.
@@ -544,9 +544,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 float rx, ry, rphi;
                 if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) {
                     const unsigned cw = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
-                    // same order, same strict '<' as the full scan: same index (eb_device.h: the range's first two groups in one round trip — three cost this kernel a wave of occupancy)
-                    if (A.scan_one_trip) bi = closest_in_range<0>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
-                    else bi = closest_in_range<2>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
+                    // same order, same strict '<' as the full scan: same index (eb_device.h; a group of entries per loop trip: prefetched groups cost this kernel two VGPRs, i.e. a wave of occupancy, and bought nothing in the rollout kernel's A/B)
+                    bi = closest_in_range<0>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
                 } else {
                     bi = closest_reduced_index(red, pt.rad + 32 * p, pt.red_len[p], ex, ey);
                     rx = red[bi].x; ry = red[bi].y; rphi = ph10[bi];
@@ -1101,7 +1100,8 @@ __global__ __launch_bounds__(NW * 64) void env_step_kernel(const EnvStepArgs A) 
 template <int TASK, int ET, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true, false, NW>(A); }
 
-hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
+hipError_t launch_env_step(int task, const EnvStepArgs& A_in, hipStream_t s) {
+    EnvStepArgs A = A_in;
     int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs
                                                                            : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand, A.flow_on != 0);
     if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0) + ES_STATIC_LDS > 156 * 1024) ET = 16;   // a forced shape that does not fit
@@ -1123,6 +1123,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A, hipStream_t s) {
     // eight waves per block only two blocks fit a CU's registers; measured at 65 536 x 60: 133 us against 104)
     const bool w8 = wforce != 4 && ET <= 32 && (n_blocks <= 3 * n_cu[dev] || wforce == 8);
     const dim3 g(n_blocks), b(w8 ? 512 : 256);
+    if (A.trace && A.trace_words < (long long)n_blocks * (w8 ? 8 : 4) * 16) A.trace = nullptr;   // a mark buffer too small for this launch: no marks
 #define EB_ENV_STEP_W(T, E, O, AU, W)                                                                                 \
     do {                                                                                                             \
         static size_t granted[64];   /* the > 48 KB opt-in is per kernel and device, and sticky */                   \

@@ -178,9 +178,9 @@ EB_DEV int env_of_item(const FusedHot<ST>& H, int item) {
 }
 
 // profiling aid: mark slot `i` of this wave's trace row with the 100 MHz wall clock (lane 0 only)
-#define EB_MARK(A, row, i) do { if ((A).trace && (threadIdx.x & 63) == 0 && (long long)(row) * 8 + (i) < (A).trace_words) (A).trace[(size_t)(row) * 8 + (i)] = wall_clock64(); } while (0)
+#define EB_MARK(A, row, i) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + (i)] = wall_clock64(); } while (0)
 // slot 7 of a wave's trace row: where it ran — HW_REG_XCC_ID << 32 | HW_REG_HW_ID (simd [5:4], cu [11:8], sh [12], se [15:13])
-#define EB_MARK_PLACE(A, row) do { if ((A).trace && (threadIdx.x & 63) == 0 && (long long)(row) * 8 + 7 < (A).trace_words) (A).trace[(size_t)(row) * 8 + 7] = \
+#define EB_MARK_PLACE(A, row) do { if ((A).trace && (threadIdx.x & 63) == 0) (A).trace[(size_t)(row) * 8 + 7] = \
     ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); } while (0)
 
 // per-wave near-record queue: normally one drain at the end; in a crowded tile the in-loop tests stop while 64
@@ -807,7 +807,7 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         araw = araw_next;
     }
     EB_MARK(A, trow, 1);
-    if (A.trace && lane == 0 && (long long)trow * 8 + 2 < A.trace_words) A.trace[(size_t)trow * 8 + 2] = waited;
+    if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 2] = waited;
 }
 
 template <int TASK, int RW, int RPT, bool FAST, bool GATED, typename ST>
@@ -901,7 +901,7 @@ EB_DEV void record_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem
     for (int k = 0; k < RPT; ++k)
         if (item_of(k) < items) Stored<ST>::store4(tout + off_of(k), rec[k]);
     EB_MARK(A, trow, 1);
-    if (A.trace && lane == 0 && (long long)trow * 8 + 2 < A.trace_words) A.trace[(size_t)trow * 8 + 2] = waited;
+    if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 2] = waited;
 }
 
 template <int TASK, int RW, int RPT, bool FAST, bool GATED, typename ST>
@@ -987,12 +987,12 @@ EB_TAPE_KERNEL(rollout_gated_4x8, 4, 8, true, 4)
 EB_TAPE_KERNEL(rollout_gated_4x4, 4, 4, true, 1)
 EB_TAPE_KERNEL(rollout_gated_1x4, 1, 4, true, 1)
 
-// The open-loop tape kernel's tile for a slot count that does not divide the 256 record lanes (the native 9 and 5) with fp32
-// rows: the 4 x 8 tile's per-record item / env / offset / turn state for eight records per lane does not fit six waves per SIMD
+// The open-loop tape kernel's tile for a slot count that does not divide the 256 record lanes (the native 9 and 5): the 4 x 8 tile's per-record item / env / offset / turn state for eight records per lane does not fit six waves per SIMD
 // (it spilled 1 008 bytes of scratch per lane, and unbounded it takes 256 VGPRs) — such tapes run on the 4 x 4 tile (93 VGPRs, no
 // scratch; every tile shape computes the same bits).  That instantiation of rollout_tape_4x8 does not exist.
 int tape_tile_variant(int variant, int n_veh, int storage_f16) {
-    return (variant == 0 && !storage_f16 && (4 * 64) % n_veh != 0) ? 1 : variant;
+    (void)storage_f16;   // (the binary16 instantiation spilled too — 8 bytes, task `straight` — and goes the same way)
+    return (variant == 0 && (4 * 64) % n_veh != 0) ? 1 : variant;
 }
 
 int fused_tile_records(int variant) {
@@ -1111,7 +1111,15 @@ hipError_t launch_gate_feed(int horizon, int n_blocks, size_t step_bytes, const 
 }
 
 // A.actions = the tape [horizon, n_env, 2], A.out5 = [horizon, 5, n_env]
-hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, int horizon, int grid, hipStream_t s) {
+// a mark buffer (eb_debug_set_trace) that does not hold a row of 8 words for every wave of the launch is dropped: the kernels do not test
+static FusedArgs trace_checked(const FusedArgs& A_in, int grid, int waves_per_block) {
+    FusedArgs A = A_in;
+    if (A.trace && A.trace_words < (long long)grid * waves_per_block * 8) A.trace = nullptr;
+    return A;
+}
+
+hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A_in, int horizon, int grid, hipStream_t s) {
+    const FusedArgs A = trace_checked(A_in, grid, (variant == 2 ? 1 : 4) + 1);   // (rows are indexed by blockIdx.x * (RW + 1) + wave: the couriers do not mark)
     if (A.gate_ready) {
         switch (variant) {
             case 0: EB_TAPE_LAUNCH(rollout_gated_4x8, 4, 2) break;
@@ -1124,9 +1132,8 @@ hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, 
         case 0: {
             const dim3 g(grid), b((4 + 1) * 64);
             const size_t dyn = (size_t)A.stage_entries * 12;
-            if (A.storage_f16) { EB_TAPE_FAST(rollout_tape_4x8, 4, _Float16) }
-            else if ((4 * 64) % A.n_veh == 0) { EB_TAPE_TASK(rollout_tape_4x8, true, float) }
-            else return hipErrorInvalidValue;            // the host routes these to the 4 x 4 tile (tape_tile_variant)
+            if ((4 * 64) % A.n_veh != 0) return hipErrorInvalidValue;            // the host routes these to the 4 x 4 tile (tape_tile_variant)
+            if (A.storage_f16) { EB_TAPE_TASK(rollout_tape_4x8, true, _Float16) } else { EB_TAPE_TASK(rollout_tape_4x8, true, float) }
         } break;
         case 1: EB_TAPE_LAUNCH(rollout_tape_4x4, 4, 0) break;
         default: EB_TAPE_LAUNCH(rollout_tape_1x4, 1, 0) break;
@@ -1134,7 +1141,8 @@ hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A, 
     return hipGetLastError();
 }
 
-hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A, int grid, hipStream_t s) {
+hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A_in, int grid, hipStream_t s) {
+    const FusedArgs A = trace_checked(A_in, grid, (variant == 2 ? 1 : 4) + 1);
     switch (variant) {
         case 0: EB_LAUNCH(rollout_fused_4x8, 4) break;
         case 1: EB_LAUNCH(rollout_fused_4x4, 4) break;

@@ -567,7 +567,7 @@ int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const u
  * form: A/B aid), 1 (default) = the first groups in one round trip; same comparisons, same bits.
  * eb_debug_set_trace: a device buffer of capacity_words int64 the kernels fill with wall-clock marks (NULL = off): the rollout
  * kernel writes rows of 8 words, one per wave — [n_blocks * waves per block][8] —, the one-launch env step rows of 16 —
- * [n_blocks * W][16] with W = 4 or 8 as above: size it for 8.  A mark that would land at or past capacity_words is dropped.
+ * [n_blocks * W][16] with W = 4 or 8 as above: size it for 8.  A launch whose marks would not fit capacity_words writes none.
  * The oracle accepts and ignores all of them. */
 int eb_debug_set_tile(eb_handle h, int32_t variant);
 int eb_debug_set_env_waves(eb_handle h, int32_t waves);
