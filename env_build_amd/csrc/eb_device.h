@@ -251,8 +251,10 @@ EB_DEV void sincos_det_k(float x, const SinCosK K, float& s_out, float& c_out) {
 
 // sn_out / cs_out: sin / cos of the record's CURRENT heading, deg2rad(rec.w) — exactly sincos_det(deg2rad(phi)), the
 // pair the collision terms need too (DAM:221-224)
+// kept_out: the heading rate was the literal zero of DAM:416-421 (a slot that does not turn, or a record outside the junction box) —
+// the next heading is the current one up to the radian round trip's rounding (and a full turn of the wrap, DAM:424-425)
 template <typename ST = float>
-EB_DEV f4u predict_record_tc(const f4u rec, const TurnC tc, const SinCosK K, float& sn_out, float& cs_out) {
+EB_DEV f4u predict_record_tc(const f4u rec, const TurnC tc, const SinCosK K, float& sn_out, float& cs_out, bool& kept_out) {
     const float v = rec.z;
     const float v10 = div_const<C10>(v);                                     // DAM:413
     const float phi_rad = div_const<C180>(rec.w * PI_F);                     // DAM:407
@@ -263,12 +265,19 @@ EB_DEV f4u predict_record_tc(const f4u rec, const TurnC tc, const SinCosK K, flo
     const bool middle = (rec.x > -HALF_CROSS && rec.x < HALF_CROSS) && (rec.y > -HALF_CROSS && rec.y < HALF_CROSS);   // DAM:409-410
     const float u = div_by(v, tc.rc);                                        // +-(v / radius), DAM:417, 419
     const float u10 = div_const<C10>(u);
-    const float dphi = (middle && tc.enabled != 0.0f) ? u10 : 0.0f;          // DAM:416-421
+    const bool turning = middle && tc.enabled != 0.0f;
+    kept_out = !turning;
+    const float dphi = turning ? u10 : 0.0f;                                 // DAM:416-421
     float nphi = phi_rad + dphi;                                             // DAM:423
     if (nphi > PI_F) nphi = nphi - TWO_PI_F;                                 // DAM:424
     if (nphi <= -PI_F) nphi = nphi + TWO_PI_F;                               // DAM:425
     const float nphi_deg = div_const<CPi>(nphi * 180.0f);                    // DAM:426
     return f4u{nx_, ny_, v, nphi_deg};                                       // DAM:422-427
+}
+template <typename ST = float>
+EB_DEV f4u predict_record_tc(const f4u rec, const TurnC tc, const SinCosK K, float& sn_out, float& cs_out) {
+    bool kept;
+    return predict_record_tc<ST>(rec, tc, K, sn_out, cs_out, kept);
 }
 
 // ---- a8: tracking error pieces, DAM:577-580, 736-760 ----------------------------------------------

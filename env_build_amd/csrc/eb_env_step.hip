@@ -221,6 +221,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     constexpr int GCH = (NW - 2) * KS + 2, GREC = GCH * 64;                      // chunks / records per staging group (8 / 512, 14 / 896)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint8_t smode[64], sturn[64], s_col[ET], s_jb[ET];
+    __shared__ float s_vmax[(ET == 16 && NW == 4 && !OBS) ? 64 : 1];                    // eb_flow_rule's v_max per slot (the fused flow rule of the 16-env tiles)
     __shared__ int s_modeq;                                                      // the next distinct mode to be walked (fill_slots)
     // tiles of up to 32 envs (LDS to spare): the candidates of every (env, mode) as a 64-bit set, OR-ed together by the staging lanes —
     // the slot pass reads ONE word pair per (env, mode) instead of scanning the env's mode bytes (15 dwords at 60 candidates)
@@ -232,7 +233,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     __shared__ float4 s_rst[AUTO ? ET : 1];                                      // (x, y, phi, v_x)
     __shared__ unsigned s_rflag[AUTO ? ET : 1];                                  // path | drawn virtual-red-light flag << 2
     __shared__ uint8_t s_finlist[AUTO ? ET : 1];
-    __shared__ unsigned s_dm[AUTO ? EB_VMODE_COUNT : 1];
+    __shared__ unsigned s_dm[(AUTO || (ET == 16 && !OBS)) ? EB_VMODE_COUNT : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * ET;
     const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
     const int nE = n_env - e0 < ET ? n_env - e0 : ET;
@@ -261,25 +262,33 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     float4* s_new = reinterpret_cast<float4*>(s_queue + 4 * ES_QCAP);           // [64][12]
     int* s_emit = reinterpret_cast<int*>(s_new + (size_t)ET * 12);               // [64][12]
     uint8_t* s_on = reinterpret_cast<uint8_t*>(s_emit + (size_t)ET * 12);        // [64][m_cand]
+    constexpr bool EVEN = ET == 16 && NW == 4;
+    constexpr bool PAIR_STEP = ET == 16 && !OBS && !RESET;   // the step's slot phase as (env, mode) pairs per lane (pair_walk below)
+    constexpr bool FUSED_FLOW = EVEN && !OBS;   // the flow rule's per-slot part inside the staging of a record (below) instead of a pass of its own
     ES_MARK(0);
-    if (tid < 64) { smode[tid] = A.modes.mode[tid]; sturn[tid] = A.tturn.t[tid]; }
-    if (tid == 0) s_modeq = 0;
-    if (ELIG)
-        for (int w = tid; w < ET * EB_VMODE_COUNT * 2; w += NT) s_elig32[w] = 0u;
-    if (AUTO && tid < EB_VMODE_COUNT) s_dm[tid] = A.dm[tid];
-    if (tid < ET) s_col[tid] = (OBS && A.row_mask && !(tid < nE && A.row_mask[e0 + tid] != 0)) ? 1 : 0;   // OBS: 1 = row not to be written
-    for (int w = tid; w < ET * TS4; w += NT) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
-    __syncthreads();   // (kernel-argument tables only: nobody waits for memory here)
-
-    // ---- phase 1 ---------------------------------------------------------------------------------------------
-    // Loads first, all of them: the candidate records of this thread (16 bytes each, consecutive threads on consecutive
-    // records), the per-env flags and — lane = slot — the slot modes; the role work of waves 0 / 1 runs under their latency.
+    // Loads first, all of them — the bytes of the small tables the block keeps in LDS (they come from the kernel-argument segment: a
+    // memory round trip, and loads return in order, so they go out AHEAD of the records), then the candidate records of this thread
+    // (16 bytes each, consecutive threads on consecutive records), further down the per-env flags and — lane = slot — the slot modes.
+    // The table set-up below and its barrier wait for the table bytes and LDS only: the records stay in flight across it (they used to
+    // be issued behind that barrier — a round trip of every block spent with nothing else outstanding), and the role work of waves
+    // 0 / 1 runs under their latency.
+    unsigned tb_mode = 0, tb_turn = 0, tb_dm = 0;
+    if (tid < 64) { tb_mode = A.modes.mode[tid]; tb_turn = A.tturn.t[tid]; }
+    if ((AUTO || (ET == 16 && !OBS)) && tid < EB_VMODE_COUNT) tb_dm = A.dm[tid];
+    float tb_vmax = 0.0f;                                                             // the flow rule's per-slot speed limit: read per record
+    if (FUSED_FLOW && A.flow_on && tid < m_cand) tb_vmax = A.flow_v_max[tid];          // (from global memory it was a round trip — and a wait for the previous record's stores — in every staged chunk)
+    const bool tb_skip = OBS && A.row_mask && tid < ET && !(tid < nE && A.row_mask[e0 + tid] != 0);   // OBS: a row not to be written
+    asm volatile("" ::: "memory");   // (program order of the loads = issue order)
     const float4* csrc = reinterpret_cast<const float4*>(A.cand) + (size_t)e0 * m_cand;
     const uint8_t* msrc = A.cand_mode + (size_t)e0 * m_cand;
     const int n_rec = nE * m_cand;
     // chunks of 64 records in groups of eight: waves 2 and 3 take three chunks of a group each, waves 0 and 1 — which
-    // have the ego step and the tyre parameters to do — one each
+    // have the ego step and the tyre parameters to do — one each.  16-env tiles on four waves (many candidates per env: the flow
+    // source's 60 are 15 chunks a tile) share the FIRST group evenly, two chunks per wave: waves 0 / 1 stood at barrier 1 for 3 us of
+    // the tile's 15 while 2 / 3 staged six chunks each; with every group shared evenly it was 2 / 3 that waited, 1.3-1.9 us (a chunk
+    // is ~0.65 us there, the ego step ~0.8, the tyre parameters ~1.3): 3 / 2 / 5 / 5 chunks now (profiles/r5_trace_flows_*.txt)
     auto rec_index = [&](int group, int k) -> int {
+        if (EVEN && group == 0) return k < 2 ? (wave + NW * k) * 64 + lane : -1;   // (the later groups as below: waves 0 / 1 have their per-env chains too)
         const int chunk = wave >= 2 ? (wave - 2) + (NW - 2) * k : (k == 0 ? (NW - 2) * KS + wave : -1);   // (NW = 4: 0 2 4 / 1 3 5 / 6 / 7)
         return chunk < 0 || k >= KS ? -1 : (group * GCH + chunk) * 64 + lane;
     };
@@ -296,6 +305,17 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 if (!OBS && A.flow_on) cm[g][k] |= (unsigned)A.flow_active[(size_t)e0 * m_cand + idx] << 8;   // (the flow rule's flag: bits 8..)
             }
         }
+    if (tid == 0) s_modeq = 0;
+    if (ELIG)
+        for (int w = tid; w < ET * EB_VMODE_COUNT * 2; w += NT) s_elig32[w] = 0u;
+    for (int w = tid; w < ET * TS4; w += NT) s_tag32[w] = 0xffffffffu;                // padding bytes never match a mode
+    if (tid < 64) { smode[tid] = (uint8_t)tb_mode; sturn[tid] = (uint8_t)tb_turn; }
+    if ((AUTO || (ET == 16 && !OBS)) && tid < EB_VMODE_COUNT) s_dm[tid] = tb_dm;
+    if (tid < ET) s_col[tid] = tb_skip ? 1 : 0;                                       // OBS: 1 = row not to be written
+    if (FUSED_FLOW && tid < 64) s_vmax[tid] = tb_vmax;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the record loads stay in flight
+
+    // ---- phase 1 ---------------------------------------------------------------------------------------------
     // (wave 1) the first batch of compute_rewards' (env, old slot) pairs: their (x, y) are needed in phase 2 only.  Phase 2's two
     // pair-parallel passes have one owner each — wave 1 the reward pairs, waves 2 and 3 the collision test — so that a wave pays
     // for ONE queue flush (a serial chain of ~250 instructions behind a sin / cos), not two
@@ -451,9 +471,45 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 else s_cand[e * RS4 + c] = v;
             } else if (OBS) s_cand[e * RS4 + c] = v;
             else {
-                const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs);
+                bool kept;
+                const f4u r = predict_record_tc(f4u{v.x, v.y, v.z, v.w}, turn_consts(sturn[c]), SK, sn, cs, kept);
                 float4 o = make_float4(r.x, r.y, r.z, r.w);
                 s_cand[e * RS4 + c] = o;
+                if (FUSED_FLOW && A.flow_on) {
+                    // eb_traffic_flow_step's per-slot part right here (16-env tiles: the flow source's shape): a vehicle far out and heading
+                    // away leaves (its record stays where the prediction put it), the others accelerate towards their vType's speed — what
+                    // the NEXT step sees goes to HBM, the LDS copy above stays this step's state.  The rule asks for the SIGN of
+                    // x cos + y sin at the NEW heading; a far record is outside the junction box, so its heading rate was the literal
+                    // zero (`kept`): the new heading is the old one up to the rounding of the radian round trip (2e-7 relative) and the
+                    // sin / cos the prediction has just made answer the question whenever the sum is not within 1 % of zero — the exact
+                    // expression (a sin / cos of its own: what the separate pass paid for every record) only for what is left.
+                    bool on = (mode >> 8) != 0;
+                    const float ax = __builtin_fabsf(o.x), ay = __builtin_fabsf(o.y);
+                    const bool far = __builtin_fmaxf(ax, ay) > A.flow_exit_range;
+                    const float sa = o.x * cs + o.y * sn;
+                    const bool sure = kept && __builtin_fabsf(v.w) <= 1000.0f && __builtin_fabsf(sa) > 0.01f * (ax + ay);
+                    bool outward = sa > 0.0f;
+                    if (__builtin_amdgcn_ballot_w64(on && far && !sure)) {
+                        float fs, fc;
+                        sincos_det(deg2rad(o.w), fs, fc);
+                        if (!sure) outward = o.x * fc + o.y * fs > 0.0f;
+                    }
+                    if (on) {
+                        if (far && outward) on = false;
+                        else {
+                            const float vn = o.z + A.flow_accel * A.flow_dt, vm = s_vmax[c];
+                            o.z = vn < vm ? vn : vm;
+                        }
+                    }
+                    s_on[idx] = on ? 1 : 0;
+                    reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;
+                    // the slot's flag and mode byte for the next step (an emission into the slot overwrites all three behind barrier 3)
+                    A.flow_active[(size_t)e0 * m_cand + idx] = on ? 1 : 0;
+                    A.flow_mode_out[(size_t)e0 * m_cand + idx] = on ? (uint8_t)fast_div(c, A.k_magic) : (uint8_t)EB_VMODE_EMPTY;
+                    s_tag[e * TS4 * 4 + c] = (uint8_t)mode;
+                    if (ELIG && (mode & 0xffu) < (unsigned)EB_VMODE_COUNT) atomicOr(&s_elig32[(e * EB_VMODE_COUNT + (int)(mode & 0xffu)) * 2 + (c >> 5)], 1u << (c & 31));
+                    return;
+                }
                 // the record goes back to HBM right here, from the lane that loaded it, with the pool's re-entry rule on the way
                 // (eb_traffic_respawn: it applies AFTER the observation and the done code saw this step's state — both read the LDS
                 // copy above).  It used to leave from LDS in phase 2, 16 KB through one wave that had the tracking chain to do.
@@ -476,6 +532,8 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             for (int k = 0; k < 3; ++k) {
                 const int idx = rec_index(g, k);
                 if (idx >= 0 && idx < n_rec) stage(idx, cv[g][k], cm[g][k]);
+                if (PAIR_STEP && g == 0 && k == 0) ES_MARK(7);                   // (16-env tiles: the slot marks 7 / 11 are free) first chunk staged
+                if (PAIR_STEP && g == 0 && k == 2) ES_MARK(11);                  // first group staged
             }
         for (int g = 2; g * GREC < n_rec; ++g) {                                // more than 16 candidates per env: one group at a time
 #pragma unroll
@@ -493,7 +551,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         }
     }
-    if (!OBS && A.flow_on) {
+    if (!OBS && !FUSED_FLOW && A.flow_on) {
         // eb_traffic_flow_step, per slot (one copy of the code, a pass of its own over this lane's records): a vehicle far out and
         // heading away leaves (its record stays where the prediction put it), the others accelerate towards their vType's speed —
         // what the NEXT step sees goes to HBM; the LDS copy stays this step's state
@@ -519,11 +577,6 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 reinterpret_cast<float4*>(A.cand)[(size_t)e0 * m_cand + idx] = o;
             }
     }
-    ES_MARK(1);
-    __syncthreads();   // barrier: s_ego, s_pts, s_oldc, s_cand, mode bytes
-    ES_MARK(8);
-
-    // ---- phase 2 ---------------------------------------------------------------------------------------------
     float delta_y = 0.0f;
     // E2E:329-338 ego vector, E2E:293-297 tracking error on path p: the head of this lane's observation row (from nx) -> s_out
     auto track_row = [&](int p) {
@@ -567,8 +620,57 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         }
     };
+    // (the step proper, wave 0) the tracking of the new pose right here, in front of barrier 1: it needs the ego step's result and the
+    // path tables, nothing of the other waves — and wave 0, which stages the fewest records, used to stand at that barrier for ~1.5 us
+    // and then run these two or three dependent table reads while waves 1-3 were at their pairs
+    constexpr bool TRACK_EARLY = false;   // (measured: the tracking in front of barrier 1 moved that barrier by the tracking's own 1-2 us — the loads of a wave return in order, its table reads queue behind its records — and phase 2 got no shorter; r5l)
+    if (TRACK_EARLY && wave == 0 && live) track_row(path_pre);
+    // eb_traffic_flow_step, per (env, route): the route's timer, and — when it is due and a slot of the route is vacant — the vehicle
+    // that enters: into LDS; stored behind the observation (phase 4).  Wave 1's job, behind its reward pairs
+    // (16-env tiles: 192 (env, route) pairs = three rounds of 64 — rounds 0 and 1 on wave 1, whose reward pairs are few there, round
+    // 2 on wave 3 behind its share of the collision pass; a round is two or three dependent round trips, ~0.8 us, and one wave doing
+    // all three was the tile's longest chain between barriers 1 and 3)
+    float ft[3] = {0.0f, 0.0f, 0.0f};
+    const int em_first = !FUSED_FLOW ? 0 : wave == 1 ? 0 : 2, em_last = !FUSED_FLOW ? (1 << 30) : wave == 1 ? 1 : wave == 3 ? 2 : -1;
+    if (FUSED_FLOW && A.flow_on) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k >= em_first && k <= em_last && lane + 64 * k < nE * 12) ft[k] = A.flow_timer[(size_t)e0 * 12 + lane + 64 * k];
+    }
+    auto flow_emission = [&]() {
+        const int K = A.flow_K;
+        for (int kq = em_first, q = lane + 64 * em_first; q < nE * 12 && kq <= em_last; q += 64, ++kq) {
+            const int e = q / 12, r = q - e * 12, ge = e0 + e;
+            const uint8_t* on = s_on + e * m_cand + r * K;
+            int vacant = -1;
+            for (int k = K - 1; k >= 0; --k)
+                if (!on[k]) vacant = k;
+            const size_t ti = (size_t)ge * 12 + r;
+            float t = ((FUSED_FLOW && kq < 3) ? (kq == 0 ? ft[0] : kq == 1 ? ft[1] : ft[2]) : A.flow_timer[ti]) + A.flow_dt;
+            const float per = A.flow_period[r];
+            int em = -1;
+            if (t >= per && vacant >= 0) {
+                const int j = r * K + vacant;
+                const uint64_t base = (A.counter << 32) + (uint64_t)ge * 128u + (uint64_t)(r * K) * 2u;
+                const float u1 = u01(A.seed, base), u2 = u01(A.seed, base + 1);
+                const float* ln = A.flow_lane + 5 * j;
+                const float along = u1 * A.flow_lane_len;
+                s_new[q] = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
+                em = vacant;
+                t = t - per;
+                atomicAdd(&A.flow_emitted[ti], 1);   // (no value returned: nothing waits for it)
+            }
+            s_emit[q] = em;
+            A.flow_timer[ti] = t;
+        }
+    };
+    ES_MARK(1);
+    __syncthreads();   // barrier: s_ego, s_pts, s_oldc, s_cand, mode bytes
+    ES_MARK(8);
+
+    // ---- phase 2 ---------------------------------------------------------------------------------------------
     if (wave == 0) {
-        if (live) track_row(RESET ? reset_path : path_pre);
+        if (!TRACK_EARLY && live) track_row(RESET ? reset_path : path_pre);
         ES_MARK(9);
         if (!OBS && live) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1), and
             // behind the tracking's dependent table reads rather than in front of them
@@ -605,35 +707,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 }
             }
             Q.flush();
-            if (A.flow_on) {
-                // eb_traffic_flow_step, per (env, route): the route's timer, and — when it is due and a slot of the route is vacant —
-                // the vehicle that enters: into LDS; the slot's own staging lane stores it behind the observation (phase 4)
-                const int K = A.flow_K;
-                for (int q = lane; q < nE * 12; q += 64) {
-                    const int e = q / 12, r = q - e * 12, ge = e0 + e;
-                    const uint8_t* on = s_on + e * m_cand + r * K;
-                    int vacant = -1;
-                    for (int k = K - 1; k >= 0; --k)
-                        if (!on[k]) vacant = k;
-                    const size_t ti = (size_t)ge * 12 + r;
-                    float t = A.flow_timer[ti] + A.flow_dt;
-                    const float per = A.flow_period[r];
-                    int em = -1;
-                    if (t >= per && vacant >= 0) {
-                        const int j = r * K + vacant;
-                        const uint64_t base = (A.counter << 32) + (uint64_t)ge * 128u + (uint64_t)(r * K) * 2u;
-                        const float u1 = u01(A.seed, base), u2 = u01(A.seed, base + 1);
-                        const float* ln = A.flow_lane + 5 * j;
-                        const float along = u1 * A.flow_lane_len;
-                        s_new[q] = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
-                        em = vacant;
-                        t = t - per;
-                        A.flow_emitted[ti] += 1;
-                    }
-                    s_emit[q] = em;
-                    A.flow_timer[ti] = t;
-                }
-            }
+            if (A.flow_on) flow_emission();
         }
         ES_MARK(5);
         if (wave == 2 || wave == 3) {   // one lane per (env, candidate): the collision test (TRF:263-295), its 10 m box first
@@ -667,6 +741,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 }
             }
             Q.flush();
+            if (FUSED_FLOW && A.flow_on && wave == 3) flow_emission();
         }
     }
     ES_MARK(2);
@@ -832,8 +907,87 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             if (on) one_mode(m, slots);      // (no lane leaves the loop early: the counter is read by the whole wave)
         }
     };
+    // One (env, distinct mode) pair per LANE — the mode per lane, its range box, key and fill value by data: slot_pair_walk's selection
+    // without a wave-uniform mode.  The auto-reset tail's slot pass (a handful of finished envs per tile), and the step's own on 16-env
+    // tiles, where a lane per env would leave three quarters of every wave idle in each of the ~8 per-mode passes.
+    auto pair_walk = [&](const bool act, const int e, const int j, const float ex, const float ey, const bool lit) {
+        const unsigned dm = s_dm[j];
+        const int m = (int)(dm & 0xffu), sa = (int)((dm >> 8) & 0xffu), sb = (int)((dm >> 16) & 0xffu);
+        const bool virt = TASK != TASK_RIGHT && lit && ey < -HALF_CROSS;                        // E2E:386-388
+        const float4* crow = s_cand + e * RS4;
+        const unsigned* trow = s_tag32 + e * TS4;
+        float* ov = s_out + e * OS + 6 + T;
+        const int nw = (m_cand + 3) >> 2;
+        unsigned long long elig = 0ull;
+        if (ELIG) {
+            const uint2 w2 = *reinterpret_cast<const uint2*>(&s_elig32[(e * EB_VMODE_COUNT + (m < EB_VMODE_COUNT ? m : 0)) * 2]);
+            elig = m < EB_VMODE_COUNT ? (unsigned long long)w2.x | (unsigned long long)w2.y << 32 : 0ull;
+        } else {
+            const unsigned mm = (unsigned)m * 0x01010101u;
+            for (int w = 0; w < nw; ++w) {
+                const unsigned x = trow[w] ^ mm;
+                const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
+                elig |= (unsigned long long)((((z >> 7) * 0x01020408u) >> 24) & 0xfu) << (4 * w);
+            }
+        }
+        if (!act) elig = 0ull;
+        const RangeBox rb = range_box(TASK, m, ex, ey);
+        const KeySpec ks = key_spec(TASK, m);
+        const V4 fill = veh_fill_value(m);
+        float2 k1 = make_float2(0.0f, 0.0f), k2 = k1;
+        int i1 = -1, i2 = -1;
+        auto offer = [&](const bool valid, const float2 kk, const int c) {        // slot_pair_walk's, the mode per lane
+            const bool first = valid & ((i1 < 0) | key_less(kk, k1));
+            const bool second = valid & !first & ((i2 < 0) | key_less(kk, k2));
+            k2.x = first ? k1.x : (second ? kk.x : k2.x); k2.y = first ? k1.y : (second ? kk.y : k2.y);
+            i2 = first ? i1 : (second ? c : i2);
+            k1.x = first ? kk.x : k1.x; k1.y = first ? kk.y : k1.y;
+            i1 = first ? c : i1;
+        };
+        const float2* cxy = reinterpret_cast<const float2*>(crow);
+        bool has = elig != 0ull;
+        int c = has ? __builtin_ctzll(elig) : 0;
+        elig &= elig - 1ull;
+        while (__builtin_amdgcn_ballot_w64(has)) {
+            const float2 xy = cxy[2 * c];
+            const bool hq = has;
+            const int cq = c;
+            has = elig != 0ull;
+            c = has ? __builtin_ctzll(elig) : 0;
+            elig &= elig - 1ull;
+            offer(hq & box_in_range(rb, xy.x, xy.y), key_of(ks, xy.x, xy.y), cq);
+        }
+        const float4 vv4 = make_float4(m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f);
+        offer(act & virt & ((m == EB_VMODE_DL) | (m == EB_VMODE_DU)) & box_in_range(rb, vv4.x, vv4.y), key_of(ks, vv4.x, vv4.y), m_cand);
+        const float4 fill4 = make_float4(fill.x, fill.y, fill.v, fill.phi);   // slice_or_fill, E2E:431-437
+        const float4 q1 = crow[i1 < 0 || i1 >= m_cand ? 0 : i1], q2 = crow[i2 < 0 || i2 >= m_cand ? 0 : i2];
+        const float4 r1 = i1 < 0 ? fill4 : (i1 >= m_cand ? vv4 : q1), r2 = i2 < 0 ? fill4 : (i2 >= m_cand ? vv4 : q2);
+        if (act) {
+            *reinterpret_cast<f4a4*>(ov + 4 * sa) = f4a4{r1.x, r1.y, r1.z, r1.w};
+            if (sb != 0xff) *reinterpret_cast<f4a4*>(ov + 4 * sb) = f4a4{r2.x, r2.y, r2.z, r2.w};
+        }
+    };
+    if (PAIR_STEP && A.dm_ok) {
+        // the step's slots on a 16-env tile: 64 (env, mode) pairs at a time, off the counter like the modes of the larger tiles
+        const unsigned long long lmask = __builtin_amdgcn_ballot_w64(light);     // lane = env: the same in every wave
+        const int n_pairs_s = nE * A.n_dm;
+        for (;;) {
+            int g = 0;
+            if (lane == 0) g = atomicAdd(&s_modeq, 1);
+            g = __builtin_amdgcn_readfirstlane(g);
+            if (g * 64 >= n_pairs_s) break;
+            const int q = g * 64 + lane;
+            const bool act = q < n_pairs_s;
+            const int e = act ? fast_div(q, A.dm_magic) : 0, j = act ? q - e * A.n_dm : 0;
+            const float4 eg = s_ego[e];
+            pair_walk(act, e, j, eg.x, eg.y, (lmask >> e) & 1ull);
+        }
+    } else
     fill_slots(live, light, true);
     ES_MARK(3);
+    // (16-env tiles with the flow rule: an entering vehicle is stored behind this barrier by ANOTHER lane than the one that stored the
+    // slot's record, flag and mode byte in phase 1 — those stores, some 4 us old, are complete before anybody passes the barrier)
+    if (FUSED_FLOW && A.flow_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // barrier: s_out complete; s_part, s_col, s_jb
     ES_MARK(10);
     // E2E:200-221, the priority chain: every wave merges the tile's done codes for itself (lane = env: a byte, a flag and delta_y
@@ -883,6 +1037,20 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         // lane that staged the slot (it stored the slot's record in phase 1 and read its mode byte: program order settles both) —
         // and the env's clock and light (every wave has used the old light: barrier 3)
         const int K = A.flow_K;
+        if (FUSED_FLOW) {
+            // 16-env tiles: the staging lanes have stored every slot's record, flag and mode byte (phase 1; complete: the wait in front
+            // of barrier 3) — what is left is the entering vehicles, from the wave that drew them (its own LDS writes)
+            if (wave == 1 || wave == 3)
+                for (int kq = em_first, q = lane + 64 * em_first; q < nE * 12 && kq <= em_last; q += 64, ++kq) {
+                    const int em = s_emit[q];
+                    if (em < 0) continue;
+                    const int e = q / 12, r = q - e * 12;
+                    const size_t sidx = (size_t)(e0 + e) * m_cand + r * K + em;
+                    reinterpret_cast<float4*>(A.cand)[sidx] = s_new[q];
+                    A.flow_active[sidx] = 1;
+                    A.flow_mode_out[sidx] = (uint8_t)r;
+                }
+        } else
         for (int g = 0; g * GREC < n_rec; ++g)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -1008,7 +1176,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 // (eight waves: the block has its CU nearly to itself and the stream's LENGTH is what counts — waves 1-7 take one distinct
                 // mode each, lanes = the finished envs, the mode wave-uniform again: no divergence in the per-mode switches)
                 const unsigned long long vmask = __builtin_amdgcn_ballot_w64(vflag);      // lane = env: the OLD flags of the tile
-                const int n_pairs_f = n_fin * A.n_dm, nw = (m_cand + 3) >> 2;
+                const int n_pairs_f = n_fin * A.n_dm;
                 const int rounds = NW == 8 ? (A.n_dm - (wave - 1) + (NW - 2)) / (NW - 1) : (n_pairs_f + 63) >> 6;
                 for (int rd = 0; rd < rounds; ++rd) {
                     int ford, j;
@@ -1020,63 +1188,9 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                         ford = act ? fast_div(q, A.dm_magic) : 0; j = act ? q - ford * A.n_dm : 0;
                     }
                     const int e = s_finlist[ford];
-                    const unsigned dm = s_dm[j];
-                    const int m = (int)(dm & 0xffu), sa = (int)((dm >> 8) & 0xffu), sb = (int)((dm >> 16) & 0xffu);
                     const float4 eg = s_rst[e];
-                    const float ex = eg.x, ey = eg.y;
                     const bool lit = ((vmask >> e) & 1ull) || (A.flow_on && s_col[e] != 0);                 // E2E:387-388: the OLD flag, or the light the flow source's reset set
-                    const bool virt = TASK != TASK_RIGHT && lit && ey < -HALF_CROSS;                        // E2E:386-388
-                    const float4* crow = s_cand + e * RS4;
-                    const unsigned* trow = s_tag32 + e * TS4;
-                    float* ov = s_out + e * OS + 6 + T;
-                    unsigned long long elig = 0ull;
-                    if (ELIG) {
-                        const uint2 w2 = *reinterpret_cast<const uint2*>(&s_elig32[(e * EB_VMODE_COUNT + (m < EB_VMODE_COUNT ? m : 0)) * 2]);
-                        elig = m < EB_VMODE_COUNT ? (unsigned long long)w2.x | (unsigned long long)w2.y << 32 : 0ull;
-                    } else {
-                        const unsigned mm = (unsigned)m * 0x01010101u;
-                        for (int w = 0; w < nw; ++w) {
-                            const unsigned x = trow[w] ^ mm;
-                            const unsigned z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte of x
-                            elig |= (unsigned long long)((((z >> 7) * 0x01020408u) >> 24) & 0xfu) << (4 * w);
-                        }
-                    }
-                    if (!act) elig = 0ull;
-                    const RangeBox rb = range_box(TASK, m, ex, ey);
-                    const KeySpec ks = key_spec(TASK, m);
-                    const V4 fill = veh_fill_value(m);
-                    float2 k1 = make_float2(0.0f, 0.0f), k2 = k1;
-                    int i1 = -1, i2 = -1;
-                    auto offer = [&](const bool valid, const float2 kk, const int c) {        // slot_pair_walk's, the mode per lane
-                        const bool first = valid & ((i1 < 0) | key_less(kk, k1));
-                        const bool second = valid & !first & ((i2 < 0) | key_less(kk, k2));
-                        k2.x = first ? k1.x : (second ? kk.x : k2.x); k2.y = first ? k1.y : (second ? kk.y : k2.y);
-                        i2 = first ? i1 : (second ? c : i2);
-                        k1.x = first ? kk.x : k1.x; k1.y = first ? kk.y : k1.y;
-                        i1 = first ? c : i1;
-                    };
-                    const float2* cxy = reinterpret_cast<const float2*>(crow);
-                    bool has = elig != 0ull;
-                    int c = has ? __builtin_ctzll(elig) : 0;
-                    elig &= elig - 1ull;
-                    while (__builtin_amdgcn_ballot_w64(has)) {
-                        const float2 xy = cxy[2 * c];
-                        const bool hq = has;
-                        const int cq = c;
-                        has = elig != 0ull;
-                        c = has ? __builtin_ctzll(elig) : 0;
-                        elig &= elig - 1ull;
-                        offer(hq & box_in_range(rb, xy.x, xy.y), key_of(ks, xy.x, xy.y), cq);
-                    }
-                    const float4 vv4 = make_float4(m == EB_VMODE_DL ? LANE_W / 2 : LANE_W * 1.5f, -HALF_CROSS + 2.5f, 0.0f, 90.0f);
-                    offer(act & virt & ((m == EB_VMODE_DL) | (m == EB_VMODE_DU)) & box_in_range(rb, vv4.x, vv4.y), key_of(ks, vv4.x, vv4.y), m_cand);
-                    const float4 fill4 = make_float4(fill.x, fill.y, fill.v, fill.phi);   // slice_or_fill, E2E:431-437
-                    const float4 q1 = crow[i1 < 0 || i1 >= m_cand ? 0 : i1], q2 = crow[i2 < 0 || i2 >= m_cand ? 0 : i2];
-                    const float4 r1 = i1 < 0 ? fill4 : (i1 >= m_cand ? vv4 : q1), r2 = i2 < 0 ? fill4 : (i2 >= m_cand ? vv4 : q2);
-                    if (act) {
-                        *reinterpret_cast<f4a4*>(ov + 4 * sa) = f4a4{r1.x, r1.y, r1.z, r1.w};
-                        if (sb != 0xff) *reinterpret_cast<f4a4*>(ov + 4 * sb) = f4a4{r2.x, r2.y, r2.z, r2.w};
-                    }
+                    pair_walk(act, e, j, eg.x, eg.y, lit);
                 }
             }
         } else {                                                                 // a mode with more than two slots: the step's own slot code

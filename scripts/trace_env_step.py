@@ -33,10 +33,10 @@ for k in (1, 2):
     print('launch %d: first wave start .. last wave end %.2f us; dead time since the previous launch %.2f us' % (k, (sp[k][1] - sp[k][0]) / 100., (sp[k][0] - sp[k - 1][1]) / 100.))
 t = trs[1].cpu().numpy().astype(np.float64); t = (t - t[:, 0].min()) / 100.0
 # marks (this wave's lane 0): see `order`
-order = [(0, 'start'), (1, 'phase 1 done: ego step / tyre params / traffic step (before barrier 1)'), (8, 'after barrier 1'),
+order = [(0, 'start'), (7, 'flows: first chunk staged') if a.flows else (0, 'start'), (11, 'flows: first group staged') if a.flows else (0, 'start'), (1, 'phase 1 done: ego step / tyre params / traffic step (before barrier 1)'), (8, 'after barrier 1'),
          (9, 'wave 0: closest point + tracking done (before the candidate store)'), (5, 'phase 2a: reward pairs done (waves 1-3)'),
          (2, 'phase 2 done: tracking + cand store | pairs + collision (before barrier 2)'), (6, 'after barrier 2 + sums (wave 1) / done code (wave 0)'),
-         (7, 'phase 3: candidate set built (last owned mode)'), (11, 'phase 3: walk done (no --auto)'), (12, 'phase 3: slots written (no --auto)'), (3, 'phase 3 done: slots built (before barrier 3)'), (10, 'after barrier 3'), (4, 'rows stored (end of the step proper)'),
+         (7, 'phase 3: candidate set built (last owned mode)') if not a.flows else (0, 'start'), (11, 'phase 3: walk done (no --auto)') if not a.flows else (0, 'start'), (12, 'phase 3: slots written (no --auto)'), (3, 'phase 3 done: slots built (before barrier 3)'), (10, 'after barrier 3'), (4, 'rows stored (end of the step proper)'),
          (11, 'auto: after the drain + barrier'), (12, 'auto: draws done, after the barrier'), (13, 'auto: pool re-entry done (before the barrier)'),
          (14, 'auto: tracking + slots done (before the barrier)'), (15, 'auto: rows stored, flags swapped (end)')]
 def q(x): return ' '.join('%6.2f' % v for v in np.percentile(x, [0, 10, 50, 90, 100])) + '   n=%d' % len(x)
@@ -48,3 +48,20 @@ for w in range(nw):
         sel = raw[w::nw, k] != 0
         if not sel.any(): continue
         print('  %-86s %s' % (n, q(t[w::nw, k][sel])))
+# per-block durations: each mark minus the same wave's previous mark (in the order above), percentiles over the blocks — what a phase
+# costs a wave, free of when its block happened to start
+print('per-block phase durations (us): this mark minus the wave\'s previous one; percentiles 10 50 90')
+for w in range(nw):
+    print('wave %d' % w)
+    prev = None
+    for k, n in order[:15]:
+        sel = raw[w::nw, k] != 0
+        if not sel.any() or (sel.sum() < nb // 2): continue
+        if prev is not None:
+            both = sel & (raw[w::nw, prev] != 0)
+            d = t[w::nw, k][both] - t[w::nw, prev][both]
+            print('  %-86s %s' % (n, ' '.join('%6.2f' % v for v in np.percentile(d, [10, 50, 90]))))
+        prev = k
+blk = t.reshape(nb, nw, 16)
+life = blk[:, :, 4].max(1) - blk[:, :, 0].min(1)
+print('tile lifetime (first wave start .. last wave rows stored): ' + ' '.join('%6.2f' % v for v in np.percentile(life, [10, 50, 90])))
