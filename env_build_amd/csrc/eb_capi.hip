@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -84,8 +86,19 @@ struct CellGrid {
     double x0, y0;
     int nx, ny;
 };
-static int build_cell_grid(const int* red_off, const int* red_len, const float* hred, int n_paths, CellGrid* out) {
-    const double cell = 1.0 / (double)eb::CELL_INV, margin = 20.0;   // beyond that: the pruned full search
+// cell: edge length (m); margin: how far the grid reaches beyond the paths' bounding box; max_range: a cell whose range would be longer
+// is marked 0xffffffff (the pruned full search is the cheaper exact answer there)
+// tight: narrow the range by witnesses.  The radius bound above admits every entry within m + 2h of the cell centre — abreast of a
+// straight at distance m that is +-sqrt(4 m h) entries, 76 of them for an 8 m cell 60 m out, although the closest entry of any one
+// position in the cell lies within a few metres of the centre's.  Entry r can be the (fp32) first minimum at a position p of the cell
+// only if it is no farther from p than any other entry w, up to the rounding of the two squared distances; |p - P_w|^2 - |p - P_r|^2
+// is LINEAR in p, so its maximum over the (slightly enlarged) cell is attained at a corner: r stays only if, for each of five witnesses
+// w — the closest entries of the centre and of the four corners — some corner has |p - P_w|^2 - |p - P_r|^2 >= -eps, with eps above
+// the fp32 rounding of those squares at this range (2e-6 of the largest squared distance in play; the kernel's expression has a
+// relative error of ~2.4e-7 per square).  The range becomes [first survivor, last survivor]: still a superset of every position's first minimum.
+// two_ranges (the coarse levels): the cell word holds one or two index ranges of at most 64 entries each (coarse_cell_ranges, eb_device.h)
+static int build_cell_grid(const int* red_off, const int* red_len, const float* hred, int n_paths, double cell, double margin, int max_range,
+                           bool tight, bool two_ranges, CellGrid* out) {
     double x0 = 1e30, x1 = -1e30, y0 = 1e30, y1 = -1e30;
     for (int k = 0; k < n_paths; ++k) {
         const float* r = hred + 2 * (size_t)red_off[k];
@@ -97,7 +110,7 @@ static int build_cell_grid(const int* red_off, const int* red_len, const float* 
     }
     x0 = std::floor(x0 - margin); y0 = std::floor(y0 - margin);
     int nx = (int)std::ceil((x1 + margin - x0) / cell), ny = (int)std::ceil((y1 + margin - y0) / cell);
-    nx = std::min(nx, 1024); ny = std::min(ny, 1024);   // positions outside the grid take the pruned full search
+    nx = std::min(nx, 1024); ny = std::min(ny, 1024);   // positions outside the grid take the next level / the pruned full search
     const double hd = cell * std::sqrt(2.0) / 2.0, win = 2.0 * hd + 0.01;
     out->cells.assign((size_t)n_paths * nx * ny, 0u);
     std::vector<double> d;
@@ -118,10 +131,101 @@ static int build_cell_grid(const int* red_off, const int* red_len, const float* 
                 int lo = 0, hi = n - 1;
                 while (d[lo] > lim) ++lo;
                 while (d[hi] > lim) --hi;
-                out->cells[((size_t)k * ny + iy) * nx + ix] = (uint32_t)lo | ((uint32_t)hi << 16);
+                if (tight && hi - lo + 1 > 4) {
+                    const double hc = cell / 2.0 + 0.01;                               // (a position the kernel's fp32 floor puts in this cell is well inside the enlarged one)
+                    const double px[4] = {cx - hc, cx + hc, cx - hc, cx + hc}, py[4] = {cy - hc, cy - hc, cy + hc, cy + hc};
+                    int wit[5];
+                    wit[0] = (int)(std::min_element(d.begin() + lo, d.begin() + hi + 1) - d.begin());
+                    double dk[4][512];
+                    for (int k = 0; k < 4; ++k) {
+                        double best = 1e300;
+                        wit[k + 1] = lo;
+                        for (int i = lo; i <= hi; ++i) {
+                            const double dx = px[k] - (double)r[2 * i], dy = py[k] - (double)r[2 * i + 1];
+                            dk[k][i] = dx * dx + dy * dy;
+                            if (dk[k][i] < best) { best = dk[k][i]; wit[k + 1] = i; }
+                        }
+                    }
+                    const double far = std::sqrt(m) + 3.0 * hd + 1.0, eps = 2e-6 * far * far + 1e-3;   // (every distance in play is below `far`; the kernel's two squares differ from the exact ones by < 4.8e-7 far^2 together)
+                    auto survives = [&](int i) {
+                        for (int w = 0; w < 5; ++w) {
+                            double g = -1e300;
+                            for (int k = 0; k < 4; ++k) g = std::max(g, dk[k][wit[w]] - dk[k][i]);
+                            if (g < -eps) return false;
+                        }
+                        return true;
+                    };
+                    while (lo < hi && !survives(lo)) ++lo;
+                    while (hi > lo && !survives(hi)) --hi;
+                    if (two_ranges && hi - lo + 1 > max_range) {
+                        // still long: a cell on the medial axis of the path (as close to one stretch as to another, e.g. the two legs
+                        // of a turn) — the survivors are two clusters with the unreachable stretch between them.  Cut at the widest gap.
+                        int g_lo = -1, g_hi = -1, prev = lo;
+                        for (int i = lo + 1; i <= hi; ++i) {
+                            if (!survives(i)) continue;
+                            if (i - prev > g_hi - g_lo) { g_lo = prev; g_hi = i; }
+                            prev = i;
+                        }
+                        if (g_lo >= 0 && g_lo - lo + 1 <= 8 && hi - g_hi + 1 <= 8) {   // (a scan trip is four entries and ~1 us in a loaded step kernel: two trips per cluster at most)
+                            out->cells[((size_t)k * ny + iy) * nx + ix] = (uint32_t)lo | (uint32_t)(g_lo - lo) << 9 | (uint32_t)g_hi << 15 |
+                                                                         (uint32_t)(hi - g_hi) << 24 | 1u << 30;
+                            continue;
+                        }
+                    }
+                }
+                if (two_ranges)   // [lo, lo + len): lo in bits 0-8, len - 1 in 9-14; a second range in 15-23 / 24-29 when bit 30 is set;
+                    // bit 31: a long range [lo, hi] (hi in bits 9-17) — the pruned search, over the blocks of that range only
+                    out->cells[((size_t)k * ny + iy) * nx + ix] = hi - lo + 1 > std::min(max_range, 64) ? (0x80000000u | (uint32_t)lo | (uint32_t)hi << 9)
+                                                                                                            : ((uint32_t)lo | (uint32_t)(hi - lo) << 9);
+                else
+                out->cells[((size_t)k * ny + iy) * nx + ix] = hi - lo + 1 > max_range ? 0xffffffffu : ((uint32_t)lo | ((uint32_t)hi << 16));
             }
     }
     out->x0 = x0; out->y0 = y0; out->nx = nx; out->ny = ny;
+    return EB_OK;
+}
+
+// The four levels of one set of path tables: every level's cell words back to back (one device buffer), the levels' geometry.
+static const double GRID_LVL_CELL[3] = {4.0, 32.0, 256.0}, GRID_LVL_MARGIN[3] = {250.0, 2000.0, 16000.0};
+struct GridSet {
+    std::vector<uint32_t> cells;    // [fine | 4 m | 32 m | 256 m]
+    CellGrid fine, lvl[3];          // geometry only (their own `cells` are moved into the buffer above)
+    size_t lvl_off[3];
+    std::vector<float> key;         // the stride-10 tables the set was built from
+    std::vector<int> key_len;
+};
+// eb_set_paths builds the levels on the host (~0.3 s for the three native paths); every handle of a task names the same tables, and a
+// process makes many handles (one per model / env / traffic handle): the sets are kept, keyed by the tables' bytes.
+static int grid_set_for(const int* red_off, const int* red_len, const float* hred, int n_paths, std::shared_ptr<const GridSet>* out) {
+    static std::mutex mu;
+    static std::vector<std::shared_ptr<const GridSet>> kept;
+    const size_t n_float = 2 * (size_t)(red_off[n_paths - 1] + red_len[n_paths - 1]);
+    std::vector<int> lens(red_len, red_len + n_paths);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const auto& g : kept)
+            if (g->key_len == lens && g->key.size() == n_float && std::memcmp(g->key.data(), hred, n_float * sizeof(float)) == 0) {
+                *out = g;
+                return EB_OK;
+            }
+    }
+    auto g = std::make_shared<GridSet>();
+    int rc = build_cell_grid(red_off, red_len, hred, n_paths, 1.0 / (double)eb::CELL_INV, 20.0, 1 << 30, true, false, &g->fine);
+    if (rc) return rc;
+    g->cells.swap(g->fine.cells);
+    for (int l = 0; l < 3; ++l) {
+        rc = build_cell_grid(red_off, red_len, hred, n_paths, GRID_LVL_CELL[l], GRID_LVL_MARGIN[l], 16, true, true, &g->lvl[l]);   // (ranges of up to 16 entries are scanned — four trips; longer ones go to the block search of the range)
+        if (rc) return rc;
+        g->lvl_off[l] = g->cells.size();
+        g->cells.insert(g->cells.end(), g->lvl[l].cells.begin(), g->lvl[l].cells.end());
+        std::vector<uint32_t>().swap(g->lvl[l].cells);
+    }
+    g->key.assign(hred, hred + n_float);
+    g->key_len = lens;
+    std::lock_guard<std::mutex> lock(mu);
+    if (kept.size() >= 16) kept.erase(kept.begin());   // (tables set by hand, one after another: the oldest set goes)
+    kept.push_back(g);
+    *out = g;
     return EB_OK;
 }
 
@@ -265,16 +369,23 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
         off += (size_t)lens[k];
     }
     const size_t bytes = phi10_byte_off + (red_total + 8) * sizeof(float);
-    CellGrid grid;
-    int rc = build_cell_grid(red_off, red_len, hred, n_paths, &grid);
+    // the corridor's level: 0.5 m cells out to 20 m around the paths (2-4 table entries per cell once narrowed by witnesses: one group
+    // of the scan); three coarser ones for the egos that have left the road or finished and drive on — 4 m cells out to 250 m, 32 m out
+    // to 2 km, 256 m out to 16 km; where a coarse cell's range(s) would still be long (abreast of a long straight, far out) the pruned
+    // full search stays the answer, as beyond 16 km.  Built once per distinct set of tables and process: handles of one task share them.
+    std::shared_ptr<const GridSet> gs;
+    int rc = grid_set_for(red_off, red_len, hred, n_paths, &gs);
     if (rc) return rc;
+    const CellGrid& grid = gs->fine;
+    const CellGrid* lvl = gs->lvl;
+    const size_t* lvl_off = gs->lvl_off;
     EB_HIP(hipSetDevice(h->cfg.device));
     float* d_tables = nullptr;
     uint32_t* d_cells = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_tables), bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cells), grid.cells.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cells), gs->cells.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(d_tables, host.data(), bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_cells, grid.cells.data(), grid.cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_cells, gs->cells.data(), gs->cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipDeviceSynchronize();   // nothing in flight reads the old tables any more
     if (e != hipSuccess) {
         if (d_tables) (void)hipFree(d_tables);
@@ -301,6 +412,8 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     pt.rad = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + rad_byte_off);
     pt.gx0 = (float)grid.x0; pt.gy0 = (float)grid.y0;   // integers: exact in fp32
     pt.gnx = grid.nx; pt.gny = grid.ny;
+    for (int l = 0; l < 3; ++l)
+        pt.coarse[l] = {d_cells + lvl_off[l], (float)lvl[l].x0, (float)lvl[l].y0, (float)(1.0 / GRID_LVL_CELL[l]), lvl[l].nx, lvl[l].ny};
     const eb::PathTables old_pt = h->pt;
     float* old_tables = h->d_tables;
     uint32_t* old_cells = h->d_cells;

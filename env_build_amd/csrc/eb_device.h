@@ -330,6 +330,15 @@ struct PathTables {
     float gx0, gy0;         // lower-left corner of the grid
     int gnx, gny;
     const float* rad;       // 3 x 32 block radii of the pruned full search (positions outside the grid), closest_reduced_index
+    // the same for positions off that grid (an ego that has left the road, or finished and drives on): three coarser levels — 4 m cells
+    // out to 250 m around the paths, 32 m cells out to 2 km, 256 m cells out to 16 km; every level's ranges are narrowed by witnesses
+    // (eb_capi.hip:build_cell_grid); a cell whose range would still be long (> 48 entries: abreast of a long straight, far out) holds
+    // 0xffffffff -> the pruned full search
+    struct Coarse {
+        const uint32_t* cells;
+        float x0, y0, inv;   // lower-left corner, 1 / cell size (a power of two: exact)
+        int nx, ny;
+    } coarse[3];
 };
 constexpr float CELL_INV = 2.0f;   // 1 / cell size (0.5 m): exact in fp32
 
@@ -337,6 +346,25 @@ constexpr float CELL_INV = 2.0f;   // 1 / cell size (0.5 m): exact in fp32
 EB_DEV int row_path(const PathTables& pt, const int* ref_idx, int path_id, int i) {
     const int p = ref_idx ? ref_idx[i] : path_id;
     return (p >= 0 && p < pt.n_paths) ? p : -1;
+}
+
+// The index ranges a coarse level names for (px, py) on path p: [lo, hi] and — a cell on the path's medial axis, as close to one stretch
+// as to another — a second one [lo2, hi2] (lo2 > hi; hi2 < lo2: none).  -> 1: scan them; 2: one LONG range [lo, hi] (abreast of a long
+// straight, far out: the pruned search over the blocks of that range); 0: off every level or NaN (the pruned search over the table).
+EB_DEV int coarse_cell_ranges(const PathTables& pt, int p, float px, float py, int& lo, int& hi, int& lo2, int& hi2) {
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        const PathTables::Coarse& g = pt.coarse[l];
+        const float fx = (px - g.x0) * g.inv, fy = (py - g.y0) * g.inv;
+        if (!(fx >= 0.0f && fx < (float)g.nx && fy >= 0.0f && fy < (float)g.ny)) continue;
+        const unsigned c = g.cells[(p * g.ny + (int)fy) * g.nx + (int)fx];
+        lo = (int)(c & 0x1ffu);
+        if (c >> 31) { hi = (int)((c >> 9) & 0x1ffu); return 2; }
+        hi = lo + (int)((c >> 9) & 0x3fu);
+        lo2 = (int)((c >> 15) & 0x1ffu); hi2 = (c >> 30) & 1u ? lo2 + (int)((c >> 24) & 0x3fu) : lo2 - 1;
+        return 1;
+    }
+    return 0;
 }
 
 // ---- closest point inside the index range a grid cell names (eb_capi.hip:build_cell_grid), one lane per env ----
@@ -390,6 +418,29 @@ EB_DEV int closest_in_range(const float* xy, const float* ph, int lo, int hi, fl
     return bi;
 }
 
+// the same over one or two ranges in index order (the coarse levels, coarse_cell_ranges): a group of four entries per trip
+EB_DEV int closest_in_ranges(const float* xy, const float* ph, int lo, int hi, int lo2, int hi2, float px, float py, float& rx, float& ry, float& rphi) {
+    typedef float f4x __attribute__((ext_vector_type(4), aligned(4)));
+    float best = __builtin_inff();
+    int bi = 0;
+    rx = xy[0]; ry = xy[1]; rphi = ph[0];
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+        const int a = part ? lo2 : lo, b = part ? hi2 : hi;
+        for (int r = a; r <= b; r += 4) {
+            const f4x q01 = *reinterpret_cast<const f4x*>(xy + 2 * r), q23 = *reinterpret_cast<const f4x*>(xy + 2 * r + 4);
+            const f4x hh = *reinterpret_cast<const f4x*>(ph + r);
+            const float d0 = sq(px - q01.x) + sq(py - q01.y), d1 = sq(px - q01.z) + sq(py - q01.w);   // DAM:712
+            const float d2 = sq(px - q23.x) + sq(py - q23.y), d3 = sq(px - q23.z) + sq(py - q23.w);
+            if (d0 < best) { best = d0; bi = r; rx = q01.x; ry = q01.y; rphi = hh.x; }                // first minimum, DAM:714
+            if (r + 1 <= b && d1 < best) { best = d1; bi = r + 1; rx = q01.z; ry = q01.w; rphi = hh.y; }
+            if (r + 2 <= b && d2 < best) { best = d2; bi = r + 2; rx = q23.x; ry = q23.y; rphi = hh.z; }
+            if (r + 3 <= b && d3 < best) { best = d3; bi = r + 3; rx = q23.z; ry = q23.w; rphi = hh.w; }
+        }
+    }
+    return bi;
+}
+
 // ---- closest point, one lane per env ---------------------------------------------------------------
 // EXACTLY the index the reference's full scan + argmin returns (DAM:702-715) while visiting ~1/5 of
 // the table.  The stride-10 table is cut into blocks of 16 consecutive points; for block b the host
@@ -402,25 +453,30 @@ EB_DEV int closest_in_range(const float* xy, const float* ph, int lo, int hi, fl
 //      strict '<' (first minimum).
 // NaN / inf coordinates end with index 0, as the full scan does.
 // The table lives in global memory (L2): loads are issued in groups so that their latencies overlap.
-EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, float px, float py) {
-    constexpr int G = 4;
+// G loads in flight per round trip: a lane out here stalls its whole wave for the length of this chain — with groups of four 8 + 8 trips
+// over the centres and 4 per surviving block, ~17 us at a loaded L2; eight per trip (the env step) halve that; the rollout kernels,
+// whose register budget is the records', stay with four
+template <int G = 4>
+EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, float px, float py, int r_first = 0, int r_last = 1 << 30) {
+    // [r_first, r_last]: a range known to hold the result (a coarse cell's long range) — only its blocks are looked at
     const int nb = (n + 15) >> 4;                 // <= 32 blocks (eb_set_paths limits a path to 512 table points)
+    const int bf = min(max(r_first, 0) >> 4, nb - 1), bl = min(r_last >> 4, nb - 1);
     float m2 = __builtin_inff();
-    for (int b0 = 0; b0 < nb; b0 += G) {
+    for (int b0 = bf; b0 <= bl; b0 += G) {
         float2 q[G];
 #pragma unroll
-        for (int u = 0; u < G; ++u) q[u] = red[min(16 * min(b0 + u, nb - 1) + 8, n - 1)];   // past the end: the last centre again
+        for (int u = 0; u < G; ++u) q[u] = red[min(16 * min(b0 + u, bl) + 8, n - 1)];   // past the end: the last centre again
 #pragma unroll
         for (int u = 0; u < G; ++u) m2 = __builtin_fminf(m2, sq(px - q[u].x) + sq(py - q[u].y));
     }
     const float m = __builtin_amdgcn_sqrtf(m2);   // approximate is enough: only feeds the slack test
     unsigned cand = 0u;
-    for (int b0 = 0; b0 < nb; b0 += G) {
+    for (int b0 = bf; b0 <= bl; b0 += G) {
         float2 q[G];
         float rr[G];
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            const int b = min(b0 + u, nb - 1);
+            const int b = min(b0 + u, bl);
             q[u] = red[min(16 * b + 8, n - 1)];
             rr[u] = rad[b];
         }
@@ -428,7 +484,7 @@ EB_DEV int closest_reduced_index(const float2* red, const float* rad, int n, flo
         for (int u = 0; u < G; ++u) {
             const float d2 = sq(px - q[u].x) + sq(py - q[u].y);
             const float thr = m + rr[u] + 0.01f;
-            cand |= (b0 + u < nb && d2 <= thr * thr) ? (1u << (b0 + u)) : 0u;
+            cand |= (b0 + u <= bl && d2 <= thr * thr) ? (1u << (b0 + u)) : 0u;
         }
     }
     float best = __builtin_inff();

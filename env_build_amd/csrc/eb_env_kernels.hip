@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
         } else {
             // an ego that has left the map (or NaN): the exact pruned search over block centres and radii — the index of
             // the reference's full scan after ~2 x 32 + 16..48 evaluations with grouped loads, instead of ~380 in a chain
-            bi = closest_reduced_index(red, pt.rad + 32 * p, pt.red_len[p], ex, ey);
+            int lo, hi, lo2, hi2;   // (the coarse level first: eb_device.h:coarse_cell_range)
+            float rx, ry, rphi;
+            const int how = coarse_cell_ranges(pt, p, ex, ey, lo, hi, lo2, hi2);
+            if (how == 1) bi = closest_in_ranges(reinterpret_cast<const float*>(red), pt.phi10[p], lo, hi, lo2, hi2, ex, ey, rx, ry, rphi);
+            else bi = closest_reduced_index<8>(red, pt.rad + 32 * p, pt.red_len[p], ex, ey, how == 2 ? lo : 0, how == 2 ? hi : 1 << 30);
         }
         const int idx = bi * 10, len = pt.len[p];
         const int ci = clamp_index(idx, len);

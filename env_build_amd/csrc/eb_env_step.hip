@@ -600,8 +600,13 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                     // same order, same strict '<' as the full scan: same index (eb_device.h; a group of entries per loop trip: prefetched groups cost this kernel two VGPRs, i.e. a wave of occupancy, and bought nothing in the rollout kernel's A/B)
                     bi = closest_in_range<0>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
                 } else {
-                    bi = closest_reduced_index(red, pt.rad + 32 * p, pt.red_len[p], ex, ey);
-                    rx = red[bi].x; ry = red[bi].y; rphi = ph10[bi];
+                    int lo, hi, lo2, hi2;   // off the corridor's grid: the coarse level (an ego that finished and drives on), then the pruned full search
+                    const int how = coarse_cell_ranges(pt, p, ex, ey, lo, hi, lo2, hi2);
+                    if (how == 1) bi = closest_in_ranges(reinterpret_cast<const float*>(red), ph10, lo, hi, lo2, hi2, ex, ey, rx, ry, rphi);
+                    else {
+                        bi = closest_reduced_index<8>(red, pt.rad + 32 * p, pt.red_len[p], ex, ey, how == 2 ? lo : 0, how == 2 ? hi : 1 << 30);
+                        rx = red[bi].x; ry = red[bi].y; rphi = ph10[bi];
+                    }
                 }
                 const int idx = bi * 10, len = pt.len[p];
                 delta_y = two2one<TASK>(ex, ey, rx, ry);

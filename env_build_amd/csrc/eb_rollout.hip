@@ -199,15 +199,27 @@ constexpr int TAPE_QCAP = 192;   // the tape kernel drains when more than 64 ent
 // tape / gated kernels keeps in LDS for its whole launch (north_star: "LDS staging of the reference path per block")
 // PRE: groups of four table entries fetched in one round trip (eb_device.h:closest_in_range) — 3 in the per-step kernel, whose tables
 // sit in L2; 0 — a group per loop trip, as before — in the tape / gated kernels (their register budget is the records', and small grids read the tables from LDS)
-template <int PRE = 3>
+// COARSE: off the corridor's grid, try the coarse level before the pruned full search (the per-step kernel; the tape / gated kernels'
+// 2048-record tile has no register for a second scan loop: 12-20 bytes of scratch with it — same index either way)
+template <int PRE = 3, bool COARSE = true>
 EB_DEV int closest_cell_index(const FusedArgs& A, const float* xy10, const float* phi10, int p, int roff, float px, float py,
                               float& rx, float& ry, float& rphi) {
     const float* xy = xy10 + 2 * roff;
     const float* ph = phi10 + roff;
     const float fx = (px - A.gx0) * CELL_INV, fy = (py - A.gy0) * CELL_INV;
     if (!(fx >= 0.0f && fx < (float)A.gnx && fy >= 0.0f && fy < (float)A.gny)) {
+        // off the corridor's grid: the coarse levels (eb_device.h:coarse_cell_ranges; described in the handle's table block — a rare
+        // path, the descriptors are read from memory rather than carried in the kernel arguments), then the pruned full search
+        int r_first = 0, r_last = 1 << 30;
+        if constexpr (COARSE) {
+            const PathTables& pt = *A.dt;
+            int lo, hi, lo2, hi2;
+            const int how = coarse_cell_ranges(pt, p, px, py, lo, hi, lo2, hi2);
+            if (how == 1) return closest_in_ranges(xy, ph, lo, hi, lo2, hi2, px, py, rx, ry, rphi);
+            if (how == 2) { r_first = lo; r_last = hi; }
+        }
         const int n = p == 0 ? A.red_len[0] : p == 1 ? A.red_len[1] : A.red_len[2];
-        const int bi = closest_reduced_index(reinterpret_cast<const float2*>(xy), A.rad_all + 32 * p, n, px, py);
+        const int bi = closest_reduced_index(reinterpret_cast<const float2*>(xy), A.rad_all + 32 * p, n, px, py, r_first, r_last);
         rx = xy[2 * bi]; ry = xy[2 * bi + 1]; rphi = ph[bi];
         return bi;
     }
@@ -764,7 +776,7 @@ EB_DEV void env_wave_tape(const FusedHot<ST>& H, const FusedArgs& A, TapeSmem<RW
         int bi = 0;
         if (p >= 0) {                                                       // DAM:334-353
             float rx = 0.0f, ry = 0.0f, rphi = 0.0f;
-            bi = closest_cell_index<0>(A, xy10, phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
+            bi = closest_cell_index<0, false>(A, xy10, phi10, p, roff, nx[3], nx[4], rx, ry, rphi);
             t0 = two2one<TASK>(nx[3], nx[4], rx, ry);                       // DAM:758
             t1 = deal_with_phi_diff(nx[5] - rphi);                          // DAM:759
             t2 = nx[0] - EXP_V;                                             // DAM:760

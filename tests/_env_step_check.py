@@ -177,7 +177,7 @@ def auto_reset_bad_args_case(make, task='left', B=40, M=8):
                    auto_reset=dict(seed=1, counter=1, training=1, pool=pool))
 
 
-def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, seed=3, strict=True):
+def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, seed=3, strict=True, hostile=False):
     """eb_env_step(flow) == eb_env_step, then eb_traffic_flow_step on what it left — every output and every piece of the flow
     source's state, bit for bit, over a closed loop that starts from an empty junction (emissions, exits, accelerations, the
     light programme all occur on the way); -> the trace of the fused path (for cross-library comparison)."""
@@ -200,6 +200,26 @@ def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, s
     along = np.where(rng.random((B, M)) < 0.15, rng.uniform(150, 175, (B, M)), along).astype(np.float32)   # through the junction and 50-75 m beyond: leaving
     cand = np.stack([lane[None, :, 0] + along * lane[None, :, 3], lane[None, :, 1] + along * lane[None, :, 4],
                      rng.uniform(0, 9, (B, M)).astype(np.float32), np.broadcast_to(lane[None, :, 2], (B, M))], 2).astype(np.float32)
+    if hostile:
+        # records no traffic source would produce — what the exit rule's "far out AND heading away" (the sign of x cos + y sin at the
+        # record's NEW heading) must still answer exactly: far-out vehicles at any heading, among them headings at a right angle to
+        # the position vector (the sum within rounding of zero, either sign), headings of many turns, far-out records on turning
+        # slots, huge speeds (from the junction box to beyond the exit range in one step), non-finite fields
+        active = (rng.random((B, M)) < 0.8).astype(np.uint8)
+        r = rng.uniform(40, 120, (B, M)); th = rng.uniform(-np.pi, np.pi, (B, M))
+        x, y = r * np.cos(th), r * np.sin(th)
+        kind = rng.integers(0, 8, (B, M))
+        phi = np.degrees(th) + np.where(kind == 0, 90.0, np.where(kind == 1, -90.0, rng.uniform(-180, 180, (B, M))))   # kinds 0, 1: tangential
+        phi = np.where(kind == 2, np.degrees(th), phi)                                   # radially outward
+        phi = np.where(kind == 3, np.degrees(th) + 180.0, phi)                           # radially inward
+        phi = np.where(kind == 4, phi + 360.0 * rng.integers(-40, 40, (B, M)), phi)      # many turns
+        v = rng.uniform(0, 9, (B, M))
+        fast = kind == 5
+        x = np.where(fast, rng.uniform(-24, 24, (B, M)), x); y = np.where(fast, rng.uniform(-24, 24, (B, M)), y)
+        v = np.where(fast, rng.uniform(500, 2000, (B, M)), v)                            # in the box now, far out after the step
+        cand = np.stack([x, y, v, phi], 2).astype(np.float32)
+        cand[::7, 3, 0] = np.nan; cand[3::11, 5, 3] = np.inf; cand[5::13, 2, 2] = np.inf; cand[1::17, 4, 1] = -np.inf
+        cand[2::5, 1] = (70.0, 0.0, 3.0, 90.0); cand[4::5, 1] = (0.0, -80.0, 3.0, 180.0)  # exactly at a right angle, on the axes
     mode = np.where(active != 0, np.array([_capi.VMODE_ID[x] for x in slot_modes], np.uint8)[None, :], _capi.VMODE_EMPTY).astype(np.uint8)
     timer = (rng.random((B, 12)) * period).astype(np.float32)
     emitted, sim_step = np.zeros((B, 12), np.int32), rng.integers(0, 600, B).astype(np.int32)
@@ -221,7 +241,7 @@ def flow_rule_case(make, task, B=300, K=5, steps=40, tile=None, light_cycle=1, s
         want = [a[0], a[1], a[2], a[3], a[4], f[0], a[6], a[7], f[1], f[2], f[3], f[4], f[5], f[6]]
         names = ['scaled', 'out5', 'dict16', 'ego', 'params', 'cand', 'obs', 'done', 'active', 'timer', 'emitted', 'sim_step', 'cand_mode', 'v_light']
         for k, (x, y) in enumerate(zip(g, want)):
-            assert np.array_equal(np.asarray(x).reshape(np.asarray(y).shape), y), (t, names[k])
+            assert np.array_equal(np.asarray(x).reshape(np.asarray(y).shape), y, equal_nan=hostile), (t, names[k])
         events['emit'] += int((f[3] != emitted).sum())
         events['exit'] += int(((active != 0) & (f[1] == 0)).sum())
         ego, cand, obs = g[3], g[5], g[6]

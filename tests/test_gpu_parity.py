@@ -517,6 +517,53 @@ def test_get_obs_egos_off_the_map(task):
 
 
 @pytest.mark.parametrize('task', TASKS)
+def test_closest_point_on_the_coarse_grid_level(task):
+    """Positions from 15 m to 7 km beyond the junction (an ego that finished and drives on): past the 0.5 m corridor grid the kernels
+    look the index range up in 8 m cells (out to 400 m around the paths), then in 256 m cells (out to 6.4 km); cells abreast of a long
+    straight hold 'long' and take the pruned full search, as everything farther out — the oracle's full scan bit for bit, through the
+    one-launch observation (every tile shape), the per-step rollout kernel and the open-loop tape kernel (tables staged in LDS)."""
+    B, M = 6000, 6
+    host, dev = _pair(task, n_veh=VEH_NUM[task])
+    ego, cand, cmode, lw, light, act, ref = _random_scene(task, B, M, 91)
+    rng = np.random.default_rng(17)
+    r, th = np.where(rng.random(B) < 0.7, rng.uniform(40, 560, B), rng.uniform(560, 7000, B)), rng.uniform(-np.pi, np.pi, B)
+    ego[:, 3], ego[:, 4] = (r * np.cos(th)).astype(np.float32), (r * np.sin(th)).astype(np.float32)
+    lanes = rng.random(B) < 0.5                                       # half of them straight on along an exit lane, where finished egos go
+    side = rng.integers(0, 4, B)
+    along, off = np.where(rng.random(B) < 0.7, rng.uniform(30, 520, B), rng.uniform(520, 6800, B)), rng.uniform(-8, 8, B)
+    ex = np.where(side == 0, off, np.where(side == 1, off, np.where(side == 2, along, -along)))
+    ey = np.where(side == 0, along, np.where(side == 1, -along, np.where(side == 2, off, off)))
+    ego[lanes, 3], ego[lanes, 4] = ex[lanes].astype(np.float32), ey[lanes].astype(np.float32)
+    o_h = host.get_obs(ego, cand, cmode, light, ref_idx=ref)
+    for tile in (0, 1, 2):
+        dev.set_tile(tile)
+        assert np.array_equal(o_h, dev.get_obs(ego, cand, cmode, light, ref_idx=ref)), tile
+    dev.set_tile(-1)
+    # many more positions through the one observation kernel: every coarse cell within reach gets a few (the ranges are narrowed by
+    # witnesses on the host — eb_capi.hip:build_cell_grid — and a cell whose range missed a position's first minimum would show here)
+    Bd = 60000
+    cd, cmd = np.tile(cand[:1], (Bd, 1, 1)), np.tile(cmode[:1], (Bd, 1))
+    for reach in (470.0, 6900.0):                                     # the 8 m level and the 256 m level (and a rim beyond each)
+        egd = np.zeros((Bd, 6), np.float32)
+        egd[:, 3], egd[:, 4] = rng.uniform(-reach, reach, Bd).astype(np.float32), rng.uniform(-reach, reach, Bd).astype(np.float32)
+        egd[:, 5] = rng.uniform(-180, 180, Bd).astype(np.float32)
+        refd = rng.integers(0, int(ref.max()) + 1, Bd).astype(np.int32)
+        assert np.array_equal(host.get_obs(egd, cd, cmd, np.zeros(Bd, np.uint8), ref_idx=refd)[:, :9],
+                              dev.get_obs(egd, cd, cmd, np.zeros(Bd, np.uint8), ref_idx=refd)[:, :9]), reach
+    # the rollout kernels: rows whose NEXT pose is out there
+    nv = VEH_NUM[task]
+    inp = make_rollout_inputs(task, B, nv, 3, seed=5)
+    obs = np.concatenate([ego, np.zeros((B, 3), np.float32), inp['veh']], 1).astype(np.float32)
+    for tile in (-1, 1, 2):
+        dev.set_tile(tile)
+        a, b = host.rollout_step(obs, inp['actions'][0], ref_idx=ref), dev.rollout_step(obs, inp['actions'][0], ref_idx=ref)
+        assert np.array_equal(a[0][:, :9], b[0][:, :9]), tile
+    dev.set_tile(-1)
+    a, b = host.rollout_tape(obs, inp['actions'], ref_idx=ref), dev.rollout_tape(obs, inp['actions'], ref_idx=ref)
+    assert np.array_equal(a[0][:, :9], b[0][:, :9])
+
+
+@pytest.mark.parametrize('task', TASKS)
 @pytest.mark.parametrize('M,NV', [(1, None), (4, None), (33, None), (64, None), (48, 32), (64, 64)])
 def test_get_obs_candidate_and_slot_counts(task, M, NV):
     """The observation kernel's LDS-staged form over candidate counts (odd / even row strides, one per env, the
@@ -740,6 +787,19 @@ def test_env_step_with_the_flow_rule(task, K, tile):
     got = flow_rule_case(lambda t, **kw: DeviceModel(t, **kw), task, B=300, K=K, tile=tile)
     for t, (a, b) in enumerate(zip(want, got)):
         _compare_auto_reset(a, b, 300, 'flow rule, step %d' % t)
+
+
+@pytest.mark.parametrize('task,K,tile', [('left', 5, -1), ('straight', 3, 2), ('right', 5, 1), ('left', 2, 2)])
+def test_flow_rule_exit_test_on_records_no_source_would_make(task, K, tile):
+    """The exit rule asks for the SIGN of x cos + y sin at a record's new heading.  The 16-env tiles answer it from the sin / cos the
+    prediction has just computed whenever that is safe and fall back to the exact expression otherwise: far-out records at any
+    heading — tangential ones (the sum within rounding of zero), many-turn headings, box-to-far jumps, NaN / inf fields — come out as
+    the two-call composite's and the oracle's, bit for bit (NaN positions equal as NaN)."""
+    from tests._env_step_check import flow_rule_case
+    want = flow_rule_case(lambda t, **kw: HostModel(oracle_lib(), t, **kw), task, B=300, K=K, steps=3, strict=False, hostile=True)
+    got = flow_rule_case(lambda t, **kw: DeviceModel(t, **kw), task, B=300, K=K, tile=tile, steps=3, strict=False, hostile=True)
+    for t, (a, b) in enumerate(zip(want, got)):
+        _compare_auto_reset(a, b, 300, 'flow rule on hostile records, step %d' % t)
 
 
 @pytest.mark.parametrize('task,K,tile', [('left', 5, -1), ('left', 5, 1), ('straight', 5, 2), ('right', 2, 0), ('left', 1, -1), ('right', 3, 1)])

@@ -54,6 +54,12 @@ def test_oracle_step_with_the_flow_rule(oracle, task, K):
     flow_rule_case(lambda t, **kw: HostModel(oracle, t, **kw), task, B=120, K=K, steps=30)
 
 
+def test_oracle_flow_rule_on_records_no_source_would_make(oracle):
+    """the composite and the two calls agree on far-out records at any heading, many-turn headings, box-to-far jumps, NaN / inf fields
+    (the inputs of the GPU test of the same name)"""
+    flow_rule_case(lambda t, **kw: HostModel(oracle, t, **kw), 'left', B=120, K=5, steps=3, strict=False, hostile=True)
+
+
 @pytest.mark.parametrize('task,K', [('left', 5), ('right', 2)])
 def test_oracle_step_with_the_flow_rule_and_auto_reset(oracle, task, K):
     """ABI 5: eb_env_step(flow + auto_reset) == eb_env_step(flow) + eb_env_reset + eb_traffic_flow_reset + eb_get_obs(mask) + flag swap"""
