@@ -982,6 +982,8 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
 EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
 EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 6, 80)   // (round 5: 64 -> 80 VGPRs — the env wave keeps three groups of table entries in flight;
 EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 6, 80)   //  these tiles run on grids of a few blocks per CU: latency, not occupancy)
+// (round 5, measured and dropped: the 2048-record tile on THREE waves — two record waves x 16 records per lane, 117 VGPRs, the same bits —
+//  so that a step launches 3 072 waves instead of 5 120: 16.8 vs 15.3 us at 65 536 x 32, 11.7 vs 9.5 at 32 768; profiles/r5_ab_tile3.txt)
 
 #define EB_TAPE_KERNEL(NAME, RW, RPT, GATED, WAVES)                                                      \
     template <int TASK, bool FAST, typename ST>                                                          \
