@@ -20,3 +20,10 @@ cp gpurun_out/${T}_pmc/pmc_traffic.json profiles/${R}_pmc_traffic.json
 [ -f $G/pmc_env_step.log ] && cp $G/pmc_env_step.log profiles/${T}_env_step_pmc.txt
 python scripts/pmc_traffic.py gpurun_out/${T}_pmc > profiles/${T}_pmc_traffic.txt
 ls profiles | grep "^${T}_"
+# round 5 additions (scripts/r5_measure.sh)
+[ -f $G/facade_rollout_out.jsonl ] && cp $G/facade_rollout_out.jsonl profiles/${T}_facade_rollout_out.jsonl
+for f in trace_rollout_65536 trace_rollout_32768 trace_env_step_flows trace_env_step_flows_auto noreset_profile; do [ -f $G/$f.txt ] && cp $G/$f.txt profiles/${T}_$f.txt; done
+[ -f $G/pmc_flows.log ] && cp $G/pmc_flows.log profiles/${T}_flows_pmc.txt
+if ls $G/fuzz_*.txt > /dev/null 2>&1; then (for f in $G/fuzz_*.txt; do echo "== $(basename $f)"; grep -v amdgpu.ids $f | tail -3; done) > profiles/${T}_fuzz.txt; fi
+[ -f $G/pytest_gpu.log ] && tail -1 $G/pytest_gpu.log > profiles/${T}_gpu_suite.txt
+ls profiles | grep "^${T}_" | wc -l

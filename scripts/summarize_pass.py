@@ -26,7 +26,9 @@ for e in d.get('extra', []):
                 print('    %-46s %.2f us per step (min %.2f), %.3g env-steps/s' % (k, v['us_per_step'], v['us_per_step_min'], v['value']))
     if 'step_with_auto_reset' in e:
         a = e['step_with_auto_reset']
-        print('    step + auto reset %.2f us (frac %.3f, finished per step %.4f); masked reset %.2f us' % (a['us_per_step'], a['frac'], a['finished_per_step_fraction'], e['masked_reset']['us_per_call']))
+        print('    step + auto reset %.2f us (frac %.3f%s)%s' % (a['us_per_step'], a['frac'],
+              ', finished per step %.4f' % a['finished_per_step_fraction'] if 'finished_per_step_fraction' in a else '',
+              '; masked reset %.2f us' % e['masked_reset']['us_per_call'] if 'masked_reset' in e else ''))
 c = d.get('cpu_baseline') or {}
 if c:
     print('cpu baseline: %.2f M on %d threads, %.3f M on one' % (c['value'] / 1e6, c['cores'], (c.get('value_1core') or 0) / 1e6))
