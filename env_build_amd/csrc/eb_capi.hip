@@ -210,7 +210,10 @@ static int grid_set_for(const int* red_off, const int* red_len, const float* hre
             }
     }
     auto g = std::make_shared<GridSet>();
-    int rc = build_cell_grid(red_off, red_len, hred, n_paths, 1.0 / (double)eb::CELL_INV, 20.0, 1 << 30, true, false, &g->fine);
+    // (a corridor cell whose narrowed range is still long sits on the path's medial axis — inside the junction, as close to one leg of a turn
+    // as to the other: its survivors are two clusters with the unreachable stretch between them, 100+ entries as ONE range, 25 scan
+    // trips for an ego that wanders there.  Such cells are marked 0xffffffff = "not on this level": the 4 m level names the two clusters.)
+    int rc = build_cell_grid(red_off, red_len, hred, n_paths, 1.0 / (double)eb::CELL_INV, 20.0, 16, true, false, &g->fine);
     if (rc) return rc;
     g->cells.swap(g->fine.cells);
     for (int l = 0; l < 3; ++l) {

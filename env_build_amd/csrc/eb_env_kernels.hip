@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void get_obs_kernel(int n_env, int D, int n_fu
         const float2* red = pt.red[p];
         const float fx = (ex - pt.gx0) * CELL_INV, fy = (ey - pt.gy0) * CELL_INV;
         int bi = 0;
-        if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) {
-            const unsigned c = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
+        unsigned c = 0xffffffffu;                                              // (also a corridor cell on the path's medial axis: eb_capi.hip)
+        if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) c = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
+        if (c != 0xffffffffu) {
             const int lo = (int)(c & 0xffffu), hi = (int)(c >> 16);
             float best = __builtin_inff();
             // four table points per trip (two 16-byte loads in flight instead of one dependent 8-byte load per point; the

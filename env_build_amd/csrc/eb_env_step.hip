@@ -578,36 +578,81 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
     }
     float delta_y = 0.0f;
-    // E2E:329-338 ego vector, E2E:293-297 tracking error on path p: the head of this lane's observation row (from nx) -> s_out
-    auto track_row = [&](int p) {
-        {
-            float* orow = s_out + lane * OS;
-            const float ex = nx[3], ey = nx[4];
+    // E2E:329-338 ego vector, E2E:293-297 tracking error on path p: the head of this lane's observation row (from nx) -> s_out.
+    // Called by EVERY lane of a wave (`on`: this lane has a row to make): the few lanes whose position no grid level answers with a
+    // short range — beyond every level, or abreast of a long straight far out — are resolved by the whole wave together, one after the
+    // other: each lane takes eight consecutive table entries (one round trip for the whole table), then a wave-wide first-minimum.
+    // A lane doing that search alone (the pruned search: ~8 dependent round trips at ~1 us each in a loaded step kernel) held its 63
+    // neighbours for as long; and a launch that is one generation of blocks lasts as long as its slowest tile.
+    auto track_row = [&](const bool on, int p) {
+        float* orow = s_out + lane * OS;
+        const float ex = nx[3], ey = nx[4];
+        const PathTables& pt = A.pt;
+        int bi = 0;
+        // the table point itself comes out of the scan — stride-10 entry bi IS path point 10 * bi (x, y, heading): no
+        // third dependent round trip to the full-resolution tables (the rollout kernel's closest_cell_index does the same)
+        float rx = 0.0f, ry = 0.0f, rphi = 0.0f;
+        bool whole = false;                                                   // this lane needs the search over the table
+        if (on) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) orow[c] = nx[c];
-            const PathTables& pt = A.pt;
+        }
+        if (on && p >= 0) {
+            const float2* red = pt.red[p];
+            const float* ph10 = pt.phi10[p];
+            const float fx = (ex - pt.gx0) * CELL_INV, fy = (ey - pt.gy0) * CELL_INV;
+            unsigned cw = 0xffffffffu;                                          // (also what a corridor cell on the path's medial axis holds: eb_capi.hip)
+            if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) cw = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
+            if (cw != 0xffffffffu) {
+                // same order, same strict '<' as the full scan: same index (eb_device.h; a group of entries per loop trip: prefetched groups cost this kernel two VGPRs, i.e. a wave of occupancy, and bought nothing in the rollout kernel's A/B)
+                bi = closest_in_range<0>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
+            } else {
+                int lo, hi, lo2, hi2;   // off the corridor's grid: the coarse levels (an ego that has left the road, or finished and drives on)
+                if (coarse_cell_ranges(pt, p, ex, ey, lo, hi, lo2, hi2) == 1)
+                    bi = closest_in_ranges(reinterpret_cast<const float*>(red), ph10, lo, hi, lo2, hi2, ex, ey, rx, ry, rphi);
+                else whole = true;
+            }
+        }
+        unsigned long long pend = __builtin_amdgcn_ballot_w64(whole);
+        if (pend != 0ull) {
+            if (__popcll(pend) <= 8) {
+                while (pend) {
+                    const int src = __builtin_ctzll(pend);
+                    pend &= pend - 1ull;
+                    const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), src));
+                    const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ey), src));
+                    const int qp = __builtin_amdgcn_readlane(p, src);
+                    const float* xy = reinterpret_cast<const float*>(pt.red[qp]);
+                    const int n = pt.red_len[qp];                             // <= 512 = 64 lanes x 8 entries
+                    typedef float f4x __attribute__((ext_vector_type(4), aligned(4)));
+                    f4x q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f4x*>(xy + 2 * min(8 * lane + 2 * u, n - 1));   // (readable 4 entries past the end)
+                    float best = __builtin_inff();
+                    int cb = 1 << 30;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = 8 * lane + 2 * u;
+                        const float d0 = sq(qx - q[u].x) + sq(qy - q[u].y), d1 = sq(qx - q[u].z) + sq(qy - q[u].w);   // DAM:712
+                        if (r < n && d0 < best) { best = d0; cb = r; }                                          // first minimum, DAM:714
+                        if (r + 1 < n && d1 < best) { best = d1; cb = r + 1; }
+                    }
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) {                        // (distance, index) minimum over the wave: the FIRST minimum
+                        const float ob = __shfl_xor(best, m, 64);
+                        const int oi = __shfl_xor(cb, m, 64);
+                        if (ob < best || (ob == best && oi < cb)) { best = ob; cb = oi; }
+                    }
+                    if (lane == src) bi = cb == (1 << 30) ? 0 : cb;           // (nothing compared below +inf — NaN / inf coordinates: index 0, as the full scan)
+                }
+            } else if (whole) {
+                bi = closest_reduced_index<8>(pt.red[p], pt.rad + 32 * p, pt.red_len[p], ex, ey);   // (a wave of far egos: every lane for itself)
+            }
+            if (whole) { rx = pt.red[p][bi].x; ry = pt.red[p][bi].y; rphi = pt.phi10[p][bi]; }
+        }
+        if (on) {
             if (p < 0) { for (int c = 0; c < T; ++c) orow[6 + c] = 0.0f; }
             else {
-                const float2* red = pt.red[p];
-                const float* ph10 = pt.phi10[p];
-                const float fx = (ex - pt.gx0) * CELL_INV, fy = (ey - pt.gy0) * CELL_INV;
-                int bi = 0;
-                // the table point itself comes out of the scan — stride-10 entry bi IS path point 10 * bi (x, y, heading): no
-                // third dependent round trip to the full-resolution tables (the rollout kernel's closest_cell_index does the same)
-                float rx, ry, rphi;
-                if (fx >= 0.0f && fx < (float)pt.gnx && fy >= 0.0f && fy < (float)pt.gny) {
-                    const unsigned cw = pt.cells[(p * pt.gny + (int)fy) * pt.gnx + (int)fx];
-                    // same order, same strict '<' as the full scan: same index (eb_device.h; a group of entries per loop trip: prefetched groups cost this kernel two VGPRs, i.e. a wave of occupancy, and bought nothing in the rollout kernel's A/B)
-                    bi = closest_in_range<0>(reinterpret_cast<const float*>(red), ph10, (int)(cw & 0xffffu), (int)(cw >> 16), ex, ey, rx, ry, rphi);
-                } else {
-                    int lo, hi, lo2, hi2;   // off the corridor's grid: the coarse level (an ego that finished and drives on), then the pruned full search
-                    const int how = coarse_cell_ranges(pt, p, ex, ey, lo, hi, lo2, hi2);
-                    if (how == 1) bi = closest_in_ranges(reinterpret_cast<const float*>(red), ph10, lo, hi, lo2, hi2, ex, ey, rx, ry, rphi);
-                    else {
-                        bi = closest_reduced_index<8>(red, pt.rad + 32 * p, pt.red_len[p], ex, ey, how == 2 ? lo : 0, how == 2 ? hi : 1 << 30);
-                        rx = red[bi].x; ry = red[bi].y; rphi = ph10[bi];
-                    }
-                }
                 const int idx = bi * 10, len = pt.len[p];
                 delta_y = two2one<TASK>(ex, ey, rx, ry);
                 orow[6] = delta_y;
@@ -629,7 +674,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     // path tables, nothing of the other waves — and wave 0, which stages the fewest records, used to stand at that barrier for ~1.5 us
     // and then run these two or three dependent table reads while waves 1-3 were at their pairs
     constexpr bool TRACK_EARLY = false;   // (measured: the tracking in front of barrier 1 moved that barrier by the tracking's own 1-2 us — the loads of a wave return in order, its table reads queue behind its records — and phase 2 got no shorter; r5l)
-    if (TRACK_EARLY && wave == 0 && live) track_row(path_pre);
+    if (TRACK_EARLY && wave == 0) track_row(live, path_pre);
     // eb_traffic_flow_step, per (env, route): the route's timer, and — when it is due and a slot of the route is vacant — the vehicle
     // that enters: into LDS; stored behind the observation (phase 4).  Wave 1's job, behind its reward pairs
     // (16-env tiles: 192 (env, route) pairs = three rounds of 64 — rounds 0 and 1 on wave 1, whose reward pairs are few there, round
@@ -675,7 +720,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
 
     // ---- phase 2 ---------------------------------------------------------------------------------------------
     if (wave == 0) {
-        if (!TRACK_EARLY && live) track_row(RESET ? reset_path : path_pre);
+        if (!TRACK_EARLY) track_row(live, RESET ? reset_path : path_pre);
         ES_MARK(9);
         if (!OBS && live) {   // E2E:135: the ego state in place — only now, when every wave has read the old one (barrier 1), and
             // behind the tracking's dependent table reads rather than in front of them
@@ -1176,7 +1221,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         // per lane (range box, key spec and fill value by data) — and waves 2, 3 wait at the barrier.
         if (A.dm_ok) {
             if (wave == 0) {
-                if (fin) track_row(reset_path);
+                track_row(fin, reset_path);
             } else if (NW == 8 || wave == 1) {
                 // (eight waves: the block has its CU nearly to itself and the stream's LENGTH is what counts — waves 1-7 take one distinct
                 // mode each, lanes = the finished envs, the mode wave-uniform again: no divergence in the per-mode switches)
@@ -1199,7 +1244,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
                 }
             }
         } else {                                                                 // a mode with more than two slots: the step's own slot code
-            if (wave == 0 && fin) track_row(reset_path);
+            if (wave == 0) track_row(fin, reset_path);
             fill_slots(fin, vflag || (A.flow_on && lane < ET && s_col[lane < ET ? lane : 0] != 0), false);
         }
         ES_MARK(14);

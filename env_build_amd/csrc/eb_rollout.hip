@@ -207,7 +207,9 @@ EB_DEV int closest_cell_index(const FusedArgs& A, const float* xy10, const float
     const float* xy = xy10 + 2 * roff;
     const float* ph = phi10 + roff;
     const float fx = (px - A.gx0) * CELL_INV, fy = (py - A.gy0) * CELL_INV;
-    if (!(fx >= 0.0f && fx < (float)A.gnx && fy >= 0.0f && fy < (float)A.gny)) {
+    unsigned c = 0xffffffffu;                                                  // (also a corridor cell on the path's medial axis: eb_capi.hip)
+    if (fx >= 0.0f && fx < (float)A.gnx && fy >= 0.0f && fy < (float)A.gny) c = A.cells[(p * A.gny + (int)fy) * A.gnx + (int)fx];
+    if (c == 0xffffffffu) {
         // off the corridor's grid: the coarse levels (eb_device.h:coarse_cell_ranges; described in the handle's table block — a rare
         // path, the descriptors are read from memory rather than carried in the kernel arguments), then the pruned full search
         int r_first = 0, r_last = 1 << 30;
@@ -223,7 +225,6 @@ EB_DEV int closest_cell_index(const FusedArgs& A, const float* xy10, const float
         rx = xy[2 * bi]; ry = xy[2 * bi + 1]; rphi = ph[bi];
         return bi;
     }
-    const unsigned c = A.cells[(p * A.gny + (int)fy) * A.gnx + (int)fx];
     if (PRE > 0 && A.scan_one_trip) return closest_in_range<0>(xy, ph, (int)(c & 0xffffu), (int)(c >> 16), px, py, rx, ry, rphi);
     return closest_in_range<PRE>(xy, ph, (int)(c & 0xffffu), (int)(c >> 16), px, py, rx, ry, rphi);
 }
