@@ -550,6 +550,21 @@ def test_closest_point_on_the_coarse_grid_level(task):
         refd = rng.integers(0, int(ref.max()) + 1, Bd).astype(np.int32)
         assert np.array_equal(host.get_obs(egd, cd, cmd, np.zeros(Bd, np.uint8), ref_idx=refd)[:, :9],
                               dev.get_obs(egd, cd, cmd, np.zeros(Bd, np.uint8), ref_idx=refd)[:, :9]), reach
+    # beyond every level (> 16 km) and NaN / inf: a few such lanes per wave are searched by the wave together (eight table entries per
+    # lane, wave-wide first minimum), a wave full of them lane by lane (the pruned search) — both against the oracle's full scan
+    for share in (1.0 / 16.0, 1.0):
+        egd = np.zeros((4096, 6), np.float32)
+        egd[:, 3], egd[:, 4] = rng.uniform(-60, 10, 4096).astype(np.float32), rng.uniform(-60, 10, 4096).astype(np.float32)
+        out = rng.random(4096) < share
+        rr, tt = rng.uniform(17000, 90000, 4096), rng.uniform(-np.pi, np.pi, 4096)
+        egd[out, 3], egd[out, 4] = (rr * np.cos(tt)).astype(np.float32)[out], (rr * np.sin(tt)).astype(np.float32)[out]
+        egd[5::97, 3] = np.nan; egd[7::89, 4] = np.inf; egd[11::83, 3] = -np.inf
+        refd = rng.integers(0, int(ref.max()) + 1, 4096).astype(np.int32)
+        for tile in (0, 1, 2):
+            dev.set_tile(tile)
+            assert np.array_equal(host.get_obs(egd, cd[:4096], cmd[:4096], np.zeros(4096, np.uint8), ref_idx=refd)[:, :9],
+                                  dev.get_obs(egd, cd[:4096], cmd[:4096], np.zeros(4096, np.uint8), ref_idx=refd)[:, :9], equal_nan=True), (share, tile)
+        dev.set_tile(-1)
     # the rollout kernels: rows whose NEXT pose is out there
     nv = VEH_NUM[task]
     inp = make_rollout_inputs(task, B, nv, 3, seed=5)
