@@ -47,6 +47,7 @@ struct eb_handle_s {
     float* d_rad_all;         // 3 x 32 block radii for the pruned closest-point search
     float* d_phi10_all;       // stride-10 headings, indexed like d_red_all
     uint32_t* d_cells;        // closest-point cell grid (PathTables::cells)
+    void* grids_ref;          // std::shared_ptr<const GridSet>*: the host copy of the levels these tables use (eb_debug_check_grids)
     double* d_partials;       // SUMMARY_MAX_PARTS x 6 doubles: stage-1 partials of eb_episode_summary
     eb::PathTables* d_pt;     // device copy of pt (+ slot turns) read by the rollout kernel
     int n_cu;                 // compute units of the device (persistent grid size)
@@ -292,6 +293,7 @@ int eb_destroy(eb_handle h) {
     (void)hipDeviceSynchronize();
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_cells) (void)hipFree(h->d_cells);
+    delete static_cast<std::shared_ptr<const GridSet>*>(h->grids_ref);
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_pt) (void)hipFree(h->d_pt);
     if (h->gate_stream) (void)hipStreamDestroy(h->gate_stream);
@@ -433,6 +435,8 @@ int eb_set_paths(eb_handle h, const float* xs, const float* ys, const float* phi
     }
     h->d_tables = d_tables;
     h->d_cells = d_cells;
+    delete static_cast<std::shared_ptr<const GridSet>*>(h->grids_ref);
+    h->grids_ref = new std::shared_ptr<const GridSet>(gs);
     h->d_red_all = d_red_all;
     h->d_rad_all = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + rad_byte_off);
     h->d_phi10_all = reinterpret_cast<float*>(reinterpret_cast<char*>(d_tables) + phi10_byte_off);
@@ -1197,6 +1201,62 @@ int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_word
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return fail(EB_EINVAL, "eb_debug_set_stage_paths: bad argument (-1 = by grid size, 0 = off, 1 = on)");
     h->stage_paths = mode;
+    return EB_OK;
+}
+
+// Self-check of the closest-point levels (host; the tables and cell words the kernels read): positions sampled in every cell of every
+// level — uniformly, and pressed against the cell's edges and corners — are mapped to their cell with the kernels' fp32 expression,
+// the reference's first minimum (DAM:712-714: fp32 squares, strict '<', index order) is taken over the WHOLE stride-10 table, and the
+// cell's range(s) must hold it.  -> *n_checked positions, *n_bad of them outside their cell's ranges.
+int eb_debug_check_grids(eb_handle h, int32_t samples_per_cell, uint64_t seed, int64_t* n_checked, int64_t* n_bad) {
+    if (!h || !h->grids_ref || samples_per_cell < 1 || !n_checked || !n_bad) return fail(EB_EINVAL, "eb_debug_check_grids: bad argument (paths set?)");
+    const GridSet& g = **static_cast<std::shared_ptr<const GridSet>*>(h->grids_ref);
+    const int n_paths = (int)g.key_len.size();
+    int64_t checked = 0, bad = 0;
+    uint64_t rs = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto u01 = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (double)(rs >> 11) * (1.0 / 9007199254740992.0); };
+    for (int l = 0; l < 4; ++l) {
+        const CellGrid& cg = l == 0 ? g.fine : g.lvl[l - 1];
+        const double cell = l == 0 ? 1.0 / (double)eb::CELL_INV : GRID_LVL_CELL[l - 1];
+        const float inv = (float)(1.0 / cell), gx0 = (float)cg.x0, gy0 = (float)cg.y0;
+        const uint32_t* words = g.cells.data() + (l == 0 ? 0 : g.lvl_off[l - 1]);
+        size_t off = 0;
+        for (int k = 0; k < n_paths; ++k) {
+            const float* r = g.key.data() + 2 * off;
+            const int n = g.key_len[k];
+            off += (size_t)n;
+            for (int iy = 0; iy < cg.ny; ++iy)
+                for (int ix = 0; ix < cg.nx; ++ix)
+                    for (int sidx = 0; sidx < samples_per_cell; ++sidx) {
+                        double ux = u01(), uy = u01();
+                        if (sidx % 3 == 1) { ux = ux < 0.5 ? ux * 1e-4 : 1.0 - ux * 1e-4; }                    // against an edge
+                        if (sidx % 3 == 2) { ux = ux < 0.5 ? ux * 1e-5 : 1.0 - ux * 1e-5; uy = uy < 0.5 ? uy * 1e-5 : 1.0 - uy * 1e-5; }   // into a corner
+                        const float px = (float)(cg.x0 + (ix + ux) * cell), py = (float)(cg.y0 + (iy + uy) * cell);
+                        const float fx = (px - gx0) * inv, fy = (py - gy0) * inv;                                // the kernels' mapping
+                        if (!(fx >= 0.0f && fx < (float)cg.nx && fy >= 0.0f && fy < (float)cg.ny)) continue;
+                        const uint32_t c = words[((size_t)k * cg.ny + (int)fy) * cg.nx + (int)fx];
+                        float best = INFINITY;
+                        int bi = 0;
+                        for (int i = 0; i < n; ++i) {
+                            const float dx = px - r[2 * i], dy = py - r[2 * i + 1];
+                            const float d = dx * dx + dy * dy;
+                            if (d < best) { best = d; bi = i; }
+                        }
+                        bool ok;
+                        if (l == 0) ok = c == 0xffffffffu || (bi >= (int)(c & 0xffffu) && bi <= (int)(c >> 16));
+                        else if (c >> 31) ok = c == 0xffffffffu || (bi >= (int)(c & 0x1ffu) && bi <= (int)((c >> 9) & 0x1ffu));
+                        else {
+                            const int lo = (int)(c & 0x1ffu), hi = lo + (int)((c >> 9) & 0x3fu);
+                            const int lo2 = (int)((c >> 15) & 0x1ffu), hi2 = lo2 + (int)((c >> 24) & 0x3fu);
+                            ok = (bi >= lo && bi <= hi) || (((c >> 30) & 1u) && bi >= lo2 && bi <= hi2);
+                        }
+                        ++checked;
+                        bad += ok ? 0 : 1;
+                    }
+        }
+    }
+    *n_checked = checked;
+    *n_bad = bad;
     return EB_OK;
 }
 

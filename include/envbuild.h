@@ -574,6 +574,13 @@ int eb_debug_set_env_waves(eb_handle h, int32_t waves);
 int eb_debug_set_tape_stepwise(eb_handle h, int32_t on);
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode);
 int eb_debug_set_scan_prefetch(eb_handle h, int32_t on);
+/* eb_debug_check_grids (host-side self-check of the closest-point search's precomputed levels, DAM:702-715): the kernels do not scan the
+ * stride-10 table; eb_set_paths precomputes, per cell of four nested grids (0.5 m / 4 m / 32 m / 256 m cells) and per path, the index
+ * range(s) that hold the reference's first-minimum argmin for EVERY position of the cell.  This samples samples_per_cell positions in
+ * every cell of every level (uniformly, against the edges, into the corners), takes the reference's argmin over the whole table with
+ * the kernels' fp32 expression and counts the positions whose argmin the cell's ranges miss: *n_bad must come back 0.  The oracle has
+ * no such levels (it IS the full scan): it reports 0 positions checked. */
+int eb_debug_check_grids(eb_handle h, int32_t samples_per_cell, uint64_t seed, int64_t* n_checked, int64_t* n_bad);
 int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words);
 
 /* ---- the policy in the loop: MLPNet + LoadPolicy.run_batch + the safety shield ----

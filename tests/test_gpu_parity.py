@@ -517,6 +517,19 @@ def test_get_obs_egos_off_the_map(task):
 
 
 @pytest.mark.parametrize('task', TASKS)
+def test_closest_point_levels_hold_the_reference_argmin_in_every_cell(task):
+    """eb_debug_check_grids: the four nested grids the kernels consult instead of scanning the stride-10 table (0.5 m / 4 m / 32 m /
+    256 m cells; ranges narrowed by witnesses, medial-axis cells with two ranges or deferred to the next level) — six positions in
+    EVERY cell of every level and path (uniform, against the edges, into the corners), mapped to their cell with the kernels' fp32
+    expression: the reference's first-minimum argmin over the whole table (DAM:712-714) lies inside the cell's range(s), every time."""
+    import ctypes as C
+    dev = DeviceModel(task, mode='training')
+    n, bad = C.c_int64(), C.c_int64()
+    dev.api.debug_check_grids(dev.h, 6, 12345, C.byref(n), C.byref(bad))
+    assert n.value > 1_000_000 and bad.value == 0, (n.value, bad.value)
+
+
+@pytest.mark.parametrize('task', TASKS)
 def test_closest_point_on_the_coarse_grid_level(task):
     """Positions from 15 m to 7 km beyond the junction (an ego that finished and drives on): past the 0.5 m corridor grid the kernels
     look the index range up in 8 m cells (out to 400 m around the paths), then in 256 m cells (out to 6.4 km); cells abreast of a long
