@@ -589,6 +589,16 @@ def test_closest_point_on_the_coarse_grid_level(task):
     dev.set_tile(-1)
     a, b = host.rollout_tape(obs, inp['actions'], ref_idx=ref), dev.rollout_tape(obs, inp['actions'], ref_idx=ref)
     assert np.array_equal(a[0][:, :9], b[0][:, :9])
+    # egos anywhere INSIDE the junction (where nobody drives: between the legs of a turn lie the corridor cells on the path's medial
+    # axis, which defer to the 4 m level — or, in the tape kernel, to the pruned search): observation, per-step and tape kernels
+    ego[:, 3], ego[:, 4] = rng.uniform(-45, 45, B).astype(np.float32), rng.uniform(-45, 45, B).astype(np.float32)
+    ego[:, 0] = rng.uniform(0, 3, B).astype(np.float32)
+    assert np.array_equal(host.get_obs(ego, cand, cmode, light, ref_idx=ref), dev.get_obs(ego, cand, cmode, light, ref_idx=ref))
+    obs = np.concatenate([ego, np.zeros((B, 3), np.float32), inp['veh']], 1).astype(np.float32)
+    a, b = host.rollout_step(obs, inp['actions'][0], ref_idx=ref), dev.rollout_step(obs, inp['actions'][0], ref_idx=ref)
+    assert np.array_equal(a[0][:, :9], b[0][:, :9])
+    a, b = host.rollout_tape(obs, inp['actions'], ref_idx=ref), dev.rollout_tape(obs, inp['actions'], ref_idx=ref)
+    assert np.array_equal(a[0][:, :9], b[0][:, :9])
 
 
 @pytest.mark.parametrize('task', TASKS)
