@@ -46,7 +46,7 @@ EB_DEV int es_tag_stride4(int m_cand) { return ((m_cand + 3) >> 2) | 1; }   // d
 EB_DEV int fast_div(int item, unsigned magic) { return magic ? (int)__umulhi((unsigned)item, magic) : item; }   // magic 0: / 1
 constexpr int ES_QCAP = 128;   // per-wave queue: flushed whenever 64 entries are waiting, so 64 + 64 suffice
 
-size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow) {
+size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow, bool four_waves) {
     const int rs4 = m_cand + ((m_cand & 1) ? 2 : 1), os = D | 1, ts4 = ((m_cand + 3) >> 2) | 1;
     const size_t E = (size_t)tile_envs;
     size_t b = E * rs4 * 16;                     // s_cand
@@ -56,7 +56,7 @@ size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow) {
     b += E * 8;                                  // s_oldc
     b += E * ts4 * 4;                            // s_tag
     b += (size_t)4 * ES_QCAP * 2;                // s_queue
-    if (flow) b += E * 12 * 16 + E * 12 * 4 + E * m_cand;   // s_new, s_emit, s_on (eb_flow_rule)
+    if (flow) b += ((tile_envs == 16 && four_waves) ? 0 : E * 12 * 16 + E * 12 * 4) + E * m_cand;   // s_new, s_emit (not on 16-env tiles x four waves: registers, FUSED_FLOW), s_on (eb_flow_rule)
     return (b + 15) & ~(size_t)15;
 }
 // envs per block: 64 for throughput; small and medium batches take 32-env tiles (16 below 1 024 envs) with EIGHT waves per block
@@ -259,9 +259,9 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     unsigned short* s_queue = reinterpret_cast<unsigned short*>(s_tag32 + (size_t)ET * TS4);   // [4][ES_QCAP]
     // eb_flow_rule (flow_on): per (env, route) the vehicle an emission puts into the route's first vacant slot and that slot (or
     // -1), per slot "a vehicle is here after the exit test"
-    float4* s_new = reinterpret_cast<float4*>(s_queue + 4 * ES_QCAP);           // [64][12]
-    int* s_emit = reinterpret_cast<int*>(s_new + (size_t)ET * 12);               // [64][12]
-    uint8_t* s_on = reinterpret_cast<uint8_t*>(s_emit + (size_t)ET * 12);        // [64][m_cand]
+    float4* s_new = reinterpret_cast<float4*>(s_queue + 4 * ES_QCAP);           // [64][12]   (not on 16-env tiles)
+    int* s_emit = reinterpret_cast<int*>(s_new + (size_t)((ET == 16 && NW == 4) ? 0 : ET) * 12);               // [64][12]   (not on 16-env tiles x four waves)
+    uint8_t* s_on = reinterpret_cast<uint8_t*>(s_emit + (size_t)((ET == 16 && NW == 4) ? 0 : ET) * 12);        // [64][m_cand]
     constexpr bool EVEN = ET == 16 && NW == 4;
     constexpr bool PAIR_STEP = ET == 16 && !OBS && !RESET;   // the step's slot phase as (env, mode) pairs per lane (pair_walk below)
     constexpr bool FUSED_FLOW = EVEN && !OBS;   // the flow rule's per-slot part inside the staging of a record (below) instead of a pass of its own
@@ -284,11 +284,14 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     const int n_rec = nE * m_cand;
     // chunks of 64 records in groups of eight: waves 2 and 3 take three chunks of a group each, waves 0 and 1 — which
     // have the ego step and the tyre parameters to do — one each.  16-env tiles on four waves (many candidates per env: the flow
-    // source's 60 are 15 chunks a tile) share the FIRST group evenly, two chunks per wave: waves 0 / 1 stood at barrier 1 for 3 us of
-    // the tile's 15 while 2 / 3 staged six chunks each; with every group shared evenly it was 2 / 3 that waited, 1.3-1.9 us (a chunk
-    // is ~0.65 us there, the ego step ~0.8, the tyre parameters ~1.3): 3 / 2 / 5 / 5 chunks now (profiles/r5_trace_flows_*.txt)
+    // source's 60 are 15 chunks a tile): waves 0 / 1 stood at barrier 1 for 3 us of the tile's 15 while 2 / 3 staged six chunks each.
+    // The plain step shares every group evenly, two chunks per wave (4 / 4 / 4 / 3): two chunk registers less per lane are what lets
+    // the kernel fit 80 VGPRs = SIX tiles per CU with the 25 KB of LDS a tile is down to (53.3 against 56-58 us at 65 536 x 60: the
+    // kernel waits 58 % of its wave cycles, a sixth tile is a sixth more in flight).  The auto-reset variant (87-95 VGPRs: five tiles
+    // either way) shares only the first group evenly: 3 / 2 / 5 / 5, waves 0 / 1 have their per-env chains too (a chunk is ~0.65 us
+    // there, the ego step ~0.8, the tyre parameters ~1.3) (profiles/r5n_trace_env_step_flows*.txt)
     auto rec_index = [&](int group, int k) -> int {
-        if (EVEN && group == 0) return k < 2 ? (wave + NW * k) * 64 + lane : -1;   // (the later groups as below: waves 0 / 1 have their per-env chains too)
+        if (EVEN && (group == 0 || !AUTO)) return k < 2 ? (group * GCH + wave + NW * k) * 64 + lane : -1;   // (the later groups as below: waves 0 / 1 have their per-env chains too)
         const int chunk = wave >= 2 ? (wave - 2) + (NW - 2) * k : (k == 0 ? (NW - 2) * KS + wave : -1);   // (NW = 4: 0 2 4 / 1 3 5 / 6 / 7)
         return chunk < 0 || k >= KS ? -1 : (group * GCH + chunk) * 64 + lane;
     };
@@ -687,6 +690,18 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         for (int k = 0; k < 3; ++k)
             if (k >= em_first && k <= em_last && lane + 64 * k < nE * 12) ft[k] = A.flow_timer[(size_t)e0 * 12 + lane + 64 * k];
     }
+    // (16-env tiles: phase 2 only DECIDES — the route's timer and its first vacant slot; the slot index stays in a register of the lane,
+    // emr[round], and the vehicle itself — two draws, the lane table — is made in phase 4 by the same lane, right where it is stored:
+    // no LDS for it (3.8 KB a tile: the sixth tile of a CU), and the draws leave the chain between barriers 1 and 3)
+    int emr[2] = {-1, -1};
+    auto flow_vehicle = [&](int q, int vacant) -> float4 {
+        const int K = A.flow_K, e = q / 12, r = q - e * 12, j = r * K + vacant;
+        const uint64_t base = (A.counter << 32) + (uint64_t)(e0 + e) * 128u + (uint64_t)(r * K) * 2u;
+        const float u1 = u01(A.seed, base), u2 = u01(A.seed, base + 1);
+        const float* ln = A.flow_lane + 5 * j;
+        const float along = u1 * A.flow_lane_len;
+        return make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
+    };
     auto flow_emission = [&]() {
         const int K = A.flow_K;
         for (int kq = em_first, q = lane + 64 * em_first; q < nE * 12 && kq <= em_last; q += 64, ++kq) {
@@ -700,17 +715,13 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             const float per = A.flow_period[r];
             int em = -1;
             if (t >= per && vacant >= 0) {
-                const int j = r * K + vacant;
-                const uint64_t base = (A.counter << 32) + (uint64_t)ge * 128u + (uint64_t)(r * K) * 2u;
-                const float u1 = u01(A.seed, base), u2 = u01(A.seed, base + 1);
-                const float* ln = A.flow_lane + 5 * j;
-                const float along = u1 * A.flow_lane_len;
-                s_new[q] = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
+                if (!FUSED_FLOW) s_new[q] = flow_vehicle(q, vacant);
                 em = vacant;
                 t = t - per;
                 atomicAdd(&A.flow_emitted[ti], 1);   // (no value returned: nothing waits for it)
             }
-            s_emit[q] = em;
+            if (FUSED_FLOW) { if (kq == em_first) emr[0] = em; else emr[1] = em; }
+            else s_emit[q] = em;
             A.flow_timer[ti] = t;
         }
     };
@@ -1089,14 +1100,14 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         const int K = A.flow_K;
         if (FUSED_FLOW) {
             // 16-env tiles: the staging lanes have stored every slot's record, flag and mode byte (phase 1; complete: the wait in front
-            // of barrier 3) — what is left is the entering vehicles, from the wave that drew them (its own LDS writes)
+            // of barrier 3) — what is left is the entering vehicles, made and stored by the lanes that decided them (emr)
             if (wave == 1 || wave == 3)
                 for (int kq = em_first, q = lane + 64 * em_first; q < nE * 12 && kq <= em_last; q += 64, ++kq) {
-                    const int em = s_emit[q];
+                    const int em = kq == em_first ? emr[0] : emr[1];
                     if (em < 0) continue;
                     const int e = q / 12, r = q - e * 12;
                     const size_t sidx = (size_t)(e0 + e) * m_cand + r * K + em;
-                    reinterpret_cast<float4*>(A.cand)[sidx] = s_new[q];
+                    reinterpret_cast<float4*>(A.cand)[sidx] = flow_vehicle(q, em);
                     A.flow_active[sidx] = 1;
                     A.flow_mode_out[sidx] = (uint8_t)r;
                 }
@@ -1260,7 +1271,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
 }
 
 template <int TASK, int ET, bool OBS, bool AUTO = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(A); }
+__global__ __launch_bounds__(NW * 64, (ET == 16 && NW == 4 && !OBS && !AUTO && TASK != TASK_RIGHT) ? 6 : 1)   /* (six tiles per CU for the flow source's step; the right-turn instantiation needs 84 VGPRs — 20 bytes of scratch under the bound — and stays at five) */ void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(A); }
 template <int TASK, int ET, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true, false, NW>(A); }
 
@@ -1269,7 +1280,6 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A_in, hipStream_t s) {
     int ET = A.tile_envs == 16 || A.tile_envs == 32 || A.tile_envs == 64 ? A.tile_envs
                                                                            : env_step_tile_envs(A.n_env, A.D, A.NV, A.m_cand, A.flow_on != 0);
     if (ET != 16 && env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0) + ES_STATIC_LDS > 156 * 1024) ET = 16;   // a forced shape that does not fit
-    const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0);
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;
@@ -1287,6 +1297,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A_in, hipStream_t s) {
     // eight waves per block only two blocks fit a CU's registers; measured at 65 536 x 60: 133 us against 104)
     const bool w8 = wforce != 4 && ET <= 32 && (n_blocks <= 3 * n_cu[dev] || wforce == 8);
     const dim3 g(n_blocks), b(w8 ? 512 : 256);
+    const size_t lds = env_step_lds_bytes(A.D, A.NV, A.m_cand, ET, A.flow_on != 0, !w8);
     if (A.trace && A.trace_words < (long long)n_blocks * (w8 ? 8 : 4) * 16) A.trace = nullptr;   // a mark buffer too small for this launch: no marks
 #define EB_ENV_STEP_W(T, E, O, AU, W)                                                                                 \
     do {                                                                                                             \

@@ -237,7 +237,7 @@ struct EnvResetArgs {                      // launch_get_obs(..., reset): what e
     const uint8_t* done_src;               // nullable: their done codes
     int* episode_step;                     // nullable: the masked rows' episode step counts are cleared
 };
-size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow = false);
+size_t env_step_lds_bytes(int D, int NV, int m_cand, int tile_envs, bool flow = false, bool four_waves = false);
 int env_step_tile_envs(int n_env, int D, int NV, int m_cand, bool flow = false);
 bool env_step_is_fused(int D, int NV, int m_cand, const float* cand, const float* ego = nullptr, const float* actions = nullptr,
                        const float* scaled = nullptr, const float* params = nullptr,   // NULL: not an argument of the call at hand
