@@ -1148,6 +1148,12 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             for (int t = 0; t < k; ++t) mbits &= mbits - 1ull;
             return __builtin_ctzll(mbits);
         };
+        // (the flow source's reset below ORs a bit per re-entered slot into the finished envs' route sets — spent since barrier 3: cleared here)
+        if (ELIG && A.flow_on)
+            for (int q = tid; q < n_fin * 12; q += NT) {
+                const int k = q / 12, w2 = (nth_fin(k) * EB_VMODE_COUNT + (q - 12 * k)) * 2;
+                s_elig32[w2] = 0u; s_elig32[w2 + 1] = 0u;
+            }
         // everybody's reads of s_ego / s_cand are over, and (the wait in front of the row store) everybody's candidate / params stores of
         // the step are complete before ANOTHER thread overwrites them below
         __syncthreads();
@@ -1176,49 +1182,49 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             }
         } else {
             // the flow source (ABI 5): Traffic.init_traffic's role for the finished envs = eb_traffic_flow_reset's arithmetic, one lane
-            // per (finished env, route): presence draws, depart position / speed, the conflict test against the NEW ego (TRF:168-192),
-            // timers, clock, light — to HBM and to the tile's LDS copy (records, mode bytes, the route's candidate set), from which
-            // the reset observation is built below.  (A route's slots carry the route's id as their mode: the lane owns that mode's
-            // words of s_elig32 outright.)
+            // per (finished env, SLOT): presence draw, depart position / speed, the conflict test against the NEW ego (TRF:168-192) —
+            // to HBM and to the tile's LDS copy (record, mode byte, a bit in the route's candidate set: zeroed in front of the barrier
+            // above), from which the reset observation is built below; a route's first slot also does the route's timer and count,
+            // route 0's the env's clock and light.  (Round 5 began with one lane per (finished env, route) walking the route's K slots:
+            // three 64-bit draws, a table read and the conflict test K times in a row on a dozen lanes — 7 us of the tail's 10.)
             const int K = A.flow_K;
-            for (int q = tid; q < n_fin * 12; q += NT) {
-                const int k = q / 12, r = q - 12 * k, e = nth_fin(k), ge = e0 + e;
+            for (int q = tid; q < n_fin * m_cand; q += NT) {
+                const int k = fast_div(q, A.m_magic), j = q - k * m_cand, e = nth_fin(k), ge = e0 + e;
+                const int r = fast_div(j, A.k_magic), kk = j - r * K;
                 const uint64_t env_base = (A.flow_reset_counter << 32) + (uint64_t)ge * 256u;
-                float expect = A.flow_lane_len / 7.5f / A.flow_period[r];
+                const float per = A.flow_period[r];
+                float expect = A.flow_lane_len / 7.5f / per;
                 if (expect > (float)K) expect = (float)K;
                 const float pp = expect / (float)K;
-                const float4 eg = s_rst[e];
-                const float ego6[6] = {eg.w, 0.0f, 0.0f, eg.x, eg.y, eg.z};
-                unsigned long long set = 0ull;
-                for (int k2 = 0; k2 < K; ++k2) {
-                    const int j = r * K + k2;
-                    const size_t sidx = (size_t)ge * m_cand + j;
-                    const float u0 = u01(A.flow_reset_seed, env_base + 4u * j), u1 = u01(A.flow_reset_seed, env_base + 4u * j + 1),
-                                u2 = u01(A.flow_reset_seed, env_base + 4u * j + 2);
-                    bool on = u0 < pp;
-                    if (on) {
-                        const float* ln = A.flow_lane + 5 * j;
-                        const float along = u1 * A.flow_lane_len;
-                        const float4 c = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
-                        reinterpret_cast<float4*>(A.cand)[sidx] = c;
-                        s_cand[e * RS4 + j] = c;
-                        if (init_conflict(ego6, 4.8f, c.x, c.y, c.w, c.z, A.flow_cand_len[j])) on = false;
-                    }
-                    A.flow_active[sidx] = on ? 1 : 0;
-                    A.flow_mode_out[sidx] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
-                    s_tag[e * TS4 * 4 + j] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
-                    if (on) set |= 1ull << j;
+                const size_t sidx = (size_t)ge * m_cand + j;
+                const float u0 = u01(A.flow_reset_seed, env_base + 4u * j), u1 = u01(A.flow_reset_seed, env_base + 4u * j + 1),
+                            u2 = u01(A.flow_reset_seed, env_base + 4u * j + 2);
+                bool on = u0 < pp;
+                if (on) {
+                    const float4 eg = s_rst[e];
+                    const float ego6[6] = {eg.w, 0.0f, 0.0f, eg.x, eg.y, eg.z};
+                    const float* ln = A.flow_lane + 5 * j;
+                    const float along = u1 * A.flow_lane_len;
+                    const float4 c = make_float4(ln[0] + along * ln[3], ln[1] + along * ln[4], u2 * A.flow_v_max[j], ln[2]);
+                    reinterpret_cast<float4*>(A.cand)[sidx] = c;
+                    s_cand[e * RS4 + j] = c;
+                    if (init_conflict(ego6, 4.8f, c.x, c.y, c.w, c.z, A.flow_cand_len[j])) on = false;
                 }
-                if (ELIG) { s_elig32[(e * EB_VMODE_COUNT + r) * 2] = (unsigned)set; s_elig32[(e * EB_VMODE_COUNT + r) * 2 + 1] = (unsigned)(set >> 32); }
-                A.flow_timer[(size_t)ge * 12 + r] = u01(A.flow_reset_seed, env_base + 4u * (r * K) + 3) * A.flow_period[r];
-                A.flow_emitted[(size_t)ge * 12 + r] = 0;
-                if (r == 0) {
-                    A.flow_sim_step[ge] = 0;
-                    const uint8_t ph = (A.flow_random_phase && u01(A.flow_reset_seed, env_base + 255u) > 0.5f) ? 2 : 0;   // TRF:158-161
-                    A.flow_phase0[ge] = ph;
-                    const uint8_t nl = A.training ? ph : 0;                                                           // TRF:222-223
-                    A.v_light_out[ge] = nl;
-                    s_col[e] = nl;            // (the step's collision flags are spent: the merge above read them) — the reset observation's light
+                A.flow_active[sidx] = on ? 1 : 0;
+                A.flow_mode_out[sidx] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+                s_tag[e * TS4 * 4 + j] = on ? (uint8_t)r : (uint8_t)EB_VMODE_EMPTY;
+                if (ELIG && on) atomicOr(&s_elig32[(e * EB_VMODE_COUNT + r) * 2 + (j >> 5)], 1u << (j & 31));
+                if (kk == 0) {
+                    A.flow_timer[(size_t)ge * 12 + r] = u01(A.flow_reset_seed, env_base + 4u * (r * K) + 3) * per;
+                    A.flow_emitted[(size_t)ge * 12 + r] = 0;
+                    if (r == 0) {
+                        A.flow_sim_step[ge] = 0;
+                        const uint8_t ph = (A.flow_random_phase && u01(A.flow_reset_seed, env_base + 255u) > 0.5f) ? 2 : 0;   // TRF:158-161
+                        A.flow_phase0[ge] = ph;
+                        const uint8_t nl = A.training ? ph : 0;                                                           // TRF:222-223
+                        A.v_light_out[ge] = nl;
+                        s_col[e] = nl;            // (the step's collision flags are spent: the merge above read them) — the reset observation's light
+                    }
                 }
             }
         }
