@@ -371,10 +371,11 @@ EB_DEV int coarse_cell_ranges(const PathTables& pt, int p, float px, float py, i
 // The reference's argmin (DAM:712-714) restricted to entries [lo, hi] of a path's stride-10 table: index order, the reference's fp32
 // expression, a strict '<' (first minimum) -> the index and the table point itself (x, y, heading).  xy: the path's (x, y) pairs,
 // ph: its headings, both readable 4 entries past the path's end.
-// The first PRE groups of four entries are fetched in ONE round trip, whatever the range's length (6-10 entries on the paths'
-// corridor, i.e. two or three groups): this chain of dependent reads — cell word, then the range — is the critical path of a wave
-// that has one lane per env, and every round trip queues behind the record streams of the same CU.  (Round 5: the groups used to be
-// fetched one per loop trip, a round trip each.)  Same comparisons in the same order: same index, same bits.
+// The first PRE groups of four entries are fetched in ONE round trip, whatever the range's length: this chain of dependent reads —
+// cell word, then the range — is the critical path of a wave that has one lane per env, and every round trip queues behind the
+// record streams of the same CU.  (When this was written a corridor range held 6-10 entries, two or three groups, and the groups were
+// fetched one per loop trip; since the ranges are narrowed by witnesses — eb_capi.hip:build_cell_grid — it holds 2-4: one group.)
+// Same comparisons in the same order: same index, same bits.
 template <int PRE = 3>
 EB_DEV int closest_in_range(const float* xy, const float* ph, int lo, int hi, float px, float py, float& rx, float& ry, float& rphi) {
     typedef float f4x __attribute__((ext_vector_type(4), aligned(4)));

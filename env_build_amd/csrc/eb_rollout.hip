@@ -192,7 +192,7 @@ constexpr int TAPE_QCAP = 192;   // the tape kernel drains when more than 64 ent
 // ---- closest point of (px, py) on path p (DAM:702-715), tables in global memory (L1/L2 resident) ----
 // The cell of the position names the index range [lo, hi] that provably holds the reference's argmin for
 // every position inside the cell (eb_capi.hip:build_cell_grid); scanning it in index order with the
-// reference's fp32 expression and a strict '<' returns the index of the full scan after ~6-10 evaluations
+// reference's fp32 expression and a strict '<' returns the index of the full scan after 2-4 evaluations (ranges narrowed by witnesses, round 5)
 // instead of ~370.  Positions outside the grid (or NaN) take the pruned full search.
 // Returns the table index and the table point itself (x, y, heading).
 // xy10 / phi10: the stride-10 tables — in global memory (the per-step kernel: L1/L2 resident), or the copy a block of the
