@@ -1006,6 +1006,23 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             i1 = first ? c : i1;
         };
         const float2* cxy = reinterpret_cast<const float2*>(crow);
+        {   // the first four members of the set without a loop, their (x, y) reads in flight together (slot_pair_walk's opening: a mode rarely
+            // has more — the flow source's routes have at most K = 5 slots —, and a loop trip is a dependent LDS round trip)
+            constexpr int UNR = 4;
+            int cs[UNR];
+            bool hs[UNR];
+            float2 q[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                hs[u] = elig != 0ull;
+                cs[u] = hs[u] ? __builtin_ctzll(elig) : 0;
+                elig &= elig - 1ull;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) q[u] = cxy[2 * cs[u]];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) offer(hs[u] & box_in_range(rb, q[u].x, q[u].y), key_of(ks, q[u].x, q[u].y), cs[u]);
+        }
         bool has = elig != 0ull;
         int c = has ? __builtin_ctzll(elig) : 0;
         elig &= elig - 1ull;
