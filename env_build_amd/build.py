@@ -16,8 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libenvbuild_hip.so')
 HASH_FILE = LIB + '.srchash'
-SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip', 'eb_env_step.hip', 'eb_policy.hip']
-HEADERS = ['eb_device.h', 'eb_kernels.h', 'eb_env_device.h', os.path.join('..', '..', 'include', 'envbuild.h')]
+SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hip', 'eb_env_step.hip', 'eb_env_step_t1.hip', 'eb_env_step_t2.hip',
+           'eb_policy.hip']   # (the env step's kernels: one translation unit per task — the three compile side by side)
+HEADERS = ['eb_device.h', 'eb_kernels.h', 'eb_env_device.h', 'eb_env_step_body.h', os.path.join('..', '..', 'include', 'envbuild.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
          '-fPIC', '-Wno-unused-value', '-Wno-pass-failed',
          '-mllvm', '-amdgpu-kernarg-preload-count=12']   # the rollout kernel's leading arguments arrive in SGPRs
@@ -37,7 +38,7 @@ def source_hash():
 
 KERNEL_SOURCES = {   # what a kernel's machine code depends on (its translation unit and the headers it includes) — pmc_traffic.py
     'rollout': ['eb_rollout.hip', 'eb_device.h', 'eb_kernels.h'],             # records these next to the HBM bytes it measures,
-    'env_step': ['eb_env_step.hip', 'eb_env_device.h', 'eb_device.h', 'eb_kernels.h'],   # bench.py refuses the bytes of other code
+    'env_step': ['eb_env_step_body.h', 'eb_env_step.hip', 'eb_env_device.h', 'eb_device.h', 'eb_kernels.h'],   # bench.py refuses the bytes of other code
 }
 
 

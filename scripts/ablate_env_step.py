@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Profiling aid (GPU box only, on the scratch copy gpurun makes): where the one-launch env step spends its time.  Each variant
-patches ONE stage out of csrc/eb_env_step.hip in place (results are wrong, timings are what is wanted), rebuilds the library and
+patches ONE stage out of csrc/eb_env_step_body.h in place (results are wrong, timings are what is wanted), rebuilds the library and
 runs `bench.py --env-step`; the source is restored at the end.  Usage: python scripts/ablate_env_step.py [--flows] [variant ...]
 (--flows: the facade's step over the flow source, 65 536 envs x 60 candidates, scripts/time_env_step.py, instead)."""
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'env_build_amd', 'csrc', 'eb_env_step.hip')
+SRC = os.path.join(ROOT, 'env_build_amd', 'csrc', 'eb_env_step_body.h')
 VARIANTS = {
     'base': [],
     'no_predict': [("            } else if (OBS) s_cand[e * RS4 + c] = v;", "            } else if (OBS || true) s_cand[e * RS4 + c] = v;")],     # (and no candidate store)
