@@ -231,13 +231,12 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
     // chunks of 64 records in groups of eight: waves 2 and 3 take three chunks of a group each, waves 0 and 1 — which
     // have the ego step and the tyre parameters to do — one each.  16-env tiles on four waves (many candidates per env: the flow
     // source's 60 are 15 chunks a tile): waves 0 / 1 stood at barrier 1 for 3 us of the tile's 15 while 2 / 3 staged six chunks each.
-    // The plain step shares every group evenly, two chunks per wave (4 / 4 / 4 / 3): two chunk registers less per lane are what lets
-    // the kernel fit 80 VGPRs = SIX tiles per CU with the 25 KB of LDS a tile is down to (53.3 against 56-58 us at 65 536 x 60: the
-    // kernel waits 58 % of its wave cycles, a sixth tile is a sixth more in flight).  The auto-reset variant (87-95 VGPRs: five tiles
-    // either way) shares only the first group evenly: 3 / 2 / 5 / 5, waves 0 / 1 have their per-env chains too (a chunk is ~0.65 us
-    // there, the ego step ~0.8, the tyre parameters ~1.3) (profiles/r5n_trace_env_step_flows*.txt)
+    // They share every group evenly, two chunks per wave (4 / 4 / 4 / 3): two chunk registers less per lane are what lets the kernel
+    // fit 80 VGPRs = SIX tiles per CU with the 25 KB of LDS a tile is down to (53 against 56-58 us at 65 536 x 60: the kernel waits
+    // 58 % of its wave cycles, a sixth tile is a sixth more in flight).  (Sharing only the first group evenly — 3 / 2 / 5 / 5, waves
+    // 0 / 1 have their per-env chains too — is 1 us less of phase 1 per tile, but costs those two registers.)
     auto rec_index = [&](int group, int k) -> int {
-        if (EVEN && (group == 0 || !AUTO)) return k < 2 ? (group * GCH + wave + NW * k) * 64 + lane : -1;   // (the later groups as below: waves 0 / 1 have their per-env chains too)
+        if (EVEN) return k < 2 ? (group * GCH + wave + NW * k) * 64 + lane : -1;
         const int chunk = wave >= 2 ? (wave - 2) + (NW - 2) * k : (k == 0 ? (NW - 2) * KS + wave : -1);   // (NW = 4: 0 2 4 / 1 3 5 / 6 / 7)
         return chunk < 0 || k >= KS ? -1 : (group * GCH + chunk) * 64 + lane;
     };
@@ -352,7 +351,11 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
         const float2* eg = reinterpret_cast<const float2*>(A.ego + 6 * (size_t)i);
         in_g0 = eg[0]; in_g1 = eg[1]; in_g2 = eg[2];
     }
-    if (AUTO && wave == (NW == 8 ? NW - 1 : 0) && live) {   // (eight waves: the last one stages the fewest records)
+    // (16-env tiles x four waves — the flow source's shape — draw in the tail instead, for the finished envs only: the speculation's
+    // registers are live together with the chunk registers, and without it the auto-reset variant fits the 80 VGPRs of SIX tiles per
+    // CU with no scratch; step + flow rule + reset 66.6 -> 61.7 us at 65 536 x 60)
+    constexpr bool DRAW_LATE = ET == 16 && NW == 4;
+    if (AUTO && !DRAW_LATE && wave == (NW == 8 ? NW - 1 : 0) && live) {   // (eight waves: the last one stages the fewest records)
         // Ahead of time, under the latency of the loads just issued: the start state a reset would give this env — the draws depend
         // on (seed, counter, env) alone.  If the step finishes the env, the tail finds its pose here instead of running eight 64-bit
         // multiplies and a dependent table read per draw behind the step.
@@ -1111,6 +1114,14 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
             for (int t = 0; t < k; ++t) mbits &= mbits - 1ull;
             return __builtin_ctzll(mbits);
         };
+        if (DRAW_LATE && wave == 0 && fin) {
+            float rs[6];
+            int rpath;
+            bool rvn;
+            draw_values(rs, rpath, rvn);
+            s_rst[lane] = make_float4(rs[3], rs[4], rs[5], rs[0]);
+            s_rflag[lane] = (unsigned)rpath | (rvn ? 4u : 0u);
+        }
         // (the flow source's reset below ORs a bit per re-entered slot into the finished envs' route sets — spent since barrier 3: cleared here)
         if (ELIG && A.flow_on)
             for (int q = tid; q < n_fin * 12; q += NT) {
@@ -1240,7 +1251,7 @@ EB_DEV void env_step_body(const EnvStepArgs A) {
 }
 
 template <int TASK, int ET, bool OBS, bool AUTO = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64, (ET == 16 && NW == 4 && !OBS && !AUTO && TASK != TASK_RIGHT) ? 6 : 1)   /* (six tiles per CU for the flow source's step; the right-turn instantiation needs 84 VGPRs — 20 bytes of scratch under the bound — and stays at five) */ void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(A); }
+__global__ __launch_bounds__(NW * 64, (ET == 16 && NW == 4 && !OBS && TASK != TASK_RIGHT) ? 6 : 1)   /* (six tiles per CU for the flow source's step, plain and with auto reset; the right-turn instantiations need 81-89 VGPRs — scratch under the bound — and stay at five) */ void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(A); }
 template <int TASK, int ET, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true, false, NW>(A); }
 
