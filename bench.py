@@ -5,7 +5,8 @@ A "step" is one rollout_out pass over the whole batch = B env-steps: ONE kernel 
 form — a policy may sit between two steps — not the fused open-loop kernel).  Headline workload at N GPUs:
 BASELINE.json configs[2] per GPU (N_env = 65 536, N_veh = 32, horizon 25, task `left`, training mode, fp32), weak
 scaling: every rank owns an independent shard of envs and there is no data-path collective; the only exchange is one
-all-gather (RCCL) of the 8-float episodic-return summary at the end of every horizon, inside the timed region.
+all-gather (RCCL) of the 8-float episodic-return summary at the end of every horizon, inside the timed region (N = 1, one
+process: no process group exists and the "gather" of the one rank's summary is a view — no launch; the summary kernels still run).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -431,7 +432,8 @@ def side_config(torch, dist, model, n_env, n_veh, seed, steps, warmup, repeats, 
     if f16 and (n_env, n_veh, lanes) == (N_ENV, 64, 1):      # configs[4]: HBM bytes from the PMC passes of scripts/pmc_traffic.sh
         out['traffic'], out['traffic_source'] = pmc_traffic('rollout', 'fp16_x64', 'hbm_bytes_per_launch')
     if with_summary:
-        out['protocol'] = 'episodic summary kernels + their gather once per horizon inside the timed region, as the headline'
+        out['protocol'] = ('episodic summary kernels + their gather once per horizon inside the timed region, as the headline '
+                           '(one process: the gather of one rank\'s summary is a view, no launch)')
     if tile is not None:
         out['tile_variant'] = tile
         model.api.debug_set_tile(model.handle, -1)
@@ -1068,8 +1070,8 @@ def main():
                                 'projected_speedup': t1['ms_per_step'] / sh['ms_per_step']}
             strong['projection'] = {'kind': 'ONE-GPU EXTRAPOLATION, NOT a multi-GPU measurement: no RCCL, no second rank ran',
                                     'what': 'per-rank shard of configs[3] at N GPUs timed on this one GPU, same protocol as the headline '
-                                            '(episodic summary + gather per horizon inside the timed region), regions of '
-                                            '%d steps; ratio = this box\'s own t(262144) / t(262144 / N)' % proj_steps,
+                                            '(episodic summary kernels per horizon inside the timed region; with one rank their gather is a '
+                                            'view, no launch), regions of %d steps; ratio = this box\'s own t(262144) / t(262144 / N)' % proj_steps,
                                     'steps_per_region': proj_steps,
                                     'one_gpu_ms_per_step': t1['ms_per_step'], 'one_gpu_frac': t1['frac'], 'by_n_gpus': proj,
                                     'projected_speedup_at_8': proj['8']['projected_speedup'],
@@ -1133,7 +1135,8 @@ def main():
             'config': {'workload': '%s: N_env=%d per GPU, N_veh=%d, horizon=%d, task=%s, mode=training, %s'
                                    % (cfg, n_env, n_veh, min(args.steps, HORIZON), TASK, form),
                        'n_env_per_gpu': n_env, 'n_veh': n_veh, 'horizon': min(args.steps, HORIZON),
-                       'parallelism': 'env-shard x%d, all-gather of the 8-float episodic summary per horizon' % world},
+                       'parallelism': 'env-shard x%d, all-gather of the 8-float episodic summary per horizon%s'
+                                      % (world, '' if use_dist else ' (one process: the gather is a view of the rank\'s own summary, no launch)')},
             'repeats': {'n': len(r['dt']), 'statistic': 'median', 'ms_per_step_min': min(r['dt']) * 1e3 / args.steps,
                         'ms_per_step_median': dt * 1e3 / args.steps, 'ms_per_step_max': max(r['dt']) * 1e3 / args.steps},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

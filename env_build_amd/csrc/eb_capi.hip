@@ -65,6 +65,10 @@ struct eb_handle_s {
     hipEvent_t gate_event;    // orders eb_gate_feed behind the caller's stream (after_stream)
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
     int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
+    // the accumulating rollouts in flight on this handle: what the step-0 launch of a workspace ran with — the later steps and the fold
+    // must see the same grid, batch and horizon (a tile shape forced in between would shift every record: refused, not folded)
+    struct AccRun { const void* ws; int grid, n_env, horizon; } acc_runs[4];
+    int acc_next;
 };
 
 // the kernel-visible copy of the tables: refreshed whenever paths or slot modes change
@@ -599,6 +603,16 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
     if (acc) {   // records are indexed by THIS grid (the same at every step of a rollout: one handle state, one n_env)
+        // the rollout a workspace belongs to is fixed by its step-0 launch
+        eb_handle_s::AccRun* run = nullptr;
+        for (auto& r : h->acc_runs) if (r.ws == acc->workspace) run = &r;
+        if (acc->step == 0) {
+            if (!run) { run = &h->acc_runs[h->acc_next]; h->acc_next = (h->acc_next + 1) % 4; }
+            *run = eb_handle_s::AccRun{acc->workspace, grid, n_env, acc->horizon};
+        } else if (run && (run->grid != grid || run->n_env != n_env || run->horizon != acc->horizon)) {
+            return fail(EB_EINVAL, "eb_rollout_step_acc: this workspace's rollout was started with another grid, batch or horizon "
+                                   "(its step-0 launch fixes them; eb_debug_set_tile in between?)");
+        }
         A.acc_rec = acc_records(acc->workspace, acc->step, (size_t)grid);
         if (acc->step > 0) { A.prev_out5 = acc->prev_out5; A.prev_rec = acc_records(acc->workspace, acc->step - 1, (size_t)grid); }
         if (acc->step == acc->horizon - 1) A.acc_final = acc_finals(acc->workspace, acc->horizon, (size_t)grid);
@@ -688,8 +702,16 @@ int eb_rollout_step_acc(eb_handle h, int32_t n_env, const float* obs_in, const f
 int eb_episode_acc_finish(eb_handle h, int32_t n_env, int32_t horizon, const void* acc, float* out8, void* stream) {
     if (!h || n_env < 0 || horizon < 1 || !out8 || (n_env > 0 && !acc)) return fail(EB_EINVAL, "eb_episode_acc_finish: bad argument");
     EB_HIP(hipSetDevice(h->cfg.device));
-    const int e = envs_per_tile(h, pick_variant(h, n_env));   // the grid the accumulating launches ran on
-    const size_t grid = (size_t)((n_env + e - 1) / e);
+    const int e = envs_per_tile(h, pick_variant(h, n_env));
+    size_t grid = (size_t)((n_env + e - 1) / e);
+    // the grid the accumulating launches ran on: the one their step-0 launch recorded (a workspace this handle has not seen a step 0
+    // of — filled through another handle of the same shape — is folded with the handle's current grid)
+    for (const auto& r : h->acc_runs)
+        if (r.ws == acc && r.ws) {
+            if (r.n_env != n_env || r.horizon != horizon)
+                return fail(EB_EINVAL, "eb_episode_acc_finish: n_env / horizon differ from the rollout that filled this workspace");
+            grid = (size_t)r.grid;
+        }
     void* ws = const_cast<void*>(acc);
     EB_HIP(eb::launch_acc_fold((int)grid, n_env, horizon, acc_records(ws, 0, grid), acc_finals(ws, horizon, grid), out8,
                                pick(h, stream)));
@@ -990,9 +1012,11 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (rc) return rc;
     if (!ref_idx && (path_id < 0 || path_id >= h->pt.n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (const eb_auto_reset* ar = auto_reset) {
-        if ((!flow && !ar->pool.entry) || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
-            ar->virtual_flag != virtual_flag || ar->v_light != v_light)
-            return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
+        if (!flow && !ar->pool.entry)
+            return fail(EB_EINVAL, "eb_env_step: auto_reset needs a traffic source to reset — the pool rule (auto_reset->pool.entry) or the flow rule of the call");
+        if (m_cand < 1 || m_cand > 64) return fail(EB_EINVAL, "eb_env_step: auto_reset needs 1..64 candidates");
+        if (!ref_idx || !virtual_flag || ar->ref_idx != ref_idx || ar->virtual_flag != virtual_flag || ar->v_light != v_light)
+            return fail(EB_EINVAL, "eb_env_step: auto_reset rewrites the ref_idx / virtual_flag / v_light arrays of the call: they must be given and be the call's own");
         if (flow && (!ar->flow_cand_len || !ar->flow_phase0))
             return fail(EB_EINVAL, "eb_env_step: auto_reset over the flow source needs flow_cand_len and flow_phase0");
         if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))
@@ -1304,7 +1328,6 @@ struct eb_plan_s {
     eb_handle h;
     hipGraph_t graph;
     hipGraphExec_t exec;
-    void* own_acc;            // the accumulator workspace of a plan with a summary whose caller passed none
 };
 
 struct eb_event_s {
@@ -1327,12 +1350,11 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
         return fail(EB_EINVAL, "eb_plan_create: obs_in, obs_work and obs_out must be distinct buffers");
     if (acc && ((uintptr_t)acc & 15) != 0) return fail(EB_EINVAL, "eb_plan_create: acc must be 16-byte aligned");
     EB_HIP(hipSetDevice(h->cfg.device));
-    void* own_acc = nullptr;   // (kept for a plan that owns a workspace; none does at present)
     hipStream_t cs = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-    if (e != hipSuccess) { if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamCreateWithFlags", e); }
+    if (e != hipSuccess) { return fail_hip("hipStreamCreateWithFlags", e); }
     e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { (void)hipStreamDestroy(cs); if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamBeginCapture", e); }
+    if (e != hipSuccess) { (void)hipStreamDestroy(cs); return fail_hip("hipStreamBeginCapture", e); }
     // the plan is the CLOSED-LOOP form: one per-step launch per rollout_out, H of them in a graph.  With a caller's accumulator they
     // are the accumulating launches and the summary (if asked for) is the fold behind them; without one the summary is
     // eb_episode_summary's second pass over out5 — the faster of the two on this GPU (profiles/r5_ab_acc_summary.txt)
@@ -1343,18 +1365,18 @@ int eb_plan_create(eb_handle h, int32_t n_env, int32_t horizon, const float* obs
     hipGraph_t graph = nullptr;
     e = hipStreamEndCapture(cs, &graph);
     (void)hipStreamDestroy(cs);
-    if (rc != EB_OK) { if (graph) (void)hipGraphDestroy(graph); if (own_acc) (void)hipFree(own_acc); return rc; }
-    if (e != hipSuccess || !graph) { if (own_acc) (void)hipFree(own_acc); return fail_hip("hipStreamEndCapture", e); }
+    if (rc != EB_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) { return fail_hip("hipStreamEndCapture", e); }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { (void)hipGraphDestroy(graph); if (own_acc) (void)hipFree(own_acc); return fail_hip("hipGraphInstantiate", e); }
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); return fail_hip("hipGraphInstantiate", e); }
     eb_plan p = new (std::nothrow) eb_plan_s();
     if (!p) {
         (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
-        if (own_acc) (void)hipFree(own_acc);
+       
         return fail(EB_ENOMEM, "eb_plan_create: out of memory");
     }
-    p->h = h; p->graph = graph; p->exec = exec; p->own_acc = own_acc;
+    p->h = h; p->graph = graph; p->exec = exec;
     *out = p;
     return EB_OK;
 }
@@ -1372,7 +1394,6 @@ int eb_plan_destroy(eb_plan p) {
     (void)hipDeviceSynchronize();
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
-    if (p->own_acc) (void)hipFree(p->own_acc);
     delete p;
     return EB_OK;
 }

@@ -332,8 +332,9 @@ struct PathTables {
     const float* rad;       // 3 x 32 block radii of the pruned full search (positions outside the grid), closest_reduced_index
     // the same for positions off that grid (an ego that has left the road, or finished and drives on): three coarser levels — 4 m cells
     // out to 250 m around the paths, 32 m cells out to 2 km, 256 m cells out to 16 km; every level's ranges are narrowed by witnesses
-    // (eb_capi.hip:build_cell_grid); a cell whose range would still be long (> 48 entries: abreast of a long straight, far out) holds
-    // 0xffffffff -> the pruned full search
+    // (eb_capi.hip:build_cell_grid).  A cell's word: one or two short ranges (lo | n - 1 << 9 | lo2 << 15 | n2 - 1 << 24 | has2 << 30),
+    // or — a range that would still be long (> 16 entries: abreast of a long straight, far out) — bit 31 | lo | hi << 9: the pruned
+    // search over the blocks of [lo, hi]; 0xffffffff = "not on this level" (the next level, then the pruned full search)
     struct Coarse {
         const uint32_t* cells;
         float x0, y0, inv;   // lower-left corner, 1 / cell size (a power of two: exact)
@@ -358,6 +359,7 @@ EB_DEV int coarse_cell_ranges(const PathTables& pt, int p, float px, float py, i
         const float fx = (px - g.x0) * g.inv, fy = (py - g.y0) * g.inv;
         if (!(fx >= 0.0f && fx < (float)g.nx && fy >= 0.0f && fy < (float)g.ny)) continue;
         const unsigned c = g.cells[(p * g.ny + (int)fy) * g.nx + (int)fx];
+        if (c == 0xffffffffu) continue;   // not on this level (it would otherwise decode as the long range [511, 511])
         lo = (int)(c & 0x1ffu);
         if (c >> 31) { hi = (int)((c >> 9) & 0x1ffu); return 2; }
         hi = lo + (int)((c >> 9) & 0x3fu);

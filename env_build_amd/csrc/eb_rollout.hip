@@ -29,6 +29,12 @@
 
 #pragma clang fp contract(off)
 
+// round-6 experiment switches (compile-time; scripts/r6_ab.sh builds one library per value): 1 = entry-time mark of the record waves,
+// 2 = write-through stores, 4 = the slot turn table's address as a preloaded kernel argument, 8 = first loads ahead of the entry barrier
+#ifndef EB_X
+#define EB_X 0
+#endif
+
 namespace eb {
 
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -50,6 +56,7 @@ template <> struct Stored<float> {
     // check — which would keep the next instruction from overwriting them — does not look inside an asm statement)
     static EB_DEV void store4_wt(float* p, f4u v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
     static EB_DEV void store1_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+    static EB_DEV void store4_wt_off(float* base, unsigned off, f4u v) { asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(off), "v"(v), "s"(base) : "memory"); }
 };
 typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
 template <> struct Stored<_Float16> {
@@ -168,6 +175,8 @@ struct FusedHot {
     unsigned nv_magic;
     int do_rewards;
     double* acc_rec;                      // episodic accumulator: this step's records, or NULL (FusedArgs::acc_rec)
+    const unsigned char* turn;            // EB_X & 4: PathTables::turn of the handle's tables
+    long long t_entry;                    // EB_X & 1
 };
 
 // item / n_veh by the multiplicative inverse nv_magic = ceil(2^32 / n_veh) (exact for item < 65 536, checked; items stay
@@ -263,6 +272,10 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
     const int trow = blockIdx.x * (RW + 1);
+    if (EB_X & 8) {
+        if (lane == 0) { S.ego_ready = 0; S.waves_done = 0; }
+        lds_barrier();
+    }
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
     const float st[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
@@ -289,7 +302,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const float devi_v = -sq(h8);                                       // DAM:207
         rew = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
               5.0f * punish_steer + 0.05f * punish_a_x;                     // DAM:297-298
-        A.out5[ge] = rew;
+        if (EB_X & 2) Stored<float>::store1_wt(A.out5 + ge, rew); else A.out5[ge] = rew;
     }
     float nx[6];
     f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);                  // DAM:387
@@ -328,9 +341,15 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         for (int c = 0; c < 3 * A.n_future; ++c) Stored<ST>::store1(otrk + c, 0.0f);   // DAM:342, 352
     }
     if (act) {
+        if (EB_X & 2) {
+            Stored<ST>::store4_wt(hout, f4u{nx[0], nx[1], nx[2], nx[3]});
+            Stored<ST>::store4_wt(hout + 4, f4u{nx[4], nx[5], t0, t1});
+            Stored<ST>::store1_wt(hout + 8, t2);
+        } else {
         Stored<ST>::store4(hout, f4u{nx[0], nx[1], nx[2], nx[3]});
         Stored<ST>::store4(hout + 4, f4u{nx[4], nx[5], t0, t1});
         Stored<ST>::store1(hout + 8, t2);
+        }
     }
     EB_MARK(A, trow, 4);                                                    // head stored
     if (!H.do_rewards) return;
@@ -356,10 +375,17 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const size_t n = (size_t)H.n_env;
         pun_t = a35 + road_t;                // DAM:299
         pun_r = a25 + road_r;                // DAM:300
+        if (EB_X & 2) {
+            Stored<float>::store1_wt(A.out5 + n + ge, pun_t);
+            Stored<float>::store1_wt(A.out5 + 2 * n + ge, pun_r);
+            Stored<float>::store1_wt(A.out5 + 3 * n + ge, a25);
+            Stored<float>::store1_wt(A.out5 + 4 * n + ge, road_r);
+        } else {
         A.out5[n + ge] = pun_t;
         A.out5[2 * n + ge] = pun_r;
         A.out5[3 * n + ge] = a25;
         A.out5[4 * n + ge] = road_r;
+        }
     }
     // The launch that ends a rollout has no successor to make its record: it makes it here, and adds the |delta_y| statistics of
     // the rows it has just written (t0 IS the final obs' column 6) — once per horizon.
@@ -433,7 +459,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     auto off_of = [&](int k) { return FAST ? off_first + k * off_step : 4 * item_of(k) + (env_of(k) + 1) * HD; };
 
     // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then every record
-    const int turn_code = A.dt->turn[lane];
+    const int turn_code = (EB_X & 4) ? H.turn[lane] : A.dt->turn[lane];
     f4u rec[RPT];
     // A tile that holds its full RL * RPT records (every tile but a batch's last one) needs no per-record bounds
     // checks: the two forms of each loop below differ only in that (wave-uniform choice, same results).
@@ -460,8 +486,10 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         pv_r = po[0]; pv_t = po[n]; pv_p = po[2 * n];
     }
     const int trow = blockIdx.x * (RW + 1) + 1 + w;
+    if (EB_X & 8) lds_barrier();
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
+    if ((EB_X & 1) && A.trace && lane == 0) A.trace[(size_t)trow * 8 + 6] = H.t_entry;
     S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
     const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
     const SinCosK SK = sincos_consts();
@@ -535,7 +563,10 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
             }
             // a 32-bit byte offset from the tile's (wave-uniform) base: the store then takes the base from SGPRs and the
             // offset from one VGPR (an element offset would be widened to a 64-bit address in three VALU instructions)
-            if (valid) Stored<ST>::store4(reinterpret_cast<ST*>(reinterpret_cast<char*>(tout) + (unsigned)off * (unsigned)sizeof(ST)), nv);
+            if (valid) {
+                if constexpr ((EB_X & 2) && std::is_same<ST, float>::value) Stored<ST>::store4_wt_off(tout, (unsigned)off * 4u, nv);
+                else Stored<ST>::store4(reinterpret_cast<ST*>(reinterpret_cast<char*>(tout) + (unsigned)off * (unsigned)sizeof(ST)), nv);
+            }
             if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
             if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
             if (k & 1) __builtin_amdgcn_sched_barrier(0);   // two records at a time: bounds the live set, leaves some ILP
@@ -954,8 +985,10 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
     __shared__ FusedSmem<RW, RPT> S;
     const int e0 = blockIdx.x * H.envs_per_tile;
     const int nE = min(H.envs_per_tile, H.n_env - e0);
+    if (!(EB_X & 8)) {
     if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
     lds_barrier();   // the only barrier: at launch, before any wave has something to wait for
+    }
     // Occupancy pad for the 2048-record tile: 4 blocks x 5 waves per CU are 5 waves per SIMD when spread evenly.
     // Holding 73-80 VGPRs caps a SIMD at 6 waves, which keeps the dispatcher from stacking 7 or 8 on one SIMD and 3
     // on another (measured: 17.2 us with 58 VGPRs, 16.2 us with 77; a cap of exactly 5 makes some blocks wait a round).
@@ -972,12 +1005,22 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
 // CU at the headline size = 5 waves per SIMD on average, but a block's 5 waves land 2-1-1-1 on the SIMDs from
 // a varying start, so one SIMD can be asked for a 6th: budget for 6 (80 VGPRs) or that block waits a whole
 // round.  (The smaller tiles had 64 VGPRs for 8 waves per SIMD until round 5: see below.)
+#if EB_X & 4
+#define EB_X_TURN_PARAM const unsigned char* turn_tab,
+#define EB_X_TURN_VAL turn_tab
+#define EB_X_TURN_ARG reinterpret_cast<const unsigned char*>(A.dt) + offsetof(PathTables, turn),
+#else
+#define EB_X_TURN_PARAM
+#define EB_X_TURN_VAL nullptr
+#define EB_X_TURN_ARG
+#endif
 #define EB_FUSED_KERNEL(NAME, RW, RPT, WAVES, VGPRS)                                                     \
     template <int TASK, bool FAST, typename ST>                                                          \
     __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
-        unsigned nv_magic, int do_rewards, double* acc_rec, const FusedArgs A) {                         \
-        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards, acc_rec}; \
+        unsigned nv_magic, int do_rewards, double* acc_rec, EB_X_TURN_PARAM const FusedArgs A) {         \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards, acc_rec, EB_X_TURN_VAL, \
+                             (EB_X & 1) ? wall_clock64() : 0ll};                                          \
         fused_body<TASK, RW, RPT, FAST, ST>(H, A);                                                       \
     }
 EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
@@ -991,7 +1034,7 @@ EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 6, 80)   //  these tiles run on grids o
     __global__ __launch_bounds__((RW + (GATED ? 3 : 1)) * 64, WAVES) void NAME(                          \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
         unsigned nv_magic, int horizon, const FusedArgs A) {                                             \
-        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1, nullptr}; \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1, nullptr, nullptr, 0ll}; \
         tape_body<TASK, RW, RPT, FAST, GATED, ST>(H, A, horizon);                                        \
     }
 EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, false, 6)
@@ -1019,12 +1062,12 @@ int fused_tile_records(int variant) {
 }
 
 #define EB_HOT_ARGS(ST) reinterpret_cast<const ST*>(A.obs_in), reinterpret_cast<ST*>(A.obs_out), A.n_env, A.obs_dim, A.n_veh, \
-                        A.envs_per_tile, A.nv_magic, A.do_rewards, A.acc_rec
+                        A.envs_per_tile, A.nv_magic, A.do_rewards, A.acc_rec, EB_X_TURN_ARG
 #define EB_LAUNCH_TASK(KERNEL, FAST_, ST)                                                                       \
     switch (task) {                                                                                             \
-        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \
-        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \
-        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break;     \
+        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST) A); break; \
+        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST) A); break; \
+        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST) A); break;     \
     }
 #define EB_LAUNCH_FAST(KERNEL, RW, ST)                                                                          \
     if ((RW * 64) % A.n_veh == 0) { EB_LAUNCH_TASK(KERNEL, true, ST) } else { EB_LAUNCH_TASK(KERNEL, false, ST) }

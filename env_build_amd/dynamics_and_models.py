@@ -153,6 +153,16 @@ def _default_device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+def _resolve_device(device):
+    """torch.device with an explicit index.  A handle (tables, scratch) lives on ONE device: a bare 'cuda' is the device current NOW, for
+    the object's whole life — a later torch.cuda.set_device(other) changes neither where it launches nor whose current stream orders
+    its launches."""
+    dev = torch.device(device) if device is not None else _default_device()
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
 def _dev(x, device, dtype=torch.float32):
     """numpy / torch / DevArray -> contiguous tensor of `dtype` on `device`."""
     x = _unwrap(x)
@@ -382,7 +392,7 @@ class EnvironmentModel(object):  # DAM:90-427
         self.state_dtype = torch.float16 if state_dtype == 'float16' else torch.float32
         self.task = training_task
         self.mode = mode
-        self.device = device if device is not None else _default_device()
+        self.device = _resolve_device(device)
         self.vehicle_dynamics = VehicleDynamics(self.device)
         self.base_frequency = 10.
         self.obses = None
@@ -410,7 +420,7 @@ class EnvironmentModel(object):  # DAM:90-427
                          else self.api.lib.eb_rollout_step)
         self.copy_outputs = bool(copy_outputs)
         self._sets, self._set_i = None, 0
-        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._dev_index = self.device.index          # (explicit since the normalisation above: the handle's device)
 
     # -- state ------------------------------------------------------------------------------
     def _obs(self, obses, dtype=torch.float32):

@@ -34,7 +34,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .dynamics_and_models import (DevArray, EnvironmentModel, ReferencePath, VehicleDynamics, _Handle, _default_device,
+from .dynamics_and_models import (DevArray, EnvironmentModel, ReferencePath, VehicleDynamics, _Handle, _resolve_device,
                                   _dev, _ptr, _stream)
 from .endtoend_env_utils import (CROSSROAD_SIZE, EXPECTED_V, L, LANE_NUMBER, LANE_WIDTH, VEH_NUM, VEHICLE_MODE_DICT,
                                  VEHICLE_MODE_LIST, W, rotate_and_shift_coordination)
@@ -292,7 +292,7 @@ class CrossroadEnd2end(object):
             copied by then; `done` and info['reward_info'] are materialised on first read and must be read in that window too."""
         if training_task not in ('left', 'straight', 'right'):
             raise ValueError("training_task must be 'left', 'straight' or 'right'")
-        self.device = device if device is not None else _default_device()
+        self.device = _resolve_device(device)
         self.n_env = int(n_env)
         if self.n_env < 1:
             raise ValueError('n_env must be >= 1')

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .dynamics_and_models import DevArray, _default_device, _dev, _stream
+from .dynamics_and_models import DevArray, _dev, _resolve_device, _stream
 
 __all__ = ['MLPNet', 'Policy4Toyota', 'LoadPolicy', 'orthogonal']
 
@@ -48,7 +48,7 @@ class MLPNet(object):
             if a not in _capi.ACT_ID:
                 raise ValueError('unsupported activation %r' % (a,))
         dev = kwargs.get('device')
-        self.device = torch.device(dev) if dev is not None else _default_device()
+        self.device = _resolve_device(dev)
         self.api = _capi.hip_api()
         self._obs_scale = None
         self._handle = None

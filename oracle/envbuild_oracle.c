@@ -1370,9 +1370,11 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
     if (!ref_idx && (path_id < 0 || path_id >= h->n_paths)) return fail(EB_EINVAL, "eb_env_step: bad path_id");
     if (auto_reset) {   /* the same checks as the HIP library, before anything is written */
         const eb_auto_reset* ar = auto_reset;
-        if ((!flow && !ar->pool.entry) || m_cand < 1 || m_cand > 64 || !ref_idx || !virtual_flag || ar->ref_idx != ref_idx ||
-            ar->virtual_flag != virtual_flag || ar->v_light != v_light)
-            return fail(EB_EINVAL, "eb_env_step: auto_reset needs the pool rule, 1..64 candidates and the ref_idx / virtual_flag / v_light arrays of the call");
+        if (!flow && !ar->pool.entry)
+            return fail(EB_EINVAL, "eb_env_step: auto_reset needs a traffic source to reset — the pool rule (auto_reset->pool.entry) or the flow rule of the call");
+        if (m_cand < 1 || m_cand > 64) return fail(EB_EINVAL, "eb_env_step: auto_reset needs 1..64 candidates");
+        if (!ref_idx || !virtual_flag || ar->ref_idx != ref_idx || ar->virtual_flag != virtual_flag || ar->v_light != v_light)
+            return fail(EB_EINVAL, "eb_env_step: auto_reset rewrites the ref_idx / virtual_flag / v_light arrays of the call: they must be given and be the call's own");
         if (flow && (!ar->flow_cand_len || !ar->flow_phase0))
             return fail(EB_EINVAL, "eb_env_step: auto_reset over the flow source needs flow_cand_len and flow_phase0");
         if (ar->final_obs && (ar->final_obs == obs_out || ar->final_obs == obs))

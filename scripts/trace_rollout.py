@@ -10,11 +10,17 @@ from env_build_amd.synthetic import make_rollout_inputs
 ap = argparse.ArgumentParser()
 ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-veh', type=int, default=32)
 ap.add_argument('--waves', type=int, default=5, help='waves per block of the kernel variant in use')
+ap.add_argument('--tile', type=int, default=-1, help='eb_debug_set_tile: 0 = 4x8, 1 = 4x4, 2 = 1x4 (then --waves 2), -1 = by batch size')
+ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one')
 a = ap.parse_args()
 W = a.waves
 dev = torch.device('cuda', 0)
+if a.lib:
+    from env_build_amd import _capi
+    _capi._hip_api = _capi.CApi(a.lib)
 inp = make_rollout_inputs('left', a.n_env, a.n_veh, 25, seed=0)
 m = EnvironmentModel('left', 0, mode='training', n_veh=a.n_veh, device=dev)
+m.api.debug_set_tile(m.handle, a.tile)
 ego = torch.from_numpy(inp['ego']).to(dev); ref = torch.from_numpy(inp['ref_idx']).to(dev)
 trk = m.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(),
                                                ego[:, 0].contiguous(), 0, ref_indexes=ref).t
@@ -52,6 +58,7 @@ t = tr.cpu().numpy()
 nb = int((t[:, 0] > 0).sum()) // W
 t = t[:nb * W].astype(np.float64)
 t0 = t[:, 0].min()
+entry = t[:, 6].copy()         # record waves of a build with the entry mark (EB_X & 1): when they reached their first instruction
 t = (t - t0) / 100.0   # us (100 MHz)
 t[t < 0] = np.nan
 env = t[0::W]; rec = np.concatenate([t[i::W] for i in range(1, W)])
@@ -61,6 +68,14 @@ for i, name in enumerate(['loads issued', 'ego published', 'bicycle step done', 
     print('env wave  %-22s %s' % (name, q(env[:, i])))
 for i, name in enumerate(['loads issued', 'first record stored', 'last record stored', 'ego seen', 'near tests done', 'end']):
     print('rec wave  %-22s %s' % (name, q(rec[:, i])))
+is_rec = np.arange(nb * W) % W != 0
+if (entry[is_rec] > 0).all():
+    en = (entry[is_rec] - entry[is_rec].min()) / 100.0
+    li = (tr.cpu().numpy()[:nb * W, 0].astype(np.float64)[is_rec] - entry[is_rec].min()) / 100.0
+    print('rec wave  %-22s %s   (since the first record wave entered)' % ('entered the kernel', q(en)))
+    print('rec wave  %-22s %s' % ('loads issued (same zero)', q(li)))
+    print('rec wave  %-22s %s' % ('entry -> loads issued', q(li - en)))
+    bw = en.reshape(W - 1, nb) if False else None
 blk_start = np.nanmin(t[:, 0].reshape(nb, W), axis=1)
 blk_end = np.nanmax(t.reshape(nb, W * 8), axis=1)
 print('block start            %s' % q(blk_start))
