@@ -34,6 +34,15 @@
 #ifndef EB_X
 #define EB_X 0
 #endif
+// 16 = two tiles per workgroup; 32 = rolling record loads: EB_PF loads in flight per lane, record k + EB_PF is requested when record k is done
+#ifndef EB_PF
+#define EB_PF 4
+#endif
+// 64 = record waves' issue priority by progress; EB_PRIO: 1 = 3 - 4k/RPT beside an env wave at 2; 2 = 2 - 3k/RPT beside an env wave at 3;
+// 3 = 1 for the first half of the records, 0 for the second, env wave at 2
+#ifndef EB_PRIO
+#define EB_PRIO 1
+#endif
 
 namespace eb {
 
@@ -47,6 +56,7 @@ template <typename ST> struct Stored;
 template <> struct Stored<float> {
     static EB_DEV f4u load4(const float* p) { return *reinterpret_cast<const f4u*>(p); }
     static EB_DEV float load1(const float* p) { return *p; }
+    static EB_DEV v2f load2(const float* p) { const f2u t = *reinterpret_cast<const f2u*>(p); return v2f{t.x, t.y}; }
     static EB_DEV void store4(float* p, f4u v) { *reinterpret_cast<f4u*>(p) = v; }
     static EB_DEV void store1(float* p, float v) { *p = v; }
     static EB_DEV float round(float v) { return v; }                    // what a store + load does to a value
@@ -65,6 +75,11 @@ template <> struct Stored<_Float16> {
         return f4u{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
     }
     static EB_DEV float load1(const _Float16* p) { return (float)*p; }
+    static EB_DEV v2f load2(const _Float16* p) {
+        typedef _Float16 h2u __attribute__((ext_vector_type(2), aligned(2)));
+        const h2u t = *reinterpret_cast<const h2u*>(p);
+        return v2f{(float)t.x, (float)t.y};
+    }
     static EB_DEV void store4(_Float16* p, f4u v) {
         *reinterpret_cast<h4u*>(p) = h4u{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
     }
@@ -135,14 +150,14 @@ EB_DEV float wave_max_f32(float v) {
 
 // One step's record of the episodic accumulator (eb_rollout_step_acc): the tile's three sums (float64 on the DPP network, a fixed
 // order) and its "punished in this step" bits — 32 bytes from lane 63, no read-modify-write.  lane = env of the tile; every lane active.
-EB_DEV void acc_record(double* recs, bool act, int lane, float v_r, float v_t, float v_p) {
+EB_DEV void acc_record(double* recs, bool act, int lane, float v_r, float v_t, float v_p, int tile) {
     const double s_r = wave_sum_f64(act ? (double)v_r : 0.0);
     const double s_t = wave_sum_f64(act ? (double)v_t : 0.0);
     const double s_p = wave_sum_f64(act ? (double)v_p : 0.0);
     const unsigned long long any = __builtin_amdgcn_ballot_w64(act && v_p > 0.0f);
     if (lane == 63) {
         typedef double d2v __attribute__((ext_vector_type(2)));
-        d2v* rec = reinterpret_cast<d2v*>(recs + (size_t)ACC_RECORD_DOUBLES * blockIdx.x);
+        d2v* rec = reinterpret_cast<d2v*>(recs + (size_t)ACC_RECORD_DOUBLES * tile);
         rec[0] = d2v{s_r, s_t};
         rec[1] = d2v{s_p, __builtin_bit_cast(double, any)};
     }
@@ -254,8 +269,8 @@ struct FusedSmem {
 
 // ---- env wave -------------------------------------------------------------------------------------
 template <int TASK, int RW, int RPT, typename ST>
-EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
-    const int lane = threadIdx.x;   // wave 0
+EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE, int tile, int tid) {
+    const int lane = tid;           // wave 0 of the tile
     const int D = H.obs_dim, NV = H.n_veh;
     const bool act = lane < nE;
     const int e = act ? lane : 0, ge = e0 + e;
@@ -271,7 +286,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int pr = A.ref_idx[ge];
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
-    const int trow = blockIdx.x * (RW + 1);
+    const int trow = tile * (RW + 1);
     if (EB_X & 8) {
         if (lane == 0) { S.ego_ready = 0; S.waves_done = 0; }
         lds_barrier();
@@ -390,13 +405,13 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     // The launch that ends a rollout has no successor to make its record: it makes it here, and adds the |delta_y| statistics of
     // the rows it has just written (t0 IS the final obs' column 6) — once per horizon.
     if (H.acc_rec && A.acc_final) {
-        acc_record(H.acc_rec, act, lane, rew, pun_t, pun_r);
+        acc_record(H.acc_rec, act, lane, rew, pun_t, pun_r, tile);
         const float dy = __builtin_fabsf(Stored<ST>::round(t0));
         const double s_dy = wave_sum_f64(act ? (double)dy : 0.0);
         const float m_dy = wave_max_f32(act && dy > 0.0f ? dy : 0.0f);       // (a NaN never becomes the maximum, as in the two-pass summary)
         if (lane == 63) {
             typedef double d2v __attribute__((ext_vector_type(2)));
-            reinterpret_cast<d2v*>(A.acc_final)[blockIdx.x] = d2v{s_dy, (double)m_dy};
+            reinterpret_cast<d2v*>(A.acc_final)[tile] = d2v{s_dy, (double)m_dy};
         }
     }
     EB_MARK(A, trow, 6);                                                    // end
@@ -443,9 +458,9 @@ EB_DEV void queue_pass_sc(const FusedHot<ST>& H, SM& S, const float4* ego, int w
 // FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
 // fixed step, so slot constants are fetched once and addresses advance by a uniform stride.
 template <int TASK, int RW, int RPT, bool FAST, typename ST>
-EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
-    constexpr int RL = RW * 64;                     // record lanes per block
-    const int rtid = threadIdx.x - 64, w = rtid >> 6, lane = rtid & 63;
+EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE, int tile, int tid) {
+    constexpr int RL = RW * 64;                     // record lanes per tile
+    const int rtid = tid - 64, w = rtid >> 6, lane = rtid & 63;
     const int NV = H.n_veh, D = H.obs_dim, HD = D - 4 * NV;
     const int items = nE * NV;
     const ST* tin = H.obs_in + (size_t)e0 * D;
@@ -460,14 +475,15 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
 
     // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then every record
     const int turn_code = (EB_X & 4) ? H.turn[lane] : A.dt->turn[lane];
-    f4u rec[RPT];
+    constexpr int PF = ((EB_X & 32) && EB_PF < RPT) ? EB_PF : RPT;   // record loads in flight per lane
+    f4u rec[PF];
     // A tile that holds its full RL * RPT records (every tile but a batch's last one) needs no per-record bounds
     // checks: the two forms of each loop below differ only in that (wave-uniform choice, same results).
     const bool full_tile = items == RL * RPT;
     auto load_records = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
+        for (int k = 0; k < PF; ++k) {
             // lanes past the tile's last record re-read the tile's last record (branch-free loads; never stored)
             const bool valid = FULL || item_of(k) < items;
             rec[k] = Stored<ST>::load4(tin + (valid ? off_of(k) : 4 * (items - 1) + nE * HD));
@@ -485,7 +501,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         const float* po = A.prev_out5 + e0 + lane;
         pv_r = po[0]; pv_t = po[n]; pv_p = po[2 * n];
     }
-    const int trow = blockIdx.x * (RW + 1) + 1 + w;
+    const int trow = tile * (RW + 1) + 1 + w;
     if (EB_X & 8) lds_barrier();
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
@@ -525,7 +541,9 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     // registers are free again after its iteration and only the queue pass is left once the stores are out.
     // Crowded tiles: once fewer than 64 queue slots are free the in-loop tests stop (k_late); the remaining records
     // are re-read (L2) and tested after the loop, with the queue drained in between.
-    if (H.do_rewards) {
+    constexpr bool EGO_MEM = (EB_X & 128) != 0;   // the near test's ego position straight from the row's head in memory (L1 / L2: the env
+                                                   // wave and the other lanes of the env read the same line) — no wait for the env wave here
+    if (H.do_rewards && !EGO_MEM) {
         lds_wait_until(&S.ego_ready, 1);                                    // ---- hand-off 1: ego poses are in LDS ----
         EB_MARK(A, trow, 3);                                                // ego seen
     }
@@ -534,14 +552,18 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     auto main_loop = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         // the ego positions of this lane's records, all LDS reads in flight at once (one wait instead of one per record)
-        v2f egoxy[RPT];
+        constexpr int NE = EGO_MEM ? PF : RPT;
+        v2f egoxy[NE];
+        auto ego_of = [&](int k) {
+            const int item = k * RL + rtid;
+            const int env = FAST ? e_first + k * epk : env_of_item(H, item);
+            const int e_ok = (FULL || item < items) ? env : 0;
+            if constexpr (EGO_MEM) return Stored<ST>::load2(tin + (size_t)e_ok * D + 3);
+            else return *reinterpret_cast<const v2f*>(&S.ego[e_ok]);
+        };
         if (test_near) {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int item = k * RL + rtid;
-                const int env = FAST ? e_first + k * epk : env_of_item(H, item);
-                egoxy[k] = *reinterpret_cast<const v2f*>(&S.ego[(FULL || item < items) ? env : 0]);
-            }
+            for (int k = 0; k < NE; ++k) egoxy[k] = ego_of(k);
         }
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -556,10 +578,27 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
             // the prediction first: it yields sin / cos of the record's heading, which a near record takes to the queue
             const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[valid ? item - env * NV : 0]);
             float sn, cs;
-            const f4u nv = predict_record_tc<ST>(rec[k], tc, SK, sn, cs);
+            const f4u nv = predict_record_tc<ST>(rec[k % PF], tc, SK, sn, cs);
+            if (EB_X & 64) {                                                        // the waves that are behind go first
+                const int pr = EB_PRIO == 1 ? 3 - (k * 4) / RPT : EB_PRIO == 2 ? 2 - (k * 3) / RPT : (k < RPT / 2 ? 1 : 0);
+                const int pr_prev = k == 0 ? -1 : (EB_PRIO == 1 ? 3 - ((k - 1) * 4) / RPT : EB_PRIO == 2 ? 2 - ((k - 1) * 3) / RPT : (k - 1 < RPT / 2 ? 1 : 0));
+                if (pr != pr_prev)
+                    switch (pr) {
+                        case 3: __builtin_amdgcn_s_setprio(3); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        default: __builtin_amdgcn_s_setprio(0); break;
+                    }
+            }
             if (k < k_late) {
-                near_test(item, egoxy[k], rec[k], v2f{sn, cs});
+                near_test(item, egoxy[k % NE], rec[k % PF], v2f{sn, cs});
                 if (qn > QCAP - 64) k_late = k + 1;
+            }
+            if (PF < RPT && k + PF < RPT) {          // this record's registers take record k + PF
+                const bool v2 = FULL || item_of(k + PF) < items;
+                rec[k % PF] = Stored<ST>::load4(tin + (v2 ? off_of(k + PF) : 4 * (items - 1) + nE * HD));
+                if (!v2) rec[k % PF].x = 1e30f;
+                if (EGO_MEM && test_near) egoxy[k % NE] = ego_of(k + PF);
             }
             // a 32-bit byte offset from the tile's (wave-uniform) base: the store then takes the base from SGPRs and the
             // offset from one VGPR (an element offset would be widened to a 64-bit address in three VALU instructions)
@@ -574,6 +613,11 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     };
     if (full_tile) main_loop(std::true_type{}); else main_loop(std::false_type{});
     if (!H.do_rewards) return;   // (eb_compute_next_obses: never an accumulating launch)
+    if (EB_X & 64) __builtin_amdgcn_s_setprio(0);
+    if (EGO_MEM) {
+        lds_wait_until(&S.ego_ready, 1);                                    // ---- hand-off 1: the queue's terms take the ego from LDS ----
+        EB_MARK(A, trow, 3);                                                // ego seen
+    }
     if (test_near && k_late < RPT) {
         for (int k = k_late; k < RPT; ++k) {       // not unrolled: rare path
             drain();
@@ -593,7 +637,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         // (the values are first TOUCHED here: otherwise the float -> double conversions — and the wait for the three loads — are
         // hoisted to the top of the wave, in front of the records' own arrival)
         asm volatile("" : "+v"(pv_r), "+v"(pv_t), "+v"(pv_p));
-        acc_record(A.prev_rec, lane < nE, lane, pv_r, pv_t, pv_p);
+        acc_record(A.prev_rec, lane < nE, lane, pv_r, pv_t, pv_p, tile);
     }
     EB_MARK(A, trow, 5);                                                    // end
 }
@@ -982,22 +1026,32 @@ EB_DEV void tape_body(const FusedHot<ST>& H, const FusedArgs& A, int horizon) {
 
 template <int TASK, int RW, int RPT, bool FAST, typename ST>
 EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
-    __shared__ FusedSmem<RW, RPT> S;
-    const int e0 = blockIdx.x * H.envs_per_tile;
+    constexpr int TILES = (EB_X & 16) ? 2 : 1;      // EB_X & 16: two tiles per workgroup (twice the waves, half the workgroups)
+    constexpr int TW = (RW + 1) * 64;               // threads of a tile
+    __shared__ FusedSmem<RW, RPT> Ss[TILES];
+    const int sub = TILES == 1 ? 0 : (int)(threadIdx.x >= TW);
+    const int tid = (int)threadIdx.x - sub * TW;
+    const int tile = blockIdx.x * TILES + sub;
+    FusedSmem<RW, RPT>& S = Ss[sub];
+    const int e0 = tile * H.envs_per_tile;
     const int nE = min(H.envs_per_tile, H.n_env - e0);
     if (!(EB_X & 8)) {
-    if (threadIdx.x == 0) { S.ego_ready = 0; S.waves_done = 0; }
+    if (tid == 0) { S.ego_ready = 0; S.waves_done = 0; }
     lds_barrier();   // the only barrier: at launch, before any wave has something to wait for
+    }
+    if (TILES > 1 && nE <= 0) {                     // the odd tile out of the grid's last workgroup
+        if (EB_X & 8) lds_barrier();
+        return;
     }
     // Occupancy pad for the 2048-record tile: 4 blocks x 5 waves per CU are 5 waves per SIMD when spread evenly.
     // Holding 73-80 VGPRs caps a SIMD at 6 waves, which keeps the dispatcher from stacking 7 or 8 on one SIMD and 3
     // on another (measured: 17.2 us with 58 VGPRs, 16.2 us with 77; a cap of exactly 5 makes some blocks wait a round).
     if (RW * RPT >= 32) asm volatile("; keep v79 allocated" ::: "v79");
-    if (threadIdx.x < 64) {
-        __builtin_amdgcn_s_setprio(2);
-        env_wave<TASK, RW, RPT, ST>(H, A, S, e0, nE);
+    if (tid < 64) {
+        if ((EB_X & 64) && EB_PRIO == 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+        env_wave<TASK, RW, RPT, ST>(H, A, S, e0, nE, tile, tid);
     } else {
-        record_wave<TASK, RW, RPT, FAST, ST>(H, A, S, e0, nE);
+        record_wave<TASK, RW, RPT, FAST, ST>(H, A, S, e0, nE, tile, tid);
     }
 }
 
@@ -1016,7 +1070,7 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
 #endif
 #define EB_FUSED_KERNEL(NAME, RW, RPT, WAVES, VGPRS)                                                     \
     template <int TASK, bool FAST, typename ST>                                                          \
-    __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
+    __global__ __launch_bounds__((RW + 1) * 64 * ((EB_X & 16) ? 2 : 1), WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
         unsigned nv_magic, int do_rewards, double* acc_rec, EB_X_TURN_PARAM const FusedArgs A) {         \
         const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards, acc_rec, EB_X_TURN_VAL, \
@@ -1073,7 +1127,7 @@ int fused_tile_records(int variant) {
     if ((RW * 64) % A.n_veh == 0) { EB_LAUNCH_TASK(KERNEL, true, ST) } else { EB_LAUNCH_TASK(KERNEL, false, ST) }
 #define EB_LAUNCH(KERNEL, RW)                                                                                   \
     {                                                                                                           \
-        const dim3 g(grid), b((RW + 1) * 64);                                                                   \
+        const dim3 g((EB_X & 16) ? (grid + 1) / 2 : grid), b((RW + 1) * 64 * ((EB_X & 16) ? 2 : 1));            \
         if (A.storage_f16) { EB_LAUNCH_FAST(KERNEL, RW, _Float16) } else { EB_LAUNCH_FAST(KERNEL, RW, float) }   \
     }
 
