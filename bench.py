@@ -1116,7 +1116,7 @@ def main():
         if n_env == N_ENV and n_veh == N_VEH and not args.open_loop:      # separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
             traffic, traffic_src = pmc_traffic('rollout', 'hbm_bytes_per_launch')
         cfg = 'configs[2]' if (n_env, n_veh) == (N_ENV, N_VEH) else 'custom'
-        kernel = 'eb::rollout_fused_4x8<0, true, float>'
+        kernel = 'eb::rollout_fused_4x8<0, true, 8, float>'   # (task left, slot count divides the record lanes, every record load up front, fp32)
         form = 'closed-loop rollout_out (one kernel launch per step, %s)' % headline_form
         if args.open_loop:
             # one launch per tape; HBM sees the initial and final obs once, actions and outputs every step

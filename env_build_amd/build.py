@@ -21,7 +21,7 @@ SOURCES = ['eb_capi.hip', 'eb_kernels.hip', 'eb_rollout.hip', 'eb_env_kernels.hi
 HEADERS = ['eb_device.h', 'eb_kernels.h', 'eb_env_device.h', 'eb_env_step_body.h', os.path.join('..', '..', 'include', 'envbuild.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
          '-fPIC', '-Wno-unused-value', '-Wno-pass-failed',
-         '-mllvm', '-amdgpu-kernarg-preload-count=12']   # the rollout kernel's leading arguments arrive in SGPRs
+         '-mllvm', '-amdgpu-kernarg-preload-count=14']   # the rollout kernel's leading arguments (14 dwords: all of FusedHot) arrive in SGPRs
 LINK_FLAGS = ['--offload-arch=gfx950', '-shared', '-fPIC']
 
 

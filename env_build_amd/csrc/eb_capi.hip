@@ -65,6 +65,7 @@ struct eb_handle_s {
     hipEvent_t gate_event;    // orders eb_gate_feed behind the caller's stream (after_stream)
     int tile_variant;         // -1 = pick by batch size; 0..2 force a tile shape (eb_debug_set_tile)
     int tape_stepwise;        // 1: eb_rollout_tape runs H per-step launches instead of the tape kernel (eb_debug_set_tape_stepwise)
+    int sched_rolling, sched_progress;   // -1 = by grid size; 0 / 1: the per-step kernel's rolling record loads / issue priority by progress (eb_debug_set_rollout_sched)
     // the accumulating rollouts in flight on this handle: what the step-0 launch of a workspace ran with — the later steps and the fold
     // must see the same grid, batch and horizon (a tile shape forced in between would shift every record: refused, not folded)
     struct AccRun { const void* ws; int grid, n_env, horizon; } acc_runs[4];
@@ -268,6 +269,7 @@ int eb_create(const eb_config* cfg, eb_handle* out) {
     h->cfg = *cfg;
     h->tile_variant = -1;
     h->stage_paths = -1;
+    h->sched_rolling = -1; h->sched_progress = -1;
     {   // rotate_coordination's coordi_rotate_d * math.pi / 180 and math.cos / math.sin (UTL:130-132), by the host's libm
         const int ang[4] = {0, 90, 180, -90};   // multi_ego.py:33
         for (int k = 0; k < 4; ++k) {
@@ -602,6 +604,13 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         A.gate_spin = gate->spin;
     }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
+    // How the per-step launch spends its memory queue and its issue slots (csrc/eb_rollout.hip, profiles/r6_ab3-5.txt): at most two
+    // 2048-record tiles per CU -> rolling loads; at most one generation of blocks (four per CU) -> the waves that are behind go first;
+    // several generations -> neither (a block that ends early makes room for the next).  Same bits every way.
+    if (variant == 0 && tape_horizon == 0) {
+        A.rolling = h->sched_rolling >= 0 ? h->sched_rolling : (grid <= 2 * h->n_cu);
+        A.by_progress = h->sched_progress >= 0 ? h->sched_progress : (grid <= 4 * h->n_cu);
+    }
     if (acc) {   // records are indexed by THIS grid (the same at every step of a rollout: one handle state, one n_env)
         // the rollout a workspace belongs to is fixed by its step-0 launch
         eb_handle_s::AccRun* run = nullptr;
@@ -1287,6 +1296,13 @@ int eb_debug_check_grids(eb_handle h, int32_t samples_per_cell, uint64_t seed, i
 int eb_debug_set_scan_prefetch(eb_handle h, int32_t on) {
     if (!h) return fail(EB_EINVAL, "eb_debug_set_scan_prefetch: null handle");
     h->scan_one_trip = on ? 0 : 1;
+    return EB_OK;
+}
+
+int eb_debug_set_rollout_sched(eb_handle h, int32_t rolling, int32_t by_progress) {
+    if (!h || rolling < -1 || rolling > 1 || by_progress < -1 || by_progress > 1)
+        return fail(EB_EINVAL, "eb_debug_set_rollout_sched: bad argument (-1 = by grid size, 0, 1)");
+    h->sched_rolling = rolling; h->sched_progress = by_progress;
     return EB_OK;
 }
 

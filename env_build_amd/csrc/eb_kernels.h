@@ -37,6 +37,9 @@ struct FusedArgs {
     int path_id, training;
     int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
     int do_rewards;            // 0: compute_next_obses only
+    int rolling;               // per-step kernel, 2048-record tile: 1 = three record loads in flight per lane, record k + 3 requested when
+                               // record k is done (grids of at most two tiles per CU); 0 = every record requested up front
+    int by_progress;           // per-step kernel: 1 = a record wave's issue priority falls as it advances (grids of one generation of blocks)
     long long* trace;          // profiling aid (eb_debug_set_trace): [n_waves][8] s_memrealtime marks, or NULL
     long long trace_words;     //   its capacity in 64-bit words: a mark past it is dropped
     int scan_one_trip;         // A/B aid (eb_debug_set_scan_prefetch 0): the closest-point range one group of entries per loop trip, as rounds 1-4

@@ -22,27 +22,22 @@
 // The hand-offs are LDS flags (see lds_publish / lds_wait_until), not barriers: neither role ever waits for
 // the other's HBM traffic.  HBM-bound: 104 + 32 n_veh algorithmic bytes per env-step; no MFMA (nothing here
 // is a dense contraction).
+//
+// What a launch's first microseconds are (round 6, per-wave entry marks — scripts/trace_rollout.py, profiles/r6_ab2.txt): every
+// one of the 5 120 waves of the headline grid is INSIDE the kernel within 0.5 us; what earlier rounds read as a 3.7 us dispatch ramp
+// is the read phase itself — a CU's miss path moves ~11 bytes per cycle (MI355X_MICROARCH.md), its 144 KB of rows take 5.5 us, and a
+// wave's load instructions issue as the queue ahead of them drains.  Hence: nothing may stand between a wave's entry and its first
+// load (the slot-turn table's address arrives as a preloaded argument, the entry barrier comes AFTER the loads are out); a grid of
+// at most two tiles per CU keeps three record loads in flight per lane and requests record k + 3 when record k is done (every wave's
+// first records come back sooner, the block's life shrinks: 9.3 -> 8.45 us per step at 32 768 x 32); a grid of one generation lets
+// the record waves that are BEHIND issue first (s_setprio by progress: the last wave, not the average one, ends a launch: 14.85 ->
+// 14.05 us at 65 536 x 32); a grid of several generations does neither (a block that finishes early makes room for the next one).
 #include <type_traits>
 
 #include "eb_device.h"
 #include "eb_kernels.h"
 
 #pragma clang fp contract(off)
-
-// round-6 experiment switches (compile-time; scripts/r6_ab.sh builds one library per value): 1 = entry-time mark of the record waves,
-// 2 = write-through stores, 4 = the slot turn table's address as a preloaded kernel argument, 8 = first loads ahead of the entry barrier
-#ifndef EB_X
-#define EB_X 0
-#endif
-// 16 = two tiles per workgroup; 32 = rolling record loads: EB_PF loads in flight per lane, record k + EB_PF is requested when record k is done
-#ifndef EB_PF
-#define EB_PF 4
-#endif
-// 64 = record waves' issue priority by progress; EB_PRIO: 1 = 3 - 4k/RPT beside an env wave at 2; 2 = 2 - 3k/RPT beside an env wave at 3;
-// 3 = 1 for the first half of the records, 0 for the second, env wave at 2
-#ifndef EB_PRIO
-#define EB_PRIO 1
-#endif
 
 namespace eb {
 
@@ -56,7 +51,6 @@ template <typename ST> struct Stored;
 template <> struct Stored<float> {
     static EB_DEV f4u load4(const float* p) { return *reinterpret_cast<const f4u*>(p); }
     static EB_DEV float load1(const float* p) { return *p; }
-    static EB_DEV v2f load2(const float* p) { const f2u t = *reinterpret_cast<const f2u*>(p); return v2f{t.x, t.y}; }
     static EB_DEV void store4(float* p, f4u v) { *reinterpret_cast<f4u*>(p) = v; }
     static EB_DEV void store1(float* p, float v) { *p = v; }
     static EB_DEV float round(float v) { return v; }                    // what a store + load does to a value
@@ -66,7 +60,6 @@ template <> struct Stored<float> {
     // check — which would keep the next instruction from overwriting them — does not look inside an asm statement)
     static EB_DEV void store4_wt(float* p, f4u v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
     static EB_DEV void store1_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
-    static EB_DEV void store4_wt_off(float* base, unsigned off, f4u v) { asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(off), "v"(v), "s"(base) : "memory"); }
 };
 typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));   // 8-byte access, 2-byte aligned
 template <> struct Stored<_Float16> {
@@ -75,11 +68,6 @@ template <> struct Stored<_Float16> {
         return f4u{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
     }
     static EB_DEV float load1(const _Float16* p) { return (float)*p; }
-    static EB_DEV v2f load2(const _Float16* p) {
-        typedef _Float16 h2u __attribute__((ext_vector_type(2), aligned(2)));
-        const h2u t = *reinterpret_cast<const h2u*>(p);
-        return v2f{(float)t.x, (float)t.y};
-    }
     static EB_DEV void store4(_Float16* p, f4u v) {
         *reinterpret_cast<h4u*>(p) = h4u{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
     }
@@ -150,14 +138,14 @@ EB_DEV float wave_max_f32(float v) {
 
 // One step's record of the episodic accumulator (eb_rollout_step_acc): the tile's three sums (float64 on the DPP network, a fixed
 // order) and its "punished in this step" bits — 32 bytes from lane 63, no read-modify-write.  lane = env of the tile; every lane active.
-EB_DEV void acc_record(double* recs, bool act, int lane, float v_r, float v_t, float v_p, int tile) {
+EB_DEV void acc_record(double* recs, bool act, int lane, float v_r, float v_t, float v_p) {   // (block = tile)
     const double s_r = wave_sum_f64(act ? (double)v_r : 0.0);
     const double s_t = wave_sum_f64(act ? (double)v_t : 0.0);
     const double s_p = wave_sum_f64(act ? (double)v_p : 0.0);
     const unsigned long long any = __builtin_amdgcn_ballot_w64(act && v_p > 0.0f);
     if (lane == 63) {
         typedef double d2v __attribute__((ext_vector_type(2)));
-        d2v* rec = reinterpret_cast<d2v*>(recs + (size_t)ACC_RECORD_DOUBLES * tile);
+        d2v* rec = reinterpret_cast<d2v*>(recs + (size_t)ACC_RECORD_DOUBLES * blockIdx.x);
         rec[0] = d2v{s_r, s_t};
         rec[1] = d2v{s_p, __builtin_bit_cast(double, any)};
     }
@@ -188,11 +176,12 @@ struct FusedHot {
     ST* obs_out;
     int n_env, obs_dim, n_veh, envs_per_tile;
     unsigned nv_magic;
-    int do_rewards;
+    int do_rewards;                       // FusedArgs::do_rewards | HOT_PRIO (host: launch_rollout_fused)
     double* acc_rec;                      // episodic accumulator: this step's records, or NULL (FusedArgs::acc_rec)
-    const unsigned char* turn;            // EB_X & 4: PathTables::turn of the handle's tables
-    long long t_entry;                    // EB_X & 1
+    const unsigned char* turn;            // PathTables::turn of the handle's tables: the record waves' first load needs no s_load
+    long long t_entry;                    // wall clock at the wave's first instruction (trace only)
 };
+constexpr int HOT_REWARDS = 1, HOT_PRIO = 2;   // bits of FusedHot::do_rewards
 
 // item / n_veh by the multiplicative inverse nv_magic = ceil(2^32 / n_veh) (exact for item < 65 536, checked; items stay
 // below 2048); n_veh == 1 has no 32-bit inverse and is flagged by nv_magic == 0
@@ -269,8 +258,8 @@ struct FusedSmem {
 
 // ---- env wave -------------------------------------------------------------------------------------
 template <int TASK, int RW, int RPT, typename ST>
-EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE, int tile, int tid) {
-    const int lane = tid;           // wave 0 of the tile
+EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
+    const int lane = threadIdx.x;   // wave 0
     const int D = H.obs_dim, NV = H.n_veh;
     const bool act = lane < nE;
     const int e = act ? lane : 0, ge = e0 + e;
@@ -286,18 +275,18 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int pr = A.ref_idx[ge];
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
-    const int trow = tile * (RW + 1);
-    if (EB_X & 8) {
-        if (lane == 0) { S.ego_ready = 0; S.waves_done = 0; }
-        lds_barrier();
-    }
+    const int trow = blockIdx.x * (RW + 1);
+    // the block's only barrier, behind the loads: it orders the flags' initial zeros before any wave polls them
+    if (lane == 0) { S.ego_ready = 0; S.waves_done = 0; }
+    lds_barrier();
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
+    const bool do_rewards = (H.do_rewards & HOT_REWARDS) != 0;
     const float st[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
     const float phi_rad = deg2rad(st[5]);
     float es, ec;
     sincos_det(phi_rad, es, ec);                                            // DAM:211 and DAM:79-80
-    if (H.do_rewards) {
+    if (do_rewards) {
         S.ego[lane] = make_float4(st[3], st[4], es, ec);
         S.mask[lane] = 0ull;
         lds_publish(&S.ego_ready, 1);                                       // ---- hand-off 1 ----
@@ -309,7 +298,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
     else { steer = araw.x; a_x = araw.y; }
     if (act && A.scaled_actions) *reinterpret_cast<f2u*>(A.scaled_actions + 2 * (size_t)ge) = f2u{steer, a_x};
     float rew = 0.0f;
-    if (act && H.do_rewards) {
+    if (act && do_rewards) {
         const float punish_steer = -sq(steer), punish_a_x = -sq(a_x);       // DAM:198-199
         const float punish_yaw_rate = -sq(st[2]);                           // DAM:202
         const float devi_y = -sq(h1.z);                                     // DAM:205
@@ -317,7 +306,7 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const float devi_v = -sq(h8);                                       // DAM:207
         rew = 0.05f * devi_v + 0.8f * devi_y + 30.0f * devi_phi + 0.02f * punish_yaw_rate +
               5.0f * punish_steer + 0.05f * punish_a_x;                     // DAM:297-298
-        if (EB_X & 2) Stored<float>::store1_wt(A.out5 + ge, rew); else A.out5[ge] = rew;
+        A.out5[ge] = rew;
     }
     float nx[6];
     f_xu_core(st, steer, a_x, TAU10, phi_rad, es, ec, nx);                  // DAM:387
@@ -356,18 +345,12 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         for (int c = 0; c < 3 * A.n_future; ++c) Stored<ST>::store1(otrk + c, 0.0f);   // DAM:342, 352
     }
     if (act) {
-        if (EB_X & 2) {
-            Stored<ST>::store4_wt(hout, f4u{nx[0], nx[1], nx[2], nx[3]});
-            Stored<ST>::store4_wt(hout + 4, f4u{nx[4], nx[5], t0, t1});
-            Stored<ST>::store1_wt(hout + 8, t2);
-        } else {
         Stored<ST>::store4(hout, f4u{nx[0], nx[1], nx[2], nx[3]});
         Stored<ST>::store4(hout + 4, f4u{nx[4], nx[5], t0, t1});
         Stored<ST>::store1(hout + 8, t2);
-        }
     }
     EB_MARK(A, trow, 4);                                                    // head stored
-    if (!H.do_rewards) return;
+    if (!do_rewards) return;
     // the road walls (DAM:231-295) need nothing from the record waves: done while those are still at work
     float road_t = 0.0f, road_r = 0.0f;
     road_terms<TASK>(st[3] + LWS * ec, st[4] + LWS * es, road_t, road_r);
@@ -390,28 +373,21 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const size_t n = (size_t)H.n_env;
         pun_t = a35 + road_t;                // DAM:299
         pun_r = a25 + road_r;                // DAM:300
-        if (EB_X & 2) {
-            Stored<float>::store1_wt(A.out5 + n + ge, pun_t);
-            Stored<float>::store1_wt(A.out5 + 2 * n + ge, pun_r);
-            Stored<float>::store1_wt(A.out5 + 3 * n + ge, a25);
-            Stored<float>::store1_wt(A.out5 + 4 * n + ge, road_r);
-        } else {
         A.out5[n + ge] = pun_t;
         A.out5[2 * n + ge] = pun_r;
         A.out5[3 * n + ge] = a25;
         A.out5[4 * n + ge] = road_r;
-        }
     }
     // The launch that ends a rollout has no successor to make its record: it makes it here, and adds the |delta_y| statistics of
     // the rows it has just written (t0 IS the final obs' column 6) — once per horizon.
     if (H.acc_rec && A.acc_final) {
-        acc_record(H.acc_rec, act, lane, rew, pun_t, pun_r, tile);
+        acc_record(H.acc_rec, act, lane, rew, pun_t, pun_r);
         const float dy = __builtin_fabsf(Stored<ST>::round(t0));
         const double s_dy = wave_sum_f64(act ? (double)dy : 0.0);
         const float m_dy = wave_max_f32(act && dy > 0.0f ? dy : 0.0f);       // (a NaN never becomes the maximum, as in the two-pass summary)
         if (lane == 63) {
             typedef double d2v __attribute__((ext_vector_type(2)));
-            reinterpret_cast<d2v*>(A.acc_final)[tile] = d2v{s_dy, (double)m_dy};
+            reinterpret_cast<d2v*>(A.acc_final)[blockIdx.x] = d2v{s_dy, (double)m_dy};
         }
     }
     EB_MARK(A, trow, 6);                                                    // end
@@ -457,10 +433,13 @@ EB_DEV void queue_pass_sc(const FusedHot<ST>& H, SM& S, const float4* ego, int w
 
 // FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
 // fixed step, so slot constants are fetched once and addresses advance by a uniform stride.
-template <int TASK, int RW, int RPT, bool FAST, typename ST>
-EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE, int tile, int tid) {
-    constexpr int RL = RW * 64;                     // record lanes per tile
-    const int rtid = tid - 64, w = rtid >> 6, lane = rtid & 63;
+// PF: record loads in flight per lane.  RPT — every record requested up front (a grid of more than two tiles per CU: the memory
+// system is what the block waits for, the deepest queue wins); less — record k + PF is requested when record k is done (a grid of
+// at most two tiles per CU: the queue ahead of a wave's first records is shorter, and a record's registers are reused).
+template <int TASK, int RW, int RPT, bool FAST, int PF, typename ST>
+EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
+    constexpr int RL = RW * 64;                     // record lanes per block
+    const int rtid = threadIdx.x - 64, w = rtid >> 6, lane = rtid & 63;
     const int NV = H.n_veh, D = H.obs_dim, HD = D - 4 * NV;
     const int items = nE * NV;
     const ST* tin = H.obs_in + (size_t)e0 * D;
@@ -473,9 +452,10 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     auto env_of = [&](int k) { return FAST ? e_first + k * epk : env_of_item(H, item_of(k)); };
     auto off_of = [&](int k) { return FAST ? off_first + k * off_step : 4 * item_of(k) + (env_of(k) + 1) * HD; };
 
-    // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then every record
-    const int turn_code = (EB_X & 4) ? H.turn[lane] : A.dt->turn[lane];
-    constexpr int PF = ((EB_X & 32) && EB_PF < RPT) ? EB_PF : RPT;   // record loads in flight per lane
+    // slot turn codes first (in-order return: the record loads behind it do not hold the table up), then the records.  Nothing
+    // here waits for a scalar load: the table's address is a preloaded argument (FusedHot::turn), as are the rows' (obs_in)
+    static_assert(PF >= 1 && PF <= RPT, "record loads in flight per lane");
+    const int turn_code = H.turn[lane];
     f4u rec[PF];
     // A tile that holds its full RL * RPT records (every tile but a batch's last one) needs no per-record bounds
     // checks: the two forms of each loop below differ only in that (wave-uniform choice, same results).
@@ -501,11 +481,17 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         const float* po = A.prev_out5 + e0 + lane;
         pv_r = po[0]; pv_t = po[n]; pv_p = po[2 * n];
     }
-    const int trow = tile * (RW + 1) + 1 + w;
-    if (EB_X & 8) lds_barrier();
+    const int trow = blockIdx.x * (RW + 1) + 1 + w;
+    lds_barrier();   // the block's only barrier (the env wave zeroes the hand-off flags in front of it), behind this wave's loads
     EB_MARK(A, trow, 0);                                                    // loads issued
     EB_MARK_PLACE(A, trow);
-    if ((EB_X & 1) && A.trace && lane == 0) A.trace[(size_t)trow * 8 + 6] = H.t_entry;
+    if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 6] = H.t_entry;    // when this wave reached its first instruction
+    const bool do_rewards = (H.do_rewards & HOT_REWARDS) != 0;
+    // Issue priority by progress (HOT_PRIO: a grid of one generation of blocks): a wave on its first records outranks one on its
+    // last — the launch ends with its LAST wave, and the hardware's oldest-first issue otherwise lets the first-placed waves of a SIMD
+    // run ahead and leave the youngest to finish alone (record waves end 4.8-10.9 us after the first entry without it, 6.0-10.7 with).
+    // The env wave runs at 2 throughout: below the record waves' first quarter, above their second half.
+    const bool by_progress = (H.do_rewards & HOT_PRIO) != 0;
     S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
     const TurnC tc_lane = turn_consts(S.turn[FAST ? j_first : 0]);
     const SinCosK SK = sincos_consts();
@@ -541,29 +527,23 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     // registers are free again after its iteration and only the queue pass is left once the stores are out.
     // Crowded tiles: once fewer than 64 queue slots are free the in-loop tests stop (k_late); the remaining records
     // are re-read (L2) and tested after the loop, with the queue drained in between.
-    constexpr bool EGO_MEM = (EB_X & 128) != 0;   // the near test's ego position straight from the row's head in memory (L1 / L2: the env
-                                                   // wave and the other lanes of the env read the same line) — no wait for the env wave here
-    if (H.do_rewards && !EGO_MEM) {
+    if (do_rewards) {
         lds_wait_until(&S.ego_ready, 1);                                    // ---- hand-off 1: ego poses are in LDS ----
         EB_MARK(A, trow, 3);                                                // ego seen
     }
-    const bool test_near = H.do_rewards;
+    const bool test_near = do_rewards;
     int k_late = test_near ? RPT : 0;
     auto main_loop = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         // the ego positions of this lane's records, all LDS reads in flight at once (one wait instead of one per record)
-        constexpr int NE = EGO_MEM ? PF : RPT;
-        v2f egoxy[NE];
-        auto ego_of = [&](int k) {
-            const int item = k * RL + rtid;
-            const int env = FAST ? e_first + k * epk : env_of_item(H, item);
-            const int e_ok = (FULL || item < items) ? env : 0;
-            if constexpr (EGO_MEM) return Stored<ST>::load2(tin + (size_t)e_ok * D + 3);
-            else return *reinterpret_cast<const v2f*>(&S.ego[e_ok]);
-        };
+        v2f egoxy[RPT];
         if (test_near) {
 #pragma unroll
-            for (int k = 0; k < NE; ++k) egoxy[k] = ego_of(k);
+            for (int k = 0; k < RPT; ++k) {
+                const int item = k * RL + rtid;
+                const int env = FAST ? e_first + k * epk : env_of_item(H, item);
+                egoxy[k] = *reinterpret_cast<const v2f*>(&S.ego[(FULL || item < items) ? env : 0]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -578,46 +558,34 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
             // the prediction first: it yields sin / cos of the record's heading, which a near record takes to the queue
             const TurnC tc = FAST ? tc_lane : turn_consts(S.turn[valid ? item - env * NV : 0]);
             float sn, cs;
+            if ((k * 4) % RPT == 0 && by_progress)                              // a quarter of the records further: one priority level down
+                switch (3 - (k * 4) / RPT) {
+                    case 3: __builtin_amdgcn_s_setprio(3); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    default: __builtin_amdgcn_s_setprio(0); break;
+                }
             const f4u nv = predict_record_tc<ST>(rec[k % PF], tc, SK, sn, cs);
-            if (EB_X & 64) {                                                        // the waves that are behind go first
-                const int pr = EB_PRIO == 1 ? 3 - (k * 4) / RPT : EB_PRIO == 2 ? 2 - (k * 3) / RPT : (k < RPT / 2 ? 1 : 0);
-                const int pr_prev = k == 0 ? -1 : (EB_PRIO == 1 ? 3 - ((k - 1) * 4) / RPT : EB_PRIO == 2 ? 2 - ((k - 1) * 3) / RPT : (k - 1 < RPT / 2 ? 1 : 0));
-                if (pr != pr_prev)
-                    switch (pr) {
-                        case 3: __builtin_amdgcn_s_setprio(3); break;
-                        case 2: __builtin_amdgcn_s_setprio(2); break;
-                        case 1: __builtin_amdgcn_s_setprio(1); break;
-                        default: __builtin_amdgcn_s_setprio(0); break;
-                    }
-            }
             if (k < k_late) {
-                near_test(item, egoxy[k % NE], rec[k % PF], v2f{sn, cs});
+                near_test(item, egoxy[k], rec[k % PF], v2f{sn, cs});
                 if (qn > QCAP - 64) k_late = k + 1;
             }
-            if (PF < RPT && k + PF < RPT) {          // this record's registers take record k + PF
+            if (k + PF < RPT) {                      // rolling loads: this record's registers take record k + PF
                 const bool v2 = FULL || item_of(k + PF) < items;
                 rec[k % PF] = Stored<ST>::load4(tin + (v2 ? off_of(k + PF) : 4 * (items - 1) + nE * HD));
                 if (!v2) rec[k % PF].x = 1e30f;
-                if (EGO_MEM && test_near) egoxy[k % NE] = ego_of(k + PF);
             }
             // a 32-bit byte offset from the tile's (wave-uniform) base: the store then takes the base from SGPRs and the
             // offset from one VGPR (an element offset would be widened to a 64-bit address in three VALU instructions)
-            if (valid) {
-                if constexpr ((EB_X & 2) && std::is_same<ST, float>::value) Stored<ST>::store4_wt_off(tout, (unsigned)off * 4u, nv);
-                else Stored<ST>::store4(reinterpret_cast<ST*>(reinterpret_cast<char*>(tout) + (unsigned)off * (unsigned)sizeof(ST)), nv);
-            }
+            if (valid) Stored<ST>::store4(reinterpret_cast<ST*>(reinterpret_cast<char*>(tout) + (unsigned)off * (unsigned)sizeof(ST)), nv);
             if (k == 0) EB_MARK(A, trow, 1);                                    // first record stored
             if (k == RPT - 1) EB_MARK(A, trow, 2);                              // last record stored
             if (k & 1) __builtin_amdgcn_sched_barrier(0);   // two records at a time: bounds the live set, leaves some ILP
         }
     };
     if (full_tile) main_loop(std::true_type{}); else main_loop(std::false_type{});
-    if (!H.do_rewards) return;   // (eb_compute_next_obses: never an accumulating launch)
-    if (EB_X & 64) __builtin_amdgcn_s_setprio(0);
-    if (EGO_MEM) {
-        lds_wait_until(&S.ego_ready, 1);                                    // ---- hand-off 1: the queue's terms take the ego from LDS ----
-        EB_MARK(A, trow, 3);                                                // ego seen
-    }
+    if (!do_rewards) return;   // (eb_compute_next_obses: never an accumulating launch)
+    if (by_progress) __builtin_amdgcn_s_setprio(0);
     if (test_near && k_late < RPT) {
         for (int k = k_late; k < RPT; ++k) {       // not unrolled: rare path
             drain();
@@ -637,7 +605,7 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
         // (the values are first TOUCHED here: otherwise the float -> double conversions — and the wait for the three loads — are
         // hoisted to the top of the wave, in front of the records' own arrival)
         asm volatile("" : "+v"(pv_r), "+v"(pv_t), "+v"(pv_p));
-        acc_record(A.prev_rec, lane < nE, lane, pv_r, pv_t, pv_p, tile);
+        acc_record(A.prev_rec, lane < nE, lane, pv_r, pv_t, pv_p);
     }
     EB_MARK(A, trow, 5);                                                    // end
 }
@@ -1024,34 +992,22 @@ EB_DEV void tape_body(const FusedHot<ST>& H, const FusedArgs& A, int horizon) {
     else if (GATED) out_courier<RW, RPT, ST>(H, A, S, *Gp, e0, nE, horizon);
 }
 
-template <int TASK, int RW, int RPT, bool FAST, typename ST>
+template <int TASK, int RW, int RPT, bool FAST, int PF, typename ST>
 EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
-    constexpr int TILES = (EB_X & 16) ? 2 : 1;      // EB_X & 16: two tiles per workgroup (twice the waves, half the workgroups)
-    constexpr int TW = (RW + 1) * 64;               // threads of a tile
-    __shared__ FusedSmem<RW, RPT> Ss[TILES];
-    const int sub = TILES == 1 ? 0 : (int)(threadIdx.x >= TW);
-    const int tid = (int)threadIdx.x - sub * TW;
-    const int tile = blockIdx.x * TILES + sub;
-    FusedSmem<RW, RPT>& S = Ss[sub];
-    const int e0 = tile * H.envs_per_tile;
+    __shared__ FusedSmem<RW, RPT> S;
+    const int e0 = blockIdx.x * H.envs_per_tile;
     const int nE = min(H.envs_per_tile, H.n_env - e0);
-    if (!(EB_X & 8)) {
-    if (tid == 0) { S.ego_ready = 0; S.waves_done = 0; }
-    lds_barrier();   // the only barrier: at launch, before any wave has something to wait for
-    }
-    if (TILES > 1 && nE <= 0) {                     // the odd tile out of the grid's last workgroup
-        if (EB_X & 8) lds_barrier();
-        return;
-    }
+    // (no barrier here: each role issues its first loads, THEN meets the others at the block's only barrier — a wave that waited
+    // for its block's last wave, and then for the scalar load of a table's address, issued its loads ~0.3 us later)
     // Occupancy pad for the 2048-record tile: 4 blocks x 5 waves per CU are 5 waves per SIMD when spread evenly.
     // Holding 73-80 VGPRs caps a SIMD at 6 waves, which keeps the dispatcher from stacking 7 or 8 on one SIMD and 3
     // on another (measured: 17.2 us with 58 VGPRs, 16.2 us with 77; a cap of exactly 5 makes some blocks wait a round).
     if (RW * RPT >= 32) asm volatile("; keep v79 allocated" ::: "v79");
-    if (tid < 64) {
-        if ((EB_X & 64) && EB_PRIO == 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
-        env_wave<TASK, RW, RPT, ST>(H, A, S, e0, nE, tile, tid);
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_s_setprio(2);
+        env_wave<TASK, RW, RPT, ST>(H, A, S, e0, nE);
     } else {
-        record_wave<TASK, RW, RPT, FAST, ST>(H, A, S, e0, nE, tile, tid);
+        record_wave<TASK, RW, RPT, FAST, PF, ST>(H, A, S, e0, nE);
     }
 }
 
@@ -1059,23 +1015,16 @@ EB_DEV void fused_body(const FusedHot<ST>& H, const FusedArgs& A) {
 // CU at the headline size = 5 waves per SIMD on average, but a block's 5 waves land 2-1-1-1 on the SIMDs from
 // a varying start, so one SIMD can be asked for a 6th: budget for 6 (80 VGPRs) or that block waits a whole
 // round.  (The smaller tiles had 64 VGPRs for 8 waves per SIMD until round 5: see below.)
-#if EB_X & 4
-#define EB_X_TURN_PARAM const unsigned char* turn_tab,
-#define EB_X_TURN_VAL turn_tab
-#define EB_X_TURN_ARG reinterpret_cast<const unsigned char*>(A.dt) + offsetof(PathTables, turn),
-#else
-#define EB_X_TURN_PARAM
-#define EB_X_TURN_VAL nullptr
-#define EB_X_TURN_ARG
-#endif
+// (the leading 14 dwords of the arguments — everything up to and including turn_tab — arrive in SGPRs: build.py's
+//  -amdgpu-kernarg-preload-count; PF: record loads in flight per lane, see record_wave)
 #define EB_FUSED_KERNEL(NAME, RW, RPT, WAVES, VGPRS)                                                     \
-    template <int TASK, bool FAST, typename ST>                                                          \
-    __global__ __launch_bounds__((RW + 1) * 64 * ((EB_X & 16) ? 2 : 1), WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
+    template <int TASK, bool FAST, int PF, typename ST>                                                  \
+    __global__ __launch_bounds__((RW + 1) * 64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void NAME( \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
-        unsigned nv_magic, int do_rewards, double* acc_rec, EB_X_TURN_PARAM const FusedArgs A) {         \
-        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards, acc_rec, EB_X_TURN_VAL, \
-                             (EB_X & 1) ? wall_clock64() : 0ll};                                          \
-        fused_body<TASK, RW, RPT, FAST, ST>(H, A);                                                       \
+        unsigned nv_magic, int do_rewards, double* acc_rec, const unsigned char* turn_tab, const FusedArgs A) { \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, do_rewards, acc_rec, turn_tab, \
+                             wall_clock64()};                                                            \
+        fused_body<TASK, RW, RPT, FAST, PF, ST>(H, A);                                                   \
     }
 EB_FUSED_KERNEL(rollout_fused_4x8, 4, 8, 6, 80)
 EB_FUSED_KERNEL(rollout_fused_4x4, 4, 4, 6, 80)   // (round 5: 64 -> 80 VGPRs — the env wave keeps three groups of table entries in flight;
@@ -1088,7 +1037,7 @@ EB_FUSED_KERNEL(rollout_fused_1x4, 1, 4, 6, 80)   //  these tiles run on grids o
     __global__ __launch_bounds__((RW + (GATED ? 3 : 1)) * 64, WAVES) void NAME(                          \
         const ST* obs_in, ST* obs_out, int n_env, int obs_dim, int n_veh, int envs_per_tile,             \
         unsigned nv_magic, int horizon, const FusedArgs A) {                                             \
-        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, 1, nullptr, nullptr, 0ll}; \
+        const FusedHot<ST> H{obs_in, obs_out, n_env, obs_dim, n_veh, envs_per_tile, nv_magic, HOT_REWARDS, nullptr, nullptr, 0ll}; \
         tape_body<TASK, RW, RPT, FAST, GATED, ST>(H, A, horizon);                                        \
     }
 EB_TAPE_KERNEL(rollout_tape_4x8, 4, 8, false, 6)
@@ -1116,19 +1065,20 @@ int fused_tile_records(int variant) {
 }
 
 #define EB_HOT_ARGS(ST) reinterpret_cast<const ST*>(A.obs_in), reinterpret_cast<ST*>(A.obs_out), A.n_env, A.obs_dim, A.n_veh, \
-                        A.envs_per_tile, A.nv_magic, A.do_rewards, A.acc_rec, EB_X_TURN_ARG
-#define EB_LAUNCH_TASK(KERNEL, FAST_, ST)                                                                       \
+                        A.envs_per_tile, A.nv_magic, (A.do_rewards ? HOT_REWARDS : 0) | (A.by_progress ? HOT_PRIO : 0), A.acc_rec, \
+                        reinterpret_cast<const unsigned char*>(A.dt) + offsetof(PathTables, turn)
+#define EB_LAUNCH_TASK(KERNEL, FAST_, PF_, ST)                                                                  \
     switch (task) {                                                                                             \
-        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST) A); break; \
-        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST) A); break; \
-        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, ST>), g, b, 0, s, EB_HOT_ARGS(ST) A); break;     \
+        case TASK_LEFT: hipLaunchKernelGGL((KERNEL<TASK_LEFT, FAST_, PF_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \
+        case TASK_STRAIGHT: hipLaunchKernelGGL((KERNEL<TASK_STRAIGHT, FAST_, PF_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \
+        default: hipLaunchKernelGGL((KERNEL<TASK_RIGHT, FAST_, PF_, ST>), g, b, 0, s, EB_HOT_ARGS(ST), A); break; \
     }
-#define EB_LAUNCH_FAST(KERNEL, RW, ST)                                                                          \
-    if ((RW * 64) % A.n_veh == 0) { EB_LAUNCH_TASK(KERNEL, true, ST) } else { EB_LAUNCH_TASK(KERNEL, false, ST) }
-#define EB_LAUNCH(KERNEL, RW)                                                                                   \
+#define EB_LAUNCH_FAST(KERNEL, RW, PF_, ST)                                                                     \
+    if ((RW * 64) % A.n_veh == 0) { EB_LAUNCH_TASK(KERNEL, true, PF_, ST) } else { EB_LAUNCH_TASK(KERNEL, false, PF_, ST) }
+#define EB_LAUNCH(KERNEL, RW, PF_)                                                                              \
     {                                                                                                           \
-        const dim3 g((EB_X & 16) ? (grid + 1) / 2 : grid), b((RW + 1) * 64 * ((EB_X & 16) ? 2 : 1));            \
-        if (A.storage_f16) { EB_LAUNCH_FAST(KERNEL, RW, _Float16) } else { EB_LAUNCH_FAST(KERNEL, RW, float) }   \
+        const dim3 g(grid), b((RW + 1) * 64);                                                                   \
+        if (A.storage_f16) { EB_LAUNCH_FAST(KERNEL, RW, PF_, _Float16) } else { EB_LAUNCH_FAST(KERNEL, RW, PF_, float) } \
     }
 
 #define EB_TAPE_ARGS(ST) reinterpret_cast<const ST*>(A.obs_in), reinterpret_cast<ST*>(A.obs_out), A.n_env, A.obs_dim, A.n_veh, \
@@ -1255,10 +1205,13 @@ hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A_i
 
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A_in, int grid, hipStream_t s) {
     const FusedArgs A = trace_checked(A_in, grid, (variant == 2 ? 1 : 4) + 1);
+    // (A.rolling / A.by_progress: decided by the grid against the device's CUs — eb_capi.hip:rollout_fused — or forced,
+    // eb_debug_set_rollout_sched; every combination computes the same bits.  Rolling loads exist for the 2048-record tile only:
+    // the smaller tiles run on grids that are launch-bound either way)
     switch (variant) {
-        case 0: EB_LAUNCH(rollout_fused_4x8, 4) break;
-        case 1: EB_LAUNCH(rollout_fused_4x4, 4) break;
-        default: EB_LAUNCH(rollout_fused_1x4, 1) break;
+        case 0: if (A.rolling) EB_LAUNCH(rollout_fused_4x8, 4, 3) else EB_LAUNCH(rollout_fused_4x8, 4, 8) break;
+        case 1: EB_LAUNCH(rollout_fused_4x4, 4, 4) break;
+        default: EB_LAUNCH(rollout_fused_1x4, 1, 4) break;
     }
     return hipGetLastError();
 }

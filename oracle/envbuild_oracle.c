@@ -1717,6 +1717,11 @@ int eb_debug_set_tape_stepwise(eb_handle h, int32_t on) { (void)on; return h ? E
 int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words) { (void)device_buf; (void)capacity_words; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_trace: null handle"); }
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode) { (void)mode; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_stage_paths: null handle"); }
 int eb_debug_set_scan_prefetch(eb_handle h, int32_t on) { (void)on; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_scan_prefetch: null handle"); }
+int eb_debug_set_rollout_sched(eb_handle h, int32_t rolling, int32_t by_progress) {
+    if (!h || rolling < -1 || rolling > 1 || by_progress < -1 || by_progress > 1)
+        return fail(EB_EINVAL, "eb_debug_set_rollout_sched: bad argument (-1 = by grid size, 0, 1)");
+    return EB_OK;
+}
 int eb_debug_check_grids(eb_handle h, int32_t samples_per_cell, uint64_t seed, int64_t* n_checked, int64_t* n_bad) {   /* the oracle's closest point IS the full scan: no levels to check */
     (void)samples_per_cell; (void)seed;
     if (!h || !n_checked || !n_bad) return fail(EB_EINVAL, "eb_debug_check_grids: bad argument");

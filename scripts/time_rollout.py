@@ -10,7 +10,7 @@ from env_build_amd.synthetic import make_rollout_inputs
 ap = argparse.ArgumentParser()
 ap.add_argument('--task', default='left'); ap.add_argument('--n-env', type=int, default=65536)
 ap.add_argument('--n-veh', type=int, default=32); ap.add_argument('--mode', default='training')
-ap.add_argument('--iters', type=int, default=200); ap.add_argument('--n-future', type=int, default=0, help='look-ahead columns (3 per point): with fp16 storage an odd row width (n_future even) leaves every other row 2 bytes off a dword'); ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one'); ap.add_argument('--lanes', type=int, default=1, help='independent env sets stepped round-robin (8: the working set leaves the Infinity Cache)'); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])'); ap.add_argument('--tile', type=int, default=-1, help='eb_debug_set_tile: 0 = 4x8 (2048 records), 1 = 4x4, 2 = 1x4, -1 = by batch size'); ap.add_argument('--scan-prefetch', type=int, default=1, help='eb_debug_set_scan_prefetch: 0 = one group of table entries per loop trip (rounds 1-4), 1 = the first groups in one round trip'); ap.add_argument('--stage-paths', type=int, default=-1, help='eb_debug_set_stage_paths: the tape / gated kernels keep the path tables in LDS (1) or not (0); -1 = by grid size')
+ap.add_argument('--iters', type=int, default=200); ap.add_argument('--n-future', type=int, default=0, help='look-ahead columns (3 per point): with fp16 storage an odd row width (n_future even) leaves every other row 2 bytes off a dword'); ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one'); ap.add_argument('--lanes', type=int, default=1, help='independent env sets stepped round-robin (8: the working set leaves the Infinity Cache)'); ap.add_argument('--f16', action='store_true', help='fp16 state storage (configs[4])'); ap.add_argument('--tile', type=int, default=-1, help='eb_debug_set_tile: 0 = 4x8 (2048 records), 1 = 4x4, 2 = 1x4, -1 = by batch size'); ap.add_argument('--scan-prefetch', type=int, default=1, help='eb_debug_set_scan_prefetch: 0 = one group of table entries per loop trip (rounds 1-4), 1 = the first groups in one round trip'); ap.add_argument('--sched', default='-1,-1', help='eb_debug_set_rollout_sched rolling,by_progress: 0 / 1 each, -1 = by grid size'); ap.add_argument('--stage-paths', type=int, default=-1, help='eb_debug_set_stage_paths: the tape / gated kernels keep the path tables in LDS (1) or not (0); -1 = by grid size')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 if a.lib:
@@ -21,6 +21,7 @@ m = EnvironmentModel(a.task, a.n_future, mode=a.mode, n_veh=a.n_veh, device=dev)
 m.api.debug_set_tile(m.handle, a.tile)
 m.api.debug_set_stage_paths(m.handle, a.stage_paths)
 m.api.debug_set_scan_prefetch(m.handle, a.scan_prefetch)
+m.api.debug_set_rollout_sched(m.handle, *[int(x) for x in a.sched.split(',')])
 ego = torch.from_numpy(inp['ego']).to(dev); ref = torch.from_numpy(inp['ref_idx']).to(dev)
 if a.mode != 'training': m.ref_path.set_path(1)
 trk = m.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(),
@@ -51,5 +52,5 @@ t2 = time.perf_counter()
 print('wall: enqueue %.2f us/step, enqueue+drain %.2f us/step; torch events %.2f us/step' % ((t1 - t0) * 1e6 / a.iters, (t2 - t0) * 1e6 / a.iters, e0.elapsed_time(e1) * 1e3 / a.iters))
 us = (t2 - t0) * 1e6 / a.iters
 alg = ((68 + 16 * a.n_veh + 12 * a.n_future) if a.f16 else (104 + 32 * a.n_veh + 24 * a.n_future)) * a.n_env
-print(('f16 ' if a.f16 else '') + 'tile=%d lanes=%d ' % (a.tile, L) + 'task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
+print(('f16 ' if a.f16 else '') + 'tile=%d sched=%s lanes=%d ' % (a.tile, a.sched, L) + 'task=%s B=%d N=%d mode=%s: %.2f us/step  %.2f G env-steps/s  alg %.0f GB/s (%.1f%% of 8 TB/s)'
       % (a.task, a.n_env, a.n_veh, a.mode, us, a.n_env / us / 1e3, alg / us / 1e3, alg / us / 1e3 / 80))

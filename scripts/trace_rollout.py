@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-veh', type=int, default=32)
 ap.add_argument('--waves', type=int, default=5, help='waves per block of the kernel variant in use')
 ap.add_argument('--tile', type=int, default=-1, help='eb_debug_set_tile: 0 = 4x8, 1 = 4x4, 2 = 1x4 (then --waves 2), -1 = by batch size')
+ap.add_argument('--sched', default='-1,-1', help='eb_debug_set_rollout_sched rolling,by_progress')
 ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one')
 a = ap.parse_args()
 W = a.waves
@@ -21,6 +22,7 @@ if a.lib:
 inp = make_rollout_inputs('left', a.n_env, a.n_veh, 25, seed=0)
 m = EnvironmentModel('left', 0, mode='training', n_veh=a.n_veh, device=dev)
 m.api.debug_set_tile(m.handle, a.tile)
+m.api.debug_set_rollout_sched(m.handle, *[int(x) for x in a.sched.split(',')])
 ego = torch.from_numpy(inp['ego']).to(dev); ref = torch.from_numpy(inp['ref_idx']).to(dev)
 trk = m.ref_path.tracking_error_vector_batched(ego[:, 3].contiguous(), ego[:, 4].contiguous(), ego[:, 5].contiguous(),
                                                ego[:, 0].contiguous(), 0, ref_indexes=ref).t

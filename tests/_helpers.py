@@ -516,6 +516,10 @@ class DeviceModel(HostModel):
         """Force the rollout kernel's tile shape (eb_debug_set_tile; -1 = pick by batch size)."""
         self.api.debug_set_tile(self.h, int(variant))
 
+    def set_rollout_sched(self, rolling=-1, by_progress=-1):
+        """eb_debug_set_rollout_sched: the per-step kernel's rolling record loads / issue priority by progress (-1 = by grid size)."""
+        self.api.debug_set_rollout_sched(self.h, int(rolling), int(by_progress))
+
     ENV_WAVES = 0     # eb_debug_set_env_waves for every DeviceModel made from now on (scripts/fuzz_env_auto.py --waves)
 
     _TD = {np.dtype(np.float32): 'float32', np.dtype(np.int32): 'int32', np.dtype(np.uint8): 'uint8',

@@ -84,9 +84,33 @@ def test_every_tile_shape_computes_the_same_bits(task, N, tile):
     assert np.array_equal(nxt, host.compute_next_obses(obs_h, inp['actions'][0] * 0.3, inp['ref_idx']))
 
 
-@pytest.mark.parametrize('tile', [0, 2])
+@pytest.mark.parametrize('rolling,by_progress', [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize('task,N,B', [('left', 32, 777), ('straight', 9, 1500), ('right', 64, 333), ('left', 16, 8200)])
+def test_every_launch_schedule_computes_the_same_bits(task, N, B, rolling, by_progress):
+    """Round 6: the 2048-record tile's two scheduling choices — every record load up front or three in flight per lane with the next
+    one requested as a record is done; the hardware's oldest-first issue or a priority that falls as a wave advances — are picked by the
+    grid's size (eb_capi.hip:rollout_fused) and change WHEN things happen, never what is computed: each combination forced on ragged
+    batches (slot counts that do and do not divide the record lanes, more than one block per CU at 8 200 envs), against the oracle."""
+    H = 4
+    host, dev = _pair(task, n_veh=N)
+    dev.set_tile(0)
+    dev.set_rollout_sched(rolling, by_progress)
+    inp = make_rollout_inputs(task, B, N, H, seed=300 + N + 2 * rolling + by_progress)
+    obs_h = obs_d = _initial_obs(host, inp)
+    for t in range(H):
+        obs_h, o5_h, _ = host.rollout_step(obs_h, inp['actions'][t], inp['ref_idx'])
+        obs_d, o5_d, _ = dev.rollout_step(obs_d, inp['actions'][t], inp['ref_idx'])
+        assert np.array_equal(obs_d, obs_h), 'step %d' % t
+        _check_out5(o5_d, o5_h, 'step %d' % t)
+    nxt = dev.compute_next_obses(obs_d, inp['actions'][0] * 0.3, inp['ref_idx'])   # the no-reward form of the kernel
+    assert np.array_equal(nxt, host.compute_next_obses(obs_h, inp['actions'][0] * 0.3, inp['ref_idx']))
+    with pytest.raises(ValueError):
+        dev.set_rollout_sched(2, 0)
+
+
+@pytest.mark.parametrize('tile,sched', [(0, (-1, -1)), (0, (0, 0)), (0, (1, 1)), (2, (-1, -1))])
 @pytest.mark.parametrize('N', [32, 9])
-def test_crowded_and_remote_scenes(N, tile):
+def test_crowded_and_remote_scenes(N, tile, sched):
     """Edge scenes of the penalty path and the closest-point search:
        * every vehicle within a few metres of the ego -> every record is queued (the queue drains mid-tile);
        * egos far outside the closest-point cell grid (and on its border) -> the pruned full search;
@@ -94,6 +118,7 @@ def test_crowded_and_remote_scenes(N, tile):
     task, B = 'left', 300
     host, dev = _pair(task, n_veh=N)
     dev.set_tile(tile)
+    dev.set_rollout_sched(*sched)
     inp = make_rollout_inputs(task, B, N, 4, seed=77)
     rng = np.random.default_rng(5)
     veh = inp['veh'].reshape(B, N, 4).copy()
@@ -321,8 +346,6 @@ def test_accumulating_rollout_is_tied_to_the_grid_of_its_first_step():
     """The records of an accumulating rollout are indexed by the launch grid: the step-0 launch fixes grid, batch and horizon for its
     workspace.  A tile shape forced between two steps is refused (EB_EINVAL, nothing launched); one forced between the last step and
     the fold does not move the fold off the records (it folds with the recorded grid); a fold asked for another batch is refused."""
-    import ctypes as C
-    from env_build_amd._capi import EbError
     host, dev = _pair('left', n_veh=32)
     B, H = 5000, 3
     inp = make_rollout_inputs('left', B, 32, H, seed=77)
@@ -339,7 +362,7 @@ def test_accumulating_rollout_is_tied_to_the_grid_of_its_first_step():
                                  dev._ptr(acc), t, H, dev._ptr(out5[t - 1]) if t else None, dev.stream)
     step(0, ob, bufs[0])
     dev.set_tile(2)                                  # another grid: the next step's records would land elsewhere
-    with pytest.raises(EbError):
+    with pytest.raises(ValueError):                  # (EB_EINVAL)
         step(1, bufs[0], bufs[1])
     dev.set_tile(1)
     step(1, bufs[0], bufs[1])
@@ -350,7 +373,7 @@ def test_accumulating_rollout_is_tied_to_the_grid_of_its_first_step():
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
     assert got[3] == want[3] and got[5] == want[5] and got[6] == B and got[7] == H
     assert np.array_equal(dev._ret(bufs[0]), out_t) and np.array_equal(dev._ret(out5), o5_t)
-    with pytest.raises(EbError):
+    with pytest.raises(ValueError):
         dev.api.episode_acc_finish(dev.h, B - 1, H, dev._ptr(acc), dev._ptr(s8), dev.stream)
     dev.set_tile(-1)
 
