@@ -598,7 +598,7 @@ def env_step_alg_bytes(D, m_cand):
     return 8 * D + 33 * m_cand + 105
 
 
-def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40, tile=None, waves=0):
+def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40, tile=None, waves=0, by_progress=None):
     """The env-side step (E2E:132-144 = action scaling, reward, ego step, traffic step, observation,
     done code, pool re-entry) through the raw C entry eb_env_step: pre-allocated ping-pong observation buffers, no Python
     allocation in the loop.  `reps` segments of `seg` steps from the same reset state (restored between segments, outside
@@ -614,6 +614,8 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40, tile=None, wav
         api.debug_set_tile(env._h, int(tile))
     if waves:
         api.debug_set_env_waves(env._h, int(waves))
+    if by_progress is not None:   # A/B aid: the step kernel's issue priority by phase forced on / off (eb_debug_set_rollout_sched)
+        api.debug_set_rollout_sched(env._h, -1, int(by_progress))
     B, M, D = n_env, env.n_cand, env.obs_dim
     g = torch.Generator(device='cpu').manual_seed(3)
     tape = torch.stack([torch.rand((seg, B), generator=g) * 0.6 - 0.3, torch.rand((seg, B), generator=g) * 0.8 - 0.2], 2).to(dev).contiguous()
@@ -748,7 +750,7 @@ def env_step_bench(torch, dev, n_env, n_cand=16, seg=10, reps=40, tile=None, wav
                                      'frac': roofline_of(alg, median(auto_us))[1]}}
 
 
-def env_step_flows_bench(torch, dev, n_env, per_route=5, seg=10, reps=24):
+def env_step_flows_bench(torch, dev, n_env, per_route=5, seg=10, reps=24, by_progress=None):
     """The env-side step over the SUMO-free FLOW traffic source (12 routes x per_route slots = 60 candidates per env; traffic.py,
     sumo_files/cross.rou.xml:18-44) through the raw C entry: (a) eb_env_step(flow) — the step with the flow rule in its launch — in
     short segments from a restored state, (b) eb_env_step(flow + auto_reset), ABI 5 — the self-sustaining loop: the step, the flow
@@ -762,6 +764,8 @@ def env_step_flows_bench(torch, dev, n_env, per_route=5, seg=10, reps=24):
     env.seed(0)
     env.reset()
     api, lib, fl = env.api, env.api.lib, env._flows
+    if by_progress is not None:   # A/B aid, as env_step_bench
+        api.debug_set_rollout_sched(env._h, -1, int(by_progress))
     B, M, D = n_env, env.n_cand, env.obs_dim
     g = torch.Generator(device='cpu').manual_seed(3)
     tape = torch.stack([torch.rand((seg, B), generator=g) * 0.6 - 0.3, torch.rand((seg, B), generator=g) * 0.8 - 0.2], 2).to(dev).contiguous()

@@ -604,12 +604,14 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         A.gate_spin = gate->spin;
     }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
-    // How the per-step launch spends its memory queue and its issue slots (csrc/eb_rollout.hip, profiles/r6_ab3-5.txt): at most two
-    // 2048-record tiles per CU -> rolling loads; at most one generation of blocks (four per CU) -> the waves that are behind go first;
-    // several generations -> neither (a block that ends early makes room for the next).  Same bits every way.
+    // How the per-step launch spends its memory queue and its issue slots (csrc/eb_rollout.hip; measured: profiles/r6_ab3-5.txt,
+    // r6_sched_sweep1-2.txt — N = 8 ... 64, fp32 and binary16 rows, 2 to 16 tiles per CU): the record waves that are behind issue first,
+    // always (never more than 1 % slower, up to 5 % faster); rolling record loads on grids of at most three tiles per CU, and at any
+    // size when a tile holds at most 32 envs (64 slots: + 4-5 % at 8 tiles per CU) — with 64-env tiles they cost 3 % at four tiles per
+    // CU and 11 % at sixteen.  Same bits every way.
     if (variant == 0 && tape_horizon == 0) {
-        A.rolling = h->sched_rolling >= 0 ? h->sched_rolling : (grid <= 2 * h->n_cu);
-        A.by_progress = h->sched_progress >= 0 ? h->sched_progress : (grid <= 4 * h->n_cu);
+        A.by_progress = h->sched_progress >= 0 ? h->sched_progress : 1;
+        A.rolling = h->sched_rolling >= 0 ? h->sched_rolling : (grid <= 3 * h->n_cu || A.envs_per_tile <= 32);
     }
     if (acc) {   // records are indexed by THIS grid (the same at every step of a rollout: one handle state, one n_env)
         // the rollout a workspace belongs to is fixed by its step-0 launch
@@ -1058,6 +1060,7 @@ int eb_env_step(eb_handle h, eb_handle traffic, int32_t n_env, const float* obs,
         A.d16 = out_dict16; A.obs_out = obs_out; A.done_code = done_code;
         A.trace = h->trace; A.trace_words = h->trace_words;
         A.tile_envs = forced_env_tile(h); A.waves = h->env_waves; A.scan_one_trip = h->scan_one_trip;
+        A.by_progress = h->sched_progress;   // (-1: launch_env_step decides by the grid)
         if (respawn) {
             A.respawn_entry = respawn->entry; A.limit = respawn->limit; A.span = respawn->span; A.v_max = respawn->v_max;
             A.seed = respawn->seed; A.counter = respawn->counter;

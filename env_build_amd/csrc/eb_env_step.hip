@@ -82,6 +82,7 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A_in, hipStream_t s) {
         n_cu[dev] = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0 ? cu : 256;
     }
     const int n_blocks = (A.n_env + ET - 1) / ET;
+    if (A.by_progress < 0) A.by_progress = 0;   // (issue priority by phase: off unless forced — eb_debug_set_rollout_sched — until measured)
     // (a grid of many small tiles — the flow source's 60 candidates force 16-env tiles at any batch size — is throughput again: with
     // eight waves per block only two blocks fit a CU's registers; measured at 65 536 x 60: 133 us against 104)
     const bool w8 = wforce != 4 && ET <= 32 && (n_blocks <= 3 * n_cu[dev] || wforce == 8);

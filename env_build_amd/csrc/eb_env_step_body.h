@@ -160,26 +160,8 @@ EB_DEV void slot_pair_walk(const float4* crow, unsigned long long elig, float ex
 // batches, where a block has its CU nearly to itself and a wave's instruction stream IS the step's duration): waves 4-7 own the
 // slot modes and walk them right after barrier 1, beside the tracking (wave 0), the reward pairs (wave 1) and the collision pass
 // (waves 2, 3); the staging is spread over six waves.
-// What a wave needs before it can request its first candidate record travels as separate kernel parameters: with build.py's
-// -amdgpu-kernarg-preload-count they arrive in SGPRs WITH the wave, instead of behind scalar loads of the argument block — the
-// prologue used to spend three dependent scalar round trips (the trace pointer, the candidate arrays, the flow rule's flags) before
-// the first record was requested (round 6).  Only the prologue reads the two pointers from here: kept live to the kernel's end they
-// cost SGPRs the kernels do not have (spills into VGPR lanes: 95 -> 99 VGPRs, scratch in the flow source's six-tile instantiation);
-// the later phases read EnvStepArgs' members as before.
-struct EsHot {
-    const float* cand;
-    const uint8_t* cand_mode;
-    const uint8_t* flow_active;
-    const float* flow_v_max;
-    int n_env, m_cand, flow_on;
-};
-#define EB_ES_HOT_PARAMS const float* hot_cand, const uint8_t* hot_mode, const uint8_t* hot_active, const float* hot_vmax, \
-                         int hot_n_env, int hot_m_cand, int hot_flow_on
-#define EB_ES_HOT_VALUE EsHot{hot_cand, hot_mode, hot_active, hot_vmax, hot_n_env, hot_m_cand, hot_flow_on}
-#define EB_ES_HOT_ARGS A.cand, A.cand_mode, A.flow_active, A.flow_v_max, A.n_env, A.m_cand, A.flow_on
-
 template <int TASK, int ET, bool OBS, bool RESET, bool AUTO = false, int NW = 4>
-EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
+EB_DEV void env_step_body(const EnvStepArgs A) {
     constexpr int NT = NW * 64;                                                  // threads per block
     constexpr int KS = NW == 4 ? 3 : 2;                                          // chunks of a group per staging wave
     constexpr int GCH = (NW - 2) * KS + 2, GREC = GCH * 64;                      // chunks / records per staging group (8 / 512, 14 / 896)
@@ -199,7 +181,7 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
     __shared__ uint8_t s_finlist[AUTO ? ET : 1];
     __shared__ unsigned s_dm[(AUTO || (ET == 16 && !OBS)) ? EB_VMODE_COUNT : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * ET;
-    const int n_env = Hh.n_env, D = A.D, NV = A.NV, m_cand = Hh.m_cand, n_future = A.n_future;
+    const int n_env = A.n_env, D = A.D, NV = A.NV, m_cand = A.m_cand, n_future = A.n_future;
     const int nE = n_env - e0 < ET ? n_env - e0 : ET;
     const int i = e0 + lane;
     const bool live = lane < nE && !(OBS && A.row_mask && A.row_mask[i] == 0);   // (a masked observation pass: the other rows are left alone)
@@ -229,7 +211,7 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
     constexpr bool EVEN = ET == 16 && NW == 4;
     constexpr bool PAIR_STEP = ET == 16 && !OBS && !RESET;   // the step's slot phase as (env, mode) pairs per lane (pair_walk below)
     constexpr bool FUSED_FLOW = EVEN && !OBS;   // the flow rule's per-slot part inside the staging of a record (below) instead of a pass of its own
-    const long long t_entry = wall_clock64();   // (slot 0 of the trace row, written once the loads are out: the mark's own test reads the argument block)
+    ES_MARK(0);
     // Loads first, all of them — the bytes of the small tables the block keeps in LDS (they come from the kernel-argument segment: a
     // memory round trip, and loads return in order, so they go out AHEAD of the records), then the candidate records of this thread
     // (16 bytes each, consecutive threads on consecutive records), further down the per-env flags and — lane = slot — the slot modes.
@@ -240,11 +222,11 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
     if (tid < 64) { tb_mode = A.modes.mode[tid]; tb_turn = A.tturn.t[tid]; }
     if ((AUTO || (ET == 16 && !OBS)) && tid < EB_VMODE_COUNT) tb_dm = A.dm[tid];
     float tb_vmax = 0.0f;                                                             // the flow rule's per-slot speed limit: read per record
-    if (FUSED_FLOW && Hh.flow_on && tid < m_cand) tb_vmax = Hh.flow_v_max[tid];          // (from global memory it was a round trip — and a wait for the previous record's stores — in every staged chunk)
+    if (FUSED_FLOW && A.flow_on && tid < m_cand) tb_vmax = A.flow_v_max[tid];          // (from global memory it was a round trip — and a wait for the previous record's stores — in every staged chunk)
     const bool tb_skip = OBS && A.row_mask && tid < ET && !(tid < nE && A.row_mask[e0 + tid] != 0);   // OBS: a row not to be written
     asm volatile("" ::: "memory");   // (program order of the loads = issue order)
-    const float4* csrc = reinterpret_cast<const float4*>(Hh.cand) + (size_t)e0 * m_cand;   // (preloaded: no scalar load in front of the records)
-    const uint8_t* msrc = Hh.cand_mode + (size_t)e0 * m_cand;
+    const float4* csrc = reinterpret_cast<const float4*>(A.cand) + (size_t)e0 * m_cand;
+    const uint8_t* msrc = A.cand_mode + (size_t)e0 * m_cand;
     const int n_rec = nE * m_cand;
     // chunks of 64 records in groups of eight: waves 2 and 3 take three chunks of a group each, waves 0 and 1 — which
     // have the ego step and the tyre parameters to do — one each.  16-env tiles on four waves (many candidates per env: the flow
@@ -268,10 +250,9 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
             cv[g][k] = make_float4(0, 0, 0, 0); cm[g][k] = EB_VMODE_EMPTY;
             if (idx >= 0 && idx < n_rec) {
                 cv[g][k] = csrc[idx]; cm[g][k] = msrc[idx];
-                if (!OBS && Hh.flow_on) cm[g][k] |= (unsigned)Hh.flow_active[(size_t)e0 * m_cand + idx] << 8;   // (the flow rule's flag: bits 8..)
+                if (!OBS && A.flow_on) cm[g][k] |= (unsigned)A.flow_active[(size_t)e0 * m_cand + idx] << 8;   // (the flow rule's flag: bits 8..)
             }
         }
-    if (A.trace && (threadIdx.x & 63) == 0) A.trace[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 16] = t_entry;   // ES_MARK(0): wave start
     if (tid == 0) s_modeq = 0;
     if (ELIG)
         for (int w = tid; w < ET * EB_VMODE_COUNT * 2; w += NT) s_elig32[w] = 0u;
@@ -280,6 +261,10 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
     if ((AUTO || (ET == 16 && !OBS)) && tid < EB_VMODE_COUNT) s_dm[tid] = tb_dm;
     if (tid < ET) s_col[tid] = tb_skip ? 1 : 0;                                       // OBS: 1 = row not to be written
     if (FUSED_FLOW && tid < 64) s_vmax[tid] = tb_vmax;
+    // Issue priority by phase (A.by_progress): a block that is still in phase 1 outranks one that is past barrier 1, and that one a
+    // block that is storing its rows — the launch ends with its LAST block (as the rollout kernel's priority by progress, round 6)
+    const bool by_phase = A.by_progress != 0;
+    if (by_phase) __builtin_amdgcn_s_setprio(2);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the record loads stay in flight
 
     // ---- phase 1 ---------------------------------------------------------------------------------------------
@@ -695,6 +680,7 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
     };
     ES_MARK(1);
     __syncthreads();   // barrier: s_ego, s_pts, s_oldc, s_cand, mode bytes
+    if (by_phase) __builtin_amdgcn_s_setprio(1);
     ES_MARK(8);
 
     // ---- phase 2 ---------------------------------------------------------------------------------------------
@@ -1035,6 +1021,7 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
     // slot's record, flag and mode byte in phase 1 — those stores, some 4 us old, are complete before anybody passes the barrier)
     if (FUSED_FLOW && A.flow_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // barrier: s_out complete; s_part, s_col, s_jb
+    if (by_phase) __builtin_amdgcn_s_setprio(0);
     ES_MARK(10);
     // E2E:200-221, the priority chain: every wave merges the tile's done codes for itself (lane = env: a byte, a flag and delta_y
     // from LDS, a dozen instructions) — the finished rows as a wave-uniform bit mask, no further barrier before the rows leave
@@ -1270,9 +1257,9 @@ EB_DEV void env_step_body(const EsHot Hh, const EnvStepArgs A) {
 }
 
 template <int TASK, int ET, bool OBS, bool AUTO = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64, (ET == 16 && NW == 4 && !OBS && TASK != TASK_RIGHT) ? 6 : 1)   /* (six tiles per CU for the flow source's step, plain and with auto reset; the right-turn instantiations need 81-89 VGPRs — scratch under the bound — and stay at five) */ void env_step_kernel(EB_ES_HOT_PARAMS, const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(EB_ES_HOT_VALUE, A); }
+__global__ __launch_bounds__(NW * 64, (ET == 16 && NW == 4 && !OBS && TASK != TASK_RIGHT) ? 6 : 1)   /* (six tiles per CU for the flow source's step, plain and with auto reset; the right-turn instantiations need 81-89 VGPRs — scratch under the bound — and stay at five) */ void env_step_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, OBS, false, AUTO, NW>(A); }
 template <int TASK, int ET, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(EB_ES_HOT_PARAMS, const EnvStepArgs A) { env_step_body<TASK, ET, true, true, false, NW>(EB_ES_HOT_VALUE, A); }
+__global__ __launch_bounds__(NW * 64) void env_reset_pool_kernel(const EnvStepArgs A) { env_step_body<TASK, ET, true, true, false, NW>(A); }
 
 // The launches of ONE task's instantiations (step / observation / auto reset / masked reset x tile shapes x waves per block): a template,
 // explicitly instantiated once per task in a translation unit of its own — the three tasks' ~20 kernels each compile side by side (the
@@ -1289,7 +1276,7 @@ hipError_t launch_env_step_task(const EnvStepArgs& A, int ET, bool w8, int n_blo
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             if (e == hipSuccess) granted[dev] = lds;                                                                 \
         }                                                                                                            \
-        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O, AU, W>), g, b, lds, s, EB_ES_HOT_ARGS, A);                 \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_step_kernel<T, E, O, AU, W>), g, b, lds, s, A);                 \
     } while (0)
 #define EB_ENV_STEP(T, E, O, AU) do { if ((E) <= 32 && w8) EB_ENV_STEP_W(T, (E) <= 32 ? (E) : 32, O, AU, 8); else EB_ENV_STEP_W(T, E, O, AU, 4); } while (0)
 #define EB_ENV_RESET_W(T, E, W)                                                                                       \
@@ -1300,7 +1287,7 @@ hipError_t launch_env_step_task(const EnvStepArgs& A, int ET, bool w8, int n_blo
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             if (e == hipSuccess) granted[dev] = lds;                                                                 \
         }                                                                                                            \
-        if (e == hipSuccess) hipLaunchKernelGGL((env_reset_pool_kernel<T, E, W>), g, b, lds, s, EB_ES_HOT_ARGS, A);                  \
+        if (e == hipSuccess) hipLaunchKernelGGL((env_reset_pool_kernel<T, E, W>), g, b, lds, s, A);                  \
     } while (0)
 #define EB_ENV_RESET(T, E) do { if ((E) <= 32 && w8) EB_ENV_RESET_W(T, (E) <= 32 ? (E) : 32, 8); else EB_ENV_RESET_W(T, E, 4); } while (0)
 #define EB_ENV_STEP_T(T)                                                                                             \

@@ -38,8 +38,8 @@ struct FusedArgs {
     int actions_raw;           // 1: raw [-1,1] actions (rollout_out), 0: already scaled
     int do_rewards;            // 0: compute_next_obses only
     int rolling;               // per-step kernel, 2048-record tile: 1 = three record loads in flight per lane, record k + 3 requested when
-                               // record k is done (grids of at most two tiles per CU); 0 = every record requested up front
-    int by_progress;           // per-step kernel: 1 = a record wave's issue priority falls as it advances (grids of one generation of blocks)
+                               // record k is done; 0 = every record requested up front (eb_capi.hip:rollout_fused decides)
+    int by_progress;           // per-step kernel: 1 = a record wave's issue priority falls as it advances
     long long* trace;          // profiling aid (eb_debug_set_trace): [n_waves][8] s_memrealtime marks, or NULL
     long long trace_words;     //   its capacity in 64-bit words: a mark past it is dropped
     int scan_one_trip;         // A/B aid (eb_debug_set_scan_prefetch 0): the closest-point range one group of entries per loop trip, as rounds 1-4
@@ -179,6 +179,7 @@ struct EnvStepArgs {
     long long trace_words;                 //   its capacity in 64-bit words: a mark past it is dropped
     int waves;                             // 0: by grid size (launch_env_step); 4 / 8: forced (eb_debug_set_env_waves)
     int scan_one_trip;                     // A/B aid (eb_debug_set_scan_prefetch 0), as FusedArgs::scan_one_trip
+    int by_progress;                       // 1: a block's issue priority falls from phase to phase (eb_debug_set_rollout_sched's by_progress; launch_env_step decides by the grid)
     int obs_only;                          // 1: eb_get_obs — ego / cand are inputs, only obs_out is written
     const uint8_t* row_mask;               // obs_only: nullable [n_env]; rows with a zero byte are left alone
     int tile_envs;                         // 0: by batch size (env_step_tile_envs); 16 / 32 / 64: forced (eb_debug_set_tile 2 / 1 / 0)

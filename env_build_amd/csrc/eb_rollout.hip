@@ -27,11 +27,12 @@
 // one of the 5 120 waves of the headline grid is INSIDE the kernel within 0.5 us; what earlier rounds read as a 3.7 us dispatch ramp
 // is the read phase itself — a CU's miss path moves ~11 bytes per cycle (MI355X_MICROARCH.md), its 144 KB of rows take 5.5 us, and a
 // wave's load instructions issue as the queue ahead of them drains.  Hence: nothing may stand between a wave's entry and its first
-// load (the slot-turn table's address arrives as a preloaded argument, the entry barrier comes AFTER the loads are out); a grid of
-// at most two tiles per CU keeps three record loads in flight per lane and requests record k + 3 when record k is done (every wave's
-// first records come back sooner, the block's life shrinks: 9.3 -> 8.45 us per step at 32 768 x 32); a grid of one generation lets
-// the record waves that are BEHIND issue first (s_setprio by progress: the last wave, not the average one, ends a launch: 14.85 ->
-// 14.05 us at 65 536 x 32); a grid of several generations does neither (a block that finishes early makes room for the next one).
+// load (the slot-turn table's address arrives as a preloaded argument, the entry barrier comes AFTER the loads are out); the record
+// waves that are BEHIND issue first (s_setprio by progress: the last wave, not the average one, ends a launch: 14.85 -> 14.0 us at
+// 65 536 x 32); a grid of at most three tiles per CU — and any grid of 32-env tiles — keeps three record loads in flight per lane
+// and requests record k + 3 when record k is done (every wave's first records come back sooner, the block's life shrinks: 9.3 ->
+// 8.5 us per step at 32 768 x 32, 25.7 -> 24.5 at 65 536 x 64).  Which grid gets what: eb_capi.hip:rollout_fused, from the sweeps of
+// profiles/r6_sched_sweep1-2.txt.
 #include <type_traits>
 
 #include "eb_device.h"
@@ -433,9 +434,8 @@ EB_DEV void queue_pass_sc(const FusedHot<ST>& H, SM& S, const float4* ego, int w
 
 // FAST: RW * 64 % n_veh == 0 — a lane keeps its vehicle slot over all its records and its env advances by a
 // fixed step, so slot constants are fetched once and addresses advance by a uniform stride.
-// PF: record loads in flight per lane.  RPT — every record requested up front (a grid of more than two tiles per CU: the memory
-// system is what the block waits for, the deepest queue wins); less — record k + PF is requested when record k is done (a grid of
-// at most two tiles per CU: the queue ahead of a wave's first records is shorter, and a record's registers are reused).
+// PF: record loads in flight per lane.  RPT — every record requested up front; less — record k + PF is requested when record k is
+// done (FusedArgs::rolling: the queue ahead of every wave's first records is shorter, and a record's registers are reused).
 template <int TASK, int RW, int RPT, bool FAST, int PF, typename ST>
 EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RPT>& S, int e0, int nE) {
     constexpr int RL = RW * 64;                     // record lanes per block
@@ -487,9 +487,9 @@ EB_DEV void record_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW,
     EB_MARK_PLACE(A, trow);
     if (A.trace && lane == 0) A.trace[(size_t)trow * 8 + 6] = H.t_entry;    // when this wave reached its first instruction
     const bool do_rewards = (H.do_rewards & HOT_REWARDS) != 0;
-    // Issue priority by progress (HOT_PRIO: a grid of one generation of blocks): a wave on its first records outranks one on its
-    // last — the launch ends with its LAST wave, and the hardware's oldest-first issue otherwise lets the first-placed waves of a SIMD
-    // run ahead and leave the youngest to finish alone (record waves end 4.8-10.9 us after the first entry without it, 6.0-10.7 with).
+    // Issue priority by progress (HOT_PRIO): a wave on its first records outranks one on its last — the launch ends with its LAST
+    // wave, and the hardware's oldest-first issue otherwise lets the first-placed waves of a SIMD run ahead and leave the youngest to
+    // finish alone (record waves end 4.8-10.9 us after the first entry without it, 6.0-10.7 with).
     // The env wave runs at 2 throughout: below the record waves' first quarter, above their second half.
     const bool by_progress = (H.do_rewards & HOT_PRIO) != 0;
     S.turn[lane] = (unsigned char)turn_code;   // same bytes from every record wave; a wave reads back its own write
@@ -1205,7 +1205,7 @@ hipError_t launch_rollout_tape_fused(int task, int variant, const FusedArgs& A_i
 
 hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A_in, int grid, hipStream_t s) {
     const FusedArgs A = trace_checked(A_in, grid, (variant == 2 ? 1 : 4) + 1);
-    // (A.rolling / A.by_progress: decided by the grid against the device's CUs — eb_capi.hip:rollout_fused — or forced,
+    // (A.rolling / A.by_progress: decided by the grid and the tile's envs — eb_capi.hip:rollout_fused — or forced,
     // eb_debug_set_rollout_sched; every combination computes the same bits.  Rolling loads exist for the 2048-record tile only:
     // the smaller tiles run on grids that are launch-bound either way)
     switch (variant) {
