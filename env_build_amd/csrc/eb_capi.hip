@@ -554,9 +554,13 @@ static double* acc_finals(void* ws, int horizon, size_t grid) {
 static int pick_variant(eb_handle h, int32_t n_env) {
     int variant = h->tile_variant;                                        // eb_debug_set_tile
     if (variant < 0 || variant > 2) {
-        // the largest tile that still gives every CU two blocks; small batches take small tiles
+        // the largest tile that still gives every CU two blocks; small batches take small tiles.  A tile holds at most 64 envs (one
+        // lane of the env wave each): with 16 slots or fewer the 2048-record tile would be at most half full — its record lanes idle
+        // through half their records — and the 1024-record tile is the faster one at every batch size (round 6, profiles/r6_tile_sweep2.txt:
+        // 65 536 envs x 16 / 9 / 8 / 5 slots 10.3 -> 9.9 / 9.7 -> 8.6 / 8.3 -> 7.6 / 8.7 -> 7.4 us per step; x 24 slots the large tile stays ahead)
         variant = 2;
         for (int v = 0; v < 2; ++v) {
+            if (v == 0 && 64 * h->cfg.n_veh <= eb::fused_tile_records(1)) continue;
             const int e = std::max(1, std::min(64, eb::fused_tile_records(v) / h->cfg.n_veh));
             if ((n_env + e - 1) / e >= 2 * h->n_cu) { variant = v; break; }
         }
@@ -605,13 +609,18 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
     // How the per-step launch spends its memory queue and its issue slots (csrc/eb_rollout.hip; measured: profiles/r6_ab3-5.txt,
-    // r6_sched_sweep1-2.txt — N = 8 ... 64, fp32 and binary16 rows, 2 to 16 tiles per CU): the record waves that are behind issue first,
-    // always (never more than 1 % slower, up to 5 % faster); rolling record loads on grids of at most three tiles per CU, and at any
+    // r6_sched_sweep1-3*.txt — N = 8 ... 64, fp32 and binary16 rows, 2 to 16 tiles per CU): the record waves that are behind issue first,
+    // always (never more than 1 % slower, up to 8 % faster); rolling record loads on grids of at most three tiles per CU, and at any
     // size when a tile holds at most 32 envs (64 slots: + 4-5 % at 8 tiles per CU) — with 64-env tiles they cost 3 % at four tiles per
     // CU and 11 % at sixteen.  Same bits every way.
     if (variant == 0 && tape_horizon == 0) {
         A.by_progress = h->sched_progress >= 0 ? h->sched_progress : 1;
         A.rolling = h->sched_rolling >= 0 ? h->sched_rolling : (grid <= 3 * h->n_cu || A.envs_per_tile <= 32);
+    } else if (tape_horizon == 0) {
+        // (the 1024-record tile — every grid of at most 16 slots, see pick_variant —: 9.85 -> 9.0 / 8.55 -> 8.05 / 7.55 -> 7.2 us at
+        // 65 536 envs x 16 / 9 / 8 slots, nothing either way at two or eight tiles per CU: profiles/r6_sched_sweep3_tile1.txt; the 256-record
+        // tile runs on grids of a few blocks per CU: off)
+        A.by_progress = h->sched_progress >= 0 ? h->sched_progress : (variant == 1 ? 1 : 0);
     }
     if (acc) {   // records are indexed by THIS grid (the same at every step of a rollout: one handle state, one n_env)
         // the rollout a workspace belongs to is fixed by its step-0 launch

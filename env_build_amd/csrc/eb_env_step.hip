@@ -82,7 +82,10 @@ hipError_t launch_env_step(int task, const EnvStepArgs& A_in, hipStream_t s) {
         n_cu[dev] = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0 ? cu : 256;
     }
     const int n_blocks = (A.n_env + ET - 1) / ET;
-    if (A.by_progress < 0) A.by_progress = 0;   // (issue priority by phase: off unless forced — eb_debug_set_rollout_sched — until measured)
+    // issue priority by phase (eb_env_step_body.h; profiles/r6_ab_envprio.txt): the 64-env tiles' step 18.2 -> 17.6 us at 65 536 x 16, with
+    // auto reset 23.8 -> 22.8; the flow source's 16-env tiles: with auto reset 62.0 -> 60.3, the plain step 53.2 -> 54.6 (off there);
+    // nothing either way at 4 096 envs.  eb_debug_set_rollout_sched forces it
+    if (A.by_progress < 0) A.by_progress = (ET == 64 || (A.flow_on && A.auto_reset)) ? 1 : 0;
     // (a grid of many small tiles — the flow source's 60 candidates force 16-env tiles at any batch size — is throughput again: with
     // eight waves per block only two blocks fit a CU's registers; measured at 65 536 x 60: 133 us against 104)
     const bool w8 = wforce != 4 && ET <= 32 && (n_blocks <= 3 * n_cu[dev] || wforce == 8);

@@ -25,6 +25,8 @@ while time.time() < t_end:
     seed = int(rng.integers(1 << 30))
     host, dev = HostModel(oracle_lib(), task, n_veh=N, n_future=nf, mode=mode), DeviceModel(task, n_veh=N, n_future=nf, mode=mode)
     dev.set_tile(tile)
+    sched = (int(rng.choice([-1, 0, 1])), int(rng.choice([-1, 0, 1])))   # eb_debug_set_rollout_sched: rolling loads / priority by progress
+    dev.set_rollout_sched(*sched)
     inp = make_rollout_inputs(task, B, N, H, seed=seed, n_future=nf)
     if mode == 'selecting':
         inp['ref_idx'][:] = int(rng.integers(3))
@@ -39,7 +41,7 @@ while time.time() < t_end:
     obs0 = assemble_obs(ego, trk, inp['veh'])
     ri = inp['ref_idx'] if mode == 'training' else None
     pid = 0 if mode == 'training' else int(inp['ref_idx'][0])
-    tag = '%s N=%d nf=%d %s B=%d H=%d tile=%d f16=%d seed=%d' % (task, N, nf, mode, B, H, tile, f16, seed)
+    tag = '%s N=%d nf=%d %s B=%d H=%d tile=%d sched=%s f16=%d seed=%d' % (task, N, nf, mode, B, H, tile, sched, f16, seed)
     try:
         if f16:
             o16 = obs0.astype(np.float16).view(np.uint16)
