@@ -1120,6 +1120,11 @@ def main():
         if n_env == N_ENV and n_veh == N_VEH and not args.open_loop:      # separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
             traffic, traffic_src = pmc_traffic('rollout', 'hbm_bytes_per_launch')
         cfg = 'configs[2]' if (n_env, n_veh) == (N_ENV, N_VEH) else 'custom'
+        plan = (C.c_int32 * 4)()
+        model.api.debug_rollout_plan(model.handle, n_env, plan)     # what eb_rollout_step launches for this batch on this device
+        launch_plan = {'tile_records': (2048, 1024, 256)[plan[0]], 'workgroups': plan[1],
+                       'record_loads': 'three in flight per lane, rolling' if plan[2] else 'all up front',
+                       'issue_priority': 'by progress (s_setprio)' if plan[3] else 'hardware (oldest first)'}
         kernel = 'eb::rollout_fused_4x8<0, true, 8, float>'   # (task left, slot count divides the record lanes, every record load up front, fp32)
         form = 'closed-loop rollout_out (one kernel launch per step, %s)' % headline_form
         if args.open_loop:
@@ -1145,7 +1150,7 @@ def main():
                         'ms_per_step_median': dt * 1e3 / args.steps, 'ms_per_step_max': max(r['dt']) * 1e3 / args.steps},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': frac, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': kernel, 'alg_bytes_per_launch': alg,
+                         'kernel': kernel, 'launch_plan': launch_plan, 'alg_bytes_per_launch': alg,
                          'avg_launch_us': launch_us, 'launches_timed': r['launches_timed'],
                          'avg_launch_us_statistic': 'HIP events around every rollout of the timed regions: mean per launch within a '
                                                     'region, median over the regions (as `value`)',

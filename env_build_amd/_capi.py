@@ -121,6 +121,7 @@ PROTOTYPES = {
     'eb_debug_set_env_waves': (C.c_int, [_P, _I]),
     'eb_debug_set_scan_prefetch': (C.c_int, [_P, _I]),
     'eb_debug_set_rollout_sched': (C.c_int, [_P, _I, _I]),
+    'eb_debug_rollout_plan': (C.c_int, [_P, _I, _P]),
     'eb_debug_check_grids': (C.c_int, [_P, _I, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'eb_traffic_flow_step': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                        _I, C.c_uint64, C.c_uint64, _P, _P, _P]),

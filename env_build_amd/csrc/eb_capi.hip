@@ -575,6 +575,17 @@ static bool stage_paths_in_lds(eb_handle h, int grid) {
     return h->stage_paths < 0 ? grid <= 2 * h->n_cu : h->stage_paths != 0;
 }
 
+// How the per-step launch spends its memory queue and its issue slots (csrc/eb_rollout.hip; measured: profiles/r6_ab3-5.txt,
+// r6_sched_sweep1-3*.txt — N = 8 ... 64, fp32 and binary16 rows, 2 to 16 tiles per CU).  The record waves that are behind issue first:
+// on the 2048- and 1024-record tiles always (never more than 1 % slower, up to 8 % faster: 9.85 -> 9.0 us at 65 536 envs x 16), off on
+// the 256-record tile (grids of a few blocks per CU).  Rolling record loads (2048-record tile): on grids of at most three tiles per CU,
+// and at any size when a tile holds at most 32 envs (64 slots: + 4-5 % at 8 tiles per CU) — with 64-env tiles they cost 3 % at four
+// tiles per CU and 11 % at sixteen.  Same bits every way; eb_debug_set_rollout_sched forces either.
+static void rollout_sched(eb_handle h, int variant, int grid, int envs_per_tile_, int* rolling, int* by_progress) {
+    *by_progress = h->sched_progress >= 0 ? h->sched_progress : (variant <= 1 ? 1 : 0);
+    *rolling = variant != 0 ? 0 : h->sched_rolling >= 0 ? h->sched_rolling : (grid <= 3 * h->n_cu || envs_per_tile_ <= 32);
+}
+
 static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* obs_in, const float* actions,
                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16,
@@ -608,20 +619,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
         A.gate_spin = gate->spin;
     }
     const int grid = (n_env + A.envs_per_tile - 1) / A.envs_per_tile;
-    // How the per-step launch spends its memory queue and its issue slots (csrc/eb_rollout.hip; measured: profiles/r6_ab3-5.txt,
-    // r6_sched_sweep1-3*.txt — N = 8 ... 64, fp32 and binary16 rows, 2 to 16 tiles per CU): the record waves that are behind issue first,
-    // always (never more than 1 % slower, up to 8 % faster); rolling record loads on grids of at most three tiles per CU, and at any
-    // size when a tile holds at most 32 envs (64 slots: + 4-5 % at 8 tiles per CU) — with 64-env tiles they cost 3 % at four tiles per
-    // CU and 11 % at sixteen.  Same bits every way.
-    if (variant == 0 && tape_horizon == 0) {
-        A.by_progress = h->sched_progress >= 0 ? h->sched_progress : 1;
-        A.rolling = h->sched_rolling >= 0 ? h->sched_rolling : (grid <= 3 * h->n_cu || A.envs_per_tile <= 32);
-    } else if (tape_horizon == 0) {
-        // (the 1024-record tile — every grid of at most 16 slots, see pick_variant —: 9.85 -> 9.0 / 8.55 -> 8.05 / 7.55 -> 7.2 us at
-        // 65 536 envs x 16 / 9 / 8 slots, nothing either way at two or eight tiles per CU: profiles/r6_sched_sweep3_tile1.txt; the 256-record
-        // tile runs on grids of a few blocks per CU: off)
-        A.by_progress = h->sched_progress >= 0 ? h->sched_progress : (variant == 1 ? 1 : 0);
-    }
+    if (tape_horizon == 0) rollout_sched(h, variant, grid, A.envs_per_tile, &A.rolling, &A.by_progress);
     if (acc) {   // records are indexed by THIS grid (the same at every step of a rollout: one handle state, one n_env)
         // the rollout a workspace belongs to is fixed by its step-0 launch
         eb_handle_s::AccRun* run = nullptr;
@@ -1315,6 +1313,15 @@ int eb_debug_set_rollout_sched(eb_handle h, int32_t rolling, int32_t by_progress
     if (!h || rolling < -1 || rolling > 1 || by_progress < -1 || by_progress > 1)
         return fail(EB_EINVAL, "eb_debug_set_rollout_sched: bad argument (-1 = by grid size, 0, 1)");
     h->sched_rolling = rolling; h->sched_progress = by_progress;
+    return EB_OK;
+}
+
+int eb_debug_rollout_plan(eb_handle h, int32_t n_env, int32_t* out4) {
+    if (!h || n_env < 1 || !out4) return fail(EB_EINVAL, "eb_debug_rollout_plan: bad argument");
+    const int variant = pick_variant(h, n_env), e = envs_per_tile(h, variant), grid = (n_env + e - 1) / e;
+    int rolling = 0, by_progress = 0;
+    rollout_sched(h, variant, grid, e, &rolling, &by_progress);
+    out4[0] = variant; out4[1] = grid; out4[2] = rolling; out4[3] = by_progress;
     return EB_OK;
 }
 

@@ -139,7 +139,7 @@ EB_DEV float wave_max_f32(float v) {
 
 // One step's record of the episodic accumulator (eb_rollout_step_acc): the tile's three sums (float64 on the DPP network, a fixed
 // order) and its "punished in this step" bits — 32 bytes from lane 63, no read-modify-write.  lane = env of the tile; every lane active.
-EB_DEV void acc_record(double* recs, bool act, int lane, float v_r, float v_t, float v_p) {   // (block = tile)
+EB_DEV void acc_record(double* recs, bool act, int lane, float v_r, float v_t, float v_p) {
     const double s_r = wave_sum_f64(act ? (double)v_r : 0.0);
     const double s_t = wave_sum_f64(act ? (double)v_t : 0.0);
     const double s_p = wave_sum_f64(act ? (double)v_p : 0.0);
@@ -1207,7 +1207,7 @@ hipError_t launch_rollout_fused(int task, int variant, const FusedArgs& A_in, in
     const FusedArgs A = trace_checked(A_in, grid, (variant == 2 ? 1 : 4) + 1);
     // (A.rolling / A.by_progress: decided by the grid and the tile's envs — eb_capi.hip:rollout_fused — or forced,
     // eb_debug_set_rollout_sched; every combination computes the same bits.  Rolling loads exist for the 2048-record tile only:
-    // the smaller tiles run on grids that are launch-bound either way)
+    // four records per lane leave little to roll, and the 256-record tile runs on grids that are launch-bound either way)
     switch (variant) {
         case 0: if (A.rolling) EB_LAUNCH(rollout_fused_4x8, 4, 3) else EB_LAUNCH(rollout_fused_4x8, 4, 8) break;
         case 1: EB_LAUNCH(rollout_fused_4x4, 4, 4) break;

@@ -569,6 +569,8 @@ int eb_traffic_flow_reset(eb_handle h, int32_t n_env, int32_t per_route, const u
  * queue and the issue slots — rolling: 1 = three record loads in flight per lane, the next one requested when a record is done,
  * 0 = every record requested up front; by_progress: 1 = a wave's issue priority falls as it advances through its records, 0 = the
  * hardware's oldest-first; -1 (default) each = by the launch's grid against the device's CUs.  Same bits every way.
+ * eb_debug_rollout_plan: what eb_rollout_step would launch for n_env envs on this handle — out4 = {tile shape (0: 2048 records,
+ * 1: 1024, 2: 256), workgroups, rolling loads 0 / 1, priority by progress 0 / 1} (the oracle has no launch: EB_EINVAL).
  * eb_debug_set_trace: a device buffer of capacity_words int64 the kernels fill with wall-clock marks (NULL = off): the rollout
  * kernel writes rows of 8 words, one per wave — [n_blocks * waves per block][8] —, the one-launch env step rows of 16 —
  * [n_blocks * W][16] with W = 4 or 8 as above: size it for 8.  A launch whose marks would not fit capacity_words writes none.
@@ -579,6 +581,7 @@ int eb_debug_set_tape_stepwise(eb_handle h, int32_t on);
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode);
 int eb_debug_set_scan_prefetch(eb_handle h, int32_t on);
 int eb_debug_set_rollout_sched(eb_handle h, int32_t rolling, int32_t by_progress);
+int eb_debug_rollout_plan(eb_handle h, int32_t n_env, int32_t* out4);
 /* eb_debug_check_grids (host-side self-check of the closest-point search's precomputed levels, DAM:702-715): the kernels do not scan the
  * stride-10 table; eb_set_paths precomputes, per cell of four nested grids (0.5 m / 4 m / 32 m / 256 m cells) and per path, the index
  * range(s) that hold the reference's first-minimum argmin for EVERY position of the cell.  This samples samples_per_cell positions in

@@ -1717,6 +1717,10 @@ int eb_debug_set_tape_stepwise(eb_handle h, int32_t on) { (void)on; return h ? E
 int eb_debug_set_trace(eb_handle h, long long* device_buf, int64_t capacity_words) { (void)device_buf; (void)capacity_words; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_trace: null handle"); }
 int eb_debug_set_stage_paths(eb_handle h, int32_t mode) { (void)mode; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_stage_paths: null handle"); }
 int eb_debug_set_scan_prefetch(eb_handle h, int32_t on) { (void)on; return h ? EB_OK : fail(EB_EINVAL, "eb_debug_set_scan_prefetch: null handle"); }
+int eb_debug_rollout_plan(eb_handle h, int32_t n_env, int32_t* out4) {
+    (void)h; (void)n_env; (void)out4;
+    return fail(EB_EINVAL, "eb_debug_rollout_plan: the CPU library launches nothing");
+}
 int eb_debug_set_rollout_sched(eb_handle h, int32_t rolling, int32_t by_progress) {
     if (!h || rolling < -1 || rolling > 1 || by_progress < -1 || by_progress > 1)
         return fail(EB_EINVAL, "eb_debug_set_rollout_sched: bad argument (-1 = by grid size, 0, 1)");

@@ -516,6 +516,12 @@ class DeviceModel(HostModel):
         """Force the rollout kernel's tile shape (eb_debug_set_tile; -1 = pick by batch size)."""
         self.api.debug_set_tile(self.h, int(variant))
 
+    def rollout_plan(self, n_env):
+        """eb_debug_rollout_plan -> (tile shape 0 / 1 / 2, workgroups, rolling loads, priority by progress) for a batch of n_env"""
+        out = (C.c_int32 * 4)()
+        self.api.debug_rollout_plan(self.h, int(n_env), out)
+        return tuple(out)
+
     def set_rollout_sched(self, rolling=-1, by_progress=-1):
         """eb_debug_set_rollout_sched: the per-step kernel's rolling record loads / issue priority by progress (-1 = by grid size)."""
         self.api.debug_set_rollout_sched(self.h, int(rolling), int(by_progress))

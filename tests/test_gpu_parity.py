@@ -108,6 +108,31 @@ def test_every_launch_schedule_computes_the_same_bits(task, N, B, rolling, by_pr
         dev.set_rollout_sched(2, 0)
 
 
+def test_rollout_launch_plan_follows_the_measured_rules():
+    """eb_debug_rollout_plan: the tile shape and launch schedule eb_rollout_step takes by itself (eb_capi.hip:pick_variant /
+    rollout_sched; the sweeps behind the rules: profiles/r6_sched_sweep*.txt, r6_tile_sweep2.txt).  Stated for the MI355X's 256 CUs."""
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip('the expectations below are for 256 CUs')
+    d32, d16, d64, d9 = (DeviceModel('left', n_veh=32), DeviceModel('left', n_veh=16), DeviceModel('left', n_veh=64),
+                         DeviceModel('straight', n_veh=9))
+    assert d32.rollout_plan(65536) == (0, 1024, 0, 1)        # the headline: every load up front, priority by progress
+    assert d32.rollout_plan(32768) == (0, 512, 1, 1)         # two tiles per CU: rolling loads
+    assert d32.rollout_plan(49152) == (0, 768, 1, 1) and d32.rollout_plan(262144) == (0, 4096, 0, 1)
+    assert d32.rollout_plan(16384) == (1, 512, 0, 1) and d32.rollout_plan(4096)[0] == 2
+    assert d64.rollout_plan(65536) == (0, 2048, 1, 1)        # 32-env tiles: rolling at any size
+    assert d16.rollout_plan(65536) == (1, 1024, 0, 1)        # at most 16 slots: the 1024-record tile
+    assert d9.rollout_plan(65536)[0] == 1 and d16.rollout_plan(4096) == (2, 256, 0, 0)
+    d32.set_rollout_sched(0, 0)
+    assert d32.rollout_plan(32768) == (0, 512, 0, 0)
+    d32.set_tile(1)
+    assert d32.rollout_plan(32768)[0] == 1
+    import ctypes
+    host = HostModel(oracle_lib(), 'left', n_veh=32)
+    with pytest.raises(ValueError):                          # the CPU library launches nothing
+        host.api.debug_rollout_plan(host.h, 100, (ctypes.c_int32 * 4)())
+
+
 @pytest.mark.parametrize('tile,sched', [(0, (-1, -1)), (0, (0, 0)), (0, (1, 1)), (2, (-1, -1))])
 @pytest.mark.parametrize('N', [32, 9])
 def test_crowded_and_remote_scenes(N, tile, sched):
