@@ -20,6 +20,8 @@ if s:
 for e in d.get('extra', []):
     print('%-62s %.2f us = %.1f %%, %.3g env-steps/s, traffic %s' % (e.get('workload', '')[:62], e.get('avg_launch_us', 0), 100 * e.get('frac', 0), e.get('value', 0),
           None if e.get('traffic') is None else '%.2f MB' % (e['traffic'] / 1e6)))
+    for o in e.get('other_tasks_and_native_shapes', []):
+        print('    %-9s N_veh=%-3d %.2f us per step = %.1f %%, %.3g env-steps/s' % (o['task'], o['n_veh'], o['ms_per_step'] * 1e3, 100 * o['frac'], o['value']))
     if 'one_launch_forms' in e:
         for k, v in e['one_launch_forms'].items():
             if isinstance(v, dict):
