@@ -535,6 +535,12 @@ struct AccArgs {
     int step, horizon;
     const float* prev_out5;
 };
+// the shield's accumulation riding on the step's launch (eb_shield_is_safe): FusedArgs::shield_*
+struct ShieldArgs {
+    float* punish;
+    uint8_t* safe;
+    int row, first, last;
+};
 static int envs_per_tile(eb_handle h, int variant) {
     return std::max(1, std::min(64, eb::fused_tile_records(variant) / h->cfg.n_veh));
 }
@@ -590,7 +596,7 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
                          const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                          float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16,
                          int tape_horizon = 0,   // > 0: `actions` is a tape [H, n_env, 2], `out5` is [H, 5, n_env], one launch
-                         const GateArgs* gate = nullptr, const AccArgs* acc = nullptr) {
+                         const GateArgs* gate = nullptr, const AccArgs* acc = nullptr, const ShieldArgs* shield = nullptr) {
     const int NV = h->cfg.n_veh;
     if (tape_horizon > 0 && !gate) variant = eb::tape_tile_variant(variant, NV, storage_f16);
     eb::FusedArgs A;
@@ -614,6 +620,10 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
     A.actions_raw = actions_raw;
     A.do_rewards = do_rewards;
     A.trace = h->trace; A.trace_words = h->trace_words; A.scan_one_trip = h->scan_one_trip;
+    if (shield) {
+        A.shield_punish = shield->punish; A.shield_safe = shield->safe; A.shield_row = shield->row;
+        A.shield_first = shield->first; A.shield_last = shield->last;
+    }
     if (gate) {
         A.gate_ready = gate->ready; A.gate_done = gate->done; A.gate_obs = gate->obs_steps; A.gate_status = gate->status;
         A.gate_spin = gate->spin;
@@ -644,9 +654,10 @@ static int rollout_fused(eb_handle h, int variant, int32_t n_env, const float* o
 static int rollout_common(eb_handle h, int32_t n_env, const float* obs_in, const float* actions,
                           const int32_t* ref_idx, int32_t path_id, float* obs_out, float* out5,
                           float* scaled_actions, int actions_raw, int do_rewards, hipStream_t s, int storage_f16 = 0,
-                          int tape_horizon = 0, const GateArgs* gate = nullptr, const AccArgs* acc = nullptr) {
+                          int tape_horizon = 0, const GateArgs* gate = nullptr, const AccArgs* acc = nullptr,
+                          const ShieldArgs* shield = nullptr) {
     return rollout_fused(h, pick_variant(h, n_env), n_env, obs_in, actions, ref_idx, path_id, obs_out, out5, scaled_actions,
-                         actions_raw, do_rewards, s, storage_f16, tape_horizon, gate, acc);
+                         actions_raw, do_rewards, s, storage_f16, tape_horizon, gate, acc, shield);
 }
 
 // blocks of a gated rollout over n_env envs, or 0 when they cannot all be resident at once next to a producer: a gated
@@ -1662,16 +1673,17 @@ int eb_shield_is_safe(eb_handle h, eb_mlp policy, int32_t n_env, const float* ob
     EB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t s = pick(h, stream);
     eb::MlpArgs A;
-    const float* pen = out5 + (size_t)(penalty == EB_PENALTY_VEH2VEH4REAL ? 3 : 2) * n_env;   // rows of rollout_out's outputs (DAM:126)
+    // punish += penalty (hier_decision.py:93-97) rides on the step's launch: the env wave that has just made out5's rows 2 / 3 adds
+    // the one asked for to the running sum and, in the last look-ahead, sets the flag — two launches per look-ahead instead of three
     const float* cur = obs_in;
     for (int t = 0; t < steps; ++t) {
         float* dst = (t & 1) ? obs_b : obs_a;
         rc = mlp_args(policy, n_env, cur, actions, eb::MLP_HEAD_ACTION, action_range, &A, "eb_shield_is_safe: null policy");
         if (rc) return rc;
         EB_HIP(eb::launch_mlp(A, s));
-        rc = rollout_common(h, n_env, cur, actions, ref_idx, path_id, dst, out5, nullptr, 1, 1, s);
+        const ShieldArgs sh{punish, safe, penalty == EB_PENALTY_VEH2VEH4REAL ? 3 : 2, t == 0, t == steps - 1};   // rows of rollout_out's outputs (DAM:126)
+        rc = rollout_common(h, n_env, cur, actions, ref_idx, path_id, dst, out5, nullptr, 1, 1, s, 0, 0, nullptr, nullptr, &sh);
         if (rc) return rc;
-        EB_HIP(eb::launch_shield_accumulate(n_env, pen, punish, safe, t == 0, t == steps - 1, s));
         cur = dst;
     }
     return EB_OK;

@@ -58,6 +58,12 @@ struct FusedArgs {
     double* prev_rec;          // where the previous step's records go
     double* acc_final;         // non-NULL in the rollout's last launch: [grid][2] = (sum, max) of |delta_y| of the rows it writes;
                                // that launch also makes its own step's record, at its tail
+    // the safety shield's accumulation inside the step's launch (eb_shield_is_safe; per-step kernel only; NULL otherwise):
+    // punish[i] = (first ? 0 : punish[i]) + out5[row][i]  (hier_decision.py:93-97), safe[i] = !(punish[i] > 0) in the last look-ahead
+    float* shield_punish;
+    uint8_t* shield_safe;
+    int shield_row;            // 2: real_punish_term, 3: veh2veh4real (rows of out5)
+    int shield_first, shield_last;
 };
 // a block's record of one step: [0..2] = float64 sums of reward, punish_term_for_training, real_punish_term over its envs,
 // [3] = bit e set when env e of the tile had real_punish_term > 0 in that step (a 64-bit mask in the double's bytes)
@@ -287,7 +293,4 @@ size_t mlp_lds_bytes(const MlpArgs& A);
 void pack_weights(const float* kernel, int k_real, int cols_real, int k_pad, int col_tiles, float* out);
 void pack_weights16(const float* kernel, int k_real, int cols_real, int k_pad, float* out);   // the output layer's 16-column tiles
 hipError_t launch_mlp(const MlpArgs& A, hipStream_t s);
-hipError_t launch_shield_accumulate(int n, const float* pen, float* punish, uint8_t* safe, int first, int last,
-                                    hipStream_t s);
-
 }  // namespace eb

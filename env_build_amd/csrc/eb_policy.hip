@@ -345,21 +345,6 @@ void pack_weights16(const float* kernel, int k_real, int cols_real, int k_pad, f
                 }
 }
 
-// punish accumulation of the shield (hier_decision.py:93-97): punish = (first ? 0 : punish) + penalty
-__global__ void shield_accumulate_kernel(int n, const float* __restrict__ pen, float* __restrict__ punish,
-                                         uint8_t* __restrict__ safe, int first, int last) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float p = (first ? 0.0f : punish[i]) + pen[i];
-    punish[i] = p;
-    if (last) safe[i] = p > 0.0f ? 0 : 1;
-}
-
-hipError_t launch_shield_accumulate(int n, const float* pen, float* punish, uint8_t* safe, int first, int last,
-                                    hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(shield_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, pen, punish, safe, first, last);
-    return hipGetLastError();
-}
+// (the shield's punish accumulation — hier_decision.py:93-97 — rides on the rollout step's launch since round 6: eb_rollout.hip, env_wave)
 
 }  // namespace eb

@@ -276,6 +276,9 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         const int pr = A.ref_idx[ge];
         p = (pr >= 0 && pr < A.n_paths) ? pr : -1;                          // DAM:342, 352
     }
+    // the shield's running penalty of this env (eb_shield_is_safe's look-aheads after the first): fetched with the head, used at the tail
+    float sh_prev = 0.0f;
+    if (A.shield_punish && !A.shield_first && act) sh_prev = A.shield_punish[ge];
     const int trow = blockIdx.x * (RW + 1);
     // the block's only barrier, behind the loads: it orders the flags' initial zeros before any wave polls them
     if (lane == 0) { S.ego_ready = 0; S.waves_done = 0; }
@@ -378,6 +381,11 @@ EB_DEV void env_wave(const FusedHot<ST>& H, const FusedArgs& A, FusedSmem<RW, RP
         A.out5[2 * n + ge] = pun_r;
         A.out5[3 * n + ge] = a25;
         A.out5[4 * n + ge] = road_r;
+        if (A.shield_punish) {   // hier_decision.py:93-97: punish += penalty — the accumulation a launch of its own used to do
+            const float pacc = sh_prev + (A.shield_row == 3 ? a25 : pun_r);
+            A.shield_punish[ge] = pacc;
+            if (A.shield_last) A.shield_safe[ge] = pacc > 0.0f ? 0 : 1;
+        }
     }
     // The launch that ends a rollout has no successor to make its record: it makes it here, and adds the |delta_y| statistics of
     // the rows it has just written (t0 IS the final obs' column 6) — once per horizon.
