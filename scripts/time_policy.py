@@ -14,9 +14,12 @@ from env_build_amd.synthetic import make_rollout_inputs
 ap = argparse.ArgumentParser()
 ap.add_argument('--n-env', type=int, default=65536); ap.add_argument('--n-veh', type=int, default=32)
 ap.add_argument('--units', type=int, default=256); ap.add_argument('--hidden', type=int, default=2)
-ap.add_argument('--reps', type=int, default=20); ap.add_argument('--act', default='elu'); ap.add_argument('--no-shield', action='store_true')
+ap.add_argument('--lib', default=None, help='A/B aid: bind this build of libenvbuild_hip.so instead of the in-tree one'); ap.add_argument('--reps', type=int, default=20); ap.add_argument('--act', default='elu'); ap.add_argument('--no-shield', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
+if a.lib:
+    from env_build_amd import _capi
+    _capi._hip_api = _capi.CApi(a.lib)
 B, N = a.n_env, a.n_veh
 model = EnvironmentModel('left', 0, mode='training', n_veh=N, device=dev)
 D = model.obs_dim
